@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors from the LIVE reference module.
+
+Runs only in the build container (needs /root/reference, which does not travel to the GPU box).
+It imports the unmodified reference ``cc_attention.functions.CrissCrossAttention``
+(/root/reference/cc_attention/functions.py:15-49), overrides the *instance* attribute ``INF``
+(functions.py:23) with a device-agnostic equivalent of functions.py:11-12 (the original
+hard-codes ``.cuda()``), runs forward + autograd backward on seeded inputs and writes
+``tests/golden/<case>.npz``.
+
+Intermediates (q, k, v, the softmaxed ``concate`` tensor and their gradients) are captured with
+forward hooks on the reference's own submodules, so every array in a fixture was produced by the
+reference's code, not by the oracle.
+
+    python tests/golden/make_golden.py            # regenerate all fixtures
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# name: (B, C, H, W, store_everything)
+CASES = {
+    "tiny_2x16x5x6": (2, 16, 5, 6, True),       # H != W, Cq = 2 (the reference's own __main__ shape family)
+    "small_1x32x9x7": (1, 32, 9, 7, True),      # H > W, B = 1
+    "small_2x64x8x8": (2, 64, 8, 8, True),
+    "cfg1_2x64x32x32": (2, 64, 32, 32, False),  # BASELINE.json configs[0]; inputs regenerated from the seed
+}
+
+
+def load_reference():
+    spec = importlib.util.spec_from_file_location(
+        "ref_cc_attention_functions", os.path.join(REF, "cc_attention", "functions.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def cpu_inf(B, H, W):
+    # same values as functions.py:11-12 without the .cuda(): -inf on the diagonal, -0.0 elsewhere
+    return -torch.diag(torch.tensor(float("inf")).repeat(H), 0).unsqueeze(0).repeat(B * W, 1, 1)
+
+
+def run_case(B, C, H, W):
+    ref = load_reference()
+    torch.manual_seed(0)
+    m = ref.CrissCrossAttention(C)              # default Conv2d init, consumes RNG first
+    with torch.no_grad():
+        m.gamma.fill_(0.5)                      # zero-init (functions.py:24) would make the branch a no-op
+    m.INF = cpu_inf
+    x = torch.randn(B, C, H, W, requires_grad=True)
+    dy = torch.randn(B, C, H, W)
+
+    cap = {}
+
+    def hook(name):
+        def f(_mod, _inp, out):
+            out.retain_grad()
+            cap[name] = out
+        return f
+
+    m.query_conv.register_forward_hook(hook("q"))
+    m.key_conv.register_forward_hook(hook("k"))
+    m.value_conv.register_forward_hook(hook("v"))
+    m.softmax.register_forward_hook(hook("A"))
+    y = m(x)
+    y.backward(dy)
+
+    out = {
+        "x": x.detach(), "dy": dy, "y": y.detach(), "dx": x.grad,
+        "q": cap["q"].detach(), "k": cap["k"].detach(), "v": cap["v"].detach(),
+        "A": cap["A"].detach(), "dq": cap["q"].grad, "dk": cap["k"].grad, "dv": cap["v"].grad,
+        "dA": cap["A"].grad,
+    }
+    for n, p in m.named_parameters():
+        out["param." + n] = p.detach()
+        out["grad." + n] = p.grad
+    return {k: v.numpy().copy() for k, v in out.items()}
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("reference tree not present: golden vectors can only be regenerated in the build container")
+    for name, (B, C, H, W, full) in CASES.items():
+        arrs = run_case(B, C, H, W)
+        if not full:
+            # keep the fixture small: inputs / params are regenerated from the seed by the tests
+            # (same torch build on the GPU box); a fingerprint guards against RNG drift.
+            keep = {k: v for k, v in arrs.items()
+                    if k in ("y", "dx") or k.startswith("grad.")}
+            keep["fingerprint.x"] = np.array([arrs["x"].sum(dtype=np.float64), arrs["x"].flat[12345]])
+            keep["fingerprint.dy"] = np.array([arrs["dy"].sum(dtype=np.float64), arrs["dy"].flat[54321]])
+            keep["fingerprint.A"] = np.array([np.square(arrs["A"]).sum(dtype=np.float64)])
+            arrs = keep
+        arrs["shape"] = np.array([B, C, H, W])
+        path = os.path.join(HERE, name + ".npz")
+        np.savez(path, **arrs)
+        print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e3:.0f} kB)")
+
+
+if __name__ == "__main__":
+    main()
