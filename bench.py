@@ -1,0 +1,357 @@
+#!/usr/bin/env python3
+"""bench.py -- criss-cross attention fwd+bwd throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: forward (q,k,v,x,gamma -> y, A) and backward
+(dy -> dq, dk, dv, dgamma) of the attention core at BASELINE.json configs[1], (8,512,97,97) fp32, R=1,
+issued through the C ABI (include/ccnet_cca.h) with every buffer already resident in HBM.  The three
+1x1 convolutions around the core stay torch ops and are reported separately (``module_ms_per_step``),
+not in ``value``.
+
+Multi-GPU: the path shards along the batch with no exchange inside the op, so every
+rank runs the same per-GPU batch on its own shard ("weak" scaling, no data-path collective); the
+timed region is bracketed by barrier + synchronize and the maximum over ranks is used.
+
+Rank 0 prints ONE JSON line: the driver contract plus ``roofline`` (dominant kernel, live HIP-event
+timing) and ``cpu_baseline`` (the CPU oracle timed on a bounded sample on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0          # measured float4-copy ceiling, same table
+F32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_16x16x4_f32 = fp32 vector rate
+
+
+# --------------------------------------------------------------------------------------------
+# accounting (DESIGN.md "algorithmic bytes")
+# --------------------------------------------------------------------------------------------
+def core_bytes(B, C, H, W, elt=4):
+    """Compulsory HBM bytes of one core fwd+bwd: six C-sized and six C/8-sized streams."""
+    return elt * B * H * W * (6 * C + 6 * (C // 8))
+
+
+def core_flops(B, C, H, W):
+    return 3 * 2 * B * H * W * (H + W) * (C + C // 8)
+
+
+def kernel_accounting(kind, B, K, H, W, row):
+    """Algorithmic bytes / flops of ONE strip-kernel launch (one branch).
+
+    weight kernel: reads X and Y (B,K,H,W) once, writes its half of the (B,H,W,H+W) attention tensor.
+    map kernel   : reads its half of the attention tensor and F (B,K,H,W), writes out (B,K,H,W); the row
+                   launch also re-reads the column partial (and the residual when there is one).
+    """
+    L = W if row else H
+    feat = 4 * B * K * H * W
+    att = 4 * B * H * W * L
+    flops = 2 * B * H * W * L * K
+    if kind == "weight":
+        return 2 * feat + att, flops
+    nbytes = att + 2 * feat
+    if row:
+        nbytes += feat                      # column partial re-read
+        if kind == "map_resid":
+            nbytes += feat                  # residual x
+    return nbytes, flops
+
+
+# --------------------------------------------------------------------------------------------
+# distributed helpers (pure host logic; covered by tests/test_dist_gloo.py on the gloo backend)
+# --------------------------------------------------------------------------------------------
+def dist_env():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    return rank, world, local
+
+
+def shard_seed(base_seed, rank):
+    """Per-rank seed as in the reference's train.py:154-155 (seed = local rank offset)."""
+    return base_seed + rank
+
+
+def max_over_ranks(seconds, device, world):
+    """MAX-reduce a local wall time over all ranks (identity for world == 1)."""
+    if world <= 1 or not dist.is_initialized():
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def aggregate_value(bytes_per_step_per_rank, steps, world, seconds):
+    """Whole-job GB/s: all ranks' bytes over the slowest rank's time."""
+    return world * bytes_per_step_per_rank * steps / seconds / 1e9
+
+
+# --------------------------------------------------------------------------------------------
+class CoreWorkload:
+    """Pre-allocated device buffers + the two C-ABI calls of one step."""
+
+    def __init__(self, lib, B, C, H, W, device, seed):
+        self.lib, self.shape, self.device = lib, (B, C, H, W), device
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        Cq = C // 8
+
+        def rnd(*s):
+            return torch.randn(*s, generator=g).to(device)
+
+        self.q, self.k = rnd(B, Cq, H, W), rnd(B, Cq, H, W)
+        self.v, self.x, self.dy = rnd(B, C, H, W), rnd(B, C, H, W), rnd(B, C, H, W)
+        self.gamma = torch.full((1,), 0.5, device=device)
+        self.y = torch.empty_like(self.x)
+        self.A = torch.empty(B, H, W, H + W, device=device)
+        self.scratch = torch.empty_like(self.A)
+        self.dq, self.dk, self.dv = torch.empty_like(self.q), torch.empty_like(self.k), torch.empty_like(self.v)
+        self.dgamma = torch.empty(1, device=device)
+        self.ws_bytes = lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
+        self.ws = torch.empty(self.ws_bytes // 4 + 1, device=device)
+
+    def stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def forward(self):
+        B, C, H, W = self.shape
+        L = self.lib
+        L.check(L.ccnet_cca_forward_f32(self.q.data_ptr(), self.k.data_ptr(), self.v.data_ptr(), self.x.data_ptr(),
+                                        self.gamma.data_ptr(), self.y.data_ptr(), self.A.data_ptr(),
+                                        B, C, C // 8, H, W, self.stream()), "cca_forward")
+
+    def backward(self):
+        B, C, H, W = self.shape
+        L = self.lib
+        L.check(L.ccnet_cca_backward_f32(self.dy.data_ptr(), self.q.data_ptr(), self.k.data_ptr(), self.v.data_ptr(),
+                                         self.A.data_ptr(), self.gamma.data_ptr(), self.dq.data_ptr(),
+                                         self.dk.data_ptr(), self.dv.data_ptr(), self.dgamma.data_ptr(),
+                                         self.scratch.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
+                                         B, C, C // 8, H, W, self.stream()), "cca_backward")
+
+    def step(self):
+        self.forward()
+        self.backward()
+
+    # ---- single-kernel launches for the roofline object (branch mask restricts to ONE kernel) ----
+    def stage_table(self):
+        B, C, H, W = self.shape
+        L, s, Cq = self.lib, self.stream, C // 8
+        P = lambda t: t.data_ptr()  # noqa: E731
+        return {
+            # name: (callable, kind, K)
+            "ca_forward[q.k]": (lambda: L.ccnet_ca_forward_f32(P(self.q), P(self.k), P(self.scratch), B, Cq, H, W, 0, s()),
+                                "weight", Cq, "weight_strip_kernel"),
+            "ca_map_forward[A.v]": (lambda: L.ccnet_ca_map_forward_f32(P(self.A), P(self.v), P(self.x), P(self.gamma),
+                                                                       P(self.y), B, C, H, W, s()),
+                                    "map_resid", C, "map_strip_kernel"),
+            "ca_map_backward.dA[dy.v]": (lambda: L.ccnet_ca_map_backward_f32(P(self.dy), P(self.A), P(self.v), P(self.gamma),
+                                                                             P(self.scratch), None, B, C, H, W, s()),
+                                         "weight", C, "weight_strip_kernel"),
+            "ca_map_backward.dv[A^T.dy]": (lambda: L.ccnet_ca_map_backward_f32(P(self.dy), P(self.A), P(self.v),
+                                                                               P(self.gamma), None, P(self.dv),
+                                                                               B, C, H, W, s()),
+                                           "map", C, "map_strip_kernel"),
+        }
+
+
+def time_region(fn, iters):
+    """HIP events on torch's current stream (the stream the C ABI launches on)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters        # ms
+
+
+def roofline_object(wl, iters=20):
+    """Time every (stage, branch) strip kernel alone and describe the slowest one."""
+    B, C, H, W = wl.shape
+    lib = wl.lib
+    rows = []
+    try:
+        for name, (fn, kind, K, kname) in wl.stage_table().items():
+            for mask, row in ((1, False), (2, True)):
+                lib.ccnet_cca_set_branch_mask(mask)
+                for _ in range(3):
+                    lib.check(fn(), name)
+                ms = time_region(lambda: lib.check(fn(), name), iters)
+                nbytes, flops = kernel_accounting(kind, B, K, H, W, row)
+                rows.append({"kernel": f"{kname}<{'row' if row else 'col'}> {name}", "ms": ms,
+                             "bytes": nbytes, "flops": flops})
+    finally:
+        lib.ccnet_cca_set_branch_mask(3)
+    dom = max(rows, key=lambda r: r["ms"])
+    t_hbm = dom["bytes"] / (HBM_PEAK_GBS * 1e9)
+    t_mfma = dom["flops"] / (F32_MFMA_PEAK_TF * 1e12)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                traffic = json.load(f).get(dom["kernel"].split(" ")[0])
+        except Exception:
+            traffic = None
+    if t_mfma >= t_hbm:
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        obj = {"bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+               "frac": round(ach / F32_MFMA_PEAK_TF, 4)}
+    else:
+        ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+        obj = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(ach / HBM_PEAK_GBS, 4)}
+    obj.update({"traffic": traffic, "kernel": dom["kernel"], "kernel_ms": round(dom["ms"], 4),
+                "algorithmic_bytes": dom["bytes"], "algorithmic_flops": dom["flops"],
+                "hbm_gbs_equiv": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1)})
+    return obj, rows
+
+
+def cpu_baseline(C, H, W, budget_s=20.0):
+    """The CPU oracle (einsum restatement of functions.py:38-49 + closed-form backward) on a bounded
+    sample of the same workload: batch 1 of (.,C,H,W), repeated for ~budget_s seconds."""
+    from oracle import cca_oracle as O
+    torch.manual_seed(0)
+    B = 1
+    q, k = torch.randn(B, C // 8, H, W), torch.randn(B, C // 8, H, W)
+    v, x, dy = torch.randn(B, C, H, W), torch.randn(B, C, H, W), torch.randn(B, C, H, W)
+    gamma = torch.full((1,), 0.5)
+
+    def one():
+        y, A = O.cca_core_forward(q, k, v, x, gamma)
+        O.cca_core_backward(dy, q, k, v, A, gamma)
+
+    one()                                            # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    gbs = core_bytes(B, C, H, W) * n / el / 1e9
+    return {"value": round(gbs, 3), "unit": "GB/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/cca_oracle.py core fwd+bwd, batch {B} of ({B},{C},{H},{W}) fp32, {n} iters in {el:.1f}s",
+            "ms_per_image": round(el / n / B * 1e3, 1)}
+
+
+def module_level_ms(B, C, H, W, device, iters=10):
+    """fwd+bwd of the whole CrissCrossAttention module (adds the three torch 1x1 convs + autograd)."""
+    from ccnet_amd import CrissCrossAttention
+    torch.manual_seed(0)
+    m = CrissCrossAttention(C).to(device)
+    with torch.no_grad():
+        m.gamma.fill_(0.5)
+    x = torch.randn(B, C, H, W, device=device, requires_grad=True)
+    dy = torch.randn(B, C, H, W, device=device)
+
+    def one():
+        m.zero_grad(set_to_none=True)
+        x.grad = None
+        m(x).backward(dy)
+
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    return time_region(one, iters)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--channels", type=int, default=512)
+    ap.add_argument("--height", type=int, default=97)
+    ap.add_argument("--width", type=int, default=97)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline/module/cpu legs (timed region only)")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank, world, local = dist_env()
+    if world != args.gpus and world > 1:
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (the product has no CPU path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)     # backend "nccl" is RCCL on ROCm
+
+    from ccnet_amd import _lib
+    lib = _lib.get_lib()
+    B, C, H, W = args.batch, args.channels, args.height, args.width
+    wl = CoreWorkload(lib, B, C, H, W, device, shard_seed(1234, rank))
+
+    for _ in range(args.warmup):
+        wl.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    local_s = time.perf_counter() - t0
+    secs = max_over_ranks(local_s, device, world)
+
+    nbytes = core_bytes(B, C, H, W)
+    value = aggregate_value(nbytes, args.steps, world, secs)
+    ms = secs / args.steps * 1e3
+    out = {
+        "metric": "CrissCrossAttention core fwd+bwd algorithmic GB/s at (B,512,97,97)",
+        "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[1]: single-op CrissCrossAttention core fwd+bwd, "
+                               f"({B},{C},{H},{W}) fp32 per GPU, R=1",
+                   "per_gpu_batch": B, "global_batch": B * world, "shape": [B, C, H, W],
+                   "parallelism": f"batch-sharded x{world} (no data-path collective)",
+                   "impl": "mfma-strip" if lib.ccnet_cca_shape_uses_mfma(B, C, H, W) else "direct"},
+        "algorithmic_bytes_per_step_per_gpu": nbytes,
+        "frac_of_hbm_roofline": round(value / world / HBM_PEAK_GBS, 4),
+        "frac_of_hbm_copy_ceiling": round(value / world / HBM_COPY_GBS, 4),
+        "tflops": round(core_flops(B, C, H, W) * world / (ms * 1e-3) / 1e12, 2),
+    }
+
+    if rank == 0 and not args.no_extras:
+        fwd_ms = time_region(wl.forward, 10)
+        bwd_ms = time_region(wl.backward, 10)
+        out["fwd_ms"], out["bwd_ms"] = round(fwd_ms, 4), round(bwd_ms, 4)
+        roof, rows = roofline_object(wl)
+        out["roofline"] = roof
+        out["kernels_ms"] = {r["kernel"]: round(r["ms"], 4) for r in rows}
+        try:
+            out["module_ms_per_step"] = round(module_level_ms(B, C, H, W, device), 4)
+        except Exception as e:          # the metric does not depend on it
+            out["module_ms_per_step"] = f"failed: {e}"
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(C, H, W, args.cpu_budget)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+"""ctypes binding of the C ABI declared in include/ccnet_cca.h.
+
+The product loads ``ccnet_amd/csrc/libccnet_cca.so`` (built for gfx950 by ``__graft_entry__.build()``).
+There is deliberately NO fallback: if the library is missing, or a tensor is not on a HIP device, the
+callers in :mod:`ccnet_amd.functions` raise.  ``import torch`` must precede the ``CDLL`` so that the HIP
+runtime already mapped by PyTorch (same SONAME ``libamdhip64.so.7``) is the one the library binds to.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from ctypes import c_char_p, c_int, c_size_t, c_void_p
+from typing import List, Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libccnet_cca.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ccnet_cca.h")
+
+CCNET_CA_ENERGY = 0
+CCNET_CA_SOFTMAX = 1
+CCNET_IMPL_AUTO = 0
+CCNET_IMPL_DIRECT = 1
+CCNET_IMPL_MFMA = 2
+
+_P = c_void_p  # every tensor argument is a raw device pointer
+
+# name -> (restype, argtypes); mirrors include/ccnet_cca.h one to one
+_PROTOTYPES = {
+    "ccnet_cca_version": (c_int, []),
+    "ccnet_cca_arch": (c_char_p, []),
+    "ccnet_cca_last_error_string": (c_char_p, []),
+    "ccnet_cca_set_impl": (c_int, [c_int]),
+    "ccnet_cca_get_impl": (c_int, []),
+    "ccnet_cca_set_branch_mask": (c_int, [c_int]),
+    "ccnet_ca_forward_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "ccnet_ca_backward_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ccnet_ca_softmax_forward_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "ccnet_ca_softmax_backward_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ccnet_ca_softmax_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, _P]),
+    "ccnet_ca_map_forward_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ccnet_ca_map_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ccnet_cca_forward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "ccnet_cca_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t,
+                                       c_int, c_int, c_int, c_int, c_int, _P]),
+    "ccnet_cca_shape_uses_mfma": (c_int, [c_int, c_int, c_int, c_int]),
+    "ccnet_cca_mfma_selftest": (c_int, [_P, _P]),
+}
+
+
+def declared_symbols(header: str = HEADER_PATH) -> List[str]:
+    """Every function name include/ccnet_cca.h declares (used by the symbol-export test)."""
+    with open(header) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(ccnet_\w+)\s*\(", text)))
+
+
+class CcaError(RuntimeError):
+    pass
+
+
+class CcaLibrary:
+    """A loaded libccnet_cca.so (or, in the CPU tests, the emulator build of the same sources)."""
+
+    def __init__(self, path: str = LIB_PATH):
+        if not os.path.exists(path):
+            raise CcaError(
+                f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()').  "
+                "ccnet_amd has no CPU or PyTorch fallback for the criss-cross attention kernels.")
+        self.path = path
+        self.dll = ctypes.CDLL(path)
+        for name, (res, args) in _PROTOTYPES.items():
+            fn = getattr(self.dll, name)      # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+
+    def last_error(self) -> str:
+        return self.ccnet_cca_last_error_string().decode()
+
+    def check(self, code: int, what: str = "") -> None:
+        if code != 0:
+            raise CcaError(f"{what or 'ccnet_cca'} failed with code {code}: {self.last_error()}")
+
+
+_lib: Optional[CcaLibrary] = None
+
+
+def get_lib() -> CcaLibrary:
+    """The process-wide device library; raises CcaError when it has not been built."""
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401  (map PyTorch's HIP runtime first, see module docstring)
+        _lib = CcaLibrary(LIB_PATH)
+    return _lib

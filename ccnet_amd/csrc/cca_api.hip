@@ -1,0 +1,315 @@
+// cca_api.hip -- extern "C" entry points of libccnet_cca.so (see include/ccnet_cca.h).
+//
+// Built for the device with   hipcc --offload-arch=gfx950 -O3 -shared -fPIC   (__graft_entry__.build()).
+// The CPU test-suite compiles this same file with the host compiler and -DCCNET_EMU against
+// tests/emu/hip_emu.hpp to execute the kernels in a SIMT emulator; that build is test-only.
+#include "../../include/ccnet_cca.h"
+
+#include "cca_common.hpp"
+#include "cca_direct.hpp"
+#include "cca_map.hpp"
+#include "cca_softmax.hpp"
+#include "cca_weight.hpp"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <string>
+
+#ifdef CCNET_EMU
+#define CCA_LAUNCH(kern, grid, block, stream, ...) \
+    emu::launch((grid), (block), [&]() { kern(__VA_ARGS__); })
+#else
+#define CCA_LAUNCH(kern, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kern, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__)
+#endif
+
+namespace {
+
+thread_local std::string g_last_error = "";
+int g_impl = CCNET_IMPL_AUTO;
+int g_branch_mask = CCNET_BRANCH_BOTH;      // profiling aid: which branch launches are issued
+
+int fail(int code, const char *what) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "ccnet_cca: %s (code %d)", what, code);
+    g_last_error = buf;
+    return code;
+}
+
+int launch_status(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "ccnet_cca: launch of %s failed: %s", what, hipGetErrorString(e));
+        g_last_error = buf;
+        return (int)e;
+    }
+    return 0;
+}
+
+int check_shape(int B, int C, int H, int W) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(CCNET_E_BADSHAPE, "non-positive dimension");
+    if (B > 65535) return fail(CCNET_E_BADSHAPE, "batch exceeds the grid limit 65535");
+    const double per_image = (double)H * W * (H + W);
+    if (per_image >= 536870912.0 || (double)C * H * W >= 536870912.0)
+        return fail(CCNET_E_BADSHAPE, "per-image tensor exceeds 2^29 elements (32-bit byte offsets)");
+    return 0;
+}
+
+// 1 = MFMA strip kernels, 0 = direct kernels, <0 = error
+int pick_impl(int H, int W) {
+    const bool fits = H <= cca::kMaxStrip && W <= cca::kMaxStrip;
+    if (g_impl == CCNET_IMPL_DIRECT) return 0;
+    if (g_impl == CCNET_IMPL_MFMA)
+        return fits ? 1 : fail(CCNET_E_BADSHAPE, "CCNET_IMPL_MFMA forced but max(H,W) > 100");
+    return fits ? 1 : 0;
+}
+
+unsigned direct_grid(size_t total) {
+    size_t blocks = (total + cca::D_BLOCK - 1) / cca::D_BLOCK;
+    const size_t cap = 256 * 32;
+    return (unsigned)(blocks < cap ? blocks : cap);
+}
+
+int map_target_blocks() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("CCNET_CCA_MAP_TARGET_BLOCKS");
+        v = e ? atoi(e) : 1024;
+        if (v < 1) v = 1;
+    }
+    return v;
+}
+
+// strips-per-image tiles and the channel split of the map kernels
+void map_grid(int B, int C, int G, dim3 &grid, int &chunks_per_block) {
+    const int tiles = (G + cca::kStripsPerBlock - 1) / cca::kStripsPerBlock;
+    const int nchunks = (C + cca::M_MC - 1) / cca::M_MC;
+    const int base = B * tiles;
+    int cs = (map_target_blocks() + base - 1) / base;
+    if (cs < 1) cs = 1;
+    if (cs > nchunks) cs = nchunks;
+    chunks_per_block = (nchunks + cs - 1) / cs;
+    cs = (nchunks + chunks_per_block - 1) / chunks_per_block;
+    grid = dim3((unsigned)tiles, (unsigned)cs, (unsigned)B);
+}
+
+// out = alpha * (column sums + row sums) + resid, both branches, strip kernels
+template <bool TRANS>
+int launch_map_pair(const float *T, const float *F, const float *resid, const float *gamma, float *out,
+                    int B, int C, int H, int W, ccnet_stream_t stream, const char *what) {
+    dim3 grid;
+    int cpb;
+    if (g_branch_mask & CCNET_BRANCH_COL) {
+        map_grid(B, C, /*G=*/W, grid, cpb);
+        CCA_LAUNCH((cca::map_strip_kernel<false, TRANS, cca::EPI_STORE>), grid, dim3(cca::kBlock), stream,
+                   T, F, (const float *)nullptr, (const float *)nullptr, out, C, H, W, cpb);
+        if (int e = launch_status(what)) return e;
+    }
+    if (g_branch_mask & CCNET_BRANCH_ROW) {
+        map_grid(B, C, /*G=*/H, grid, cpb);
+        CCA_LAUNCH((cca::map_strip_kernel<true, TRANS, cca::EPI_FINAL>), grid, dim3(cca::kBlock), stream,
+                   T, F, resid, gamma, out, C, H, W, cpb);
+        return launch_status(what);
+    }
+    return 0;
+}
+
+template <bool MASK>
+int launch_weight_pair(const float *X, const float *Y, float *T, int B, int Cx, int H, int W,
+                       ccnet_stream_t stream, const char *what) {
+    const int tc = (W + cca::kStripsPerBlock - 1) / cca::kStripsPerBlock;
+    const int tr = (H + cca::kStripsPerBlock - 1) / cca::kStripsPerBlock;
+    if (g_branch_mask & CCNET_BRANCH_COL) {
+        CCA_LAUNCH((cca::weight_strip_kernel<false, MASK>), dim3(tc, B), dim3(cca::kBlock), stream, X, Y, T, Cx, H, W);
+        if (int e = launch_status(what)) return e;
+    }
+    if (g_branch_mask & CCNET_BRANCH_ROW) {
+        CCA_LAUNCH((cca::weight_strip_kernel<true, MASK>), dim3(tr, B), dim3(cca::kBlock), stream, X, Y, T, Cx, H, W);
+        return launch_status(what);
+    }
+    return 0;
+}
+
+int softmax_forward(const float *E, float *A, int B, int H, int W, ccnet_stream_t stream) {
+    const int npix = B * H * W, S = H + W;
+    const dim3 grid((npix + cca::SM_WAVES - 1) / cca::SM_WAVES), block(cca::SM_BLOCK);
+    if (S <= 256)      CCA_LAUNCH((cca::softmax_fwd_kernel<4>), grid, block, stream, E, A, npix, S);
+    else if (S <= 512) CCA_LAUNCH((cca::softmax_fwd_kernel<8>), grid, block, stream, E, A, npix, S);
+    else               CCA_LAUNCH(cca::softmax_fwd_generic_kernel, grid, block, stream, E, A, npix, S);
+    return launch_status("softmax_fwd");
+}
+
+}  // namespace
+
+extern "C" {
+
+int ccnet_cca_version(void) { return CCNET_CCA_VERSION; }
+const char *ccnet_cca_arch(void) { return "gfx950"; }
+const char *ccnet_cca_last_error_string(void) { return g_last_error.c_str(); }
+int ccnet_cca_set_impl(int impl) {
+    const int prev = g_impl;
+    if (impl == CCNET_IMPL_AUTO || impl == CCNET_IMPL_DIRECT || impl == CCNET_IMPL_MFMA) g_impl = impl;
+    return prev;
+}
+int ccnet_cca_get_impl(void) { return g_impl; }
+int ccnet_cca_set_branch_mask(int mask) {
+    const int prev = g_branch_mask;
+    if (mask >= 1 && mask <= 3) g_branch_mask = mask;
+    return prev;
+}
+
+int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W) {
+    (void)B; (void)C;
+    return (g_impl != CCNET_IMPL_DIRECT && H <= cca::kMaxStrip && W <= cca::kMaxStrip) ? 1 : 0;
+}
+
+int ccnet_ca_softmax_forward_f32(const float *energy, float *out, int B, int H, int W, ccnet_stream_t stream) {
+    if (int e = check_shape(B, 1, H, W)) return e;
+    if (!energy || !out) return fail(CCNET_E_NULLPTR, "softmax_forward: null tensor");
+    return softmax_forward(energy, out, B, H, W, stream);
+}
+
+int ccnet_ca_forward_f32(const float *q, const float *k, float *out, int B, int Cq, int H, int W, int flags,
+                         ccnet_stream_t stream) {
+    if (int e = check_shape(B, Cq, H, W)) return e;
+    if (!q || !k || !out) return fail(CCNET_E_NULLPTR, "ca_forward: null tensor");
+    if (flags != CCNET_CA_ENERGY && flags != CCNET_CA_SOFTMAX) return fail(CCNET_E_BADFLAGS, "ca_forward: bad flags");
+    const int impl = pick_impl(H, W);
+    if (impl < 0) return impl;
+    if (impl == 1) {
+        if (int e = launch_weight_pair<true>(q, k, out, B, Cq, H, W, stream, "ca_forward")) return e;
+    } else {
+        const size_t total = (size_t)B * H * W * (H + W);
+        CCA_LAUNCH((cca::direct_weight_kernel<true>), dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
+                   q, k, out, Cq, H, W, total);
+        if (int e = launch_status("ca_forward(direct)")) return e;
+    }
+    if (flags == CCNET_CA_SOFTMAX) return softmax_forward(out, out, B, H, W, stream);
+    return 0;
+}
+
+int ccnet_ca_backward_f32(const float *dE, const float *q, const float *k, float *dq, float *dk,
+                          int B, int Cq, int H, int W, ccnet_stream_t stream) {
+    if (int e = check_shape(B, Cq, H, W)) return e;
+    if (!dE || !q || !k || !dq || !dk) return fail(CCNET_E_NULLPTR, "ca_backward: null tensor");
+    const int impl = pick_impl(H, W);
+    if (impl < 0) return impl;
+    if (impl == 1) {
+        if (int e = launch_map_pair<false>(dE, k, nullptr, nullptr, dq, B, Cq, H, W, stream, "ca_backward(dq)")) return e;
+        return launch_map_pair<true>(dE, q, nullptr, nullptr, dk, B, Cq, H, W, stream, "ca_backward(dk)");
+    }
+    const size_t total = (size_t)B * Cq * H * W;
+    CCA_LAUNCH(cca::direct_map_kernel, dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
+               dE, k, (const float *)nullptr, (const float *)nullptr, dq, Cq, H, W, total);
+    if (int e = launch_status("ca_backward(dq,direct)")) return e;
+    CCA_LAUNCH(cca::direct_mapT_kernel, dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
+               dE, q, (const float *)nullptr, dk, Cq, H, W, total);
+    return launch_status("ca_backward(dk,direct)");
+}
+
+size_t ccnet_ca_softmax_backward_workspace_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t npix = (size_t)B * H * W;
+    return ((npix + cca::SM_WAVES - 1) / cca::SM_WAVES) * sizeof(float);
+}
+
+int ccnet_ca_softmax_backward_f32(const float *A, const float *dA, const float *gamma, float *dE, float *dgamma,
+                                  void *workspace, size_t workspace_bytes, int B, int H, int W,
+                                  ccnet_stream_t stream) {
+    if (int e = check_shape(B, 1, H, W)) return e;
+    if (!A || !dA || !dE) return fail(CCNET_E_NULLPTR, "softmax_backward: null tensor");
+    const int npix = B * H * W, S = H + W;
+    const int nblocks = (npix + cca::SM_WAVES - 1) / cca::SM_WAVES;
+    float *partials = nullptr;
+    if (dgamma) {
+        if (!workspace || workspace_bytes < (size_t)nblocks * sizeof(float))
+            return fail(CCNET_E_WORKSPACE, "softmax_backward: workspace missing or too small");
+        partials = static_cast<float *>(workspace);
+    }
+    const dim3 grid(nblocks), block(cca::SM_BLOCK);
+    if (S <= 256)      CCA_LAUNCH((cca::softmax_bwd_kernel<4>), grid, block, stream, A, dA, gamma, dE, partials, npix, S);
+    else if (S <= 512) CCA_LAUNCH((cca::softmax_bwd_kernel<8>), grid, block, stream, A, dA, gamma, dE, partials, npix, S);
+    else               CCA_LAUNCH(cca::softmax_bwd_generic_kernel, grid, block, stream, A, dA, gamma, dE, partials, npix, S);
+    if (int e = launch_status("softmax_bwd")) return e;
+    if (dgamma) {
+        CCA_LAUNCH(cca::reduce_partials_kernel, dim3(1), block, stream, (const float *)partials, nblocks, dgamma);
+        return launch_status("reduce_partials");
+    }
+    return 0;
+}
+
+int ccnet_ca_map_forward_f32(const float *A, const float *v, const float *x, const float *gamma, float *out,
+                             int B, int C, int H, int W, ccnet_stream_t stream) {
+    if (int e = check_shape(B, C, H, W)) return e;
+    if (!A || !v || !out) return fail(CCNET_E_NULLPTR, "ca_map_forward: null tensor");
+    const int impl = pick_impl(H, W);
+    if (impl < 0) return impl;
+    if (impl == 1) return launch_map_pair<false>(A, v, x, gamma, out, B, C, H, W, stream, "ca_map_forward");
+    const size_t total = (size_t)B * C * H * W;
+    CCA_LAUNCH(cca::direct_map_kernel, dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
+               A, v, x, gamma, out, C, H, W, total);
+    return launch_status("ca_map_forward(direct)");
+}
+
+int ccnet_ca_map_backward_f32(const float *dout, const float *A, const float *v, const float *gamma,
+                              float *dA, float *dv, int B, int C, int H, int W, ccnet_stream_t stream) {
+    if (int e = check_shape(B, C, H, W)) return e;
+    if (!dout || !A || !v) return fail(CCNET_E_NULLPTR, "ca_map_backward: null tensor");
+    const int impl = pick_impl(H, W);
+    if (impl < 0) return impl;
+    if (dA) {
+        if (impl == 1) {
+            if (int e = launch_weight_pair<false>(dout, v, dA, B, C, H, W, stream, "ca_map_backward(dA)")) return e;
+        } else {
+            const size_t total = (size_t)B * H * W * (H + W);
+            CCA_LAUNCH((cca::direct_weight_kernel<false>), dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
+                       dout, v, dA, C, H, W, total);
+            if (int e = launch_status("ca_map_backward(dA,direct)")) return e;
+        }
+    }
+    if (dv) {
+        if (impl == 1) return launch_map_pair<true>(A, dout, nullptr, gamma, dv, B, C, H, W, stream, "ca_map_backward(dv)");
+        const size_t total = (size_t)B * C * H * W;
+        CCA_LAUNCH(cca::direct_mapT_kernel, dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
+                   A, dout, gamma, dv, C, H, W, total);
+        return launch_status("ca_map_backward(dv,direct)");
+    }
+    return 0;
+}
+
+int ccnet_cca_forward_f32(const float *q, const float *k, const float *v, const float *x, const float *gamma,
+                          float *y, float *A, int B, int C, int Cq, int H, int W, ccnet_stream_t stream) {
+    if (!q || !k || !v || !x || !gamma || !y || !A) return fail(CCNET_E_NULLPTR, "cca_forward: null tensor");
+    if (int e = ccnet_ca_forward_f32(q, k, A, B, Cq, H, W, CCNET_CA_SOFTMAX, stream)) return e;
+    return ccnet_ca_map_forward_f32(A, v, x, gamma, y, B, C, H, W, stream);
+}
+
+int ccnet_cca_backward_f32(const float *dy, const float *q, const float *k, const float *v, const float *A,
+                           const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
+                           void *workspace, size_t workspace_bytes, int B, int C, int Cq, int H, int W,
+                           ccnet_stream_t stream) {
+    if (!dy || !q || !k || !v || !A || !gamma || !dq || !dk || !dv || !dgamma || !scratch)
+        return fail(CCNET_E_NULLPTR, "cca_backward: null tensor");
+    // t = un-scaled dA into scratch, dv = gamma * (A^T-weighted sums of dy)
+    if (int e = ccnet_ca_map_backward_f32(dy, A, v, gamma, scratch, dv, B, C, H, W, stream)) return e;
+    // dgamma = sum A*t ; dE = gamma * A * (t - sum_s A t), in place
+    if (int e = ccnet_ca_softmax_backward_f32(A, scratch, gamma, scratch, dgamma, workspace, workspace_bytes,
+                                              B, H, W, stream)) return e;
+    return ccnet_ca_backward_f32(scratch, q, k, dq, dk, B, Cq, H, W, stream);
+}
+
+int ccnet_cca_mfma_selftest(float *scratch, ccnet_stream_t stream) {
+    if (!scratch) return fail(CCNET_E_NULLPTR, "mfma_selftest: null scratch");
+    CCA_LAUNCH(cca::mfma_selftest_kernel, dim3(1), dim3(cca::kWave), stream, scratch);
+    if (int e = launch_status("mfma_selftest")) return e;
+    float bad = -1.f;
+    if (hipMemcpyAsync(&bad, scratch, sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+        return fail(1, "mfma_selftest: copy-back failed");
+    if (bad != 0.f) return fail(1000 + (int)bad, "mfma_selftest: fragment layout mismatch");
+    return 0;
+}
+
+}  // extern "C"

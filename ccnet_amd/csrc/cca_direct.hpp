@@ -1,0 +1,103 @@
+// cca_direct.hpp -- one-thread-per-output kernels for ANY (B, C, H, W).
+//
+// They implement the same six contractions as the strip kernels (cca_weight.hpp / cca_map.hpp)
+// straight from the index definitions of /root/reference/cc_attention/functions.py:38-47 and its
+// autograd.  They serve shapes the strip kernels do not cover (a strip longer than 100) and are the
+// on-device cross-check of the MFMA path (tests/test_gpu_parity.py runs both).  Threads are laid out
+// with w fastest so feature reads coalesce; accumulation is a plain fmaf chain in slot order.
+#pragma once
+#include "cca_common.hpp"
+
+namespace cca {
+
+constexpr int D_BLOCK = 256;
+
+// T[b,h,w,s] = sum_c X[b,c,h,w] * Y[b,c,src(s)];   column self slot -> -inf when MASK
+template <bool MASK>
+__global__ __launch_bounds__(D_BLOCK) void direct_weight_kernel(const float *X, const float *Y, float *T,
+                                                                int Cx, int H, int W, size_t total) {
+    const int S = H + W, HW = H * W;
+    for (size_t idx = (size_t)blockIdx.x * D_BLOCK + threadIdx.x; idx < total; idx += (size_t)gridDim.x * D_BLOCK) {
+        // idx enumerates (b, h, s, w) with w fastest so that a wave reads contiguous w
+        const int w = int(idx % W);
+        size_t rest = idx / W;
+        const int s = int(rest % S);
+        rest /= S;
+        const int h = int(rest % H);
+        const int b = int(rest / H);
+        const int sh = (s < H) ? s : h, sw = (s < H) ? w : s - H;
+        const float *xp = X + (size_t)b * Cx * HW + (size_t)h * W + w;
+        const float *yp = Y + (size_t)b * Cx * HW + (size_t)sh * W + sw;
+        float acc = 0.f;
+        for (int c = 0; c < Cx; ++c) acc = fmaf(xp[(size_t)c * HW], yp[(size_t)c * HW], acc);
+        if (MASK && s == h) acc = -INFINITY;
+        T[(((size_t)b * H + h) * W + w) * S + s] = acc;
+    }
+}
+
+// out[b,c,h,w] = alpha * sum_s T[b,h,w,s] * F[b,c,src(s)] + resid
+__global__ __launch_bounds__(D_BLOCK) void direct_map_kernel(const float *T, const float *F, const float *resid,
+                                                             const float *gamma, float *out,
+                                                             int C, int H, int W, size_t total) {
+    const int S = H + W, HW = H * W;
+    const float alpha = gamma ? gamma[0] : 1.f;
+    for (size_t idx = (size_t)blockIdx.x * D_BLOCK + threadIdx.x; idx < total; idx += (size_t)gridDim.x * D_BLOCK) {
+        const int w = int(idx % W);
+        size_t rest = idx / W;
+        const int h = int(rest % H);
+        rest /= H;
+        const int c = int(rest % C);
+        const int b = int(rest / C);
+        const float *t = T + (((size_t)b * H + h) * W + w) * S;
+        const float *f = F + ((size_t)b * C + c) * HW;
+        float acc = 0.f;
+        for (int j = 0; j < H; ++j) acc = fmaf(t[j], f[(size_t)j * W + w], acc);
+        for (int j = 0; j < W; ++j) acc = fmaf(t[H + j], f[(size_t)h * W + j], acc);
+        float val = alpha * acc;
+        if (resid) val += resid[idx];
+        out[idx] = val;
+    }
+}
+
+// out[b,c,j,w] = alpha * ( sum_h T[b,h,w,j] * F[b,c,h,w]  +  sum_w' T[b,j,w',H+w] * F[b,c,j,w'] )
+__global__ __launch_bounds__(D_BLOCK) void direct_mapT_kernel(const float *T, const float *F, const float *gamma,
+                                                              float *out, int C, int H, int W, size_t total) {
+    const int S = H + W, HW = H * W;
+    const float alpha = gamma ? gamma[0] : 1.f;
+    for (size_t idx = (size_t)blockIdx.x * D_BLOCK + threadIdx.x; idx < total; idx += (size_t)gridDim.x * D_BLOCK) {
+        const int w = int(idx % W);
+        size_t rest = idx / W;
+        const int j = int(rest % H);
+        rest /= H;
+        const int c = int(rest % C);
+        const int b = int(rest / C);
+        const float *tb = T + (size_t)b * HW * S;
+        const float *f = F + ((size_t)b * C + c) * HW;
+        float acc = 0.f;
+        for (int h = 0; h < H; ++h) acc = fmaf(tb[((size_t)h * W + w) * S + j], f[(size_t)h * W + w], acc);
+        for (int w2 = 0; w2 < W; ++w2) acc = fmaf(tb[((size_t)j * W + w2) * S + H + w], f[(size_t)j * W + w2], acc);
+        out[idx] = alpha * acc;
+    }
+}
+
+// Device self-test of the v_mfma_f32_16x16x4_f32 fragment layout assumed by cca_common.hpp.
+// Asymmetric, exactly representable operands; result[0] = number of mismatching accumulator entries.
+__global__ __launch_bounds__(kWave) void mfma_selftest_kernel(float *result) {
+    const int l = lane_id();
+    // A[i][k] = 1 + i/4 + 3k ; B[k][j] = 1/2 + 7k - j/8
+    const float a = 1.f + 0.25f * (l & 15) + 3.f * (l >> 4);
+    const float b = 0.5f + 7.f * (l >> 4) - 0.125f * (l & 15);
+    f32x4 d = mfma_16x16x4(a, b, f32x4{0.f, 0.f, 0.f, 0.f});
+    float bad = 0.f;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (l >> 4) + r, col = l & 15;
+        float ref = 0.f;
+        for (int k = 0; k < 4; ++k)
+            ref = fmaf(1.f + 0.25f * row + 3.f * k, 0.5f + 7.f * k - 0.125f * col, ref);
+        if (d[r] != ref) bad += 1.f;
+    }
+    bad = wave_sum(bad);
+    if (l == 0) result[0] = bad;
+}
+
+}  // namespace cca

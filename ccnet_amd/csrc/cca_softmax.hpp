@@ -1,0 +1,149 @@
+// cca_softmax.hpp -- the (H+W)-wide masked softmax over attention slots and its adjoint.
+//
+// forward   A = softmax_s(E)                       /root/reference/cc_attention/functions.py:40
+//           (the column self slot holds -inf -> exp() == 0 exactly, the reference's structural zero)
+// backward  dE = g * A * (dA - sum_s A dA),  dgamma = sum_pixels sum_s A dA
+//
+// One wavefront per pixel: the S = H+W slots of a pixel are contiguous (776 B at 97x97), each lane
+// keeps ceil(S/64) of them in registers, max / sum are wave-64 butterfly reductions (no LDS, no atomics;
+// the dgamma partials are combined in a fixed order so the result is run-to-run deterministic).
+#pragma once
+#include "cca_common.hpp"
+
+namespace cca {
+
+constexpr int SM_WAVES = 4;                       // pixels per workgroup
+constexpr int SM_BLOCK = SM_WAVES * kWave;
+
+template <int NREG>                               // S <= 64 * NREG
+__global__ __launch_bounds__(SM_BLOCK) void softmax_fwd_kernel(const float *E, float *A, int npix, int S) {
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const int pix = blockIdx.x * SM_WAVES + wv;
+    if (pix >= npix) return;                      // wave-uniform
+    const float *e = E + (size_t)pix * S;
+    float *a = A + (size_t)pix * S;
+    float v[NREG];
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+        const int s = lane + r * kWave;
+        v[r] = (s < S) ? e[s] : -INFINITY;
+        m = fmaxf(m, v[r]);
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+        v[r] = expf(v[r] - m);
+        sum += v[r];
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+        const int s = lane + r * kWave;
+        if (s < S) a[s] = v[r] * inv;
+    }
+}
+
+// any S: three passes over the pixel's slots (they stay in L1/L2)
+__global__ __launch_bounds__(SM_BLOCK) void softmax_fwd_generic_kernel(const float *E, float *A, int npix, int S) {
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const int pix = blockIdx.x * SM_WAVES + wv;
+    if (pix >= npix) return;
+    const float *e = E + (size_t)pix * S;
+    float *a = A + (size_t)pix * S;
+    float m = -INFINITY;
+    for (int s = lane; s < S; s += kWave) m = fmaxf(m, e[s]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int s = lane; s < S; s += kWave) sum += expf(e[s] - m);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int s = lane; s < S; s += kWave) a[s] = expf(e[s] - m) * inv;
+}
+
+template <int NREG>
+__global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_kernel(const float *A, const float *dA,
+                                                               const float *gamma, float *dE,
+                                                               float *partials, int npix, int S) {
+    __shared__ float red[SM_WAVES];
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const int pix = blockIdx.x * SM_WAVES + wv;
+    const bool active = pix < npix;
+    const float g = gamma ? gamma[0] : 1.f;
+    float rsum = 0.f;
+    if (active) {
+        const float *a = A + (size_t)pix * S;
+        const float *d = dA + (size_t)pix * S;
+        float *o = dE + (size_t)pix * S;
+        float av[NREG], dv[NREG];
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+            const int s = lane + r * kWave;
+            av[r] = (s < S) ? a[s] : 0.f;
+            dv[r] = (s < S) ? d[s] : 0.f;
+            rsum += av[r] * dv[r];
+        }
+        rsum = wave_sum(rsum);
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+            const int s = lane + r * kWave;
+            if (s < S) o[s] = g * av[r] * (dv[r] - rsum);
+        }
+    }
+    if (partials) {
+        if (lane == 0) red[wv] = active ? rsum : 0.f;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < SM_WAVES; ++i) t += red[i];
+            partials[blockIdx.x] = t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_generic_kernel(const float *A, const float *dA,
+                                                                       const float *gamma, float *dE,
+                                                                       float *partials, int npix, int S) {
+    __shared__ float red[SM_WAVES];
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const int pix = blockIdx.x * SM_WAVES + wv;
+    const bool active = pix < npix;
+    const float g = gamma ? gamma[0] : 1.f;
+    float rsum = 0.f;
+    if (active) {
+        const float *a = A + (size_t)pix * S;
+        const float *d = dA + (size_t)pix * S;
+        float *o = dE + (size_t)pix * S;
+        for (int s = lane; s < S; s += kWave) rsum += a[s] * d[s];
+        rsum = wave_sum(rsum);
+        for (int s = lane; s < S; s += kWave) o[s] = g * a[s] * (d[s] - rsum);
+    }
+    if (partials) {
+        if (lane == 0) red[wv] = active ? rsum : 0.f;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int i = 0; i < SM_WAVES; ++i) t += red[i];
+            partials[blockIdx.x] = t;
+        }
+    }
+}
+
+// fixed-order reduction of the per-workgroup partial sums -> out[0]  (single workgroup)
+__global__ __launch_bounds__(SM_BLOCK) void reduce_partials_kernel(const float *partials, int n, float *out) {
+    __shared__ float red[SM_BLOCK];
+    float t = 0.f;
+    for (int i = threadIdx.x; i < n; i += SM_BLOCK) t += partials[i];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int s = SM_BLOCK / 2; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+}  // namespace cca

@@ -1,0 +1,274 @@
+"""Host-side mirror of the reference's ``cc_attention/functions.py`` for MI355X.
+
+Same public surface as /root/reference/cc_attention/functions.py:
+
+    INF(B, H, W)                          functions.py:11-12  (kept for attribute parity; device-agnostic)
+    CrissCrossAttention(in_dim)           functions.py:15-49  same ctor, same parameter / submodule names
+                                          (query_conv, key_conv, value_conv, gamma, softmax, INF), same
+                                          forward(x) -> tensor of x's shape
+
+plus the autograd surface the reference's CUDA-extension branches expose and BASELINE.json's
+north_star names (``ca_forward/ca_backward`` behind ``CA_Weight``, ``ca_map_forward/ca_map_backward``
+behind ``CA_Map``) and the fused ``CrissCrossFunction`` the module uses.  The three 1x1 convolutions
+(functions.py:29,32,35) stay torch ops (dense GEMMs -> MIOpen/hipBLASLt); everything between them and
+the output -- the layout shuffles, both bmm pairs, INF, cat, softmax and the gamma/residual epilogue
+(functions.py:30-49) -- runs in the hand-written HIP kernels of ``csrc/`` through the C ABI of
+``include/ccnet_cca.h``.
+
+There is no CPU / pure-PyTorch fallback: CPU tensors, non-fp32 tensors or a missing
+``libccnet_cca.so`` raise.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from torch.autograd.function import once_differentiable
+from torch.nn import Softmax
+
+from . import _lib
+from ._lib import CCNET_CA_ENERGY, CCNET_CA_SOFTMAX
+
+__all__ = ["INF", "CA_Weight", "CA_Map", "CrissCrossFunction", "ca_weight", "ca_map", "ca_softmax",
+           "criss_cross_attention", "CrissCrossAttention"]
+
+
+def INF(B, H, W, device=None):
+    """Same values as the reference's ``INF`` (functions.py:11-12) without the hard-coded ``.cuda()``.
+
+    The kernels never materialise this (B*W, H, H) tensor -- the mask is the predicate ``j == h`` --
+    it exists so that code poking at ``module.INF`` keeps working.
+    """
+    return -torch.diag(torch.tensor(float("inf"), device=device).repeat(H), 0).unsqueeze(0).repeat(B * W, 1, 1)
+
+
+# ----------------------------------------------------------------------------------------------
+# argument plumbing
+# ----------------------------------------------------------------------------------------------
+def _dev_f32(name: str, t: torch.Tensor) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name}: tensor is on '{t.device}'. ccnet_amd's criss-cross attention runs only as HIP kernels on "
+            "an AMD GPU (gfx950); there is no CPU fallback.")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _same_device(*ts):
+    dev = ts[0].device
+    for t in ts[1:]:
+        if t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check_qk(q, k):
+    if q.dim() != 4 or q.shape != k.shape:
+        raise RuntimeError(f"query/key must both be (B, C/8, H, W); got {tuple(q.shape)} and {tuple(k.shape)}")
+
+
+def _check_attn(A, v):
+    B, C, H, W = v.shape
+    if A.dim() != 4 or tuple(A.shape) != (B, H, W, H + W):
+        raise RuntimeError(f"attention must be (B, H, W, H+W) = {(B, H, W, H + W)}; got {tuple(A.shape)}")
+
+
+# ----------------------------------------------------------------------------------------------
+# CA_Weight: affinity  (ca_forward / ca_backward)
+# ----------------------------------------------------------------------------------------------
+class CA_Weight(torch.autograd.Function):
+    """energy = CA_Weight.apply(query, key): (B,C/8,H,W) x2 -> (B,H,W,H+W), column self slot = -inf.
+
+    Replaces functions.py:30-34,38-40 up to (not including) the softmax.
+    """
+
+    @staticmethod
+    def forward(ctx, t, f):
+        q, k = _dev_f32("query", t), _dev_f32("key", f)
+        _check_qk(q, k)
+        _same_device(q, k)
+        B, Cq, H, W = q.shape
+        lib = _lib.get_lib()
+        out = torch.empty((B, H, W, H + W), device=q.device, dtype=torch.float32)
+        with torch.cuda.device(q.device):
+            lib.check(lib.ccnet_ca_forward_f32(q.data_ptr(), k.data_ptr(), out.data_ptr(), B, Cq, H, W,
+                                               CCNET_CA_ENERGY, _stream()), "ca_forward")
+        ctx.save_for_backward(q, k)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dw):
+        q, k = ctx.saved_tensors
+        dw = _dev_f32("grad_energy", dw)
+        B, Cq, H, W = q.shape
+        lib = _lib.get_lib()
+        dq, dk = torch.empty_like(q), torch.empty_like(k)
+        with torch.cuda.device(q.device):
+            lib.check(lib.ccnet_ca_backward_f32(dw.data_ptr(), q.data_ptr(), k.data_ptr(), dq.data_ptr(),
+                                                dk.data_ptr(), B, Cq, H, W, _stream()), "ca_backward")
+        return dq, dk
+
+
+# ----------------------------------------------------------------------------------------------
+# CA_Map: aggregation  (ca_map_forward / ca_map_backward)
+# ----------------------------------------------------------------------------------------------
+class CA_Map(torch.autograd.Function):
+    """out = CA_Map.apply(attention, value): (B,H,W,H+W), (B,C,H,W) -> (B,C,H,W) = out_H + out_W.
+
+    Replaces functions.py:36-37,42,45-47.
+    """
+
+    @staticmethod
+    def forward(ctx, weight, g):
+        A, v = _dev_f32("attention", weight), _dev_f32("value", g)
+        _check_attn(A, v)
+        _same_device(A, v)
+        B, C, H, W = v.shape
+        lib = _lib.get_lib()
+        out = torch.empty_like(v)
+        with torch.cuda.device(v.device):
+            lib.check(lib.ccnet_ca_map_forward_f32(A.data_ptr(), v.data_ptr(), None, None, out.data_ptr(),
+                                                   B, C, H, W, _stream()), "ca_map_forward")
+        ctx.save_for_backward(A, v)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        A, v = ctx.saved_tensors
+        dout = _dev_f32("grad_out", dout)
+        B, C, H, W = v.shape
+        lib = _lib.get_lib()
+        dA, dv = torch.empty_like(A), torch.empty_like(v)
+        with torch.cuda.device(v.device):
+            lib.check(lib.ccnet_ca_map_backward_f32(dout.data_ptr(), A.data_ptr(), v.data_ptr(), None,
+                                                    dA.data_ptr(), dv.data_ptr(), B, C, H, W, _stream()),
+                      "ca_map_backward")
+        return dA, dv
+
+
+class _CA_Softmax(torch.autograd.Function):
+    """softmax over the H+W slots (functions.py:40) on the HIP kernels, differentiable."""
+
+    @staticmethod
+    def forward(ctx, energy):
+        e = _dev_f32("energy", energy)
+        B, H, W, S = e.shape
+        if S != H + W:
+            raise RuntimeError(f"energy must be (B, H, W, H+W); got {tuple(e.shape)}")
+        lib = _lib.get_lib()
+        A = torch.empty_like(e)
+        with torch.cuda.device(e.device):
+            lib.check(lib.ccnet_ca_softmax_forward_f32(e.data_ptr(), A.data_ptr(), B, H, W, _stream()), "ca_softmax")
+        ctx.save_for_backward(A)
+        return A
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dA):
+        (A,) = ctx.saved_tensors
+        dA = _dev_f32("grad_attention", dA)
+        B, H, W, _ = A.shape
+        lib = _lib.get_lib()
+        dE = torch.empty_like(A)
+        with torch.cuda.device(A.device):
+            lib.check(lib.ccnet_ca_softmax_backward_f32(A.data_ptr(), dA.data_ptr(), None, dE.data_ptr(), None,
+                                                        None, 0, B, H, W, _stream()), "ca_softmax_backward")
+        return dE
+
+
+ca_weight = CA_Weight.apply
+ca_map = CA_Map.apply
+ca_softmax = _CA_Softmax.apply
+
+
+# ----------------------------------------------------------------------------------------------
+# fused core used by the module
+# ----------------------------------------------------------------------------------------------
+class CrissCrossFunction(torch.autograd.Function):
+    """y = gamma * (out_H + out_W) + x from (q, k, v, x, gamma)  -- functions.py:38-49 in two launches
+    families forward (affinity+softmax, aggregation+epilogue) and three backward."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, x, gamma):
+        q, k = _dev_f32("query", q), _dev_f32("key", k)
+        v, x = _dev_f32("value", v), _dev_f32("x", x)
+        gamma = _dev_f32("gamma", gamma)
+        _check_qk(q, k)
+        _same_device(q, k, v, x, gamma)
+        B, C, H, W = v.shape
+        if x.shape != v.shape or q.shape[0] != B or tuple(q.shape[2:]) != (H, W):
+            raise RuntimeError(f"shape mismatch: q {tuple(q.shape)}, v {tuple(v.shape)}, x {tuple(x.shape)}")
+        if gamma.numel() != 1:
+            raise RuntimeError("gamma must hold exactly one element")
+        lib = _lib.get_lib()
+        y = torch.empty_like(x)
+        A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            lib.check(lib.ccnet_cca_forward_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), x.data_ptr(),
+                                                gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
+                                                B, C, q.shape[1], H, W, _stream()), "cca_forward")
+        ctx.save_for_backward(q, k, v, A, gamma)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        q, k, v, A, gamma = ctx.saved_tensors
+        dy = _dev_f32("grad_output", dy)
+        B, C, H, W = v.shape
+        lib = _lib.get_lib()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dgamma = torch.empty_like(gamma)
+        scratch = torch.empty_like(A)
+        nbytes = lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
+        ws = torch.empty((nbytes + 3) // 4, device=v.device, dtype=torch.float32)
+        with torch.cuda.device(v.device):
+            lib.check(lib.ccnet_cca_backward_f32(dy.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                                 A.data_ptr(), gamma.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                                 dv.data_ptr(), dgamma.data_ptr(), scratch.data_ptr(),
+                                                 ws.data_ptr(), nbytes, B, C, q.shape[1], H, W, _stream()),
+                      "cca_backward")
+        return dq, dk, dv, dy, dgamma.view_as(gamma)
+
+
+def criss_cross_attention(q, k, v, x, gamma):
+    """Functional form of the fused core."""
+    return CrissCrossFunction.apply(q, k, v, x, gamma)
+
+
+# ----------------------------------------------------------------------------------------------
+# the module (drop-in for networks/ccnet.py:13,105)
+# ----------------------------------------------------------------------------------------------
+class CrissCrossAttention(nn.Module):
+    """Criss-Cross Attention Module -- same constructor, attributes, parameter names and forward
+    contract as the reference (functions.py:15-49), so reference checkpoints load unchanged."""
+
+    def __init__(self, in_dim):
+        super(CrissCrossAttention, self).__init__()
+        self.query_conv = nn.Conv2d(in_channels=in_dim, out_channels=in_dim // 8, kernel_size=1)
+        self.key_conv = nn.Conv2d(in_channels=in_dim, out_channels=in_dim // 8, kernel_size=1)
+        self.value_conv = nn.Conv2d(in_channels=in_dim, out_channels=in_dim, kernel_size=1)
+        self.softmax = Softmax(dim=3)      # attribute parity only; the softmax runs inside the HIP path
+        self.INF = INF
+        self.gamma = nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError(
+                "CrissCrossAttention (ccnet_amd): input is on the CPU. This module runs its attention core as HIP "
+                "kernels on an AMD GPU and has no CPU fallback; move the module and its input to the device.")
+        proj_query = self.query_conv(x)
+        proj_key = self.key_conv(x)
+        proj_value = self.value_conv(x)
+        if x.dtype != torch.float32:       # autocast / half inputs: the kernels compute in fp32
+            out = CrissCrossFunction.apply(proj_query.float(), proj_key.float(), proj_value.float(),
+                                           x.float(), self.gamma.float())
+            return out.to(x.dtype)
+        return CrissCrossFunction.apply(proj_query, proj_key, proj_value, x, self.gamma)

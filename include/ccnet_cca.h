@@ -1,0 +1,126 @@
+/*
+ * ccnet_cca.h -- C ABI of the MI355X-native criss-cross attention library (libccnet_cca.so).
+ *
+ * This is the drop-in boundary for CCNet's hot path.  The mounted reference is the pure-python
+ * branch, so there is no FFI in the tree to bind; each entry point below replaces a chain of
+ * torch ops in /root/reference/cc_attention/functions.py (cited per function) and carries the
+ * name the reference's CUDA-extension branches use for the same quantity (ca_forward /
+ * ca_backward / ca_map_forward / ca_map_backward, BASELINE.json north_star).  The reference-side
+ * binding a maintainer would add (a ctypes stub in cc_attention/functions.py) is in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (PyTorch's caching allocator in the Python host).  The library never allocates or frees.
+ *   - feature maps are NCHW-contiguous fp32:  q,k (B,Cq,H,W);  v,x,y and their grads (B,C,H,W).
+ *   - attention-shaped tensors (energy, A, dA, dE) are (B,H,W,H+W) contiguous, slot-fastest, in
+ *     the reference's ``concate`` order (functions.py:40): slots [0,H) are the column branch
+ *     (key/value at (j,w); slot j==h is the masked self slot), slots [H,H+W) the row branch
+ *     (key/value at (h,j)).
+ *   - outputs are fully overwritten; nothing relies on pre-zeroed buffers.
+ *   - launches go to ``stream`` (a hipStream_t; NULL = the legacy default stream); no call
+ *     synchronises.  All entry points are re-entrant and keep no state between calls.
+ *   - return value: 0 on success; a positive hipError_t if a launch failed; a negative
+ *     CCNET_E_* code for argument errors.  ccnet_cca_last_error_string() describes the last
+ *     failure on the calling thread.
+ *   - ``gamma`` is always a DEVICE pointer to one float (the module's nn.Parameter), so no
+ *     host synchronisation is needed to read it.
+ */
+#ifndef CCNET_CCA_H
+#define CCNET_CCA_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCNET_CCA_VERSION 100          /* 0.1.0 */
+
+#define CCNET_E_BADSHAPE   (-1)        /* non-positive dimension, or a size the kernels cannot index */
+#define CCNET_E_NULLPTR    (-2)        /* a required pointer is NULL */
+#define CCNET_E_BADFLAGS   (-3)
+#define CCNET_E_WORKSPACE  (-4)        /* workspace missing or too small */
+
+/* ccnet_ca_forward flags */
+#define CCNET_CA_ENERGY    0           /* write raw energies, masked slot = -inf (functions.py:38-40, pre-softmax) */
+#define CCNET_CA_SOFTMAX   1           /* write A = softmax over the H+W slots (functions.py:40) */
+
+/* kernel family selection (debug / A-B testing; default AUTO picks MFMA when the shape fits) */
+#define CCNET_IMPL_AUTO    0
+#define CCNET_IMPL_DIRECT  1           /* one-thread-per-output kernels, any shape */
+#define CCNET_IMPL_MFMA    2           /* LDS-staged f32-MFMA strip kernels (max(H,W) <= 100) */
+
+/* profiling aid: restrict the strip-kernel launches of every entry point to one branch so a single
+ * kernel can be timed in isolation (results are then partial).  Default CCNET_BRANCH_BOTH. */
+#define CCNET_BRANCH_COL   1
+#define CCNET_BRANCH_ROW   2
+#define CCNET_BRANCH_BOTH  3
+
+typedef void *ccnet_stream_t;          /* hipStream_t */
+
+int         ccnet_cca_version(void);
+const char *ccnet_cca_arch(void);                  /* "gfx950" */
+const char *ccnet_cca_last_error_string(void);
+int         ccnet_cca_set_impl(int impl);          /* returns the previous setting */
+int         ccnet_cca_get_impl(void);
+int         ccnet_cca_set_branch_mask(int mask);   /* returns the previous mask */
+
+/* Affinity: replaces functions.py:30-34 (layout shuffles), :38 (bmm + INF), :39 (bmm), :40 (cat
+ * [+ Softmax when CCNET_CA_SOFTMAX]).  out (B,H,W,H+W). */
+int ccnet_ca_forward_f32(const float *q, const float *k, float *out,
+                         int B, int Cq, int H, int W, int flags, ccnet_stream_t stream);
+
+/* Adjoint of the affinity (autograd of functions.py:38-39): dE (B,H,W,H+W) -> dq, dk (B,Cq,H,W).
+ * dE at the masked column self slot must be 0 (it is for every softmax-derived gradient, A == 0 there). */
+int ccnet_ca_backward_f32(const float *dE, const float *q, const float *k, float *dq, float *dk,
+                          int B, int Cq, int H, int W, ccnet_stream_t stream);
+
+/* Softmax over the H+W slots in isolation (functions.py:40), in place allowed (out == energy). */
+int ccnet_ca_softmax_forward_f32(const float *energy, float *out,
+                                 int B, int H, int W, ccnet_stream_t stream);
+
+/* Adjoint of the softmax: dE = g * A * (dA - sum_s A dA) with g = *gamma (1 if gamma == NULL);
+ * if dgamma != NULL also writes dgamma[0] = sum A*dA (= sum dy*(out_H+out_W), the gradient of
+ * functions.py:49's gamma when dA is the un-scaled map adjoint).  dE may alias dA.
+ * workspace: ccnet_ca_softmax_backward_workspace_bytes() bytes when dgamma != NULL. */
+size_t ccnet_ca_softmax_backward_workspace_bytes(int B, int H, int W);
+int ccnet_ca_softmax_backward_f32(const float *A, const float *dA, const float *gamma, float *dE,
+                                  float *dgamma, void *workspace, size_t workspace_bytes,
+                                  int B, int H, int W, ccnet_stream_t stream);
+
+/* Aggregation: replaces functions.py:36-37,42,45 (layout shuffles), :46-47 (bmm x2), :49 (epilogue).
+ * out = g * (out_H + out_W) + x, with g = *gamma (1 if NULL) and x optional (NULL -> no residual).
+ * With gamma == NULL and x == NULL this is the plain ca_map_forward of the extension API. */
+int ccnet_ca_map_forward_f32(const float *A, const float *v, const float *x, const float *gamma,
+                             float *out, int B, int C, int H, int W, ccnet_stream_t stream);
+
+/* Adjoint of the aggregation (autograd of functions.py:42-47):
+ *   dA (B,H,W,H+W) = un-scaled map adjoint  (sum_c dout * v at the slot's source pixel); may be NULL
+ *   dv (B,C,H,W)   = g * (A^T-weighted sums of dout), g = *gamma (1 if NULL); may be NULL */
+int ccnet_ca_map_backward_f32(const float *dout, const float *A, const float *v, const float *gamma,
+                              float *dA, float *dv, int B, int C, int H, int W, ccnet_stream_t stream);
+
+/* Fused core, forward: (q,k,v,x,gamma) -> y and the saved attention A  (functions.py:38-49). */
+int ccnet_cca_forward_f32(const float *q, const float *k, const float *v, const float *x,
+                          const float *gamma, float *y, float *A,
+                          int B, int C, int Cq, int H, int W, ccnet_stream_t stream);
+
+/* Fused core, backward: dy + saved (q,k,v,A,gamma) -> dq, dk, dv, dgamma (dx == dy is the caller's).
+ * ``scratch`` is an attention-shaped (B,H,W,H+W) fp32 buffer; ``workspace`` as for softmax_backward. */
+int ccnet_cca_backward_f32(const float *dy, const float *q, const float *k, const float *v,
+                           const float *A, const float *gamma, float *dq, float *dk, float *dv,
+                           float *dgamma, float *scratch, void *workspace, size_t workspace_bytes,
+                           int B, int C, int Cq, int H, int W, ccnet_stream_t stream);
+
+/* 1 if the MFMA strip kernels serve this shape under CCNET_IMPL_AUTO, else 0 (direct kernels). */
+int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W);
+
+/* Device self-test of the MFMA fragment layout the kernels assume (asymmetric operands).
+ * ``scratch`` >= 64 bytes of device memory.  The one entry point that synchronises ``stream`` (it copies
+ * the verdict back).  Returns 0 when the layout matches, 1000 + #mismatches otherwise. */
+int ccnet_cca_mfma_selftest(float *scratch, ccnet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCNET_CCA_H */

@@ -1,0 +1,129 @@
+"""Build and drive the CPU SIMT-emulator build of the kernel sources (tests/emu/).
+
+The emulator library exports the same C ABI as libccnet_cca.so (it is the same cca_api.hip compiled
+for the host with -DCCNET_EMU), so the tests drive it through ccnet_amd._lib.CcaLibrary with numpy
+buffers standing in for device memory.  Test infrastructure only.
+"""
+import os
+import subprocess
+
+import numpy as np
+
+from ccnet_amd._lib import CCNET_CA_ENERGY, CCNET_CA_SOFTMAX, CcaLibrary
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+CSRC = os.path.join(ROOT, "ccnet_amd", "csrc")
+EMU_LIB = os.path.join(EMU_DIR, "libcca_emu.so")
+HOST_CXX = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def _sources():
+    srcs = [os.path.join(EMU_DIR, f) for f in ("hip_emu.cpp", "hip_emu.hpp")]
+    srcs += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
+    srcs.append(os.path.join(ROOT, "include", "ccnet_cca.h"))
+    return srcs
+
+
+def build_emu(force=False):
+    cxx = HOST_CXX if os.path.exists(HOST_CXX) else "g++"
+    if not force and os.path.exists(EMU_LIB):
+        if os.path.getmtime(EMU_LIB) >= max(os.path.getmtime(s) for s in _sources()):
+            return EMU_LIB
+    cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DCCNET_EMU",
+           "-I" + EMU_DIR, "-I" + CSRC, os.path.join(CSRC, "cca_api.hip"),
+           os.path.join(EMU_DIR, "hip_emu.cpp"), "-o", EMU_LIB]
+    subprocess.run(cmd, check=True, cwd=ROOT)
+    return EMU_LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+class EmuOps:
+    """numpy front-end of the emulated C ABI; every method mirrors one entry point."""
+
+    def __init__(self):
+        self.lib = CcaLibrary(build_emu())
+
+    def set_impl(self, impl):
+        return self.lib.ccnet_cca_set_impl(impl)
+
+    def ca_forward(self, q, k, softmax=False):
+        B, Cq, H, W = q.shape
+        out = np.full((B, H, W, H + W), np.nan, np.float32)
+        self.lib.check(self.lib.ccnet_ca_forward_f32(_p(q), _p(k), _p(out), B, Cq, H, W,
+                                                     CCNET_CA_SOFTMAX if softmax else CCNET_CA_ENERGY, None))
+        return out
+
+    def ca_backward(self, dE, q, k):
+        B, Cq, H, W = q.shape
+        dq = np.full_like(q, np.nan)
+        dk = np.full_like(k, np.nan)
+        self.lib.check(self.lib.ccnet_ca_backward_f32(_p(dE), _p(q), _p(k), _p(dq), _p(dk), B, Cq, H, W, None))
+        return dq, dk
+
+    def softmax_forward(self, e):
+        B, H, W, S = e.shape
+        out = np.full_like(e, np.nan)
+        self.lib.check(self.lib.ccnet_ca_softmax_forward_f32(_p(e), _p(out), B, H, W, None))
+        return out
+
+    def softmax_backward(self, A, dA, gamma=None, want_dgamma=True):
+        B, H, W, S = A.shape
+        dE = np.full_like(A, np.nan)
+        dgamma = np.full(1, np.nan, np.float32) if want_dgamma else None
+        nbytes = self.lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
+        ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
+        self.lib.check(self.lib.ccnet_ca_softmax_backward_f32(_p(A), _p(dA), _p(gamma), _p(dE), _p(dgamma),
+                                                              _p(ws), nbytes, B, H, W, None))
+        return dE, dgamma
+
+    def ca_map_forward(self, A, v, x=None, gamma=None):
+        B, C, H, W = v.shape
+        out = np.full_like(v, np.nan)
+        self.lib.check(self.lib.ccnet_ca_map_forward_f32(_p(A), _p(v), _p(x), _p(gamma), _p(out), B, C, H, W, None))
+        return out
+
+    def ca_map_backward(self, dout, A, v, gamma=None):
+        B, C, H, W = v.shape
+        dA = np.full_like(A, np.nan)
+        dv = np.full_like(v, np.nan)
+        self.lib.check(self.lib.ccnet_ca_map_backward_f32(_p(dout), _p(A), _p(v), _p(gamma), _p(dA), _p(dv),
+                                                          B, C, H, W, None))
+        return dA, dv
+
+    def cca_forward(self, q, k, v, x, gamma):
+        B, C, H, W = v.shape
+        y = np.full_like(v, np.nan)
+        A = np.full((B, H, W, H + W), np.nan, np.float32)
+        self.lib.check(self.lib.ccnet_cca_forward_f32(_p(q), _p(k), _p(v), _p(x), _p(gamma), _p(y), _p(A),
+                                                      B, C, q.shape[1], H, W, None))
+        return y, A
+
+    def cca_backward(self, dy, q, k, v, A, gamma):
+        B, C, H, W = v.shape
+        dq, dk, dv = np.full_like(q, np.nan), np.full_like(k, np.nan), np.full_like(v, np.nan)
+        dgamma = np.full(1, np.nan, np.float32)
+        scratch = np.full_like(A, np.nan)
+        nbytes = self.lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
+        ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
+        self.lib.check(self.lib.ccnet_cca_backward_f32(_p(dy), _p(q), _p(k), _p(v), _p(A), _p(gamma), _p(dq), _p(dk),
+                                                       _p(dv), _p(dgamma), _p(scratch), _p(ws), nbytes,
+                                                       B, C, q.shape[1], H, W, None))
+        return dq, dk, dv, dgamma
+
+    def mfma_selftest(self):
+        scratch = np.zeros(16, np.float32)
+        return self.lib.ccnet_cca_mfma_selftest(_p(scratch), None)
+
+
+def emu_stats(ops, reset=False):
+    """(lds_read_instr, lds_read_cycles, lds_write_instr, lds_write_cycles, mfma lane-calls, launches)."""
+    import ctypes
+    buf = (ctypes.c_ulonglong * 6)()
+    ops.lib.dll.cca_emu_stats(buf)
+    if reset:
+        ops.lib.dll.cca_emu_reset_stats()
+    return tuple(buf)

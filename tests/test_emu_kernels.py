@@ -1,0 +1,236 @@
+"""CPU execution of the HIP kernel sources in the SIMT emulator (tests/emu/) against the oracle.
+
+The container has no GPU; these tests compile ccnet_amd/csrc/cca_api.hip for the host with -DCCNET_EMU
+and run every entry point of the C ABI on numpy buffers.  They validate index maps, LDS layouts, the
+MFMA fragment maps (as documented for v_mfma_f32_16x16x4_f32), barriers and epilogues before the code
+ever reaches the MI355X.  Parity on the device itself is tests/test_gpu_parity.py (-m gpu).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import SMALL_CASES, load_golden
+from emu_util import EmuOps, emu_stats
+from oracle import cca_oracle as O
+
+DIRECT, MFMA = 1, 2
+TOL = 2e-5
+
+SHAPES = [
+    (2, 16, 5, 6),      # the reference's own __main__ shape family, H != W, Cq = 2
+    (1, 32, 9, 7),
+    (1, 24, 17, 20),    # C not a multiple of 16 (partial MFMA M-tile), Cq = 3
+    (1, 8, 1, 1),       # single pixel: only the row self slot survives
+    (1, 16, 1, 9),      # single row
+    (1, 16, 9, 1),      # single column
+    (2, 40, 33, 18),    # partial strip tiles (33 = 2*16+1), 18 strips -> 3 workgroups, last one ragged
+]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    o = EmuOps()
+    yield o
+    o.set_impl(0)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def rand_case(B, C, H, W, seed=0):
+    rng = np.random.default_rng(seed)
+    Cq = max(C // 8, 1)
+    f = lambda *s: rng.standard_normal(s, dtype=np.float32)  # noqa: E731
+    return dict(q=f(B, Cq, H, W), k=f(B, Cq, H, W), v=f(B, C, H, W), x=f(B, C, H, W), dy=f(B, C, H, W),
+                gamma=np.array([0.5], np.float32))
+
+
+def maxerr(a, b):
+    return float(np.abs(a - np.asarray(b)).max())
+
+
+def test_mfma_fragment_layout_selftest(ops):
+    assert ops.mfma_selftest() == 0
+
+
+@pytest.mark.parametrize("impl", [DIRECT, MFMA])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_every_entry_point_matches_oracle(ops, impl, shape):
+    ops.set_impl(impl)
+    c = rand_case(*shape)
+    H = shape[2]
+    q, k, v, x, dy, gamma = (c[n] for n in ("q", "k", "v", "x", "dy", "gamma"))
+
+    # ca_forward: raw energies, -inf exactly on the column self slot
+    e = ops.ca_forward(q, k)
+    eo = O.ca_forward(T(q), T(k)).numpy()
+    assert np.array_equal(np.isneginf(e), np.isneginf(eo))
+    fin = np.isfinite(eo)
+    assert maxerr(e[fin], eo[fin]) < TOL
+    # softmax, standalone and fused into ca_forward
+    Ao = O.ca_softmax(T(eo)).numpy()
+    assert maxerr(ops.softmax_forward(e), Ao) < TOL
+    A = ops.ca_forward(q, k, softmax=True)
+    assert maxerr(A, Ao) < TOL
+    idx = np.arange(H)
+    assert np.all(A[:, idx, :, idx] == 0.0)                  # structural zero (functions.py:11-12)
+    assert np.allclose(A.sum(-1), 1.0, atol=1e-5)
+
+    # ca_map_forward plain and with the gamma / residual epilogue
+    oo = O.ca_map_forward(T(Ao), T(v)).numpy()
+    assert maxerr(ops.ca_map_forward(Ao, v), oo) < TOL
+    assert maxerr(ops.ca_map_forward(Ao, v, x, gamma), gamma * oo + x) < TOL
+
+    # ca_map_backward: un-scaled dA, gamma-scaled dv
+    dAo, dvo = O.ca_map_backward(T(dy), T(Ao), T(v))
+    dA, dv = ops.ca_map_backward(dy, Ao, v, gamma)
+    assert maxerr(dA, dAo.numpy()) < TOL * 4
+    assert maxerr(dv, 0.5 * dvo.numpy()) < TOL
+    dA1, dv1 = ops.ca_map_backward(dy, Ao, v, None)
+    assert maxerr(dv1, dvo.numpy()) < TOL
+
+    # softmax backward (+ dgamma)
+    dE, dg = ops.softmax_backward(Ao, dAo.numpy(), gamma)
+    dEo = O.ca_softmax_backward(T(Ao), 0.5 * dAo).numpy()
+    assert maxerr(dE, dEo) < TOL
+    assert dg[0] == pytest.approx(float((T(Ao) * dAo).sum()), rel=1e-4, abs=1e-4)
+
+    # ca_backward
+    dq, dk = ops.ca_backward(dEo, q, k)
+    dqo, dko = O.ca_backward(T(dEo), T(q), T(k))
+    assert maxerr(dq, dqo.numpy()) < TOL and maxerr(dk, dko.numpy()) < TOL
+
+    # fused core
+    y, A2 = ops.cca_forward(q, k, v, x, gamma)
+    yo, _ = O.cca_core_forward(T(q), T(k), T(v), T(x), T(gamma))
+    assert maxerr(y, yo.numpy()) < TOL and maxerr(A2, Ao) < TOL
+    g = O.cca_core_backward(T(dy), T(q), T(k), T(v), T(Ao), T(gamma))
+    dq, dk, dv, dg = ops.cca_backward(dy, q, k, v, A2, gamma)
+    assert maxerr(dq, g["dq"].numpy()) < TOL * 2 and maxerr(dk, g["dk"].numpy()) < TOL * 2
+    assert maxerr(dv, g["dv"].numpy()) < TOL
+    assert dg[0] == pytest.approx(float(g["dgamma"]), rel=1e-4, abs=1e-4)
+
+
+@pytest.mark.parametrize("impl", [DIRECT, MFMA])
+@pytest.mark.parametrize("case", SMALL_CASES)
+def test_golden_vectors_from_live_reference(ops, impl, case):
+    """Kernels vs the arrays the reference module itself produced (tests/golden/*.npz)."""
+    ops.set_impl(impl)
+    g = {k: v.numpy() for k, v in load_golden(case).items()}
+    gamma = g["param.gamma"]
+    y, A = ops.cca_forward(g["q"], g["k"], g["v"], g["x"], gamma)
+    assert maxerr(A, g["A"]) < TOL and maxerr(y, g["y"]) < TOL
+    dq, dk, dv, dg = ops.cca_backward(g["dy"], g["q"], g["k"], g["v"], g["A"], gamma)
+    assert maxerr(dq, g["dq"]) < TOL * 2 and maxerr(dk, g["dk"]) < TOL * 2 and maxerr(dv, g["dv"]) < TOL
+    assert dg[0] == pytest.approx(float(g["grad.gamma"][0]), rel=1e-4, abs=1e-4)
+    # un-fused API: CA_Map adjoint w.r.t. the attention equals what autograd put on the softmax output
+    dA, _ = ops.ca_map_backward(g["dy"], g["A"], g["v"], None)
+    assert maxerr(gamma * dA, g["dA"]) < TOL * 2
+
+
+def test_full_length_strips_97(ops):
+    """One image at the headline 97x97 geometry (all 7x7 tiles, 25 k-steps: the FULL code path)."""
+    ops.set_impl(MFMA)
+    c = rand_case(1, 16, 97, 97, seed=3)
+    y, A = ops.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
+    yo, Ao = O.cca_core_forward(*(T(c[n]) for n in ("q", "k", "v", "x", "gamma")))
+    assert maxerr(y, yo.numpy()) < TOL and maxerr(A, Ao.numpy()) < TOL
+    dq, dk, dv, dg = ops.cca_backward(c["dy"], c["q"], c["k"], c["v"], A, c["gamma"])
+    g = O.cca_core_backward(T(c["dy"]), T(c["q"]), T(c["k"]), T(c["v"]), Ao, T(c["gamma"]))
+    assert maxerr(dq, g["dq"].numpy()) < 1e-4 and maxerr(dk, g["dk"].numpy()) < 1e-4
+    assert maxerr(dv, g["dv"].numpy()) < TOL
+
+
+def test_rectangular_100_by_40(ops):
+    ops.set_impl(MFMA)
+    c = rand_case(1, 16, 100, 40, seed=4)     # column strips at the 100 limit, row strips partial
+    y, A = ops.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
+    yo, Ao = O.cca_core_forward(*(T(c[n]) for n in ("q", "k", "v", "x", "gamma")))
+    assert maxerr(y, yo.numpy()) < TOL
+    dq, dk, dv, _ = ops.cca_backward(c["dy"], c["q"], c["k"], c["v"], A, c["gamma"])
+    g = O.cca_core_backward(T(c["dy"]), T(c["q"]), T(c["k"]), T(c["v"]), Ao, T(c["gamma"]))
+    assert maxerr(dq, g["dq"].numpy()) < 1e-4 and maxerr(dk, g["dk"].numpy()) < 1e-4
+    assert maxerr(dv, g["dv"].numpy()) < TOL
+
+
+def test_auto_dispatch_falls_back_to_direct_kernels_beyond_100(ops):
+    ops.set_impl(0)
+    assert ops.lib.ccnet_cca_shape_uses_mfma(1, 8, 97, 97) == 1
+    assert ops.lib.ccnet_cca_shape_uses_mfma(1, 8, 101, 20) == 0
+    c = rand_case(1, 8, 101, 3, seed=5)
+    y, A = ops.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
+    yo, _ = O.cca_core_forward(*(T(c[n]) for n in ("q", "k", "v", "x", "gamma")))
+    assert maxerr(y, yo.numpy()) < TOL
+    ops.set_impl(MFMA)
+    e = np.empty((1, 101, 3, 104), np.float32)
+    rc = ops.lib.ccnet_ca_forward_f32(c["q"].ctypes.data, c["k"].ctypes.data, e.ctypes.data, 1, 1, 101, 3, 0, None)
+    assert rc == -1 and "100" in ops.lib.last_error()
+
+
+@pytest.mark.parametrize("impl", [DIRECT, MFMA])
+def test_gamma_zero_is_bit_exact_identity_and_kills_grads(ops, impl):
+    ops.set_impl(impl)
+    c = rand_case(1, 16, 12, 10, seed=6)
+    g0 = np.zeros(1, np.float32)
+    y, A = ops.cca_forward(c["q"], c["k"], c["v"], c["x"], g0)
+    assert np.array_equal(y, c["x"])
+    dq, dk, dv, dg = ops.cca_backward(c["dy"], c["q"], c["k"], c["v"], A, g0)
+    assert not dq.any() and not dk.any() and not dv.any()
+    assert abs(dg[0]) > 0
+
+
+@pytest.mark.parametrize("impl", [DIRECT, MFMA])
+def test_run_to_run_bit_identical(ops, impl):
+    ops.set_impl(impl)
+    c = rand_case(2, 16, 20, 11, seed=7)
+    r1 = ops.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
+    r2 = ops.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
+    assert all(np.array_equal(a, b) for a, b in zip(r1, r2))
+    b1 = ops.cca_backward(c["dy"], c["q"], c["k"], c["v"], r1[1], c["gamma"])
+    b2 = ops.cca_backward(c["dy"], c["q"], c["k"], c["v"], r1[1], c["gamma"])
+    assert all(np.array_equal(a, b) for a, b in zip(b1, b2))
+
+
+def test_peaky_softmax_and_large_logits(ops):
+    """|q.k| ~ 1e2: exp underflow on most slots must not produce NaN, winners must match."""
+    ops.set_impl(MFMA)
+    c = rand_case(1, 64, 9, 9, seed=8)
+    q, k = c["q"] * 6, c["k"] * 6
+    A = ops.ca_forward(q, k, softmax=True)
+    Ao = O.ca_softmax(O.ca_forward(T(q), T(k))).numpy()
+    assert np.isfinite(A).all() and maxerr(A, Ao) < 1e-4
+
+
+def test_argument_errors(ops):
+    ops.set_impl(0)
+    a = np.zeros(16, np.float32)
+    lib = ops.lib
+    assert lib.ccnet_ca_forward_f32(a.ctypes.data, a.ctypes.data, a.ctypes.data, 0, 1, 2, 2, 0, None) == -1
+    assert lib.ccnet_ca_forward_f32(None, a.ctypes.data, a.ctypes.data, 1, 1, 2, 2, 0, None) == -2
+    assert lib.ccnet_ca_forward_f32(a.ctypes.data, a.ctypes.data, a.ctypes.data, 1, 1, 2, 2, 7, None) == -3
+    assert lib.ccnet_ca_softmax_backward_f32(a.ctypes.data, a.ctypes.data, None, a.ctypes.data, a.ctypes.data,
+                                             None, 0, 1, 1, 2, None) == -4
+    assert "workspace" in lib.last_error()
+
+
+def test_lds_layouts_are_bank_conflict_free():
+    """The padding constants in cca_weight.hpp / cca_map.hpp: fragment reads conflict-free, stores <= 2-way
+    (a 2-way ds_write_b32 conflict is free on gfx950, MI355X_MICROARCH.md section LDS)."""
+    os.environ["CCA_EMU_LDS"] = "1"
+    try:
+        o = EmuOps()
+        o.set_impl(MFMA)
+        c = rand_case(1, 16, 97, 97, seed=9)
+        emu_stats(o, reset=True)
+        y, A = o.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
+        o.cca_backward(c["dy"], c["q"], c["k"], c["v"], A, c["gamma"])
+        rd_i, rd_c, wr_i, wr_c, mfma, launches = emu_stats(o, reset=True)
+        assert rd_i > 0 and wr_i > 0 and mfma > 0
+        assert rd_c == 2 * rd_i                      # one LDS cycle per 32-lane half: conflict-free
+        assert wr_c <= 2.5 * wr_i                    # mostly 1 cycle per half, never worse than 2-way on average
+        o.set_impl(0)
+    finally:
+        os.environ.pop("CCA_EMU_LDS", None)
