@@ -1,0 +1,319 @@
+"""Parity of the HIP path on a real MI355X (``-m gpu``), called through the C ABI / the Python host layer.
+
+Bars (BASELINE.json north_star): outputs within 1e-3 fp32 of the reference's pure-python module on
+identical inputs; the index map (slot order, structural zero of the column self slot) bit-exact.
+The checker is the CPU oracle (oracle/cca_oracle.py, pinned to the live reference by
+tests/test_oracle.py) and the golden vectors the reference itself produced (tests/golden/).
+/root/reference does not exist on the GPU box and is never read here.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import SMALL_CASES, load_golden, make_core_inputs, regenerate_module_inputs
+from oracle import cca_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3          # the north_star tolerance (max abs, fp32)
+TIGHT = 5e-5        # what exact-fp32 MFMA actually delivers on O(1) data
+DIRECT, MFMA = 1, 2
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ccnet_amd import _lib
+    L = _lib.get_lib()          # raises if libccnet_cca.so is missing: there is no fallback to hide behind
+    yield L
+    L.ccnet_cca_set_impl(0)
+    L.ccnet_cca_set_branch_mask(3)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def err(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+
+
+def test_native_library_is_loaded_and_mfma_layout_holds(lib, dev):
+    assert lib.ccnet_cca_arch() == b"gfx950"
+    scratch = torch.zeros(64, device=dev)
+    rc = lib.ccnet_cca_mfma_selftest(scratch.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.last_error()
+    with open("/proc/self/maps") as f:
+        assert "libccnet_cca.so" in f.read()
+
+
+@pytest.mark.parametrize("impl", [DIRECT, MFMA])
+@pytest.mark.parametrize("shape", [(2, 16, 5, 6), (1, 32, 9, 7), (1, 24, 17, 20), (1, 8, 1, 1), (1, 16, 1, 9),
+                                   (1, 16, 9, 1), (2, 40, 33, 18), (2, 64, 32, 32), (1, 64, 100, 40)])
+def test_autograd_functions_match_oracle(lib, dev, impl, shape):
+    """CA_Weight / softmax / CA_Map (the extension-style API) and the fused function, fwd + bwd."""
+    from ccnet_amd import CA_Map, CA_Weight, ca_softmax, criss_cross_attention
+    lib.ccnet_cca_set_impl(impl)
+    B, C, H, W = shape
+    q, k, v, x, dy = make_core_inputs(B, C, H, W, seed=11)
+    gamma = torch.tensor([0.5])
+    yo, Ao = O.cca_core_forward(q, k, v, x, gamma)
+    go = O.cca_core_backward(dy, q, k, v, Ao, gamma)
+
+    qd, kd, vd, xd = (t.to(dev).requires_grad_(True) for t in (q, k, v, x))
+    gd = gamma.to(dev).requires_grad_(True)
+    # un-fused chain, as the extension branches of the reference write it
+    energy = CA_Weight.apply(qd, kd)
+    eo = O.ca_forward(q, k)
+    assert torch.equal(torch.isneginf(energy).cpu(), torch.isneginf(eo))
+    A = ca_softmax(energy)
+    idx = torch.arange(H)
+    assert bool((A[:, idx, :, idx] == 0).all())            # structural zero, bit-exact
+    out = CA_Map.apply(A, vd)
+    y = gd * out + xd
+    assert err(A, Ao) < TIGHT and err(y, yo) < TIGHT
+    y.backward(dy.to(dev))
+    got = {"dq": qd.grad, "dk": kd.grad, "dv": vd.grad, "dx": xd.grad, "dgamma": gd.grad}
+    for n in ("dq", "dk", "dv", "dx"):
+        assert err(got[n], go[n]) < TIGHT * 4, n
+    assert float(got["dgamma"].cpu()) == pytest.approx(float(go["dgamma"]), rel=2e-4, abs=2e-3)
+
+    # fused function
+    q2, k2, v2, x2 = (t.to(dev).requires_grad_(True) for t in (q, k, v, x))
+    g2 = gamma.to(dev).requires_grad_(True)
+    y2 = criss_cross_attention(q2, k2, v2, x2, g2)
+    assert err(y2, yo) < TIGHT
+    y2.backward(dy.to(dev))
+    for n, t in (("dq", q2), ("dk", k2), ("dv", v2), ("dx", x2)):
+        assert err(t.grad, go[n]) < TIGHT * 4, n
+    assert float(g2.grad.cpu()) == pytest.approx(float(go["dgamma"]), rel=2e-4, abs=2e-3)
+
+
+@pytest.mark.parametrize("impl", [DIRECT, MFMA])
+@pytest.mark.parametrize("case", SMALL_CASES)
+def test_module_matches_live_reference_golden_vectors(lib, dev, impl, case):
+    """CrissCrossAttention module (convs + HIP core) vs what the reference module produced."""
+    from cc_attention import CrissCrossAttention       # the drop-in import path (networks/ccnet.py:13)
+    lib.ccnet_cca_set_impl(impl)
+    g = load_golden(case)
+    B, C, H, W = g["x"].shape
+    m = CrissCrossAttention(C)
+    missing = m.load_state_dict({k[len("param."):]: v for k, v in g.items() if k.startswith("param.")})
+    assert not missing.missing_keys and not missing.unexpected_keys
+    m = m.to(dev)
+    x = g["x"].to(dev).requires_grad_(True)
+    y = m(x)
+    y.backward(g["dy"].to(dev))
+    assert err(y, g["y"]) < TOL and err(x.grad, g["dx"]) < TOL
+    assert err(y, g["y"]) < TIGHT * 2
+    for n, p in m.named_parameters():
+        assert err(p.grad, g["grad." + n]) < TOL, n
+
+
+def test_config1_module_matches_reference(lib, dev):
+    """BASELINE.json configs[0]: (2,64,32,32) fp32, gamma 0.5 -- y, dx and all 7 parameter grads."""
+    from ccnet_amd import CrissCrossAttention
+    lib.ccnet_cca_set_impl(0)
+    g = load_golden("cfg1_2x64x32x32")
+    B, C, H, W = [int(v) for v in g["shape"]]
+    x, dy, params = regenerate_module_inputs(B, C, H, W)
+    if abs(float(x.double().sum()) - float(g["fingerprint.x"][0])) > 1e-6:
+        pytest.skip("torch RNG stream differs from the build container's")
+    m = CrissCrossAttention(C)
+    m.load_state_dict(params)
+    m = m.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    y = m(xd)
+    y.backward(dy.to(dev))
+    assert err(y, g["y"]) < TOL and err(xd.grad, g["dx"]) < TOL
+    for n, p in m.named_parameters():
+        assert err(p.grad, g["grad." + n]) < TOL * 5, n     # weight grads sum 2048 pixels: abs 5e-3 on O(10) values
+
+
+def test_headline_shape_against_oracle_and_direct_kernels(lib, dev):
+    """(8,512,97,97) fp32 -- BASELINE.json configs[1].  MFMA path vs the CPU oracle on the full
+    tensors, vs the direct kernels on the device, plus size-independent properties."""
+    from ccnet_amd import criss_cross_attention
+    B, C, H, W = 8, 512, 97, 97
+    q, k, v, x, dy = make_core_inputs(B, C, H, W, seed=21)
+    gamma = torch.tensor([0.5])
+    res = {}
+    for impl in (MFMA, DIRECT):
+        lib.ccnet_cca_set_impl(impl)
+        qd, kd, vd, xd = (t.to(dev).requires_grad_(True) for t in (q, k, v, x))
+        gd = gamma.to(dev).requires_grad_(True)
+        y = criss_cross_attention(qd, kd, vd, xd, gd)
+        y.backward(dy.to(dev))
+        torch.cuda.synchronize()
+        res[impl] = {"y": y.detach().cpu(), "dq": qd.grad.cpu(), "dk": kd.grad.cpu(), "dv": vd.grad.cpu(),
+                     "dgamma": gd.grad.cpu()}
+    lib.ccnet_cca_set_impl(0)
+    assert lib.ccnet_cca_shape_uses_mfma(B, C, H, W) == 1
+    for n in ("y", "dq", "dk", "dv"):
+        assert err(res[MFMA][n], res[DIRECT][n]) < 2e-4, n
+    yo, Ao = O.cca_core_forward(q, k, v, x, gamma)
+    go = O.cca_core_backward(dy, q, k, v, Ao, gamma)
+    report = {n: err(res[MFMA][n], t) for n, t in (("y", yo), ("dq", go["dq"]), ("dk", go["dk"]), ("dv", go["dv"]))}
+    print("headline max-abs errors vs oracle:", report)
+    assert all(e < TOL for e in report.values()), report
+    assert float(res[MFMA]["dgamma"]) == pytest.approx(float(go["dgamma"]), rel=1e-3)
+
+
+def test_headline_shape_properties(lib, dev):
+    """Size-independent properties at the full size: rows of A sum to 1, structural zero, linearity of
+    the aggregation in v, and the adjoint identity <map(A,v), d> == <v, map^T(A,d)>."""
+    from ccnet_amd import _lib as L
+    lib.ccnet_cca_set_impl(0)
+    B, C, H, W = 8, 512, 97, 97
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cpu").manual_seed(5)
+    q = torch.randn(B, C // 8, H, W, generator=g).to(dev)
+    k = torch.randn(B, C // 8, H, W, generator=g).to(dev)
+    v1 = torch.randn(B, C, H, W, generator=g).to(dev)
+    v2 = torch.randn(B, C, H, W, generator=g).to(dev)
+    d = torch.randn(B, C, H, W, generator=g).to(dev)
+    A = torch.empty(B, H, W, H + W, device=dev)
+    lib.check(lib.ccnet_ca_forward_f32(q.data_ptr(), k.data_ptr(), A.data_ptr(), B, C // 8, H, W, L.CCNET_CA_SOFTMAX, s))
+    assert float((A.sum(-1) - 1).abs().max()) < 1e-5
+    idx = torch.arange(H, device=dev)
+    assert bool((A[:, idx, :, idx] == 0).all())
+    assert bool((A >= 0).all())
+
+    def fmap(vv):
+        o = torch.full_like(vv, float("nan"))
+        lib.check(lib.ccnet_ca_map_forward_f32(A.data_ptr(), vv.data_ptr(), None, None, o.data_ptr(), B, C, H, W, s))
+        return o
+
+    o1, o2, o12 = fmap(v1), fmap(v2), fmap(v1 + v2)
+    assert not torch.isnan(o12).any()
+    assert float((o12 - (o1 + o2)).abs().max()) < 1e-4                  # linearity
+    dv = torch.full_like(v1, float("nan"))
+    lib.check(lib.ccnet_ca_map_backward_f32(d.data_ptr(), A.data_ptr(), v1.data_ptr(), None, None, dv.data_ptr(),
+                                            B, C, H, W, s))
+    lhs = float((o1.double() * d.double()).sum())
+    rhs = float((v1.double() * dv.double()).sum())
+    assert lhs == pytest.approx(rhs, rel=1e-5)                          # adjoint identity
+
+
+@pytest.mark.parametrize("impl", [DIRECT, MFMA])
+def test_determinism_full_overwrite_and_no_out_of_bounds(lib, dev, impl):
+    """Bit-identical over repeated runs; NaN-poisoned outputs fully overwritten; canaries around every
+    output buffer untouched (odd sizes 97/33 exercise every ragged edge)."""
+    lib.ccnet_cca_set_impl(impl)
+    from ccnet_amd import _lib as L
+    s = torch.cuda.current_stream().cuda_stream
+    for (B, C, H, W) in [(2, 24, 33, 18), (1, 32, 97, 97)]:
+        q, k, v, x, dy = (t.to(dev) for t in make_core_inputs(B, C, H, W, seed=31))
+        gamma = torch.full((1,), 0.5, device=dev)
+        PAD = 4096
+
+        def guarded(n):
+            buf = torch.full((n + 2 * PAD,), float("nan"), device=dev)
+            buf[:PAD] = 777.0
+            buf[-PAD:] = 777.0
+            return buf, buf[PAD:PAD + n]
+
+        runs = []
+        for _ in range(2):
+            bufs = {n: guarded(t.numel()) for n, t in (("y", x), ("dq", q), ("dk", k), ("dv", v))}
+            bufs["A"] = guarded(B * H * W * (H + W))
+            bufs["scratch"] = guarded(B * H * W * (H + W))
+            bufs["dgamma"] = guarded(1)
+            nbytes = lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
+            ws = torch.empty(nbytes // 4 + 1, device=dev)
+            P = lambda n: bufs[n][1].data_ptr()  # noqa: E731
+            lib.check(lib.ccnet_cca_forward_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), x.data_ptr(), gamma.data_ptr(),
+                                                P("y"), P("A"), B, C, C // 8, H, W, s))
+            lib.check(lib.ccnet_cca_backward_f32(dy.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), P("A"),
+                                                 gamma.data_ptr(), P("dq"), P("dk"), P("dv"), P("dgamma"),
+                                                 P("scratch"), ws.data_ptr(), nbytes, B, C, C // 8, H, W, s))
+            torch.cuda.synchronize()
+            for n, (full, view) in bufs.items():
+                assert bool((full[:PAD] == 777.0).all()) and bool((full[-PAD:] == 777.0).all()), f"{n}: canary hit"
+                assert not torch.isnan(view).any(), f"{n}: not fully overwritten"
+            runs.append({n: bufs[n][1].clone() for n in ("y", "A", "dq", "dk", "dv", "dgamma")})
+        for n in runs[0]:
+            assert torch.equal(runs[0][n], runs[1][n]), f"{n}: run-to-run difference"
+
+
+def test_gamma_zero_identity_and_zero_init_module(lib, dev):
+    """functions.py:24 zero-initialises gamma: step-0 output must equal x bit-exactly and q/k/v grads vanish."""
+    from ccnet_amd import CrissCrossAttention
+    lib.ccnet_cca_set_impl(0)
+    torch.manual_seed(2)
+    m = CrissCrossAttention(64).to(dev)
+    x = torch.randn(2, 64, 20, 24, device=dev, requires_grad=True)
+    y = m(x)
+    assert torch.equal(y, x)
+    y.backward(torch.randn_like(x))
+    assert float(m.value_conv.weight.grad.abs().max()) == 0.0
+    assert float(m.query_conv.weight.grad.abs().max()) == 0.0
+    assert float(m.gamma.grad.abs()) > 0.0
+
+
+def test_recurrence_two_shares_weights_and_eval_mode(lib, dev):
+    """RCCAModule.forward (networks/ccnet.py:118-119): the same module applied R=2 times; also the
+    no_grad / eval path of evaluate.py:222,246 and a non-default stream."""
+    from ccnet_amd import CrissCrossAttention
+    lib.ccnet_cca_set_impl(0)
+    torch.manual_seed(3)
+    C, H, W = 64, 24, 31
+    m = CrissCrossAttention(C)
+    with torch.no_grad():
+        m.gamma.fill_(0.5)
+    x = torch.randn(1, C, H, W)
+    dy = torch.randn(1, C, H, W)
+    params = {n: p.detach().clone() for n, p in m.state_dict().items()}
+    # oracle: two applications with shared parameters, gradients accumulate
+    xo = x.clone().double().requires_grad_(True)
+    po = {n: p.double().requires_grad_(True) for n, p in params.items()}
+    h = xo
+    for _ in range(2):
+        h, _ = O.cca_module_forward(h, po)
+    h.backward(dy.double())
+
+    m = m.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out = xd
+        for _ in range(2):
+            out = m(out)
+        out.backward(dy.to(dev))
+    side.synchronize()
+    assert err(out, h) < TOL and err(xd.grad, xo.grad) < TOL
+    for n, p in m.named_parameters():
+        assert err(p.grad, po[n].grad) < TOL * 5, n
+    m.eval()
+    with torch.no_grad():
+        out2 = m(m(x.to(dev)))
+    assert err(out2, h) < TOL
+
+
+def test_host_layer_rejects_cpu_and_wrong_dtype(lib, dev):
+    from ccnet_amd import CA_Weight, CrissCrossAttention
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        CA_Weight.apply(torch.randn(1, 2, 4, 4), torch.randn(1, 2, 4, 4))
+    with pytest.raises(RuntimeError, match="float32"):
+        CA_Weight.apply(torch.randn(1, 2, 4, 4, device=dev).half(), torch.randn(1, 2, 4, 4, device=dev).half())
+    m = CrissCrossAttention(16).to(dev)
+    with pytest.raises(RuntimeError, match="CPU"):
+        m(torch.randn(1, 16, 4, 4))
+
+
+def test_stock_pytorch_reference_formulation_on_device(lib, dev):
+    """The reference's own op sequence (bmm / cat / softmax of functions.py:38-47, re-stated with torch
+    ops on the GPU) as a second, code-disjoint checker at a mid-size shape."""
+    from ccnet_amd import criss_cross_attention
+    lib.ccnet_cca_set_impl(0)
+    B, C, H, W = 2, 128, 48, 65
+    q, k, v, x, _ = (t.to(dev) for t in make_core_inputs(B, C, H, W, seed=41))
+    gamma = torch.tensor([0.7], device=dev)
+    eH = torch.einsum("bchw,bcjw->bhwj", q, k)
+    eH = eH.masked_fill(torch.eye(H, dtype=torch.bool, device=dev)[None, :, None, :], float("-inf"))
+    eW = torch.einsum("bchw,bchj->bhwj", q, k)
+    A = torch.softmax(torch.cat([eH, eW], 3), 3)
+    ref = gamma * (torch.einsum("bhwj,bcjw->bchw", A[..., :H], v) + torch.einsum("bhwj,bchj->bchw", A[..., H:], v)) + x
+    y = criss_cross_attention(q, k, v, x, gamma)
+    assert err(y, ref) < TOL and err(y, ref) < 2e-4

@@ -1,0 +1,125 @@
+"""CPU-side checks of the drop-in boundary: C-ABI symbol export, module surface, error behaviour,
+and that the product never routes through the oracle or any CPU fallback."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+REF_KEYS = {  # state_dict of the reference module (functions.py:19-24) for in_dim = C
+    "gamma": lambda C: (1,),
+    "query_conv.weight": lambda C: (C // 8, C, 1, 1), "query_conv.bias": lambda C: (C // 8,),
+    "key_conv.weight": lambda C: (C // 8, C, 1, 1), "key_conv.bias": lambda C: (C // 8,),
+    "value_conv.weight": lambda C: (C, C, 1, 1), "value_conv.bias": lambda C: (C,),
+}
+
+
+@pytest.fixture(scope="module")
+def device_lib_path():
+    import __graft_entry__ as g
+    g.build()                      # hipcc cross-compiles gfx950 without a GPU
+    from ccnet_amd import _lib
+    return _lib.LIB_PATH
+
+
+def test_device_library_exports_every_declared_symbol(device_lib_path):
+    from ccnet_amd import _lib
+    names = _lib.declared_symbols()
+    assert len(names) >= 15 and set(names) == set(_lib._PROTOTYPES)
+    dll = ctypes.CDLL(device_lib_path)          # loads without a GPU; no compute call is made
+    for n in names:
+        assert hasattr(dll, n), f"{n} declared in include/ccnet_cca.h but not exported"
+    lib = _lib.CcaLibrary(device_lib_path)
+    assert lib.ccnet_cca_version() == 100 and lib.ccnet_cca_arch() == b"gfx950"
+    # argument validation happens before any launch, so it is checkable here
+    assert lib.ccnet_ca_forward_f32(None, None, None, 1, 1, 2, 2, 0, None) == -2
+    assert lib.ccnet_ca_forward_f32(None, None, None, 0, 1, 2, 2, 0, None) == -1
+    assert "ccnet_cca" in lib.last_error()
+    assert lib.ccnet_ca_softmax_backward_workspace_bytes(8, 97, 97) == ((8 * 97 * 97 + 3) // 4) * 4
+
+
+def test_device_library_contains_gfx950_code_object(device_lib_path):
+    blob = open(device_lib_path, "rb").read()
+    assert b"gfx950" in blob and b"weight_strip_kernel" in blob and b"map_strip_kernel" in blob
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from ccnet_amd import _lib
+    with pytest.raises(_lib.CcaError, match="no CPU or PyTorch fallback"):
+        _lib.CcaLibrary(str(tmp_path / "libccnet_cca.so"))
+
+
+@pytest.mark.parametrize("C", [16, 64, 512])
+def test_module_surface_matches_reference(C):
+    from cc_attention import CrissCrossAttention as ViaDropIn
+    from cc_attention.functions import CrissCrossAttention as ViaFunctions
+    from ccnet_amd import CrissCrossAttention
+    assert ViaDropIn is CrissCrossAttention and ViaFunctions is CrissCrossAttention
+    m = CrissCrossAttention(C)
+    sd = m.state_dict()
+    assert set(sd) == set(REF_KEYS)
+    for k, shp in REF_KEYS.items():
+        assert tuple(sd[k].shape) == shp(C), k
+    assert float(m.gamma) == 0.0                                   # functions.py:24
+    assert isinstance(m.softmax, torch.nn.Softmax) and m.softmax.dim == 3
+    assert callable(m.INF)
+    inf = m.INF(2, 3, 4)                                           # functions.py:11-12 semantics
+    assert tuple(inf.shape) == (8, 3, 3)
+    assert torch.isneginf(torch.diagonal(inf, dim1=1, dim2=2)).all()
+    off = inf[~torch.eye(3, dtype=torch.bool).expand(8, 3, 3)]
+    assert (off == 0).all()
+
+
+def test_reference_checkpoint_loads_strictly():
+    from ccnet_amd import CrissCrossAttention
+    g = load_golden("small_2x64x8x8")
+    m = CrissCrossAttention(64)
+    res = m.load_state_dict({k[len("param."):]: v for k, v in g.items() if k.startswith("param.")}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert float(m.gamma) == 0.5
+
+
+def test_cpu_input_raises_instead_of_falling_back():
+    from ccnet_amd import CA_Map, CA_Weight, CrissCrossAttention, criss_cross_attention
+    m = CrissCrossAttention(16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.randn(1, 16, 4, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        CA_Weight.apply(torch.randn(1, 2, 4, 4), torch.randn(1, 2, 4, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        CA_Map.apply(torch.randn(1, 4, 4, 8), torch.randn(1, 16, 4, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        criss_cross_attention(torch.randn(1, 2, 4, 4), torch.randn(1, 2, 4, 4), torch.randn(1, 16, 4, 4),
+                              torch.randn(1, 16, 4, 4), torch.zeros(1))
+
+
+def test_product_never_imports_the_oracle_or_the_emulator():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    bad = []
+    for pkg in ("ccnet_amd", "cc_attention"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, pkg)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h")):
+                    text = open(os.path.join(dirpath, f)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", text, re.M) or "cca_oracle" in text:
+                        bad.append(os.path.join(dirpath, f))
+                    if f.endswith(".py") and ("hip_emu" in text or "libcca_emu" in text):
+                        bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle import", bench)]
+    lo = bench.index("def cpu_baseline")
+    hi = bench.index("\ndef ", lo + 1)
+    assert len(uses) == 1 and lo < uses[0] < hi, "bench.py may use the oracle only inside cpu_baseline()"
+
+
+def test_bench_accounting_matches_survey():
+    import bench
+    assert bench.core_bytes(8, 512, 97, 97) == 1_040_560_128
+    assert round(bench.core_flops(8, 512, 97, 97) / 1e9, 2) == 50.47
+    nbytes, flops = bench.kernel_accounting("weight", 8, 512, 97, 97, row=False)
+    assert nbytes == 2 * 4 * 8 * 512 * 97 * 97 + 4 * 8 * 97 * 97 * 97
+    assert flops == 2 * 8 * 97 * 97 * 97 * 512
