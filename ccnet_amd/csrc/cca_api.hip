@@ -72,6 +72,23 @@ unsigned direct_grid(size_t total) {
     return (unsigned)(blocks < cap ? blocks : cap);
 }
 
+int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// strips per workgroup of the strip kernels: 8 (512 threads) or 4 (256 threads, two workgroups per CU)
+int weight_strips() {
+    static int v = 0;
+    if (!v) v = env_int("CCNET_CCA_WEIGHT_STRIPS", 8) == 4 ? 4 : 8;
+    return v;
+}
+int map_strips() {
+    static int v = 0;
+    if (!v) v = env_int("CCNET_CCA_MAP_STRIPS", 8) == 4 ? 4 : 8;
+    return v;
+}
+
 int map_target_blocks() {
     static int v = -1;
     if (v < 0) {
@@ -83,8 +100,8 @@ int map_target_blocks() {
 }
 
 // strips-per-image tiles and the channel split of the map kernels
-void map_grid(int B, int C, int G, dim3 &grid, int &chunks_per_block) {
-    const int tiles = (G + cca::kStripsPerBlock - 1) / cca::kStripsPerBlock;
+void map_grid(int ns, int B, int C, int G, dim3 &grid, int &chunks_per_block) {
+    const int tiles = (G + ns - 1) / ns;
     const int nchunks = (C + cca::M_MC - 1) / cca::M_MC;
     const int base = B * tiles;
     int cs = (map_target_blocks() + base - 1) / base;
@@ -96,40 +113,49 @@ void map_grid(int B, int C, int G, dim3 &grid, int &chunks_per_block) {
 }
 
 // out = alpha * (column sums + row sums) + resid, both branches, strip kernels
-template <bool TRANS>
-int launch_map_pair(const float *T, const float *F, const float *resid, const float *gamma, float *out,
-                    int B, int C, int H, int W, ccnet_stream_t stream, const char *what) {
+template <int NS, bool TRANS>
+int launch_map_pair_ns(const float *T, const float *F, const float *resid, const float *gamma, float *out,
+                       int B, int C, int H, int W, ccnet_stream_t stream, const char *what) {
     dim3 grid;
     int cpb;
     if (g_branch_mask & CCNET_BRANCH_COL) {
-        map_grid(B, C, /*G=*/W, grid, cpb);
-        CCA_LAUNCH((cca::map_strip_kernel<false, TRANS, cca::EPI_STORE>), grid, dim3(cca::kBlock), stream,
+        map_grid(NS, B, C, /*G=*/W, grid, cpb);
+        CCA_LAUNCH((cca::map_strip_kernel<NS, false, TRANS, cca::EPI_STORE>), grid, dim3(cca::kWave * NS), stream,
                    T, F, (const float *)nullptr, (const float *)nullptr, out, C, H, W, cpb);
         if (int e = launch_status(what)) return e;
     }
     if (g_branch_mask & CCNET_BRANCH_ROW) {
-        map_grid(B, C, /*G=*/H, grid, cpb);
-        CCA_LAUNCH((cca::map_strip_kernel<true, TRANS, cca::EPI_FINAL>), grid, dim3(cca::kBlock), stream,
+        map_grid(NS, B, C, /*G=*/H, grid, cpb);
+        CCA_LAUNCH((cca::map_strip_kernel<NS, true, TRANS, cca::EPI_FINAL>), grid, dim3(cca::kWave * NS), stream,
                    T, F, resid, gamma, out, C, H, W, cpb);
         return launch_status(what);
     }
     return 0;
 }
 
+template <bool TRANS>
+int launch_map_pair(const float *T, const float *F, const float *resid, const float *gamma, float *out,
+                    int B, int C, int H, int W, ccnet_stream_t stream, const char *what) {
+    return map_strips() == 4 ? launch_map_pair_ns<4, TRANS>(T, F, resid, gamma, out, B, C, H, W, stream, what)
+                             : launch_map_pair_ns<8, TRANS>(T, F, resid, gamma, out, B, C, H, W, stream, what);
+}
+
+// both branches in ONE launch (column workgroups first, then row workgroups)
+template <int NS, bool MASK>
+int launch_weight_ns(const float *X, const float *Y, float *T, int B, int Cx, int H, int W,
+                     ccnet_stream_t stream, const char *what) {
+    const int tc = (g_branch_mask & CCNET_BRANCH_COL) ? (W + NS - 1) / NS : 0;
+    const int tr = (g_branch_mask & CCNET_BRANCH_ROW) ? (H + NS - 1) / NS : 0;
+    CCA_LAUNCH((cca::weight_strip_kernel<NS, MASK>), dim3(tc + tr, B), dim3(cca::kWave * NS), stream,
+               X, Y, T, Cx, H, W, tc);
+    return launch_status(what);
+}
+
 template <bool MASK>
 int launch_weight_pair(const float *X, const float *Y, float *T, int B, int Cx, int H, int W,
                        ccnet_stream_t stream, const char *what) {
-    const int tc = (W + cca::kStripsPerBlock - 1) / cca::kStripsPerBlock;
-    const int tr = (H + cca::kStripsPerBlock - 1) / cca::kStripsPerBlock;
-    if (g_branch_mask & CCNET_BRANCH_COL) {
-        CCA_LAUNCH((cca::weight_strip_kernel<false, MASK>), dim3(tc, B), dim3(cca::kBlock), stream, X, Y, T, Cx, H, W);
-        if (int e = launch_status(what)) return e;
-    }
-    if (g_branch_mask & CCNET_BRANCH_ROW) {
-        CCA_LAUNCH((cca::weight_strip_kernel<true, MASK>), dim3(tr, B), dim3(cca::kBlock), stream, X, Y, T, Cx, H, W);
-        return launch_status(what);
-    }
-    return 0;
+    return weight_strips() == 4 ? launch_weight_ns<4, MASK>(X, Y, T, B, Cx, H, W, stream, what)
+                                : launch_weight_ns<8, MASK>(X, Y, T, B, Cx, H, W, stream, what);
 }
 
 int softmax_forward(const float *E, float *A, int B, int H, int W, ccnet_stream_t stream) {

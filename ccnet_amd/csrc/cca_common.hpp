@@ -23,8 +23,9 @@ namespace cca {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;                 // CDNA wavefront
-constexpr int kStripsPerBlock = 8;        // one wavefront per strip, 8 strips (=8 adjacent w or h) per workgroup
-constexpr int kBlock = kWave * kStripsPerBlock;
+// Strip kernels are templated on NS = strips per workgroup (one wavefront per strip, NS adjacent w or h):
+//   NS = 8: 512 threads, one workgroup per CU;  NS = 4: 256 threads, two independent workgroups per CU
+constexpr int kMaxStripsPerBlock = 8;
 constexpr int kTile = 16;                 // v_mfma_f32_16x16x4_f32 output tile
 constexpr int kMaxTiles = 7;              // strips up to 112 long in the W-kernel
 constexpr int kMaxStrip = 100;            // strip-stationary kernels hold 25 k-steps x 7 n-tiles of attention
@@ -105,10 +106,20 @@ struct FBuf {
 __device__ inline FBuf make_fbuf(const float *p, size_t bytes) { return FBuf{(const char *)p, (uint32_t)bytes}; }
 __device__ inline float fbuf_load(const FBuf &b, int voff_bytes, int soff_bytes) {
     const uint32_t o = (uint32_t)voff_bytes + (uint32_t)soff_bytes;
-    if ((size_t)o + 4 > b.bytes) return 0.f;
+    if ((uint32_t)voff_bytes >= b.bytes || (size_t)o + 4 > b.bytes) return 0.f;
     float r;
     memcpy(&r, b.base + o, 4);
     return r;
+}
+__device__ inline void fbuf_store(const FBuf &b, float v, int voff_bytes, int soff_bytes) {
+    const uint32_t o = (uint32_t)voff_bytes + (uint32_t)soff_bytes;
+    if ((uint32_t)voff_bytes >= b.bytes || (size_t)o + 4 > b.bytes) return;      // out-of-range stores are dropped
+    memcpy(const_cast<char *>(b.base) + o, &v, 4);
+}
+// LDS-DMA: every lane fetches one dword and the wave deposits the 64 dwords CONTIGUOUSLY at
+// lds_wave_base + lane (buffer_load_dword ... lds).  The emulator completes it synchronously.
+__device__ inline void fbuf_load_to_lds(const FBuf &b, float *lds_wave_base, int voff_bytes, int soff_bytes) {
+    lds_wave_base[emu::lane_id()] = fbuf_load(b, voff_bytes, soff_bytes);
 }
 
 #define CCA_LDS_REGISTER(arr) do { emu::lds_register((void *)(arr), sizeof(arr)); __syncthreads(); } while (0)
@@ -136,6 +147,17 @@ __device__ __forceinline__ FBuf make_fbuf(const float *p, size_t bytes) {
 __device__ __forceinline__ float fbuf_load(const FBuf &b, int voff_bytes, int soff_bytes) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, voff_bytes, soff_bytes, 0));
 }
+// stores whose per-lane offset is out of range (kOobOffset) are dropped by the buffer range check
+__device__ __forceinline__ void fbuf_store(const FBuf &b, float v, int voff_bytes, int soff_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), b, voff_bytes, soff_bytes, 0);
+}
+// LDS-DMA (buffer_load_dword ... lds): no staging VGPRs, no ds_write pass; the 64 dwords of the wave land
+// contiguously at the wave-uniform LDS address (M0) + lane * 4.  Completion is tracked by vmcnt; the
+// compiler drains it before the next __syncthreads(), which is exactly the double-buffer hand-over.
+__device__ __forceinline__ void fbuf_load_to_lds(const FBuf &b, float *lds_wave_base, int voff_bytes, int soff_bytes) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void *)lds_wave_base, 4,
+                                             voff_bytes, soff_bytes, 0, 0);
+}
 
 #define CCA_LDS_REGISTER(arr) do { } while (0)
 #define CCA_LDS_LD(p) (*(p))
@@ -153,6 +175,55 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int m = kWave / 2; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));
     return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Strip-tile geometry shared by the strip kernels: the NS strips x L positions of ONE channel form a
+// lane-linear LDS image of ceil(NS*L/64) DMA pieces (64 dwords each), element at index p:
+//   column branch  p = i * NS + (gg ^ swz(i))    NS consecutive w per position -> 4*NS-byte segments; the XOR
+//                  swizzle makes stride-NS fragment reads bank-conflict-free (with an odd channel pitch)
+//   row branch     p = gg * L + i                the NS rows are contiguous in memory: 256-byte pieces
+// ---------------------------------------------------------------------------------------------
+constexpr int kOobOffset = 0x7ffffff0;            // per-lane byte offset that is out of range for every view
+
+__host__ __device__ constexpr int strip_pieces_c(int ns) { return (ns * kMaxStrip + 63) / 64; }   // 13 (NS=8) / 7 (NS=4)
+
+template <int NS>
+__device__ __forceinline__ int col_swizzle(int i) {
+    return NS == 8 ? 2 * ((i >> 2) & 3) : 2 * ((i >> 3) & 1);
+}
+
+// LDS index of (position i, strip gg) inside a channel image
+template <int NS, bool ROW>
+__device__ __forceinline__ int strip_lds_index(int i, int gg, int L) {
+    return ROW ? gg * L + i : i * NS + (gg ^ col_swizzle<NS>(i));
+}
+
+// byte offset (inside one channel plane) of the element that LDS index p = m*64 + lane holds, or -1 when
+// that index is padding / a strip outside the image
+template <int NS, bool ROW>
+__device__ __forceinline__ int strip_elem_offset(int m, int lane, int L, int W, int g0, int gvalid) {
+    if (ROW) {
+        const int p = m * 64 + lane;
+        return (p < gvalid * L) ? 4 * (g0 * W + p) : -1;
+    }
+    const int i = m * (64 / NS) + lane / NS;
+    const int gg = (lane % NS) ^ col_swizzle<NS>(i);
+    return (i < L && gg < gvalid) ? 4 * (i * W + g0 + gg) : -1;
+}
+
+// LDS-DMA of one channel plane slice into its image; invalid lanes fetch element 0 of the plane (valid
+// memory) and land in padding / never-stored strips
+// (FULL: npieces is the compile-time maximum, the loop is fully unrolled without guards)
+template <int NS, bool ROW, bool FULL>
+__device__ __forceinline__ void strip_dma_channel(const FBuf &src, float *dst, int soff, int lane, int npieces,
+                                                  int L, int W, int g0, int gvalid) {
+#pragma unroll
+    for (int m = 0; m < strip_pieces_c(NS); ++m)
+        if (FULL || m < npieces) {
+            const int off = strip_elem_offset<NS, ROW>(m, lane, L, W, g0, gvalid);
+            fbuf_load_to_lds(src, dst + m * 64, off < 0 ? 0 : off, soff);
+        }
 }
 
 }  // namespace cca

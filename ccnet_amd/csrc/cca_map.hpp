@@ -12,60 +12,74 @@
 //
 // i.e. per strip the (channels x L) * (L x L) GEMM  F_g P_g^T  resp.  F_g P_g.
 //
-// Work decomposition (MI355X): one workgroup = 8 adjacent strips x a range of 16-channel chunks.  Each
-// wavefront owns one strip and keeps that strip's whole attention block STATIONARY in registers as
+// Work decomposition (MI355X): one workgroup = NS adjacent strips x a range of 16-channel chunks, one
+// wavefront per strip.  Each wavefront keeps its strip's whole attention block STATIONARY in registers as
 // the B operands of v_mfma_f32_16x16x4_f32 (25 k-steps x 7 n-tiles = 175 VGPRs for L <= 100), so the
-// attention tensor is read once per workgroup; feature chunks stream through LDS (coalesced along w
-// for the column branch, along the row for the row branch) and every MFMA needs a single
-// ds_read_b32.  Exact fp32: the MFMA is bit-identical to an fmaf chain.
+// attention tensor is read once per workgroup.  Feature chunks stream through a DOUBLE-BUFFERED LDS image
+// filled by LDS-DMA (chunk n+1 in flight while chunk n is multiplied); every MFMA needs one ds_read_b32.
+// Results go back through the SAME LDS image (each wavefront overwrites only its own strip's slots) and
+// leave the workgroup as coalesced tile stores mirroring the DMA pattern.  Exact fp32 throughout.
 //
 // The two branches of one output are combined without atomics: the column launch stores its partial
 // sum into ``out`` (EPI_STORE); the row launch then computes, per element and in the same thread that
 // re-reads it,  out = alpha * (row_sum + out) + resid   (EPI_FINAL), alpha = *gamma or 1.
-//
-// LDS image of a feature chunk: [strip 8][channel 16][position k, pitch 102] + 4 floats per strip:
-//   fragment reads (lane -> channel = l & 15 stride 102 (== 6 mod 32, even/2 odd), k = l >> 4 unit) conflict-free
-//   column-loader writes (lane -> strip fastest, stride 1636 == 4 mod 32)                           conflict-free
-//   row-loader writes    (lane -> k fastest)                                                         conflict-free
 #pragma once
 #include "cca_common.hpp"
 
 namespace cca {
 
 constexpr int M_MC = 16;                          // channels per chunk = one MFMA M tile
-constexpr int M_LDK = 102;                        // >= kMaxStrip, == 2 mod 4
-constexpr int M_GS = M_MC * M_LDK + 4;            // 1636
 constexpr int M_KS = kMaxStrip / 4;               // 25 k-steps
-constexpr int M_SLOTS = 2;                        // ceil(8 * 100 / 512)
 constexpr int EPI_STORE = 0, EPI_FINAL = 1;
+// channel pitch of the LDS image: pieces * 64 + 17 (odd: see strip geometry in cca_common.hpp; >= NS*L + 3)
+__host__ __device__ constexpr int m_cp(int ns) { return strip_pieces_c(ns) * 64 + 17; }
+__host__ __device__ constexpr int m_lds_floats(int ns) { return 2 * M_MC * m_cp(ns); }    // two buffers
 
 // FULL: the strip needs all 25 k-steps and 7 n-tiles (97..100 long) -> no guards in the hot loop
-template <bool ROW, bool TRANS, int EPI, bool FULL>
+template <int NS, bool ROW, bool TRANS, int EPI, bool FULL>
 __device__ __forceinline__ void map_strip_body(float *lds, const float *__restrict__ T,
                                                const float *__restrict__ F, const float *__restrict__ resid,
                                                const float *__restrict__ gamma, float *out,
                                                int C, int H, int W, int chunks_per_block) {
+    constexpr int CP = m_cp(NS), BUF = M_MC * CP, kBlock = kWave * NS;
     const Branch br = make_branch(ROW, H, W);
     const int L = br.L, HW = H * W, S = H + W;
-    const int b = blockIdx.z, g0 = blockIdx.x * kStripsPerBlock;
+    const int b = blockIdx.z, g0 = blockIdx.x * NS;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
     const int g = g0 + wv;
     const bool active = g < br.G;
     const int nt = FULL ? kMaxTiles : (L + kTile - 1) / kTile;
     const int nks = FULL ? M_KS : (L + 3) / 4;
+    const int npieces = FULL ? strip_pieces_c(NS) : (NS * L + 63) / 64;     // FULL: L in 97..100
+    const int gvalid = (br.G - g0 < NS) ? br.G - g0 : NS;
     const int nchunks = (C + M_MC - 1) / M_MC;
     const int ch_begin = blockIdx.y * chunks_per_block;
     const int ch_end = (ch_begin + chunks_per_block < nchunks) ? ch_begin + chunks_per_block : nchunks;
     const int ln = lane & 15, lk = lane >> 4;
 
-    // K-padding of the feature image must be a true zero (0 * garbage could be NaN): clear [L, pitch)
-    {
-        const int padw = M_LDK - L;
-        for (int idx = tid; idx < kStripsPerBlock * M_MC * padw; idx += kBlock) {
-            const int row = idx / padw, col = L + idx - row * padw;
-            CCA_LDS_ST(&lds[(row / M_MC) * M_GS + (row % M_MC) * M_LDK + col], 0.f);
+    const FBuf Fb = make_fbuf(F + (size_t)b * C * HW, (size_t)C * HW * sizeof(float));
+    const FBuf Ob = make_fbuf(out + (size_t)b * C * HW, (size_t)C * HW * sizeof(float));
+    const FBuf Rb = make_fbuf(resid ? resid + (size_t)b * C * HW : out, (size_t)C * HW * sizeof(float));
+    const bool has_resid = resid != nullptr;
+    const float alpha = (EPI == EPI_FINAL && gamma) ? gamma[0] : 1.f;
+
+    // channels of a chunk are dealt round-robin to the NS waves, for the DMA and for the tile stores
+    auto issue = [&](int ch, int buf) {
+#pragma unroll
+        for (int pr = 0; pr < M_MC / NS; ++pr) {
+            const int cc = wv + pr * NS, c = ch * M_MC + cc;
+            float *dst = lds + buf * BUF + cc * CP;
+            if (c < C) strip_dma_channel<NS, ROW, FULL>(Fb, dst, c * HW * 4, lane, npieces, L, W, g0, gvalid);
+            else for (int m = 0; m < npieces; ++m) CCA_LDS_ST(&dst[m * 64 + lane], 0.f);
         }
+    };
+
+    // the few slots between the last DMA piece and the pitch are read as K padding: make them true zeros
+    for (int idx = tid; idx < 2 * M_MC * (CP - npieces * 64); idx += kBlock) {
+        const int rowi = idx / (CP - npieces * 64), col = npieces * 64 + idx % (CP - npieces * 64);
+        CCA_LDS_ST(&lds[rowi * CP + col], 0.f);
     }
+    if (ch_begin < ch_end) issue(ch_begin, 0);
 
     // stationary attention block of this wavefront's strip, as MFMA B fragments:
     //   B[k][n] with k = contraction index, n = output position.  Unconditional loads from clamped
@@ -87,105 +101,79 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
             }
     }
 
-    // loader slots (position k along the strip, strip gg) as in the weight kernel
-    int goff[M_SLOTS], loff[M_SLOTS];
-    bool lin[M_SLOTS], lok[M_SLOTS];
-#pragma unroll
-    for (int n = 0; n < M_SLOTS; ++n) {
-        const int r = tid + n * kBlock;
-        int k, gg;
-        if (ROW) { k = r % L; gg = r / L; }
-        else     { gg = r & (kStripsPerBlock - 1); k = r >> 3; }
-        lin[n] = r < kStripsPerBlock * L;
-        lok[n] = lin[n] && (g0 + gg < br.G);
-        goff[n] = lok[n] ? 4 * (k * br.fs_i + (g0 + gg) * br.fs_g) : 0;     // bytes; clamped: always valid
-        loff[n] = gg * M_GS + k;
-    }
-
-    const FBuf Fb = make_fbuf(F + (size_t)b * C * HW, (size_t)C * HW * sizeof(float));
-    float *Ob = out + (size_t)b * C * HW;
-    const float *Rb = resid ? resid + (size_t)b * C * HW : nullptr;
-    const float alpha = (EPI == EPI_FINAL && gamma) ? gamma[0] : 1.f;
-    const float *as = lds + wv * M_GS + ln * M_LDK + lk;   // A fragment: channel = l & 15, k = l >> 4
-    const int opos = g * br.fs_g;
+    // A fragment: channel = l & 15 (pitch CP), contraction position k = 4 ks + (l >> 4)
+    //   column image: k * NS + (strip ^ swz(k)), swz constant inside a k-step;  row image: strip * L + k
+    const float *as = lds + ln * CP + (ROW ? wv * L + lk : lk * NS);
 
     for (int ch = ch_begin; ch < ch_end; ++ch) {
-        const int c0 = ch * M_MC;
-        __syncthreads();                                   // previous chunk consumed (and pad cleared)
-        // stage the 16-channel chunk in two halves of 8 channels (16 staging registers)
+        const int buf = (ch - ch_begin) & 1;
+        __syncthreads();                 // chunk ch landed (vmcnt drained); the other buffer's tile stores are done
+        if (ch + 1 < ch_end) issue(ch + 1, buf ^ 1);
+        float *img = lds + buf * BUF;
+        if (active) {
+            f32x4 acc[kMaxTiles];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float rf[M_MC / 2][M_SLOTS];
+            for (int t = 0; t < kMaxTiles; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float *ab = as + buf * BUF;
 #pragma unroll
-            for (int cc = 0; cc < M_MC / 2; ++cc) {
-                const int c = c0 + half * (M_MC / 2) + cc;
-                const bool cin = c < C;                                       // scalar
-                const int soff = (cin ? c : C - 1) * HW * 4;                  // scalar byte offset
+            for (int ks = 0; ks < M_KS; ++ks)
+                if (FULL || ks < nks) {
+                    const int koff = ROW ? ks * 4 : ks * 4 * NS + (wv ^ col_swizzle<NS>(ks * 4));
+                    const float a = CCA_LDS_LD(ab + koff);
 #pragma unroll
-                for (int n = 0; n < M_SLOTS; ++n) {
-                    const float t = fbuf_load(Fb, goff[n], soff);
-                    rf[cc][n] = (cin && lok[n]) ? t : 0.f;
+                    for (int t = 0; t < kMaxTiles; ++t)
+                        if (FULL || t < nt) acc[t] = mfma_16x16x4(a, bf[ks][t], acc[t]);
                 }
-            }
+            // D[m = channel 4*(l>>4)+r][n = position t*16 + (l&15)] -> this strip's slots of the image
 #pragma unroll
-            for (int n = 0; n < M_SLOTS; ++n)
-                if (lin[n]) {
+            for (int t = 0; t < kMaxTiles; ++t)
+                if (FULL || t < nt) {
+                    const int pos = t * kTile + ln;
+                    if (pos < L) {
+                        float *d = img + (4 * lk) * CP + strip_lds_index<NS, ROW>(pos, wv, L);
 #pragma unroll
-                    for (int cc = 0; cc < M_MC / 2; ++cc)
-                        CCA_LDS_ST(&lds[loff[n] + (half * (M_MC / 2) + cc) * M_LDK], rf[cc][n]);
-                }
-        }
-        __syncthreads();
-        if (!active) continue;
-
-        f32x4 acc[kMaxTiles];
-#pragma unroll
-        for (int t = 0; t < kMaxTiles; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < M_KS; ++ks)
-            if (FULL || ks < nks) {
-                const float a = CCA_LDS_LD(as + ks * 4);
-#pragma unroll
-                for (int t = 0; t < kMaxTiles; ++t)
-                    if (FULL || t < nt) acc[t] = mfma_16x16x4(a, bf[ks][t], acc[t]);
-            }
-
-        // D[m = channel 4*(l>>4)+r][n = position t*16 + (l&15)]
-#pragma unroll
-        for (int t = 0; t < kMaxTiles; ++t)
-            if (FULL || t < nt) {
-                const int pos = t * kTile + ln;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = c0 + 4 * lk + r;
-                    if (pos < L && c < C) {
-                        const int o = c * HW + pos * br.fs_i + opos;
-                        float val = acc[t][r];
-                        if (EPI == EPI_FINAL) {
-                            val = alpha * (val + Ob[o]);
-                            if (Rb) val += Rb[o];
-                        }
-                        Ob[o] = val;
+                        for (int r = 0; r < 4; ++r) CCA_LDS_ST(&d[r * CP], acc[t][r]);
                     }
                 }
+        }
+        __syncthreads();                 // the whole 16-channel output tile is in the image
+#pragma unroll
+        for (int pr = 0; pr < M_MC / NS; ++pr) {
+            const int cc = wv + pr * NS, c = ch * M_MC + cc;
+            if (c < C) {
+                const int soff = c * HW * 4;
+                const float *src = img + cc * CP;
+#pragma unroll
+                for (int m = 0; m < strip_pieces_c(NS); ++m)
+                    if (FULL || m < npieces) {
+                        const int off = strip_elem_offset<NS, ROW>(m, lane, L, W, g0, gvalid);
+                        const int voff = off < 0 ? kOobOffset : off;    // out-of-range lanes: load 0, store dropped
+                        float val = CCA_LDS_LD(&src[m * 64 + lane]);
+                        if (EPI == EPI_FINAL) {
+                            val = alpha * (val + fbuf_load(Ob, voff, soff));
+                            if (has_resid) val += fbuf_load(Rb, voff, soff);
+                        }
+                        fbuf_store(Ob, val, voff, soff);
+                    }
             }
+        }
     }
 }
 
-template <bool ROW, bool TRANS, int EPI>
-__global__ __launch_bounds__(kBlock) void map_strip_kernel(const float *__restrict__ T,
-                                                           const float *__restrict__ F,
-                                                           const float *__restrict__ resid,
-                                                           const float *__restrict__ gamma,
-                                                           float *out, int C, int H, int W,
-                                                           int chunks_per_block) {
-    __shared__ float lds[kStripsPerBlock * M_GS];
+template <int NS, bool ROW, bool TRANS, int EPI>
+__global__ __launch_bounds__(kWave * NS, 2) void map_strip_kernel(const float *__restrict__ T,
+                                                                   const float *__restrict__ F,
+                                                                   const float *__restrict__ resid,
+                                                                   const float *__restrict__ gamma,
+                                                                   float *out, int C, int H, int W,
+                                                                   int chunks_per_block) {
+    __shared__ float lds[m_lds_floats(NS)];
     CCA_LDS_REGISTER(lds);
     const int L = ROW ? W : H;
     if (L > (M_KS - 1) * 4)
-        map_strip_body<ROW, TRANS, EPI, true>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block);
+        map_strip_body<NS, ROW, TRANS, EPI, true>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block);
     else
-        map_strip_body<ROW, TRANS, EPI, false>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block);
+        map_strip_body<NS, ROW, TRANS, EPI, false>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block);
 }
 
 }  // namespace cca

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Time every strip kernel of several builds of the library (ablation / A-B variants) in ONE process.
+usage: python tools/ablate.py name=path.so [name=path.so ...]   (first is the baseline)"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from ccnet_amd import _lib
+
+def main():
+    dev = torch.device("cuda:0")
+    B, C, H, W = 8, 512, 97, 97
+    res = {}
+    rounds = int(os.environ.get("ABL_ROUNDS", "3"))
+    libs = []
+    for spec in sys.argv[1:]:
+        name, path = spec.split("=")
+        libs.append((name, _lib.CcaLibrary(os.path.join(ROOT, path))))
+    wls = {name: bench.CoreWorkload(lib, B, C, H, W, dev, 1234) for name, lib in libs}
+    for name, lib in libs:
+        wls[name].forward()          # A must be a valid attention for later stages
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        for name, lib in libs:
+            wl = wls[name]
+            _, rows = bench.roofline_object(wl, iters=10)
+            step = bench.time_region(wl.step, 10)
+            d = res.setdefault(name, {})
+            for row in rows:
+                d.setdefault(row["kernel"], []).append(row["ms"])
+            d.setdefault("STEP fwd+bwd", []).append(step)
+    names = [n for n, _ in libs]
+    keys = list(res[names[0]].keys())
+    print("%-62s" % "kernel (min ms over rounds)", " ".join("%12s" % n for n in names))
+    for k in keys:
+        print("%-62s" % k[:62], " ".join("%12.4f" % min(res[n][k]) for n in names))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "ablate_%s.json" % os.environ.get("ABL_TAG", "x")), "w"))
+
+if __name__ == "__main__":
+    main()
