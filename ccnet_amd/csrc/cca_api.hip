@@ -80,7 +80,7 @@ int env_int(const char *name, int dflt) {
 // strips per workgroup of the strip kernels: 8 (512 threads) or 4 (256 threads, two workgroups per CU)
 int weight_strips() {
     static int v = 0;
-    if (!v) v = env_int("CCNET_CCA_WEIGHT_STRIPS", 8) == 4 ? 4 : 8;
+    if (!v) v = env_int("CCNET_CCA_WEIGHT_STRIPS", 4) == 8 ? 8 : 4;
     return v;
 }
 int map_strips() {
@@ -93,23 +93,23 @@ int map_target_blocks() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("CCNET_CCA_MAP_TARGET_BLOCKS");
-        v = e ? atoi(e) : 1024;
+        v = e ? atoi(e) : 512;
         if (v < 1) v = 1;
     }
     return v;
 }
 
 // strips-per-image tiles and the channel split of the map kernels
-void map_grid(int ns, int B, int C, int G, dim3 &grid, int &chunks_per_block) {
-    const int tiles = (G + ns - 1) / ns;
+void map_grid(int ns, int B, int C, int G, dim3 &grid, int &chunks_per_block, int &tiles, int &cs) {
+    tiles = (G + ns - 1) / ns;
     const int nchunks = (C + cca::M_MC - 1) / cca::M_MC;
     const int base = B * tiles;
-    int cs = (map_target_blocks() + base - 1) / base;
+    cs = (map_target_blocks() + base - 1) / base;
     if (cs < 1) cs = 1;
     if (cs > nchunks) cs = nchunks;
     chunks_per_block = (nchunks + cs - 1) / cs;
     cs = (nchunks + chunks_per_block - 1) / chunks_per_block;
-    grid = dim3((unsigned)tiles, (unsigned)cs, (unsigned)B);
+    grid = dim3((unsigned)(tiles * cs * B));       // 1-D: the kernel decodes an XCD-aware logical id
 }
 
 // out = alpha * (column sums + row sums) + resid, both branches, strip kernels
@@ -117,17 +117,17 @@ template <int NS, bool TRANS>
 int launch_map_pair_ns(const float *T, const float *F, const float *resid, const float *gamma, float *out,
                        int B, int C, int H, int W, ccnet_stream_t stream, const char *what) {
     dim3 grid;
-    int cpb;
+    int cpb, tiles, cs;
     if (g_branch_mask & CCNET_BRANCH_COL) {
-        map_grid(NS, B, C, /*G=*/W, grid, cpb);
-        CCA_LAUNCH((cca::map_strip_kernel<NS, false, TRANS, cca::EPI_STORE>), grid, dim3(cca::kWave * NS), stream,
-                   T, F, (const float *)nullptr, (const float *)nullptr, out, C, H, W, cpb);
+        map_grid(NS, B, C, /*G=*/W, grid, cpb, tiles, cs);
+        CCA_LAUNCH((cca::map_strip_kernel<NS, false, TRANS, cca::EPI_COL>), grid, dim3(cca::kWave * NS), stream,
+                   T, F, resid, gamma, out, C, H, W, cpb, tiles, cs);
         if (int e = launch_status(what)) return e;
     }
     if (g_branch_mask & CCNET_BRANCH_ROW) {
-        map_grid(NS, B, C, /*G=*/H, grid, cpb);
-        CCA_LAUNCH((cca::map_strip_kernel<NS, true, TRANS, cca::EPI_FINAL>), grid, dim3(cca::kWave * NS), stream,
-                   T, F, resid, gamma, out, C, H, W, cpb);
+        map_grid(NS, B, C, /*G=*/H, grid, cpb, tiles, cs);
+        CCA_LAUNCH((cca::map_strip_kernel<NS, true, TRANS, cca::EPI_ROW>), grid, dim3(cca::kWave * NS), stream,
+                   T, F, (const float *)nullptr, gamma, out, C, H, W, cpb, tiles, cs);
         return launch_status(what);
     }
     return 0;
@@ -146,8 +146,8 @@ int launch_weight_ns(const float *X, const float *Y, float *T, int B, int Cx, in
                      ccnet_stream_t stream, const char *what) {
     const int tc = (g_branch_mask & CCNET_BRANCH_COL) ? (W + NS - 1) / NS : 0;
     const int tr = (g_branch_mask & CCNET_BRANCH_ROW) ? (H + NS - 1) / NS : 0;
-    CCA_LAUNCH((cca::weight_strip_kernel<NS, MASK>), dim3(tc + tr, B), dim3(cca::kWave * NS), stream,
-               X, Y, T, Cx, H, W, tc);
+    CCA_LAUNCH((cca::weight_strip_kernel<NS, MASK>), dim3((tc + tr) * B), dim3(cca::kWave * NS), stream,
+               X, Y, T, Cx, H, W, tc, tr);
     return launch_status(what);
 }
 

@@ -177,6 +177,18 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// XCD-aware workgroup order.  The dispatcher places workgroup L on XCD L % 8, each with a private 4 MiB L2
+// (MI355X_MICROARCH.md, workgroup dispatch).  Neighbouring strip tiles of one image share every 128-byte
+// line of the column branch (a tile only uses 4*NS bytes of it), so they must sit on the SAME XCD or each
+// L2 re-fetches the line from HBM.  This bijection hands every XCD a contiguous range of logical ids
+// (cdna_hip_programming.md T1); the kernels then decode image-major / tile-fastest from the logical id.
+// Placement only affects speed, never results.
+__device__ __forceinline__ int xcd_logical_id(int linear, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = linear & 7, idx = linear >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Strip-tile geometry shared by the strip kernels: the NS strips x L positions of ONE channel form a
 // lane-linear LDS image of ceil(NS*L/64) DMA pieces (64 dwords each), element at index p:
@@ -199,31 +211,49 @@ __device__ __forceinline__ int strip_lds_index(int i, int gg, int L) {
     return ROW ? gg * L + i : i * NS + (gg ^ col_swizzle<NS>(i));
 }
 
-// byte offset (inside one channel plane) of the element that LDS index p = m*64 + lane holds, or -1 when
-// that index is padding / a strip outside the image
+// Per-lane addressing of the DMA pieces of one channel image.  Piece m covers LDS indices [64 m, 64 m + 64);
+// the element a lane moves is  plane[ vb[m & 1] + piece_soff(m) ]  -- one of two precomputed per-lane byte
+// offsets (the column swizzle alternates with the parity of m) plus a wave-uniform advance, so a piece
+// costs one select and one scalar add.  Lanes whose index is padding or belongs to a strip outside the
+// image are reported invalid: loads then fetch a clamped valid address, stores use kOobOffset and are dropped.
 template <int NS, bool ROW>
-__device__ __forceinline__ int strip_elem_offset(int m, int lane, int L, int W, int g0, int gvalid) {
-    if (ROW) {
-        const int p = m * 64 + lane;
-        return (p < gvalid * L) ? 4 * (g0 * W + p) : -1;
-    }
-    const int i = m * (64 / NS) + lane / NS;
-    const int gg = (lane % NS) ^ col_swizzle<NS>(i);
-    return (i < L && gg < gvalid) ? 4 * (i * W + g0 + gg) : -1;
-}
+struct StripLanes {
+    int vb[2];
+    bool okg[2];
+    int li;
+    int lim;
 
-// LDS-DMA of one channel plane slice into its image; invalid lanes fetch element 0 of the plane (valid
-// memory) and land in padding / never-stored strips
-// (FULL: npieces is the compile-time maximum, the loop is fully unrolled without guards)
+    __device__ __forceinline__ void init(int lane, int L, int W, int g0, int gvalid) {
+        if (ROW) {
+            li = lane;
+            lim = gvalid * L;
+            vb[0] = vb[1] = 4 * (g0 * W + lane);
+            okg[0] = okg[1] = true;
+        } else {
+            li = lane / NS;
+            lim = L;
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                const int gg = (lane % NS) ^ col_swizzle<NS>(par * (64 / NS) + li);
+                okg[par] = gg < gvalid;
+                vb[par] = 4 * (li * W + g0 + gg);
+            }
+        }
+    }
+    __device__ __forceinline__ int piece_soff(int m, int W) const { return ROW ? m * 256 : m * (64 / NS) * W * 4; }
+    __device__ __forceinline__ bool valid(int m) const {
+        return ROW ? (m * 64 + li < lim) : (okg[m & 1] && m * (64 / NS) + li < lim);
+    }
+};
+
+// LDS-DMA of one channel plane slice into its image (FULL: npieces is the compile-time maximum)
 template <int NS, bool ROW, bool FULL>
-__device__ __forceinline__ void strip_dma_channel(const FBuf &src, float *dst, int soff, int lane, int npieces,
-                                                  int L, int W, int g0, int gvalid) {
+__device__ __forceinline__ void strip_dma_channel(const FBuf &src, float *dst, int soff, int npieces, int W,
+                                                  const StripLanes<NS, ROW> &sl) {
 #pragma unroll
     for (int m = 0; m < strip_pieces_c(NS); ++m)
-        if (FULL || m < npieces) {
-            const int off = strip_elem_offset<NS, ROW>(m, lane, L, W, g0, gvalid);
-            fbuf_load_to_lds(src, dst + m * 64, off < 0 ? 0 : off, soff);
-        }
+        if (FULL || m < npieces)
+            fbuf_load_to_lds(src, dst + m * 64, sl.valid(m) ? sl.vb[m & 1] : 0, soff + sl.piece_soff(m, W));
 }
 
 }  // namespace cca

@@ -20,9 +20,12 @@
 // Results go back through the SAME LDS image (each wavefront overwrites only its own strip's slots) and
 // leave the workgroup as coalesced tile stores mirroring the DMA pattern.  Exact fp32 throughout.
 //
-// The two branches of one output are combined without atomics: the column launch stores its partial
-// sum into ``out`` (EPI_STORE); the row launch then computes, per element and in the same thread that
-// re-reads it,  out = alpha * (row_sum + out) + resid   (EPI_FINAL), alpha = *gamma or 1.
+// The two branches of one output are combined without atomics, alpha = *gamma or 1:
+//   column launch (EPI_COL)   out = alpha * col_sum + resid      (resid optional)
+//   row launch    (EPI_ROW)   out = alpha * row_sum + out        (re-read by the thread that rewrites it)
+// The tile of ``resid`` / ``out`` a workgroup needs at the end of a chunk is fetched by LDS-DMA into a third
+// LDS image BEFORE the chunk's MFMAs, so its latency hides under them and costs no registers
+// (3 images x 16 channels x 849 floats = 163,008 B of the 163,840 B LDS at NS = 8).
 #pragma once
 #include "cca_common.hpp"
 
@@ -30,21 +33,25 @@ namespace cca {
 
 constexpr int M_MC = 16;                          // channels per chunk = one MFMA M tile
 constexpr int M_KS = kMaxStrip / 4;               // 25 k-steps
-constexpr int EPI_STORE = 0, EPI_FINAL = 1;
+constexpr int EPI_COL = 0, EPI_ROW = 1;
 // channel pitch of the LDS image: pieces * 64 + 17 (odd: see strip geometry in cca_common.hpp; >= NS*L + 3)
 __host__ __device__ constexpr int m_cp(int ns) { return strip_pieces_c(ns) * 64 + 17; }
-__host__ __device__ constexpr int m_lds_floats(int ns) { return 2 * M_MC * m_cp(ns); }    // two buffers
+__host__ __device__ constexpr int m_lds_floats(int ns) { return 3 * M_MC * m_cp(ns); }    // 2 feature buffers + addend
 
 // FULL: the strip needs all 25 k-steps and 7 n-tiles (97..100 long) -> no guards in the hot loop
 template <int NS, bool ROW, bool TRANS, int EPI, bool FULL>
 __device__ __forceinline__ void map_strip_body(float *lds, const float *__restrict__ T,
                                                const float *__restrict__ F, const float *__restrict__ resid,
                                                const float *__restrict__ gamma, float *out,
-                                               int C, int H, int W, int chunks_per_block) {
-    constexpr int CP = m_cp(NS), BUF = M_MC * CP, kBlock = kWave * NS;
+                                               int C, int H, int W, int chunks_per_block, int tiles, int nsplit) {
+    constexpr int CP = m_cp(NS), BUF = M_MC * CP, kBlock = kWave * NS, PIECES = strip_pieces_c(NS);
+    constexpr int CPW = M_MC / NS;                // channels per wave in the DMA / tile-store phases
     const Branch br = make_branch(ROW, H, W);
     const int L = br.L, HW = H * W, S = H + W;
-    const int b = blockIdx.z, g0 = blockIdx.x * NS;
+    // logical id -> (image, channel split, tile), tile fastest: neighbouring tiles share an XCD's L2
+    const int id = xcd_logical_id(blockIdx.x, gridDim.x);
+    const int b = id / (tiles * nsplit), rem = id - b * (tiles * nsplit);
+    const int split = rem / tiles, g0 = (rem - split * tiles) * NS;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
     const int g = g0 + wv;
     const bool active = g < br.G;
@@ -53,15 +60,20 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
     const int npieces = FULL ? strip_pieces_c(NS) : (NS * L + 63) / 64;     // FULL: L in 97..100
     const int gvalid = (br.G - g0 < NS) ? br.G - g0 : NS;
     const int nchunks = (C + M_MC - 1) / M_MC;
-    const int ch_begin = blockIdx.y * chunks_per_block;
+    const int ch_begin = split * chunks_per_block;
     const int ch_end = (ch_begin + chunks_per_block < nchunks) ? ch_begin + chunks_per_block : nchunks;
     const int ln = lane & 15, lk = lane >> 4;
 
+    StripLanes<NS, ROW> sl;
+    sl.init(lane, L, W, g0, gvalid);
+
     const FBuf Fb = make_fbuf(F + (size_t)b * C * HW, (size_t)C * HW * sizeof(float));
     const FBuf Ob = make_fbuf(out + (size_t)b * C * HW, (size_t)C * HW * sizeof(float));
-    const FBuf Rb = make_fbuf(resid ? resid + (size_t)b * C * HW : out, (size_t)C * HW * sizeof(float));
-    const bool has_resid = resid != nullptr;
-    const float alpha = (EPI == EPI_FINAL && gamma) ? gamma[0] : 1.f;
+    // the tensor added in the epilogue: the residual (column launch, optional) or the column partial (row launch)
+    const bool has_add = (EPI == EPI_ROW) || resid != nullptr;
+    const FBuf Ab = make_fbuf((EPI == EPI_ROW || !resid) ? out + (size_t)b * C * HW : resid + (size_t)b * C * HW,
+                              (size_t)C * HW * sizeof(float));
+    const float alpha = gamma ? gamma[0] : 1.f;
 
     // channels of a chunk are dealt round-robin to the NS waves, for the DMA and for the tile stores
     auto issue = [&](int ch, int buf) {
@@ -69,13 +81,13 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
         for (int pr = 0; pr < M_MC / NS; ++pr) {
             const int cc = wv + pr * NS, c = ch * M_MC + cc;
             float *dst = lds + buf * BUF + cc * CP;
-            if (c < C) strip_dma_channel<NS, ROW, FULL>(Fb, dst, c * HW * 4, lane, npieces, L, W, g0, gvalid);
+            if (c < C) strip_dma_channel<NS, ROW, FULL>(Fb, dst, c * HW * 4, npieces, W, sl);
             else for (int m = 0; m < npieces; ++m) CCA_LDS_ST(&dst[m * 64 + lane], 0.f);
         }
     };
 
     // the few slots between the last DMA piece and the pitch are read as K padding: make them true zeros
-    for (int idx = tid; idx < 2 * M_MC * (CP - npieces * 64); idx += kBlock) {
+    for (int idx = tid; idx < 2 * M_MC * (CP - npieces * 64); idx += kBlock) {   // (feature buffers only)
         const int rowi = idx / (CP - npieces * 64), col = npieces * 64 + idx % (CP - npieces * 64);
         CCA_LDS_ST(&lds[rowi * CP + col], 0.f);
     }
@@ -96,8 +108,12 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                 const int kidx = ks * 4 + lk, nidx = t * kTile + ln;
                 const int iq = TRANS ? kidx : nidx, j = TRANS ? nidx : kidx;
                 const bool ok = iq < L && j < L;
+#ifdef CCA_ABL_NOPROLOGUE
+                bf[ks][t] = ok ? 0.001f * (float)lane : 0.f;
+#else
                 const float v = fbuf_load(Tb, ok ? 4 * (iq * br.as_q + j) : 0, tsoff);
                 bf[ks][t] = ok ? v : 0.f;
+#endif
             }
     }
 
@@ -108,8 +124,18 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int buf = (ch - ch_begin) & 1;
         __syncthreads();                 // chunk ch landed (vmcnt drained); the other buffer's tile stores are done
+#ifndef CCA_ABL_NOLOAD
         if (ch + 1 < ch_end) issue(ch + 1, buf ^ 1);
+#endif
         float *img = lds + buf * BUF;
+        // fetch the addend tile of THIS chunk (lands under the MFMAs below; drained by the next barrier)
+        if (has_add) {
+#pragma unroll
+            for (int pr = 0; pr < CPW; ++pr) {
+                const int cc = wv + pr * NS, c = ch * M_MC + cc;
+                if (c < C) strip_dma_channel<NS, ROW, FULL>(Ab, lds + 2 * BUF + cc * CP, c * HW * 4, npieces, W, sl);
+            }
+        }
         if (active) {
             f32x4 acc[kMaxTiles];
 #pragma unroll
@@ -117,7 +143,11 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
             const float *ab = as + buf * BUF;
 #pragma unroll
             for (int ks = 0; ks < M_KS; ++ks)
+#ifdef CCA_ABL_NOMFMA
+                if (ks < 2) {
+#else
                 if (FULL || ks < nks) {
+#endif
                     const int koff = ROW ? ks * 4 : ks * 4 * NS + (wv ^ col_swizzle<NS>(ks * 4));
                     const float a = CCA_LDS_LD(ab + koff);
 #pragma unroll
@@ -146,14 +176,13 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
 #pragma unroll
                 for (int m = 0; m < strip_pieces_c(NS); ++m)
                     if (FULL || m < npieces) {
-                        const int off = strip_elem_offset<NS, ROW>(m, lane, L, W, g0, gvalid);
-                        const int voff = off < 0 ? kOobOffset : off;    // out-of-range lanes: load 0, store dropped
-                        float val = CCA_LDS_LD(&src[m * 64 + lane]);
-                        if (EPI == EPI_FINAL) {
-                            val = alpha * (val + fbuf_load(Ob, voff, soff));
-                            if (has_resid) val += fbuf_load(Rb, voff, soff);
-                        }
-                        fbuf_store(Ob, val, voff, soff);
+                        const int voff = sl.valid(m) ? sl.vb[m & 1] : kOobOffset;     // invalid lanes: store dropped
+                        float val = alpha * CCA_LDS_LD(&src[m * 64 + lane]);
+#ifdef CCA_ABL_NOSTORE
+                        if (val != 123.456f) continue;
+#endif
+                        if (has_add) val += CCA_LDS_LD(&lds[2 * BUF + cc * CP + m * 64 + lane]);
+                        fbuf_store(Ob, val, voff, soff + sl.piece_soff(m, W));
                     }
             }
         }
@@ -166,14 +195,14 @@ __global__ __launch_bounds__(kWave * NS, 2) void map_strip_kernel(const float *_
                                                                    const float *__restrict__ resid,
                                                                    const float *__restrict__ gamma,
                                                                    float *out, int C, int H, int W,
-                                                                   int chunks_per_block) {
+                                                                   int chunks_per_block, int tiles, int nsplit) {
     __shared__ float lds[m_lds_floats(NS)];
     CCA_LDS_REGISTER(lds);
     const int L = ROW ? W : H;
     if (L > (M_KS - 1) * 4)
-        map_strip_body<NS, ROW, TRANS, EPI, true>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block);
+        map_strip_body<NS, ROW, TRANS, EPI, true>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit);
     else
-        map_strip_body<NS, ROW, TRANS, EPI, false>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block);
+        map_strip_body<NS, ROW, TRANS, EPI, false>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit);
 }
 
 }  // namespace cca

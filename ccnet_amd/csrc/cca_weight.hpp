@@ -37,13 +37,13 @@ __host__ __device__ constexpr int w_lds_floats(int ns) { return 4 * w_op(ns); } 
 
 // FULL: the strip needs all 7x7 tiles (97..100 long) -> no per-tile guards in the hot loop
 template <int NS, bool ROW, bool MASK, bool FULL>
-__device__ __forceinline__ void weight_strip_body(float *lds, int tile, const float *__restrict__ X,
+__device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, const float *__restrict__ X,
                                                   const float *__restrict__ Y, float *__restrict__ T,
                                                   int Cx, int H, int W) {
     constexpr int CP = w_cp(NS, ROW), OP = w_op(NS);
     const Branch br = make_branch(ROW, H, W);
     const int L = br.L, HW = H * W, S = H + W;
-    const int b = blockIdx.y, g0 = tile * NS;
+    const int g0 = tile * NS;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
     const int g = g0 + wv;
     const bool active = g < br.G;
@@ -51,6 +51,9 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int tile, const fl
     const int npieces = FULL ? strip_pieces_c(NS) : (NS * L + 63) / 64;     // FULL: L in 97..100
     const int gvalid = (br.G - g0 < NS) ? br.G - g0 : NS;          // strips of this tile inside the image
 #define CCA_TILE_ON(t) (FULL || (t) < nt)
+
+    StripLanes<NS, ROW> sl;
+    sl.init(lane, L, W, g0, gvalid);
 
     const FBuf Xb = make_fbuf(X + (size_t)b * Cx * HW, (size_t)Cx * HW * sizeof(float));
     const FBuf Yb = make_fbuf(Y + (size_t)b * Cx * HW, (size_t)Cx * HW * sizeof(float));
@@ -66,7 +69,7 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int tile, const fl
             if (c < Cx) {
                 const FBuf &src = op ? Yb : Xb;
                 const int soff = c * HW * 4;
-                strip_dma_channel<NS, ROW, FULL>(src, dst, soff, lane, npieces, L, W, g0, gvalid);
+                strip_dma_channel<NS, ROW, FULL>(src, dst, soff, npieces, W, sl);
             } else {
                 for (int m = 0; m < npieces; ++m) CCA_LDS_ST(&dst[m * 64 + lane], 0.f);   // K padding must be 0
             }
@@ -132,24 +135,28 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int tile, const fl
 #undef CCA_TILE_ON
 }
 
-// One launch covers BOTH branches: workgroups [0, tiles_col) own column strips, the rest row strips.
+// One launch covers BOTH branches and all images: 1-D grid of B * (tiles_col + tiles_row) workgroups in
+// XCD-aware order, image-major, then column tiles, then row tiles.
 template <int NS, bool MASK>
 __global__ __launch_bounds__(kWave * NS, 2) void weight_strip_kernel(const float *__restrict__ X,
                                                                       const float *__restrict__ Y,
                                                                       float *__restrict__ T, int Cx, int H, int W,
-                                                                      int tiles_col) {
+                                                                      int tiles_col, int tiles_row) {
     __shared__ float lds[w_lds_floats(NS)];
     CCA_LDS_REGISTER(lds);
-    const bool row = (int)blockIdx.x >= tiles_col;
-    const int tile = row ? blockIdx.x - tiles_col : blockIdx.x;
+    const int per_image = tiles_col + tiles_row;
+    const int id = xcd_logical_id(blockIdx.x, gridDim.x);
+    const int b = id / per_image, t = id - b * per_image;
+    const bool row = t >= tiles_col;
+    const int tile = row ? t - tiles_col : t;
     const int L = row ? W : H;
     const bool full = L > (kMaxTiles - 1) * kTile;
     if (row) {
-        if (full) weight_strip_body<NS, true, MASK, true>(lds, tile, X, Y, T, Cx, H, W);
-        else      weight_strip_body<NS, true, MASK, false>(lds, tile, X, Y, T, Cx, H, W);
+        if (full) weight_strip_body<NS, true, MASK, true>(lds, b, tile, X, Y, T, Cx, H, W);
+        else      weight_strip_body<NS, true, MASK, false>(lds, b, tile, X, Y, T, Cx, H, W);
     } else {
-        if (full) weight_strip_body<NS, false, MASK, true>(lds, tile, X, Y, T, Cx, H, W);
-        else      weight_strip_body<NS, false, MASK, false>(lds, tile, X, Y, T, Cx, H, W);
+        if (full) weight_strip_body<NS, false, MASK, true>(lds, b, tile, X, Y, T, Cx, H, W);
+        else      weight_strip_body<NS, false, MASK, false>(lds, b, tile, X, Y, T, Cx, H, W);
     }
 }
 
