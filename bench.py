@@ -181,7 +181,7 @@ def roofline_object(wl, iters=20):
     """Time every (stage, branch) strip kernel alone and describe the slowest one."""
     B, C, H, W = wl.shape
     lib = wl.lib
-    rows = []
+    rows, stages = [], {}
     try:
         for name, (fn, kind, K, kname) in wl.stage_table().items():
             for mask, row in ((1, False), (2, True)):
@@ -192,8 +192,14 @@ def roofline_object(wl, iters=20):
                 nbytes, flops = kernel_accounting(kind, B, K, H, W, row)
                 rows.append({"kernel": f"{kname}<{'row' if row else 'col'}> {name}", "ms": ms,
                              "bytes": nbytes, "flops": flops})
+        lib.ccnet_cca_set_branch_mask(3)
+        for name, (fn, kind, K, kname) in wl.stage_table().items():      # both branches, as a step issues them
+            for _ in range(3):
+                lib.check(fn(), name)
+            stages[name] = time_region(lambda: lib.check(fn(), name), iters)
     finally:
         lib.ccnet_cca_set_branch_mask(3)
+    roofline_object.stages = stages
     dom = max(rows, key=lambda r: r["ms"])
     t_hbm = dom["bytes"] / (HBM_PEAK_GBS * 1e9)
     t_mfma = dom["flops"] / (F32_MFMA_PEAK_TF * 1e12)
@@ -339,6 +345,7 @@ def main():
         roof, rows = roofline_object(wl)
         out["roofline"] = roof
         out["kernels_ms"] = {r["kernel"]: round(r["ms"], 4) for r in rows}
+        out["stages_ms"] = {k: round(v, 4) for k, v in roofline_object.stages.items()}
         try:
             out["module_ms_per_step"] = round(module_level_ms(B, C, H, W, device), 4)
         except Exception as e:          # the metric does not depend on it

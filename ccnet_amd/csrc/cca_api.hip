@@ -80,7 +80,7 @@ int env_int(const char *name, int dflt) {
 // strips per workgroup of the strip kernels: 8 (512 threads) or 4 (256 threads, two workgroups per CU)
 int weight_strips() {
     static int v = 0;
-    if (!v) v = env_int("CCNET_CCA_WEIGHT_STRIPS", 4) == 8 ? 8 : 4;
+    if (!v) v = env_int("CCNET_CCA_WEIGHT_STRIPS", 8) == 4 ? 4 : 8;
     return v;
 }
 int map_strips() {
@@ -89,24 +89,44 @@ int map_strips() {
     return v;
 }
 
-int map_target_blocks() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("CCNET_CCA_MAP_TARGET_BLOCKS");
-        v = e ? atoi(e) : 512;
-        if (v < 1) v = 1;
+// number of CUs the channel split is balanced for (MI355X: 256)
+int num_cus() {
+    static int v = 0;
+    if (!v) {
+        v = env_int("CCNET_CCA_NUM_CUS", 0);
+#ifndef CCNET_EMU
+        if (v <= 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                v = prop.multiProcessorCount;
+        }
+#endif
+        if (v <= 0) v = 256;
     }
     return v;
 }
 
-// strips-per-image tiles and the channel split of the map kernels
+// Channel split of the map kernels.  A workgroup (one per CU: its LDS images fill the CU) pays a fixed
+// prologue (loading the stationary attention blocks, worth about kPrologueChunks chunks) and then
+// chunks_per_block chunks; the grid runs in ceil(workgroups / CUs) waves.  Pick the split that minimises
+// waves * (chunks_per_block + prologue).  CCNET_CCA_MAP_SPLIT overrides.
 void map_grid(int ns, int B, int C, int G, dim3 &grid, int &chunks_per_block, int &tiles, int &cs) {
     tiles = (G + ns - 1) / ns;
     const int nchunks = (C + cca::M_MC - 1) / cca::M_MC;
-    const int base = B * tiles;
-    cs = (map_target_blocks() + base - 1) / base;
-    if (cs < 1) cs = 1;
-    if (cs > nchunks) cs = nchunks;
+    const int base = B * tiles, cus = num_cus();
+    static const int forced = env_int("CCNET_CCA_MAP_SPLIT", 0);
+    static const double prologue = env_int("CCNET_CCA_MAP_PROLOGUE_X10", 30) / 10.0;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= nchunks; ++s) {
+        const int cpb = (nchunks + s - 1) / s;
+        const int real_s = (nchunks + cpb - 1) / cpb;
+        const int waves = (base * real_s + cus - 1) / cus;
+        const double cost = waves * (cpb + prologue);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = real_s; }
+    }
+    cs = (forced > 0) ? (forced < nchunks ? forced : nchunks) : best;
     chunks_per_block = (nchunks + cs - 1) / cs;
     cs = (nchunks + chunks_per_block - 1) / chunks_per_block;
     grid = dim3((unsigned)(tiles * cs * B));       // 1-D: the kernel decodes an XCD-aware logical id

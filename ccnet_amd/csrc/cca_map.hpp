@@ -36,7 +36,13 @@ constexpr int M_KS = kMaxStrip / 4;               // 25 k-steps
 constexpr int EPI_COL = 0, EPI_ROW = 1;
 // channel pitch of the LDS image: pieces * 64 + 17 (odd: see strip geometry in cca_common.hpp; >= NS*L + 3)
 __host__ __device__ constexpr int m_cp(int ns) { return strip_pieces_c(ns) * 64 + 17; }
-__host__ __device__ constexpr int m_lds_floats(int ns) { return 3 * M_MC * m_cp(ns); }    // 2 feature buffers + addend
+// prologue images of the attention blocks: 4 strips x 100 rows x pitch 102 (>= 100, == 2 mod 4: the
+// stride-pitch fragment reads of the non-transposed orientation are bank-conflict-free)
+constexpr int M_PP = kMaxStrip + 2, M_SIMG = kMaxStrip * M_PP, M_SPP = 4;
+// LDS: max(2 feature buffers + addend image, prologue images) = 40,800 floats = 163,200 B of 163,840 B
+__host__ __device__ constexpr int m_lds_floats(int ns) {
+    return 3 * M_MC * m_cp(ns) > M_SPP * M_SIMG ? 3 * M_MC * m_cp(ns) : M_SPP * M_SIMG;
+}
 
 // FULL: the strip needs all 25 k-steps and 7 n-tiles (97..100 long) -> no guards in the hot loop
 template <int NS, bool ROW, bool TRANS, int EPI, bool FULL>
@@ -86,36 +92,70 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
         }
     };
 
+    // ---- prologue: this wavefront's stationary attention block, as MFMA B fragments B[k][n] (k = contraction
+    // index, n = output position).  Reading the fragments straight from global memory is a 16-segment gather
+    // per instruction; instead the rows of the block (L contiguous floats each) are brought into LDS by
+    // coalesced LDS-DMA, four strips at a time (4 images of 100 rows x pitch 102 fill the LDS), and the fragments are read
+    // from there -- the same image serves both orientations.
+    float bf[M_KS][kMaxTiles];
+    {
+        constexpr int PP = M_PP, SIMG = M_SIMG, SPP = M_SPP;
+        const FBuf Tb = make_fbuf(T + (size_t)b * HW * S, (size_t)HW * S * sizeof(float));
+#pragma unroll
+        for (int ph = 0; ph < NS / SPP; ++ph) {
+            if (ph) __syncthreads();                      // previous phase's fragments are in registers
+            // rows are dealt round-robin to the NS waves
+            for (int s = 0; s < SPP; ++s) {
+                const int gs = g0 + ph * SPP + s;
+                if (gs >= br.G) continue;
+                float *img = lds + s * SIMG;
+                for (int iq = wv; iq < L; iq += NS) {
+                    const int soff = 4 * (iq * br.as_q + gs * br.as_g + br.a_off);
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        const int j = pc * 64 + lane;
+                        if (j < L) fbuf_load_to_lds(Tb, img + iq * PP + pc * 64, 4 * j, soff);
+                    }
+                }
+            }
+            __syncthreads();                              // images landed (vmcnt drained by the barrier)
+            if (wv / SPP == ph) {
+                const float *img = lds + (wv % SPP) * SIMG;
+#pragma unroll
+                for (int ks = 0; ks < M_KS; ++ks)
+#pragma unroll
+                    for (int t = 0; t < kMaxTiles; ++t) {
+                        const int kidx = ks * 4 + lk, nidx = t * kTile + ln;
+                        const int iq = TRANS ? kidx : nidx, j = TRANS ? nidx : kidx;
+                        const bool ok = active && iq < L && j < L;
+#ifdef CCA_ABL_NOPROLOGUE
+                        bf[ks][t] = ok ? 0.001f * (float)lane : 0.f;
+#else
+                        const float v = CCA_LDS_LD(&img[ok ? iq * PP + j : 0]);
+                        bf[ks][t] = ok ? v : 0.f;
+#endif
+                    }
+            }
+        }
+        __syncthreads();                                  // images consumed: the LDS becomes the chunk buffers
+    }
+#ifdef CCA_ABL_PROLOGUE_ONLY
+    {
+        float sum = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < M_KS; ++ks)
+#pragma unroll
+            for (int t = 0; t < kMaxTiles; ++t) sum += bf[ks][t];
+        if (sum != 123.456f) return;
+    }
+#endif
+
     // the few slots between the last DMA piece and the pitch are read as K padding: make them true zeros
     for (int idx = tid; idx < 2 * M_MC * (CP - npieces * 64); idx += kBlock) {   // (feature buffers only)
         const int rowi = idx / (CP - npieces * 64), col = npieces * 64 + idx % (CP - npieces * 64);
         CCA_LDS_ST(&lds[rowi * CP + col], 0.f);
     }
     if (ch_begin < ch_end) issue(ch_begin, 0);
-
-    // stationary attention block of this wavefront's strip, as MFMA B fragments:
-    //   B[k][n] with k = contraction index, n = output position.  Unconditional loads from clamped
-    //   addresses, zeroed by a select (no branch per load).
-    float bf[M_KS][kMaxTiles];
-    {
-        const int gc = active ? g : br.G - 1;
-        const FBuf Tb = make_fbuf(T + (size_t)b * HW * S, (size_t)HW * S * sizeof(float));
-        const int tsoff = 4 * (gc * br.as_g + br.a_off);                 // scalar
-#pragma unroll
-        for (int ks = 0; ks < M_KS; ++ks)
-#pragma unroll
-            for (int t = 0; t < kMaxTiles; ++t) {
-                const int kidx = ks * 4 + lk, nidx = t * kTile + ln;
-                const int iq = TRANS ? kidx : nidx, j = TRANS ? nidx : kidx;
-                const bool ok = iq < L && j < L;
-#ifdef CCA_ABL_NOPROLOGUE
-                bf[ks][t] = ok ? 0.001f * (float)lane : 0.f;
-#else
-                const float v = fbuf_load(Tb, ok ? 4 * (iq * br.as_q + j) : 0, tsoff);
-                bf[ks][t] = ok ? v : 0.f;
-#endif
-            }
-    }
 
     // A fragment: channel = l & 15 (pitch CP), contraction position k = 4 ks + (l >> 4)
     //   column image: k * NS + (strip ^ swz(k)), swz constant inside a k-step;  row image: strip * L + k

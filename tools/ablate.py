@@ -29,6 +29,10 @@ def main():
             d = res.setdefault(name, {})
             for row in rows:
                 d.setdefault(row["kernel"], []).append(row["ms"])
+            for k, v in bench.roofline_object.stages.items():
+                d.setdefault("STAGE " + k, []).append(v)
+            d.setdefault("STAGE forward", []).append(bench.time_region(wl.forward, 10))
+            d.setdefault("STAGE backward", []).append(bench.time_region(wl.backward, 10))
             d.setdefault("STEP fwd+bwd", []).append(step)
     names = [n for n, _ in libs]
     keys = list(res[names[0]].keys())
