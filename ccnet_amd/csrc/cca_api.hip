@@ -140,8 +140,14 @@ int launch_map_pair_ns(const float *T, const float *F, const float *resid, const
     int cpb, tiles, cs;
     if (g_branch_mask & CCNET_BRANCH_COL) {
         map_grid(NS, B, C, /*G=*/W, grid, cpb, tiles, cs);
-        CCA_LAUNCH((cca::map_strip_kernel<NS, false, TRANS, cca::EPI_COL>), grid, dim3(cca::kWave * NS), stream,
-                   T, F, resid, gamma, out, C, H, W, cpb, tiles, cs);
+        if (resid) {
+            if (TRANS) return fail(CCNET_E_BADFLAGS, "residual epilogue only exists for the forward aggregation");
+            CCA_LAUNCH((cca::map_strip_kernel<NS, false, false, cca::EPI_COL_RESID>), grid, dim3(cca::kWave * NS),
+                       stream, T, F, resid, gamma, out, C, H, W, cpb, tiles, cs);
+        } else {
+            CCA_LAUNCH((cca::map_strip_kernel<NS, false, TRANS, cca::EPI_COL>), grid, dim3(cca::kWave * NS), stream,
+                       T, F, resid, gamma, out, C, H, W, cpb, tiles, cs);
+        }
         if (int e = launch_status(what)) return e;
     }
     if (g_branch_mask & CCNET_BRANCH_ROW) {

@@ -122,6 +122,8 @@ __device__ inline void fbuf_load_to_lds(const FBuf &b, float *lds_wave_base, int
     lds_wave_base[emu::lane_id()] = fbuf_load(b, voff_bytes, soff_bytes);
 }
 
+__device__ inline void barrier_lds_only() { __syncthreads(); }
+
 #define CCA_LDS_REGISTER(arr) do { emu::lds_register((void *)(arr), sizeof(arr)); __syncthreads(); } while (0)
 #define CCA_LDS_LD(p) (emu::lds_note_read((const void *)(p), __LINE__), *(p))
 #define CCA_LDS_ST(p, v) do { emu::lds_note_write((const void *)(p), __LINE__); *(p) = (v); } while (0)
@@ -157,6 +159,15 @@ __device__ __forceinline__ void fbuf_store(const FBuf &b, float v, int voff_byte
 __device__ __forceinline__ void fbuf_load_to_lds(const FBuf &b, float *lds_wave_base, int voff_bytes, int soff_bytes) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void *)lds_wave_base, 4,
                                              voff_bytes, soff_bytes, 0, 0);
+}
+
+// Workgroup barrier that orders LDS traffic only: waits for this wave's LDS operations (lgkmcnt) but NOT for
+// its outstanding global stores / loads (vmcnt).  __syncthreads() drains vmcnt as well whenever an LDS-DMA
+// has been issued, which would stall every chunk on the acknowledgement of the tile stores.
+__device__ __forceinline__ void barrier_lds_only() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
 #define CCA_LDS_REGISTER(arr) do { } while (0)

@@ -21,7 +21,7 @@
 // leave the workgroup as coalesced tile stores mirroring the DMA pattern.  Exact fp32 throughout.
 //
 // The two branches of one output are combined without atomics, alpha = *gamma or 1:
-//   column launch (EPI_COL)   out = alpha * col_sum + resid      (resid optional)
+//   column launch (EPI_COL / EPI_COL_RESID)   out = alpha * col_sum [+ resid]
 //   row launch    (EPI_ROW)   out = alpha * row_sum + out        (re-read by the thread that rewrites it)
 // The tile of ``resid`` / ``out`` a workgroup needs at the end of a chunk is fetched by LDS-DMA into a third
 // LDS image BEFORE the chunk's MFMAs, so its latency hides under them and costs no registers
@@ -33,7 +33,7 @@ namespace cca {
 
 constexpr int M_MC = 16;                          // channels per chunk = one MFMA M tile
 constexpr int M_KS = kMaxStrip / 4;               // 25 k-steps
-constexpr int EPI_COL = 0, EPI_ROW = 1;
+constexpr int EPI_COL = 0, EPI_ROW = 1, EPI_COL_RESID = 2;    // column launch without / row launch / column launch with residual
 // channel pitch of the LDS image: pieces * 64 + 17 (odd: see strip geometry in cca_common.hpp; >= NS*L + 3)
 __host__ __device__ constexpr int m_cp(int ns) { return strip_pieces_c(ns) * 64 + 17; }
 // prologue images of the attention blocks: 4 strips x 100 rows x pitch 102 (>= 100, == 2 mod 4: the
@@ -76,9 +76,8 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
     const FBuf Fb = make_fbuf(F + (size_t)b * C * HW, (size_t)C * HW * sizeof(float));
     const FBuf Ob = make_fbuf(out + (size_t)b * C * HW, (size_t)C * HW * sizeof(float));
     // the tensor added in the epilogue: the residual (column launch, optional) or the column partial (row launch)
-    const bool has_add = (EPI == EPI_ROW) || resid != nullptr;
-    const FBuf Ab = make_fbuf((EPI == EPI_ROW || !resid) ? out + (size_t)b * C * HW : resid + (size_t)b * C * HW,
-                              (size_t)C * HW * sizeof(float));
+    constexpr bool has_add = EPI != EPI_COL;
+    const FBuf Ab = make_fbuf((EPI == EPI_COL_RESID ? resid : out) + (size_t)b * C * HW, (size_t)C * HW * sizeof(float));
     const float alpha = gamma ? gamma[0] : 1.f;
 
     // channels of a chunk are dealt round-robin to the NS waves, for the DMA and for the tile stores
@@ -87,8 +86,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
         for (int pr = 0; pr < M_MC / NS; ++pr) {
             const int cc = wv + pr * NS, c = ch * M_MC + cc;
             float *dst = lds + buf * BUF + cc * CP;
-            if (c < C) strip_dma_channel<NS, ROW, FULL>(Fb, dst, c * HW * 4, npieces, W, sl);
-            else for (int m = 0; m < npieces; ++m) CCA_LDS_ST(&dst[m * 64 + lane], 0.f);
+            strip_dma_channel<NS, ROW, FULL>(Fb, dst, (c < C ? c : C - 1) * HW * 4, npieces, W, sl);
         }
     };
 
@@ -156,33 +154,46 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
         CCA_LDS_ST(&lds[rowi * CP + col], 0.f);
     }
     if (ch_begin < ch_end) issue(ch_begin, 0);
+    __syncthreads();                     // first chunk landed (the compiler drains vmcnt before the barrier)
 
     // A fragment: channel = l & 15 (pitch CP), contraction position k = 4 ks + (l >> 4)
     //   column image: k * NS + (strip ^ swz(k)), swz constant inside a k-step;  row image: strip * L + k
     const float *as = lds + ln * CP + (ROW ? wv * L + lk : lk * NS);
 
+    // DMA work of one chunk iteration, cut into single pieces so that it can be interleaved with the MFMAs
+    // (a piece costs ~60-100 issue cycles; 52 of them in front of the MFMAs would add ~40 % to a chunk):
+    //   q in [0, QF)        feature chunk ch+1 -> the other buffer   (channel pr of this wave, piece m)
+    //   q in [QF, QF + QA)  addend tile of chunk ch -> third image
+    constexpr int QF = CPW * PIECES, QA = CPW * PIECES, QT = QF + QA;
+    // Branch-free in the FULL path: channels beyond C are clamped (they are output rows that are never
+    // stored), and when there is no next chunk the current one is simply fetched again into the idle buffer.
+    auto dma_piece = [&](int q, int ch, int chn, int buf) {
+        const bool feat = q < QF;
+        const int rem = feat ? q : q - QF;
+        const int pr = rem / PIECES, m = rem % PIECES;
+        if (!(FULL || m < npieces)) return;
+        if (!feat && !has_add) return;
+        const int cc = wv + pr * NS;
+        const int c = (feat ? chn : ch) * M_MC + cc;
+        float *dst = lds + (feat ? (buf ^ 1) : 2) * BUF + cc * CP + m * 64;
+        fbuf_load_to_lds(feat ? Fb : Ab, dst, sl.valid(m) ? sl.vb[m & 1] : 0,
+                         (c < C ? c : C - 1) * HW * 4 + sl.piece_soff(m, W));
+    };
+
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int buf = (ch - ch_begin) & 1;
-        __syncthreads();                 // chunk ch landed (vmcnt drained); the other buffer's tile stores are done
-#ifndef CCA_ABL_NOLOAD
-        if (ch + 1 < ch_end) issue(ch + 1, buf ^ 1);
-#endif
+        const int chn = (ch + 1 < ch_end) ? ch + 1 : ch;
         float *img = lds + buf * BUF;
-        // fetch the addend tile of THIS chunk (lands under the MFMAs below; drained by the next barrier)
-        if (has_add) {
-#pragma unroll
-            for (int pr = 0; pr < CPW; ++pr) {
-                const int cc = wv + pr * NS, c = ch * M_MC + cc;
-                if (c < C) strip_dma_channel<NS, ROW, FULL>(Ab, lds + 2 * BUF + cc * CP, c * HW * 4, npieces, W, sl);
-            }
-        }
         if (active) {
             f32x4 acc[kMaxTiles];
 #pragma unroll
             for (int t = 0; t < kMaxTiles; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float *ab = as + buf * BUF;
 #pragma unroll
-            for (int ks = 0; ks < M_KS; ++ks)
+            for (int ks = 0; ks < M_KS; ++ks) {
+                // this k-step's share of the DMA pieces: next feature chunk + this chunk's addend tile
+#pragma unroll
+                for (int q = ks * QT / M_KS; q < (ks + 1) * QT / M_KS; ++q) dma_piece(q, ch, chn, buf);
 #ifdef CCA_ABL_NOMFMA
                 if (ks < 2) {
 #else
@@ -194,6 +205,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                     for (int t = 0; t < kMaxTiles; ++t)
                         if (FULL || t < nt) acc[t] = mfma_16x16x4(a, bf[ks][t], acc[t]);
                 }
+            }
             // D[m = channel 4*(l>>4)+r][n = position t*16 + (l&15)] -> this strip's slots of the image
 #pragma unroll
             for (int t = 0; t < kMaxTiles; ++t)
@@ -205,8 +217,11 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                         for (int r = 0; r < 4; ++r) CCA_LDS_ST(&d[r * CP], acc[t][r]);
                     }
                 }
+        } else {
+#pragma unroll
+            for (int q = 0; q < QT; ++q) dma_piece(q, ch, chn, buf);   // strips outside the image still own channels
         }
-        __syncthreads();                 // the whole 16-channel output tile is in the image
+        __syncthreads();                 // output tile complete; addend tile and chunk ch+1 landed (vmcnt drained)
 #pragma unroll
         for (int pr = 0; pr < M_MC / NS; ++pr) {
             const int cc = wv + pr * NS, c = ch * M_MC + cc;
@@ -226,6 +241,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                     }
             }
         }
+        barrier_lds_only();              // images free for the next iteration; the tile stores stay in flight
     }
 }
 
