@@ -178,22 +178,32 @@ def time_region(fn, iters):
 
 
 def roofline_object(wl, iters=20):
-    """Time every (stage, branch) strip kernel alone and describe the slowest one."""
+    """Time every strip-kernel launch of a step alone and describe the slowest one.
+
+    A step issues the weight kernel ONCE for both branches (column and row workgroups of one launch) and
+    the map kernel once per branch, so those are the units timed here (branch mask 3 for the weight
+    stages, 1 / 2 for the map stages); the single-branch weight timings are kept as extra rows."""
     B, C, H, W = wl.shape
     lib = wl.lib
     rows, stages = [], {}
     try:
         for name, (fn, kind, K, kname) in wl.stage_table().items():
-            for mask, row in ((1, False), (2, True)):
+            masks = ((3, None),) if kind == "weight" else ((1, False), (2, True))
+            for mask, row in masks:
                 lib.ccnet_cca_set_branch_mask(mask)
                 for _ in range(3):
                     lib.check(fn(), name)
                 ms = time_region(lambda: lib.check(fn(), name), iters)
-                nbytes, flops = kernel_accounting(kind, B, K, H, W, row)
-                rows.append({"kernel": f"{kname}<{'row' if row else 'col'}> {name}", "ms": ms,
-                             "bytes": nbytes, "flops": flops})
+                if row is None:                 # both branches: inputs once, the whole attention tensor out
+                    feat, att = 4 * B * K * H * W, 4 * B * H * W * (H + W)
+                    nbytes, flops = 2 * feat + att, 2 * B * H * W * (H + W) * K
+                    label = f"{kname} {name}"
+                else:
+                    nbytes, flops = kernel_accounting(kind, B, K, H, W, row)
+                    label = f"{kname}<{'row' if row else 'col'}> {name}"
+                rows.append({"kernel": label, "ms": ms, "bytes": nbytes, "flops": flops})
         lib.ccnet_cca_set_branch_mask(3)
-        for name, (fn, kind, K, kname) in wl.stage_table().items():      # both branches, as a step issues them
+        for name, (fn, kind, K, kname) in wl.stage_table().items():      # whole stages, as a step issues them
             for _ in range(3):
                 lib.check(fn(), name)
             stages[name] = time_region(lambda: lib.check(fn(), name), iters)
@@ -208,7 +218,7 @@ def roofline_object(wl, iters=20):
     if os.path.exists(tpath):
         try:
             with open(tpath) as f:
-                traffic = json.load(f).get(dom["kernel"].split(" ")[0])
+                traffic = json.load(f).get(dom["kernel"])
         except Exception:
             traffic = None
     if t_mfma >= t_hbm:
