@@ -165,6 +165,20 @@ class CoreWorkload:
                                            "map", C, "map_strip_kernel"),
         }
 
+    def extra_stages(self):
+        """Stages that are not single strip-kernel launches (timed as stages only)."""
+        B, C, H, W = self.shape
+        L, s, Cq = self.lib, self.stream, C // 8
+        P = lambda t: t.data_ptr()  # noqa: E731
+        return {
+            "ca_backward[dq,dk]": lambda: L.ccnet_ca_backward_f32(P(self.scratch), P(self.q), P(self.k), P(self.dq),
+                                                                  P(self.dk), B, Cq, H, W, s()),
+            "softmax_forward": lambda: L.ccnet_ca_softmax_forward_f32(P(self.scratch), P(self.A), B, H, W, s()),
+            "softmax_backward+dgamma": lambda: L.ccnet_ca_softmax_backward_f32(P(self.A), P(self.scratch), P(self.gamma),
+                                                                               P(self.scratch), P(self.dgamma),
+                                                                               P(self.ws), self.ws_bytes, B, H, W, s()),
+        }
+
 
 def time_region(fn, iters):
     """HIP events on torch's current stream (the stream the C ABI launches on)."""
@@ -207,6 +221,11 @@ def roofline_object(wl, iters=20):
             for _ in range(3):
                 lib.check(fn(), name)
             stages[name] = time_region(lambda: lib.check(fn(), name), iters)
+        for name, fn in wl.extra_stages().items():
+            for _ in range(3):
+                lib.check(fn(), name)
+            stages[name] = time_region(lambda: lib.check(fn(), name), iters)
+        wl.forward()                                  # leave A / scratch consistent again
     finally:
         lib.ccnet_cca_set_branch_mask(3)
     roofline_object.stages = stages

@@ -22,6 +22,8 @@ CCNET_CA_SOFTMAX = 1
 CCNET_IMPL_AUTO = 0
 CCNET_IMPL_DIRECT = 1
 CCNET_IMPL_MFMA = 2
+CCNET_PRECISION_F32 = 0
+CCNET_PRECISION_BF16X3 = 1
 
 _P = c_void_p  # every tensor argument is a raw device pointer
 
@@ -33,6 +35,7 @@ _PROTOTYPES = {
     "ccnet_cca_set_impl": (c_int, [c_int]),
     "ccnet_cca_get_impl": (c_int, []),
     "ccnet_cca_set_branch_mask": (c_int, [c_int]),
+    "ccnet_cca_set_precision": (c_int, [c_int]),
     "ccnet_ca_forward_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ccnet_ca_backward_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ccnet_ca_softmax_forward_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),

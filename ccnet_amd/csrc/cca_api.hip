@@ -83,6 +83,17 @@ int weight_strips() {
     if (!v) v = env_int("CCNET_CCA_WEIGHT_STRIPS", 8) == 4 ? 4 : 8;
     return v;
 }
+// arithmetic of the map kernels: 0 = exact f32 MFMA (default), 1 = split-bf16 x3 on the bf16 matrix pipe
+// (strips 97..100 long, NS = 8).  Measured on MI355X the map kernels are HBM-bound either way (the row launch
+// moves 491 MB at 4.2 TB/s), so the 5x cheaper MFMA phase buys < 8 % and the exact path stays the default.
+// CCNET_CCA_MAP_BF16=1 or ccnet_cca_set_precision(CCNET_PRECISION_BF16X3) select the split path.
+int g_map_bf16 = -1;
+bool map_bf16(int H, int W) {
+    if (g_map_bf16 < 0) g_map_bf16 = env_int("CCNET_CCA_MAP_BF16", 0) ? 1 : 0;
+    const int lo = H < W ? H : W, hi = H < W ? W : H;
+    return g_map_bf16 == 1 && lo > 96 && hi <= cca::kMaxStrip;
+}
+
 int map_strips() {
     static int v = 0;
     if (!v) v = env_int("CCNET_CCA_MAP_STRIPS", 8) == 4 ? 4 : 8;
@@ -133,7 +144,7 @@ void map_grid(int ns, int B, int C, int G, dim3 &grid, int &chunks_per_block, in
 }
 
 // out = alpha * (column sums + row sums) + resid, both branches, strip kernels
-template <int NS, bool TRANS>
+template <int NS, bool TRANS, bool BF>
 int launch_map_pair_ns(const float *T, const float *F, const float *resid, const float *gamma, float *out,
                        int B, int C, int H, int W, ccnet_stream_t stream, const char *what) {
     dim3 grid;
@@ -142,17 +153,17 @@ int launch_map_pair_ns(const float *T, const float *F, const float *resid, const
         map_grid(NS, B, C, /*G=*/W, grid, cpb, tiles, cs);
         if (resid) {
             if (TRANS) return fail(CCNET_E_BADFLAGS, "residual epilogue only exists for the forward aggregation");
-            CCA_LAUNCH((cca::map_strip_kernel<NS, false, false, cca::EPI_COL_RESID>), grid, dim3(cca::kWave * NS),
+            CCA_LAUNCH((cca::map_strip_kernel<NS, false, false, cca::EPI_COL_RESID, BF>), grid, dim3(cca::kWave * NS),
                        stream, T, F, resid, gamma, out, C, H, W, cpb, tiles, cs);
         } else {
-            CCA_LAUNCH((cca::map_strip_kernel<NS, false, TRANS, cca::EPI_COL>), grid, dim3(cca::kWave * NS), stream,
+            CCA_LAUNCH((cca::map_strip_kernel<NS, false, TRANS, cca::EPI_COL, BF>), grid, dim3(cca::kWave * NS), stream,
                        T, F, resid, gamma, out, C, H, W, cpb, tiles, cs);
         }
         if (int e = launch_status(what)) return e;
     }
     if (g_branch_mask & CCNET_BRANCH_ROW) {
         map_grid(NS, B, C, /*G=*/H, grid, cpb, tiles, cs);
-        CCA_LAUNCH((cca::map_strip_kernel<NS, true, TRANS, cca::EPI_ROW>), grid, dim3(cca::kWave * NS), stream,
+        CCA_LAUNCH((cca::map_strip_kernel<NS, true, TRANS, cca::EPI_ROW, BF>), grid, dim3(cca::kWave * NS), stream,
                    T, F, (const float *)nullptr, gamma, out, C, H, W, cpb, tiles, cs);
         return launch_status(what);
     }
@@ -162,8 +173,9 @@ int launch_map_pair_ns(const float *T, const float *F, const float *resid, const
 template <bool TRANS>
 int launch_map_pair(const float *T, const float *F, const float *resid, const float *gamma, float *out,
                     int B, int C, int H, int W, ccnet_stream_t stream, const char *what) {
-    return map_strips() == 4 ? launch_map_pair_ns<4, TRANS>(T, F, resid, gamma, out, B, C, H, W, stream, what)
-                             : launch_map_pair_ns<8, TRANS>(T, F, resid, gamma, out, B, C, H, W, stream, what);
+    if (map_strips() == 4) return launch_map_pair_ns<4, TRANS, false>(T, F, resid, gamma, out, B, C, H, W, stream, what);
+    if (map_bf16(H, W)) return launch_map_pair_ns<8, TRANS, true>(T, F, resid, gamma, out, B, C, H, W, stream, what);
+    return launch_map_pair_ns<8, TRANS, false>(T, F, resid, gamma, out, B, C, H, W, stream, what);
 }
 
 // both branches in ONE launch (column workgroups first, then row workgroups)
@@ -206,6 +218,11 @@ int ccnet_cca_set_impl(int impl) {
     return prev;
 }
 int ccnet_cca_get_impl(void) { return g_impl; }
+int ccnet_cca_set_precision(int precision) {
+    const int prev = g_map_bf16 < 0 ? (env_int("CCNET_CCA_MAP_BF16", 0) ? 1 : 0) : g_map_bf16;
+    if (precision == CCNET_PRECISION_F32 || precision == CCNET_PRECISION_BF16X3) g_map_bf16 = precision;
+    return prev;
+}
 int ccnet_cca_set_branch_mask(int mask) {
     const int prev = g_branch_mask;
     if (mask >= 1 && mask <= 3) g_branch_mask = mask;
@@ -360,7 +377,14 @@ int ccnet_cca_mfma_selftest(float *scratch, ccnet_stream_t stream) {
     if (hipMemcpyAsync(&bad, scratch, sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
         hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
         return fail(1, "mfma_selftest: copy-back failed");
-    if (bad != 0.f) return fail(1000 + (int)bad, "mfma_selftest: fragment layout mismatch");
+    if (bad != 0.f) return fail(1000 + (int)bad, "mfma_selftest: f32 fragment layout mismatch");
+    CCA_LAUNCH(cca::mfma_bf16_selftest_kernel, dim3(1), dim3(cca::kWave), stream, scratch);
+    if (int e = launch_status("mfma_bf16_selftest")) return e;
+    bad = -1.f;
+    if (hipMemcpyAsync(&bad, scratch, sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+        return fail(1, "mfma_selftest: copy-back failed");
+    if (bad != 0.f) return fail(2000 + (int)bad, "mfma_selftest: bf16 fragment layout mismatch");
     return 0;
 }
 

@@ -21,6 +21,7 @@
 namespace cca {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // 8 packed bf16 (element e in dword e/2, low half = even e)
 
 constexpr int kWave = 64;                 // CDNA wavefront
 // Strip kernels are templated on NS = strips per workgroup (one wavefront per strip, NS adjacent w or h):
@@ -97,6 +98,49 @@ __device__ inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
 
 __device__ inline int uniform(int v) { return v; }
 
+// round-to-nearest-even fp32 -> bf16 (as the device's v_cvt_pk_bf16_f32), two values into one dword
+__device__ inline uint32_t emu_bf16_rne(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;     // NaN stays NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ inline uint32_t cvt_pk_bf16(float lo_elem, float hi_elem) {
+    return emu_bf16_rne(lo_elem) | (emu_bf16_rne(hi_elem) << 16);
+}
+__device__ inline float emu_bf16_to_f32(uint32_t h) {
+    uint32_t u = h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// D = A(16x32) * B(32x16) + C for v_mfma_f32_16x16x32_bf16:
+//   a: lane l holds A[i = l & 15][k = 8 (l >> 4) + e], e = 0..7;   b: lane l holds B[k = 8 (l >> 4) + e][j = l & 15]
+//   c/d as the f32 16x16 forms.  Products are exact in fp32; the emulator sums them in double.
+__device__ inline f32x4 mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
+    uint32_t mine[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    const unsigned char *s = emu::wave_exchange_bytes(mine, 32);
+    const int l = emu::lane_id(), col = l & 15, rg = l >> 4;
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * rg + r;
+        double acc = c[r];
+        for (int kg = 0; kg < 4; ++kg) {
+            uint32_t wa[8], wb[8];
+            memcpy(wa, s + size_t(kg * 16 + row) * 32, 32);
+            memcpy(wb, s + size_t(kg * 16 + col) * 32, 32);
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t ha = (wa[e / 2] >> (16 * (e & 1))) & 0xffffu;
+                const uint32_t hb = (wb[4 + e / 2] >> (16 * (e & 1))) & 0xffffu;
+                acc += (double)emu_bf16_to_f32(ha) * (double)emu_bf16_to_f32(hb);
+            }
+        }
+        d[r] = (float)acc;
+    }
+    emu::stats().mfma++;
+    return d;
+}
+
 // Read-only view of one image's worth of a tensor, addressed by (per-lane byte offset) +
 // (wave-uniform byte offset).  Out-of-range reads return 0 like a raw buffer resource.
 struct FBuf {
@@ -134,6 +178,17 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, kWave); }
 __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// v_cvt_pk_bf16_f32: two fp32 -> two bf16 (round to nearest even) in one dword, first operand in the low half
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo_elem, float hi_elem) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo_elem, hi_elem}, bf16x2_t));
+}
+__device__ __forceinline__ f32x4 mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
 // tell the compiler a value is wave-uniform (it is: derived from the wave id) so it lives in SGPRs
@@ -186,6 +241,24 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int m = kWave / 2; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));
     return v;
+}
+
+// Split-bf16: x = hi + lo + O(2^-17 |x|) with hi = bf16_rne(x), lo = bf16_rne(x - hi).  A product a*b is then
+// replaced by a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix pipe (16x the fp32 MFMA rate, 3 products:
+// ~5x net), fp32 accumulate; the dropped terms are O(2^-16 |a b|)  (SURVEY.md section 0, fact 5).
+struct BfSplit {
+    u32x4 hi, lo;
+};
+__device__ __forceinline__ BfSplit bf16_split8(const float (&x)[8]) {
+    BfSplit s;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t h = cvt_pk_bf16(x[2 * p], x[2 * p + 1]);
+        const float h0 = __builtin_bit_cast(float, h << 16), h1 = __builtin_bit_cast(float, h & 0xffff0000u);
+        s.hi[p] = h;
+        s.lo[p] = cvt_pk_bf16(x[2 * p] - h0, x[2 * p + 1] - h1);
+    }
+    return s;
 }
 
 // XCD-aware workgroup order.  The dispatcher places workgroup L on XCD L % 8, each with a private 4 MiB L2

@@ -100,4 +100,28 @@ __global__ __launch_bounds__(kWave) void mfma_selftest_kernel(float *result) {
     if (l == 0) result[0] = bad;
 }
 
+// Same for v_mfma_f32_16x16x32_bf16 (A[i][k], B[k][j] with k = 8 (l >> 4) + e).  Small integers: exact in bf16.
+__global__ __launch_bounds__(kWave) void mfma_bf16_selftest_kernel(float *result) {
+    const int l = lane_id();
+    float av[8], bv[8];
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * (l >> 4) + e;
+        av[e] = (float)(1 + (l & 15) + 2 * (k % 5));            // A[i][k]
+        bv[e] = (float)(3 + 2 * k - (l & 15));                  // B[k][j]
+    }
+    const BfSplit a = bf16_split8(av), b = bf16_split8(bv);
+    f32x4 d = mfma_bf16_16x16x32(a.hi, b.hi, f32x4{0.f, 0.f, 0.f, 0.f});
+    float bad = 0.f;
+    for (int e = 0; e < 4; ++e)
+        if (a.lo[e] != 0u || b.lo[e] != 0u) bad += 100.f;       // small integers must split with a zero low part
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (l >> 4) + r, col = l & 15;
+        float ref = 0.f;
+        for (int k = 0; k < 32; ++k) ref += (float)(1 + row + 2 * (k % 5)) * (float)(3 + 2 * k - col);
+        if (d[r] != ref) bad += 1.f;
+    }
+    bad = wave_sum(bad);
+    if (l == 0) result[0] = bad;
+}
+
 }  // namespace cca

@@ -33,6 +33,7 @@ namespace cca {
 
 constexpr int M_MC = 16;                          // channels per chunk = one MFMA M tile
 constexpr int M_KS = kMaxStrip / 4;               // 25 k-steps
+constexpr int M_BKS = 3;                          // bf16 path: 3 k-steps of 32 cover k < 96
 constexpr int EPI_COL = 0, EPI_ROW = 1, EPI_COL_RESID = 2;    // column launch without / row launch / column launch with residual
 // channel pitch of the LDS image: pieces * 64 + 17 (odd: see strip geometry in cca_common.hpp; >= NS*L + 3)
 __host__ __device__ constexpr int m_cp(int ns) { return strip_pieces_c(ns) * 64 + 17; }
@@ -45,7 +46,9 @@ __host__ __device__ constexpr int m_lds_floats(int ns) {
 }
 
 // FULL: the strip needs all 25 k-steps and 7 n-tiles (97..100 long) -> no guards in the hot loop
-template <int NS, bool ROW, bool TRANS, int EPI, bool FULL>
+// BF: split-bf16 x3 on v_mfma_f32_16x16x32_bf16 for k < 96 (+ one exact f32 k-step for k = 96..99);
+//     only instantiated together with FULL (strips 97..100 long)
+template <int NS, bool ROW, bool TRANS, int EPI, bool FULL, bool BF>
 __device__ __forceinline__ void map_strip_body(float *lds, const float *__restrict__ T,
                                                const float *__restrict__ F, const float *__restrict__ resid,
                                                const float *__restrict__ gamma, float *out,
@@ -95,7 +98,9 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
     // per instruction; instead the rows of the block (L contiguous floats each) are brought into LDS by
     // coalesced LDS-DMA, four strips at a time (4 images of 100 rows x pitch 102 fill the LDS), and the fragments are read
     // from there -- the same image serves both orientations.
-    float bf[M_KS][kMaxTiles];
+    float bf[BF ? 1 : M_KS][kMaxTiles];          // f32 path: 25 k-steps of 4
+    u32x4 bh[BF ? M_BKS : 1][kMaxTiles], bl[BF ? M_BKS : 1][kMaxTiles];   // bf16 path: 3 k-steps of 32, hi / lo
+    float btail[kMaxTiles];                      // bf16 path: exact f32 fragments of k = 96..99
     {
         constexpr int PP = M_PP, SIMG = M_SIMG, SPP = M_SPP;
         const FBuf Tb = make_fbuf(T + (size_t)b * HW * S, (size_t)HW * S * sizeof(float));
@@ -119,20 +124,43 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
             __syncthreads();                              // images landed (vmcnt drained by the barrier)
             if (wv / SPP == ph) {
                 const float *img = lds + (wv % SPP) * SIMG;
+                if constexpr (BF) {
 #pragma unroll
-                for (int ks = 0; ks < M_KS; ++ks)
+                    for (int ks = 0; ks < M_BKS; ++ks)
 #pragma unroll
-                    for (int t = 0; t < kMaxTiles; ++t) {
-                        const int kidx = ks * 4 + lk, nidx = t * kTile + ln;
-                        const int iq = TRANS ? kidx : nidx, j = TRANS ? nidx : kidx;
-                        const bool ok = active && iq < L && j < L;
-#ifdef CCA_ABL_NOPROLOGUE
-                        bf[ks][t] = ok ? 0.001f * (float)lane : 0.f;
-#else
-                        const float v = CCA_LDS_LD(&img[ok ? iq * PP + j : 0]);
-                        bf[ks][t] = ok ? v : 0.f;
-#endif
+                        for (int t = 0; t < kMaxTiles; ++t) {
+                            const int nidx = t * kTile + ln;
+                            float x[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const int kidx = ks * 32 + lk * 8 + e;                     // < 96 <= L
+                                const bool ok = active && nidx < L;
+                                const float v = CCA_LDS_LD(&img[ok ? (TRANS ? kidx * PP + nidx : nidx * PP + kidx) : 0]);
+                                x[e] = ok ? v : 0.f;
+                            }
+                            const BfSplit sp = bf16_split8(x);
+                            bh[ks][t] = sp.hi;
+                            bl[ks][t] = sp.lo;
+                        }
+#pragma unroll
+                    for (int t = 0; t < kMaxTiles; ++t) {                                   // exact f32 tail k = 96..99
+                        const int kidx = 96 + lk, nidx = t * kTile + ln;
+                        const bool ok = active && kidx < L && nidx < L;
+                        const float v = CCA_LDS_LD(&img[ok ? (TRANS ? kidx * PP + nidx : nidx * PP + kidx) : 0]);
+                        btail[t] = ok ? v : 0.f;
                     }
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < M_KS; ++ks)
+#pragma unroll
+                        for (int t = 0; t < kMaxTiles; ++t) {
+                            const int kidx = ks * 4 + lk, nidx = t * kTile + ln;
+                            const int iq = TRANS ? kidx : nidx, j = TRANS ? nidx : kidx;
+                            const bool ok = active && iq < L && j < L;
+                            const float v = CCA_LDS_LD(&img[ok ? iq * PP + j : 0]);
+                            bf[ks][t] = ok ? v : 0.f;
+                        }
+                }
             }
         }
         __syncthreads();                                  // images consumed: the LDS becomes the chunk buffers
@@ -143,7 +171,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
 #pragma unroll
         for (int ks = 0; ks < M_KS; ++ks)
 #pragma unroll
-            for (int t = 0; t < kMaxTiles; ++t) sum += bf[ks][t];
+            for (int t = 0; t < kMaxTiles; ++t) sum += bf[BF ? 0 : ks][t];
         if (sum != 123.456f) return;
     }
 #endif
@@ -189,6 +217,40 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
 #pragma unroll
             for (int t = 0; t < kMaxTiles; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float *ab = as + buf * BUF;
+            if constexpr (BF) {
+                // per-lane strip slot of the column image for the two halves of an 8-element k group
+                const int sw0 = wv ^ col_swizzle<NS>(8 * lk), sw1 = wv ^ col_swizzle<NS>(8 * lk + 4);
+                const float *abf = lds + buf * BUF + ln * CP + (ROW ? wv * L + 8 * lk : 8 * lk * NS);
+                constexpr int SLOTS = M_BKS * kMaxTiles + kMaxTiles;        // 28 interleave slots
+#pragma unroll
+                for (int ks = 0; ks < M_BKS; ++ks) {
+                    float x[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        x[e] = CCA_LDS_LD(abf + (ROW ? ks * 32 + e : (ks * 32 + e) * NS + (e < 4 ? sw0 : sw1)));
+                    const BfSplit sp = bf16_split8(x);
+#pragma unroll
+                    for (int t = 0; t < kMaxTiles; ++t) {
+                        const int sidx = ks * kMaxTiles + t;
+#pragma unroll
+                        for (int q = sidx * QT / SLOTS; q < (sidx + 1) * QT / SLOTS; ++q) dma_piece(q, ch, chn, buf);
+                        acc[t] = mfma_bf16_16x16x32(sp.hi, bh[ks][t], acc[t]);
+                        acc[t] = mfma_bf16_16x16x32(sp.hi, bl[ks][t], acc[t]);
+                        acc[t] = mfma_bf16_16x16x32(sp.lo, bh[ks][t], acc[t]);
+                    }
+                }
+                {
+                    const int koff = ROW ? 96 : 96 * NS + (wv ^ col_swizzle<NS>(96));
+                    const float a = CCA_LDS_LD(ab + koff);
+#pragma unroll
+                    for (int t = 0; t < kMaxTiles; ++t) {
+                        const int sidx = M_BKS * kMaxTiles + t;
+#pragma unroll
+                        for (int q = sidx * QT / SLOTS; q < (sidx + 1) * QT / SLOTS; ++q) dma_piece(q, ch, chn, buf);
+                        acc[t] = mfma_16x16x4(a, btail[t], acc[t]);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int ks = 0; ks < M_KS; ++ks) {
                 // this k-step's share of the DMA pieces: next feature chunk + this chunk's addend tile
@@ -205,6 +267,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                     for (int t = 0; t < kMaxTiles; ++t)
                         if (FULL || t < nt) acc[t] = mfma_16x16x4(a, bf[ks][t], acc[t]);
                 }
+            }
             }
             // D[m = channel 4*(l>>4)+r][n = position t*16 + (l&15)] -> this strip's slots of the image
 #pragma unroll
@@ -245,7 +308,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
     }
 }
 
-template <int NS, bool ROW, bool TRANS, int EPI>
+template <int NS, bool ROW, bool TRANS, int EPI, bool BF>
 __global__ __launch_bounds__(kWave * NS, 2) void map_strip_kernel(const float *__restrict__ T,
                                                                    const float *__restrict__ F,
                                                                    const float *__restrict__ resid,
@@ -255,10 +318,14 @@ __global__ __launch_bounds__(kWave * NS, 2) void map_strip_kernel(const float *_
     __shared__ float lds[m_lds_floats(NS)];
     CCA_LDS_REGISTER(lds);
     const int L = ROW ? W : H;
-    if (L > (M_KS - 1) * 4)
-        map_strip_body<NS, ROW, TRANS, EPI, true>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit);
-    else
-        map_strip_body<NS, ROW, TRANS, EPI, false>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit);
+    if constexpr (BF) {           // the host only selects BF for strips 97..100 long
+        map_strip_body<NS, ROW, TRANS, EPI, true, true>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit);
+    } else {
+        if (L > (M_KS - 1) * 4)
+            map_strip_body<NS, ROW, TRANS, EPI, true, false>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit);
+        else
+            map_strip_body<NS, ROW, TRANS, EPI, false, false>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit);
+    }
 }
 
 }  // namespace cca

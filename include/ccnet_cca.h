@@ -50,6 +50,13 @@ extern "C" {
 #define CCNET_IMPL_DIRECT  1           /* one-thread-per-output kernels, any shape */
 #define CCNET_IMPL_MFMA    2           /* LDS-staged f32-MFMA strip kernels (max(H,W) <= 100) */
 
+/* arithmetic of the aggregation-type (map) strip kernels.  F32 (default): exact fp32 MFMA (bit-identical to an
+ * fmaf chain).  BF16X3: every fp32 operand is split into bf16 hi + lo and a product is
+ * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix pipe with fp32 accumulation (relative error ~2^-16 per
+ * product, far inside the 1e-3 fp32 parity bar); it applies when both H and W are in 97..100. */
+#define CCNET_PRECISION_F32     0
+#define CCNET_PRECISION_BF16X3  1
+
 /* profiling aid: restrict the strip-kernel launches of every entry point to one branch so a single
  * kernel can be timed in isolation (results are then partial).  Default CCNET_BRANCH_BOTH. */
 #define CCNET_BRANCH_COL   1
@@ -64,6 +71,7 @@ const char *ccnet_cca_last_error_string(void);
 int         ccnet_cca_set_impl(int impl);          /* returns the previous setting */
 int         ccnet_cca_get_impl(void);
 int         ccnet_cca_set_branch_mask(int mask);   /* returns the previous mask */
+int         ccnet_cca_set_precision(int precision);/* returns the previous setting */
 
 /* Affinity: replaces functions.py:30-34 (layout shuffles), :38 (bmm + INF), :39 (bmm), :40 (cat
  * [+ Softmax when CCNET_CA_SOFTMAX]).  out (B,H,W,H+W). */

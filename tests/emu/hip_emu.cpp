@@ -35,6 +35,7 @@ struct Fiber {
 constexpr size_t kStack = 256 * 1024;
 std::vector<Fiber> fibers;
 std::vector<uint64_t> xbuf;          // [wave][parity][64]
+std::vector<unsigned char> xwide;    // [wave][parity][64][32]
 void *sched_sp = nullptr;
 Fiber *cur_fiber = nullptr;
 const std::function<void()> *cur_body = nullptr;
@@ -121,6 +122,7 @@ void analyse_lds(int nthreads) {
 void run_block(int nthreads) {
     int nwaves = (nthreads + 63) / 64;
     xbuf.assign(size_t(nwaves) * 2 * 64, 0);
+    xwide.assign(size_t(nwaves) * 2 * 64 * 32, 0);
     for (int t = 0; t < nthreads; ++t) prepare(fibers[t]);
     for (;;) {
         bool progressed = false, all_done = true;
@@ -206,6 +208,17 @@ const uint64_t *wave_exchange(uint64_t mine) {
     uint64_t *slots = &xbuf[(size_t(wave) * 2 + f.xparity) * 64];
     f.xparity ^= 1;
     slots[f.index & 63] = mine;
+    f.state = WAIT_WAVE;
+    yield_to_scheduler();
+    return slots;
+}
+
+const unsigned char *wave_exchange_bytes(const void *mine, size_t nbytes) {
+    Fiber &f = *cur_fiber;
+    int wave = f.index / 64;
+    unsigned char *slots = &xwide[(size_t(wave) * 2 + f.xparity) * 64 * 32];
+    f.xparity ^= 1;
+    std::memcpy(slots + size_t(f.index & 63) * 32, mine, nbytes <= 32 ? nbytes : 32);
     f.state = WAIT_WAVE;
     yield_to_scheduler();
     return slots;

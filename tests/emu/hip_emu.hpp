@@ -58,6 +58,8 @@ void block_barrier();
 // exchange one 64-bit payload per lane across the calling lane's wave; returns pointer to the
 // wave's 64 payload slots (valid until the lane's next collective).
 const uint64_t *wave_exchange(uint64_t mine);
+// wider payloads: up to 32 bytes per lane; returns the wave's 64 slots of 32 bytes each
+const unsigned char *wave_exchange_bytes(const void *mine, size_t nbytes);
 int lane_id();
 
 // LDS instrumentation: kernels register their __shared__ array so it can be poisoned and so

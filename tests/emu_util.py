@@ -30,7 +30,7 @@ def build_emu(force=False):
     if not force and os.path.exists(EMU_LIB):
         if os.path.getmtime(EMU_LIB) >= max(os.path.getmtime(s) for s in _sources()):
             return EMU_LIB
-    cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DCCNET_EMU",
+    cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DCCNET_EMU", "-Wno-pass-failed",
            "-I" + EMU_DIR, "-I" + CSRC, os.path.join(CSRC, "cca_api.hip"),
            os.path.join(EMU_DIR, "hip_emu.cpp"), "-o", EMU_LIB]
     subprocess.run(cmd, check=True, cwd=ROOT)

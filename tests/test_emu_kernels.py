@@ -144,6 +144,25 @@ def test_full_length_strips_97(ops):
     assert maxerr(dv, g["dv"].numpy()) < TOL
 
 
+def test_split_bf16_option_at_97(ops):
+    """Optional split-bf16 x3 arithmetic of the map kernels (3 k-steps of 32 on the bf16 MFMA + one exact f32
+    k-step for k = 96..99): inside a few 1e-5 of the oracle on O(1) data."""
+    ops.set_impl(MFMA)
+    prev = ops.lib.ccnet_cca_set_precision(1)
+    try:
+        for shape, seed in (((1, 32, 97, 97), 3), ((1, 16, 100, 98), 4)):
+            c = rand_case(*shape, seed=seed)
+            y, A = ops.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
+            yo, Ao = O.cca_core_forward(*(T(c[n]) for n in ("q", "k", "v", "x", "gamma")))
+            assert maxerr(A, Ao.numpy()) < TOL and 0 < maxerr(y, yo.numpy()) < 2e-4
+            dq, dk, dv, dg = ops.cca_backward(c["dy"], c["q"], c["k"], c["v"], A, c["gamma"])
+            g = O.cca_core_backward(T(c["dy"]), T(c["q"]), T(c["k"]), T(c["v"]), Ao, T(c["gamma"]))
+            assert maxerr(dq, g["dq"].numpy()) < 5e-4 and maxerr(dk, g["dk"].numpy()) < 5e-4
+            assert maxerr(dv, g["dv"].numpy()) < 2e-4
+    finally:
+        ops.lib.ccnet_cca_set_precision(prev)
+
+
 def test_rectangular_100_by_40(ops):
     ops.set_impl(MFMA)
     c = rand_case(1, 16, 100, 40, seed=4)     # column strips at the 100 limit, row strips partial

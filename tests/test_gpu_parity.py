@@ -149,8 +149,9 @@ def test_headline_shape_against_oracle_and_direct_kernels(lib, dev):
                      "dgamma": gd.grad.cpu()}
     lib.ccnet_cca_set_impl(0)
     assert lib.ccnet_cca_shape_uses_mfma(B, C, H, W) == 1
-    for n in ("y", "dq", "dk", "dv"):
-        assert err(res[MFMA][n], res[DIRECT][n]) < 2e-4, n
+    cross = {n: err(res[MFMA][n], res[DIRECT][n]) for n in ("y", "dq", "dk", "dv")}
+    print("headline strip-vs-direct kernels:", cross)
+    assert all(e < 2e-4 for e in cross.values()), cross
     yo, Ao = O.cca_core_forward(q, k, v, x, gamma)
     go = O.cca_core_backward(dy, q, k, v, Ao, gamma)
     report = {n: err(res[MFMA][n], t) for n, t in (("y", yo), ("dq", go["dq"]), ("dk", go["dk"]), ("dv", go["dv"]))}
@@ -317,3 +318,29 @@ def test_stock_pytorch_reference_formulation_on_device(lib, dev):
     ref = gamma * (torch.einsum("bhwj,bcjw->bchw", A[..., :H], v) + torch.einsum("bhwj,bchj->bchw", A[..., H:], v)) + x
     y = criss_cross_attention(q, k, v, x, gamma)
     assert err(y, ref) < TOL and err(y, ref) < 2e-4
+
+
+def test_split_bf16_precision_option(lib, dev):
+    """The optional split-bf16 x3 arithmetic of the map kernels (ccnet_cca_set_precision): still inside the
+    1e-3 parity bar at the headline geometry, and switched off again afterwards."""
+    from ccnet_amd import _lib as L
+    from ccnet_amd import criss_cross_attention
+    lib.ccnet_cca_set_impl(0)
+    B, C, H, W = 2, 256, 97, 97
+    q, k, v, x, dy = make_core_inputs(B, C, H, W, seed=51)
+    gamma = torch.tensor([0.5])
+    yo, Ao = O.cca_core_forward(q, k, v, x, gamma)
+    go = O.cca_core_backward(dy, q, k, v, Ao, gamma)
+    prev = lib.ccnet_cca_set_precision(L.CCNET_PRECISION_BF16X3)
+    try:
+        qd, kd, vd, xd = (t.to(dev).requires_grad_(True) for t in (q, k, v, x))
+        gd = gamma.to(dev).requires_grad_(True)
+        y = criss_cross_attention(qd, kd, vd, xd, gd)
+        y.backward(dy.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        lib.ccnet_cca_set_precision(prev)
+    report = {"y": err(y, yo), "dq": err(qd.grad, go["dq"]), "dk": err(kd.grad, go["dk"]), "dv": err(vd.grad, go["dv"])}
+    print("split-bf16 x3 max-abs errors vs oracle:", report)
+    assert all(e < TOL for e in report.values()), report
+    assert report["y"] > 0      # it really is a different arithmetic than the exact path
