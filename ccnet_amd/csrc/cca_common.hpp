@@ -165,8 +165,15 @@ __device__ inline void fbuf_store(const FBuf &b, float v, int voff_bytes, int so
 __device__ inline void fbuf_load_to_lds(const FBuf &b, float *lds_wave_base, int voff_bytes, int soff_bytes) {
     lds_wave_base[emu::lane_id()] = fbuf_load(b, voff_bytes, soff_bytes);
 }
+// 16-byte form: every lane moves 4 consecutive dwords to lds_wave_base + 4 * lane
+__device__ inline void fbuf_load_to_lds_x4(const FBuf &b, float *lds_wave_base, int voff_bytes, int soff_bytes) {
+    for (int e = 0; e < 4; ++e)
+        lds_wave_base[4 * emu::lane_id() + e] = fbuf_load(b, voff_bytes + 4 * e, soff_bytes);
+}
 
 __device__ inline void barrier_lds_only() { __syncthreads(); }
+template <int KEEP>
+__device__ inline void barrier_dma_keep() { __syncthreads(); }
 
 #define CCA_LDS_REGISTER(arr) do { emu::lds_register((void *)(arr), sizeof(arr)); __syncthreads(); } while (0)
 #define CCA_LDS_LD(p) (emu::lds_note_read((const void *)(p), __LINE__), *(p))
@@ -216,11 +223,29 @@ __device__ __forceinline__ void fbuf_load_to_lds(const FBuf &b, float *lds_wave_
                                              voff_bytes, soff_bytes, 0, 0);
 }
 
+// 16-byte form (buffer_load_dwordx4 ... lds): 1 KiB per wave instruction.  Neither the global nor the LDS
+// address needs more than 4-byte alignment (probed on MI355X: tools/probes/dma_x4_probe.hip).
+__device__ __forceinline__ void fbuf_load_to_lds_x4(const FBuf &b, float *lds_wave_base, int voff_bytes, int soff_bytes) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void *)lds_wave_base, 16,
+                                             voff_bytes, soff_bytes, 0, 0);
+}
+
 // Workgroup barrier that orders LDS traffic only: waits for this wave's LDS operations (lgkmcnt) but NOT for
 // its outstanding global stores / loads (vmcnt).  __syncthreads() drains vmcnt as well whenever an LDS-DMA
 // has been issued, which would stall every chunk on the acknowledgement of the tile stores.
 __device__ __forceinline__ void barrier_lds_only() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Workgroup barrier for a DMA pipeline that is more than one chunk deep: waits until at most KEEP of this
+// wave's vector-memory operations (the LDS-DMA pieces of the newest chunk) are still in flight, then
+// synchronises.  __syncthreads() would drain vmcnt to 0 and stall on the chunk that was only just requested
+// (cdna_hip_programming.md, "Pipelining across barriers": counted vmcnt + raw s_barrier).
+template <int KEEP>
+__device__ __forceinline__ void barrier_dma_keep() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KEEP) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
@@ -275,18 +300,23 @@ __device__ __forceinline__ int xcd_logical_id(int linear, int nwg) {
 
 // ---------------------------------------------------------------------------------------------
 // Strip-tile geometry shared by the strip kernels: the NS strips x L positions of ONE channel form a
-// lane-linear LDS image of ceil(NS*L/64) DMA pieces (64 dwords each), element at index p:
-//   column branch  p = i * NS + (gg ^ swz(i))    NS consecutive w per position -> 4*NS-byte segments; the XOR
-//                  swizzle makes stride-NS fragment reads bank-conflict-free (with an odd channel pitch)
-//   row branch     p = gg * L + i                the NS rows are contiguous in memory: 256-byte pieces
+// linear LDS image, element (position i, strip gg) at index p:
+//   column branch  p = i * NS + (gg ^ swz(i))    NS consecutive w per position; the swizzle only swaps the two
+//                  16-byte halves (swz = 4 * ((i >> 2) & 1), NS = 8) so that a 16-byte DMA lane stays contiguous
+//                  in memory while the stride-NS fragment reads spread over more banks
+//   row branch     p = gg * L + i                the NS rows are contiguous in memory
+// The image is filled by 16-byte LDS-DMA pieces of 256 floats (lane l moves p = 256 m + 4 l .. + 3: 16 B of one
+// (c, i) position in the column branch, 16 B of a row in the row branch) and drained, in the map kernel, by
+// 4-byte tile stores over 64-float pieces.  Lanes whose data would lie outside the strip tile are masked.
 // ---------------------------------------------------------------------------------------------
 constexpr int kOobOffset = 0x7ffffff0;            // per-lane byte offset that is out of range for every view
 
-__host__ __device__ constexpr int strip_pieces_c(int ns) { return (ns * kMaxStrip + 63) / 64; }   // 13 (NS=8) / 7 (NS=4)
+__host__ __device__ constexpr int strip_pieces_c(int ns) { return (ns * kMaxStrip + 63) / 64; }      // 13 / 7 dword pieces
+__host__ __device__ constexpr int strip_pieces4_c(int ns) { return (ns * kMaxStrip + 255) / 256; }   // 4 / 2 16-byte pieces
 
 template <int NS>
 __device__ __forceinline__ int col_swizzle(int i) {
-    return NS == 8 ? 2 * ((i >> 2) & 3) : 2 * ((i >> 3) & 1);
+    return NS == 8 ? 4 * ((i >> 2) & 1) : 0;
 }
 
 // LDS index of (position i, strip gg) inside a channel image
@@ -295,11 +325,8 @@ __device__ __forceinline__ int strip_lds_index(int i, int gg, int L) {
     return ROW ? gg * L + i : i * NS + (gg ^ col_swizzle<NS>(i));
 }
 
-// Per-lane addressing of the DMA pieces of one channel image.  Piece m covers LDS indices [64 m, 64 m + 64);
-// the element a lane moves is  plane[ vb[m & 1] + piece_soff(m) ]  -- one of two precomputed per-lane byte
-// offsets (the column swizzle alternates with the parity of m) plus a wave-uniform advance, so a piece
-// costs one select and one scalar add.  Lanes whose index is padding or belongs to a strip outside the
-// image are reported invalid: loads then fetch a clamped valid address, stores use kOobOffset and are dropped.
+// Per-lane addressing of the 4-byte pieces (tile stores).  Piece m covers LDS indices [64 m, 64 m + 64); the
+// element a lane moves is plane[vb + piece_soff(m)] when valid(m).
 template <int NS, bool ROW>
 struct StripLanes {
     int vb[2];
@@ -330,14 +357,49 @@ struct StripLanes {
     }
 };
 
-// LDS-DMA of one channel plane slice into its image (FULL: npieces is the compile-time maximum)
+// Per-lane addressing of the 16-byte DMA pieces.  Piece m covers LDS indices [256 m, 256 m + 256); lane l moves
+// the 4 consecutive elements starting at plane[vb + piece_soff(m)] when valid(m).  A valid lane may fetch up to
+// 3 elements past its strip tile (next strips / next row: mapped memory inside the view, or 0 beyond it); they
+// land in LDS slots of strips whose results are never stored.
+template <int NS, bool ROW>
+struct StripLanes4 {
+    int vb;
+    bool okg;
+    int li;
+    int lim;
+
+    __device__ __forceinline__ void init(int lane, int L, int W, int g0, int gvalid) {
+        if (ROW) {
+            li = 4 * lane;
+            lim = gvalid * L;
+            vb = 4 * (g0 * W + 4 * lane);
+            okg = true;
+        } else {
+            constexpr int GPP = NS / 4;                    // 16-byte groups per position (2 for NS = 8, 1 for NS = 4)
+            li = lane / GPP;                               // position inside the piece
+            const int grp = lane % GPP;                    // LDS half
+            const int gg0 = 4 * grp ^ col_swizzle<NS>(li); // first strip of the group in memory
+            okg = gg0 < gvalid;
+            vb = 4 * (li * W + g0 + gg0);
+            lim = L;
+        }
+    }
+    __device__ __forceinline__ int piece_soff(int m, int W) const {
+        return ROW ? m * 1024 : m * (256 / NS) * W * 4;
+    }
+    __device__ __forceinline__ bool valid(int m) const {
+        return ROW ? (m * 256 + li < lim) : (okg && m * (256 / NS) + li < lim);
+    }
+};
+
+// LDS-DMA of one channel plane slice into its image (FULL: npieces4 is the compile-time maximum)
 template <int NS, bool ROW, bool FULL>
-__device__ __forceinline__ void strip_dma_channel(const FBuf &src, float *dst, int soff, int npieces, int W,
-                                                  const StripLanes<NS, ROW> &sl) {
+__device__ __forceinline__ void strip_dma_channel(const FBuf &src, float *dst, int soff, int npieces4, int W,
+                                                  const StripLanes4<NS, ROW> &sl) {
 #pragma unroll
-    for (int m = 0; m < strip_pieces_c(NS); ++m)
-        if (FULL || m < npieces)
-            fbuf_load_to_lds(src, dst + m * 64, sl.valid(m) ? sl.vb[m & 1] : 0, soff + sl.piece_soff(m, W));
+    for (int m = 0; m < strip_pieces4_c(NS); ++m)
+        if (FULL || m < npieces4)
+            if (sl.valid(m)) fbuf_load_to_lds_x4(src, dst + m * 256, sl.vb, soff + sl.piece_soff(m, W));
 }
 
 }  // namespace cca

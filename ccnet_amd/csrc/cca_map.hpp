@@ -55,6 +55,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                                                int C, int H, int W, int chunks_per_block, int tiles, int nsplit) {
     constexpr int CP = m_cp(NS), BUF = M_MC * CP, kBlock = kWave * NS, PIECES = strip_pieces_c(NS);
     constexpr int CPW = M_MC / NS;                // channels per wave in the DMA / tile-store phases
+    constexpr int PIECES4 = strip_pieces4_c(NS);
     const Branch br = make_branch(ROW, H, W);
     const int L = br.L, HW = H * W, S = H + W;
     // logical id -> (image, channel split, tile), tile fastest: neighbouring tiles share an XCD's L2
@@ -73,8 +74,11 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
     const int ch_end = (ch_begin + chunks_per_block < nchunks) ? ch_begin + chunks_per_block : nchunks;
     const int ln = lane & 15, lk = lane >> 4;
 
-    StripLanes<NS, ROW> sl;
+    StripLanes<NS, ROW> sl;                       // 4-byte pieces: tile stores
     sl.init(lane, L, W, g0, gvalid);
+    StripLanes4<NS, ROW> sl4;                     // 16-byte pieces: LDS-DMA
+    sl4.init(lane, L, W, g0, gvalid);
+    const int npieces4 = FULL ? strip_pieces4_c(NS) : (NS * L + 255) / 256;
 
     const FBuf Fb = make_fbuf(F + (size_t)b * C * HW, (size_t)C * HW * sizeof(float));
     const FBuf Ob = make_fbuf(out + (size_t)b * C * HW, (size_t)C * HW * sizeof(float));
@@ -89,7 +93,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
         for (int pr = 0; pr < M_MC / NS; ++pr) {
             const int cc = wv + pr * NS, c = ch * M_MC + cc;
             float *dst = lds + buf * BUF + cc * CP;
-            strip_dma_channel<NS, ROW, FULL>(Fb, dst, (c < C ? c : C - 1) * HW * 4, npieces, W, sl);
+            strip_dma_channel<NS, ROW, FULL>(Fb, dst, (c < C ? c : C - 1) * HW * 4, npieces4, W, sl4);
         }
     };
 
@@ -176,11 +180,10 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
     }
 #endif
 
-    // the few slots between the last DMA piece and the pitch are read as K padding: make them true zeros
-    for (int idx = tid; idx < 2 * M_MC * (CP - npieces * 64); idx += kBlock) {   // (feature buffers only)
-        const int rowi = idx / (CP - npieces * 64), col = npieces * 64 + idx % (CP - npieces * 64);
-        CCA_LDS_ST(&lds[rowi * CP + col], 0.f);
-    }
+    // masked DMA lanes leave their LDS slots untouched, and slots just past a strip are read as K padding
+    // (multiplied by zero fragments): start from an all-zero LDS so that they can never hold a NaN
+    for (int idx = tid; idx < 3 * BUF; idx += kBlock) CCA_LDS_ST(&lds[idx], 0.f);
+    __syncthreads();
     if (ch_begin < ch_end) issue(ch_begin, 0);
     __syncthreads();                     // first chunk landed (the compiler drains vmcnt before the barrier)
 
@@ -192,20 +195,20 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
     // (a piece costs ~60-100 issue cycles; 52 of them in front of the MFMAs would add ~40 % to a chunk):
     //   q in [0, QF)        feature chunk ch+1 -> the other buffer   (channel pr of this wave, piece m)
     //   q in [QF, QF + QA)  addend tile of chunk ch -> third image
-    constexpr int QF = CPW * PIECES, QA = CPW * PIECES, QT = QF + QA;
+    constexpr int QF = CPW * PIECES4, QA = CPW * PIECES4, QT = QF + QA;
     // Branch-free in the FULL path: channels beyond C are clamped (they are output rows that are never
     // stored), and when there is no next chunk the current one is simply fetched again into the idle buffer.
     auto dma_piece = [&](int q, int ch, int chn, int buf) {
         const bool feat = q < QF;
         const int rem = feat ? q : q - QF;
-        const int pr = rem / PIECES, m = rem % PIECES;
-        if (!(FULL || m < npieces)) return;
+        const int pr = rem / PIECES4, m = rem % PIECES4;
+        if (!(FULL || m < npieces4)) return;
         if (!feat && !has_add) return;
         const int cc = wv + pr * NS;
         const int c = (feat ? chn : ch) * M_MC + cc;
-        float *dst = lds + (feat ? (buf ^ 1) : 2) * BUF + cc * CP + m * 64;
-        fbuf_load_to_lds(feat ? Fb : Ab, dst, sl.valid(m) ? sl.vb[m & 1] : 0,
-                         (c < C ? c : C - 1) * HW * 4 + sl.piece_soff(m, W));
+        float *dst = lds + (feat ? (buf ^ 1) : 2) * BUF + cc * CP + m * 256;
+        if (sl4.valid(m))
+            fbuf_load_to_lds_x4(feat ? Fb : Ab, dst, sl4.vb, (c < C ? c : C - 1) * HW * 4 + sl4.piece_soff(m, W));
     };
 
     for (int ch = ch_begin; ch < ch_end; ++ch) {

@@ -9,31 +9,28 @@
 // Work decomposition (MI355X): one workgroup = NS adjacent strips, one wavefront per strip; column and
 // row strips are workgroups of the SAME launch.  Each wavefront keeps its whole L x L output stationary
 // in registers as up to 7x7 tiles of the exact-fp32 v_mfma_f32_16x16x4_f32 (bit-identical to an fmaf
-// chain).  Both operands stream through a DOUBLE-BUFFERED LDS image in chunks of 8 channels, filled by
-// LDS-DMA (buffer_load_dword ... lds: no staging registers, no ds_write pass); chunk n+1 is in flight
-// while chunk n is multiplied, and the single __syncthreads() per chunk is the hand-over (the compiler
-// drains vmcnt in front of it).
+// chain).  Both operands stream through a TRIPLE-BUFFERED LDS image in chunks of 8 channels, filled by
+// LDS-DMA (buffer_load_dword ... lds: no staging registers, no ds_write pass): while chunk n is multiplied,
+// chunk n+1 is landing and the pieces of chunk n+2 are issued between the MFMAs; the one barrier per chunk
+// waits with a COUNTED vmcnt that leaves the newest chunk's pieces in flight.
 //
-// LDS image of one channel of one operand: the NS strips' L positions as ONE lane-linear array of
-// ceil(NS*L/64) DMA pieces (64 dwords each):
-//   column branch  p = i * NS + (gg ^ swz(i))   8 (4) consecutive w per position -> 32 B (16 B) segments;
-//                  the XOR swizzle (2*((i>>2)&3) for NS=8, 2*((i>>3)&1) for NS=4) + channel pitch == 1 mod 32
-//                  makes the stride-NS fragment reads bank-conflict-free
-//   row branch     p = gg * L + i               the NS rows are contiguous in memory: fully coalesced 256 B
-//                  pieces; channel pitch == 16 mod 32 keeps the unit-stride fragment reads conflict-free
-// Out-of-range lanes (position >= L, strip outside the image) fetch a clamped, always-valid address and
-// land in padding or in strips whose results are never stored; channels >= Cx are zero-filled.
+// LDS image of one channel of one operand: see "Strip-tile geometry" in cca_common.hpp (16-byte DMA pieces of
+// 256 floats; one DMA instruction moves 1 KiB -- with 4-byte pieces the DMA *issue* alone cost a third of the
+// kernel).  Lanes outside the strip tile are masked; channels >= Cx are fetched clamped and zeroed at
+// fragment-read time.
 #pragma once
 #include "cca_common.hpp"
+
+#include <type_traits>
 
 namespace cca {
 
 constexpr int W_KC = 8;                                     // channels per chunk = 2 MFMA k-steps
-__host__ __device__ constexpr int w_pieces(int ns) { return strip_pieces_c(ns); }             // 13 / 7
+__host__ __device__ constexpr int w_pieces(int ns) { return strip_pieces_c(ns); }             // image length in 64-float units
 __host__ __device__ constexpr int w_cp(int ns, bool row) { return w_pieces(ns) * 64 + (row ? 16 : 1); }
 __host__ __device__ constexpr int w_cpmax(int ns) { return w_pieces(ns) * 64 + 16; }
 __host__ __device__ constexpr int w_op(int ns) { return W_KC * w_cpmax(ns); }   // floats per operand per buffer
-__host__ __device__ constexpr int w_lds_floats(int ns) { return 4 * w_op(ns); }  // 2 operands x 2 buffers
+__host__ __device__ constexpr int w_lds_floats(int ns) { return 6 * w_op(ns); }  // 2 operands x 3 buffers (162,816 B at NS = 8)
 
 // FULL: the strip needs all 7x7 tiles (97..100 long) -> no per-tile guards in the hot loop
 template <int NS, bool ROW, bool MASK, bool FULL>
@@ -48,11 +45,11 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
     const int g = g0 + wv;
     const bool active = g < br.G;
     const int nt = FULL ? kMaxTiles : (L + kTile - 1) / kTile;
-    const int npieces = FULL ? strip_pieces_c(NS) : (NS * L + 63) / 64;     // FULL: L in 97..100
+    const int npieces = FULL ? strip_pieces4_c(NS) : (NS * L + 255) / 256;  // 16-byte DMA pieces; FULL: L in 97..100
     const int gvalid = (br.G - g0 < NS) ? br.G - g0 : NS;          // strips of this tile inside the image
 #define CCA_TILE_ON(t) (FULL || (t) < nt)
 
-    StripLanes<NS, ROW> sl;
+    StripLanes4<NS, ROW> sl;
     sl.init(lane, L, W, g0, gvalid);
 
     const FBuf Xb = make_fbuf(X + (size_t)b * Cx * HW, (size_t)Cx * HW * sizeof(float));
@@ -65,14 +62,8 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
             const int pair = wv + pr * NS;                           // 0 .. 2*W_KC-1, wave-uniform
             const int op = pair / W_KC, cc = pair % W_KC;
             float *dst = lds + (buf * 2 + op) * OP + cc * CP;
-            const int c = c0 + cc;
-            if (c < Cx) {
-                const FBuf &src = op ? Yb : Xb;
-                const int soff = c * HW * 4;
-                strip_dma_channel<NS, ROW, FULL>(src, dst, soff, npieces, W, sl);
-            } else {
-                for (int m = 0; m < npieces; ++m) CCA_LDS_ST(&dst[m * 64 + lane], 0.f);   // K padding must be 0
-            }
+            const int c = (c0 + cc < Cx) ? c0 + cc : Cx - 1;          // clamped: the K padding is zeroed at fragment read
+            strip_dma_channel<NS, ROW, FULL>(op ? Yb : Xb, dst, c * HW * 4, npieces, W, sl);
         }
     };
 
@@ -87,29 +78,72 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
     const int fr = lk * CP + strip_lds_index<NS, ROW>(ln, wv, L);
     const int tstep = ROW ? kTile : kTile * NS;                    // LDS distance between position tiles
 
+    // DMA of the next chunk cut into single pieces, interleaved with the MFMAs of the current one (a piece costs
+    // ~60-100 issue cycles: 26 of them in front of 98 MFMAs would add a third to every chunk)
+    constexpr int PIECES = strip_pieces4_c(NS), PW = 2 * W_KC / NS, QT = PW * PIECES, SLOTS = (W_KC / 4) * kMaxTiles;
+    auto dma_piece = [&](int q, int c0, int buf) {
+        const int pr = q / PIECES, m = q % PIECES;
+        if (!(FULL || m < npieces)) return;
+        const int pair = wv + pr * NS;
+        const int op = pair / W_KC, cc = pair % W_KC;
+        const int c = (c0 + cc < Cx) ? c0 + cc : Cx - 1;
+        if (sl.valid(m))
+            fbuf_load_to_lds_x4(op ? Yb : Xb, lds + (buf * 2 + op) * OP + cc * CP + m * 256, sl.vb,
+                                c * HW * 4 + sl.piece_soff(m, W));
+    };
+
     const int nchunks = (Cx + W_KC - 1) / W_KC;
+    const int lastc = (nchunks - 1) * W_KC;
     issue(0, 0);
+    issue(nchunks > 1 ? W_KC : 0, 1);
     for (int n = 0; n < nchunks; ++n) {
-        __syncthreads();                      // chunk n landed (vmcnt drained) and buffer (n+1)&1 is free again
-        if (n + 1 < nchunks) issue((n + 1) * W_KC, (n + 1) & 1);
+        // chunk n landed; chunk n+1 (the newest QT pieces of every wave) may still be in flight
+#ifndef CCA_ABL_W_NOBARRIER
+        // (the counted wait needs every wave to have issued exactly QT pieces per chunk: full tiles of full strips)
+        if (FULL && gvalid == NS) barrier_dma_keep<QT>();
+        else                      __syncthreads();
+#endif
+        // chunk n+2 -> buffer (n+2) % 3, last read in iteration n-1 (past the end: re-fetch the last chunk, harmless)
+        const int c1 = ((n + 2) * W_KC < lastc) ? (n + 2) * W_KC : lastc;
+        const int bnext = (n + 2) % 3, bcur = n % 3;
         if (active) {
-            const float *xs = lds + ((n & 1) * 2 + 0) * OP + fr;
-            const float *ys = lds + ((n & 1) * 2 + 1) * OP + fr;
+            const float *xs = lds + (bcur * 2 + 0) * OP + fr;
+            const float *ys = lds + (bcur * 2 + 1) * OP + fr;
 #pragma unroll
             for (int ks = 0; ks < W_KC / 4; ++ks) {
+                const bool kin = n * W_KC + ks * 4 + lk < Cx;        // channels beyond Cx hold clamped data: zero A
                 float a[kMaxTiles];
 #pragma unroll
                 for (int t = 0; t < kMaxTiles; ++t)
-                    if (CCA_TILE_ON(t)) a[t] = CCA_LDS_LD(xs + ks * 4 * CP + t * tstep);
+                    if (CCA_TILE_ON(t)) {
+#ifdef CCA_ABL_W_NOLDS
+                        const float v = 0.001f * (float)(lane + t + ks + n);
+#else
+                        const float v = CCA_LDS_LD(xs + ks * 4 * CP + t * tstep);
+#endif
+                        a[t] = kin ? v : 0.f;
+                    }
 #pragma unroll
-                for (int rn = 0; rn < kMaxTiles; ++rn)
+                for (int rn = 0; rn < kMaxTiles; ++rn) {
+                    const int sidx = ks * kMaxTiles + rn;
+#ifndef CCA_ABL_W_NODMA
+#pragma unroll
+                    for (int q = sidx * QT / SLOTS; q < (sidx + 1) * QT / SLOTS; ++q) dma_piece(q, c1, bnext);
+#endif
                     if (CCA_TILE_ON(rn)) {
+#ifdef CCA_ABL_W_NOLDS
+                        const float bb = 0.002f * (float)(lane + rn + ks + n);
+#else
                         const float bb = CCA_LDS_LD(ys + ks * 4 * CP + rn * tstep);
+#endif
 #pragma unroll
                         for (int rm = 0; rm < kMaxTiles; ++rm)
                             if (CCA_TILE_ON(rm)) acc[rm][rn] = mfma_16x16x4(a[rm], bb, acc[rm][rn]);
                     }
+                }
             }
+        } else {
+            issue(c1, bnext);                 // strips outside the image still own DMA channels
         }
     }
 
