@@ -122,7 +122,7 @@ int num_cus() {
 // prologue (loading the stationary attention blocks, worth about kPrologueChunks chunks) and then
 // chunks_per_block chunks; the grid runs in ceil(workgroups / CUs) waves.  Pick the split that minimises
 // waves * (chunks_per_block + prologue).  CCNET_CCA_MAP_SPLIT overrides.
-void map_grid(int ns, int B, int C, int G, dim3 &grid, int &chunks_per_block, int &tiles, int &cs) {
+void map_grid(int ns, int B, int C, int G, dim3 &grid, int &chunks_per_block, int &tiles, int &cs, int problems = 1) {
     tiles = (G + ns - 1) / ns;
     const int nchunks = (C + cca::M_MC - 1) / cca::M_MC;
     const int base = B * tiles, cus = num_cus();
@@ -133,14 +133,14 @@ void map_grid(int ns, int B, int C, int G, dim3 &grid, int &chunks_per_block, in
     for (int s = 1; s <= nchunks; ++s) {
         const int cpb = (nchunks + s - 1) / s;
         const int real_s = (nchunks + cpb - 1) / cpb;
-        const int waves = (base * real_s + cus - 1) / cus;
+        const int waves = (base * real_s * problems + cus - 1) / cus;
         const double cost = waves * (cpb + prologue);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = real_s; }
     }
     cs = (forced > 0) ? (forced < nchunks ? forced : nchunks) : best;
     chunks_per_block = (nchunks + cs - 1) / cs;
     cs = (nchunks + chunks_per_block - 1) / chunks_per_block;
-    grid = dim3((unsigned)(tiles * cs * B));       // 1-D: the kernel decodes an XCD-aware logical id
+    grid = dim3((unsigned)(tiles * cs * B * problems));   // 1-D: the kernel decodes an XCD-aware logical id
 }
 
 // out = alpha * (column sums + row sums) + resid, both branches, strip kernels
@@ -165,6 +165,27 @@ int launch_map_pair_ns(const float *T, const float *F, const float *resid, const
         map_grid(NS, B, C, /*G=*/H, grid, cpb, tiles, cs);
         CCA_LAUNCH((cca::map_strip_kernel<NS, true, TRANS, cca::EPI_ROW, BF>), grid, dim3(cca::kWave * NS), stream,
                    T, F, (const float *)nullptr, gamma, out, C, H, W, cpb, tiles, cs);
+        return launch_status(what);
+    }
+    return 0;
+}
+
+// dq (non-transposed, F0 = k) and dk (transposed, F1 = q) in one launch per branch
+template <int NS>
+int launch_map_dual_ns(const float *T, const float *F0, float *out0, const float *F1, float *out1,
+                       int B, int C, int H, int W, ccnet_stream_t stream, const char *what) {
+    dim3 grid;
+    int cpb, tiles, cs;
+    if (g_branch_mask & CCNET_BRANCH_COL) {
+        map_grid(NS, B, C, /*G=*/W, grid, cpb, tiles, cs, 2);
+        CCA_LAUNCH((cca::map_strip_dual_kernel<NS, false, cca::EPI_COL>), grid, dim3(cca::kWave * NS), stream,
+                   T, F0, out0, F1, out1, (const float *)nullptr, C, H, W, cpb, tiles, cs);
+        if (int e = launch_status(what)) return e;
+    }
+    if (g_branch_mask & CCNET_BRANCH_ROW) {
+        map_grid(NS, B, C, /*G=*/H, grid, cpb, tiles, cs, 2);
+        CCA_LAUNCH((cca::map_strip_dual_kernel<NS, true, cca::EPI_ROW>), grid, dim3(cca::kWave * NS), stream,
+                   T, F0, out0, F1, out1, (const float *)nullptr, C, H, W, cpb, tiles, cs);
         return launch_status(what);
     }
     return 0;
@@ -266,6 +287,10 @@ int ccnet_ca_backward_f32(const float *dE, const float *q, const float *k, float
     const int impl = pick_impl(H, W);
     if (impl < 0) return impl;
     if (impl == 1) {
+        static const int dual = env_int("CCNET_CCA_DUAL_QK", 1);
+        if (dual)
+            return map_strips() == 4 ? launch_map_dual_ns<4>(dE, k, dq, q, dk, B, Cq, H, W, stream, "ca_backward(dq,dk)")
+                                     : launch_map_dual_ns<8>(dE, k, dq, q, dk, B, Cq, H, W, stream, "ca_backward(dq,dk)");
         if (int e = launch_map_pair<false>(dE, k, nullptr, nullptr, dq, B, Cq, H, W, stream, "ca_backward(dq)")) return e;
         return launch_map_pair<true>(dE, q, nullptr, nullptr, dk, B, Cq, H, W, stream, "ca_backward(dk)");
     }
@@ -290,7 +315,8 @@ int ccnet_ca_softmax_backward_f32(const float *A, const float *dA, const float *
     if (int e = check_shape(B, 1, H, W)) return e;
     if (!A || !dA || !dE) return fail(CCNET_E_NULLPTR, "softmax_backward: null tensor");
     const int npix = B * H * W, S = H + W;
-    const int nblocks = (npix + cca::SM_WAVES - 1) / cca::SM_WAVES;
+    const int want = (npix + cca::SM_WAVES - 1) / cca::SM_WAVES;
+    const int nblocks = want < cca::SM_MAX_BLOCKS ? want : cca::SM_MAX_BLOCKS;
     float *partials = nullptr;
     if (dgamma) {
         if (!workspace || workspace_bytes < (size_t)nblocks * sizeof(float))

@@ -52,14 +52,15 @@ template <int NS, bool ROW, bool TRANS, int EPI, bool FULL, bool BF>
 __device__ __forceinline__ void map_strip_body(float *lds, const float *__restrict__ T,
                                                const float *__restrict__ F, const float *__restrict__ resid,
                                                const float *__restrict__ gamma, float *out,
-                                               int C, int H, int W, int chunks_per_block, int tiles, int nsplit) {
+                                               int C, int H, int W, int chunks_per_block, int tiles, int nsplit,
+                                               int wg_linear, int wg_count) {
     constexpr int CP = m_cp(NS), BUF = M_MC * CP, kBlock = kWave * NS, PIECES = strip_pieces_c(NS);
     constexpr int CPW = M_MC / NS;                // channels per wave in the DMA / tile-store phases
     constexpr int PIECES4 = strip_pieces4_c(NS);
     const Branch br = make_branch(ROW, H, W);
     const int L = br.L, HW = H * W, S = H + W;
     // logical id -> (image, channel split, tile), tile fastest: neighbouring tiles share an XCD's L2
-    const int id = xcd_logical_id(blockIdx.x, gridDim.x);
+    const int id = xcd_logical_id(wg_linear, wg_count);
     const int b = id / (tiles * nsplit), rem = id - b * (tiles * nsplit);
     const int split = rem / tiles, g0 = (rem - split * tiles) * NS;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
@@ -321,13 +322,40 @@ __global__ __launch_bounds__(kWave * NS, 2) void map_strip_kernel(const float *_
     __shared__ float lds[m_lds_floats(NS)];
     CCA_LDS_REGISTER(lds);
     const int L = ROW ? W : H;
+    const int wg_linear = blockIdx.x, wg_count = gridDim.x;
     if constexpr (BF) {           // the host only selects BF for strips 97..100 long
-        map_strip_body<NS, ROW, TRANS, EPI, true, true>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit);
+        map_strip_body<NS, ROW, TRANS, EPI, true, true>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count);
     } else {
         if (L > (M_KS - 1) * 4)
-            map_strip_body<NS, ROW, TRANS, EPI, true, false>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit);
+            map_strip_body<NS, ROW, TRANS, EPI, true, false>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count);
         else
-            map_strip_body<NS, ROW, TRANS, EPI, false, false>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit);
+            map_strip_body<NS, ROW, TRANS, EPI, false, false>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count);
+    }
+}
+
+// Two independent map problems that share the attention-shaped operand T in ONE launch: workgroups
+// [0, n) run the non-transposed problem (F0 -> out0), workgroups [n, 2n) the transposed one (F1 -> out1).
+// Used for ca_backward (dq from k, dk from q): each half alone would leave most CUs idle.
+template <int NS, bool ROW, int EPI>
+__global__ __launch_bounds__(kWave * NS, 2) void map_strip_dual_kernel(const float *__restrict__ T,
+                                                                        const float *__restrict__ F0, float *out0,
+                                                                        const float *__restrict__ F1, float *out1,
+                                                                        const float *__restrict__ gamma,
+                                                                        int C, int H, int W,
+                                                                        int chunks_per_block, int tiles, int nsplit) {
+    __shared__ float lds[m_lds_floats(NS)];
+    CCA_LDS_REGISTER(lds);
+    const int L = ROW ? W : H;
+    const int half = gridDim.x / 2;
+    const bool second = (int)blockIdx.x >= half;
+    const int wg_linear = second ? blockIdx.x - half : blockIdx.x, wg_count = half;
+    const bool full = L > (M_KS - 1) * 4;
+    if (!second) {
+        if (full) map_strip_body<NS, ROW, false, EPI, true, false>(lds, T, F0, nullptr, gamma, out0, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count);
+        else      map_strip_body<NS, ROW, false, EPI, false, false>(lds, T, F0, nullptr, gamma, out0, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count);
+    } else {
+        if (full) map_strip_body<NS, ROW, true, EPI, true, false>(lds, T, F1, nullptr, gamma, out1, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count);
+        else      map_strip_body<NS, ROW, true, EPI, false, false>(lds, T, F1, nullptr, gamma, out1, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count);
     }
 }
 

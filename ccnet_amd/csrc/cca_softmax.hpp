@@ -63,21 +63,24 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_fwd_generic_kernel(const flo
     for (int s = lane; s < S; s += kWave) a[s] = expf(e[s] - m) * inv;
 }
 
+// The grid is capped (SM_MAX_BLOCKS) and strides over the pixels, so at most SM_MAX_BLOCKS partial sums of
+// dgamma are produced; each wavefront adds its pixels in a fixed order: deterministic.
+constexpr int SM_MAX_BLOCKS = 2048;
+
 template <int NREG>
 __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_kernel(const float *A, const float *dA,
                                                                const float *gamma, float *dE,
                                                                float *partials, int npix, int S) {
     __shared__ float red[SM_WAVES];
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
-    const int pix = blockIdx.x * SM_WAVES + wv;
-    const bool active = pix < npix;
     const float g = gamma ? gamma[0] : 1.f;
-    float rsum = 0.f;
-    if (active) {
+    float wsum = 0.f;
+    for (int pix = blockIdx.x * SM_WAVES + wv; pix < npix; pix += gridDim.x * SM_WAVES) {   // wave-uniform
         const float *a = A + (size_t)pix * S;
         const float *d = dA + (size_t)pix * S;
         float *o = dE + (size_t)pix * S;
         float av[NREG], dv[NREG];
+        float rsum = 0.f;
 #pragma unroll
         for (int r = 0; r < NREG; ++r) {
             const int s = lane + r * kWave;
@@ -91,7 +94,10 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_kernel(const float *A, c
             const int s = lane + r * kWave;
             if (s < S) o[s] = g * av[r] * (dv[r] - rsum);
         }
+        wsum += rsum;
     }
+    const bool active = true;
+    const float rsum = wsum;
     if (partials) {
         if (lane == 0) red[wv] = active ? rsum : 0.f;
         __syncthreads();
@@ -109,18 +115,20 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_generic_kernel(const flo
                                                                        float *partials, int npix, int S) {
     __shared__ float red[SM_WAVES];
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
-    const int pix = blockIdx.x * SM_WAVES + wv;
-    const bool active = pix < npix;
     const float g = gamma ? gamma[0] : 1.f;
-    float rsum = 0.f;
-    if (active) {
+    float wsum = 0.f;
+    for (int pix = blockIdx.x * SM_WAVES + wv; pix < npix; pix += gridDim.x * SM_WAVES) {   // wave-uniform
         const float *a = A + (size_t)pix * S;
         const float *d = dA + (size_t)pix * S;
         float *o = dE + (size_t)pix * S;
+        float rsum = 0.f;
         for (int s = lane; s < S; s += kWave) rsum += a[s] * d[s];
         rsum = wave_sum(rsum);
         for (int s = lane; s < S; s += kWave) o[s] = g * a[s] * (d[s] - rsum);
+        wsum += rsum;
     }
+    const bool active = true;
+    const float rsum = wsum;
     if (partials) {
         if (lane == 0) red[wv] = active ? rsum : 0.f;
         __syncthreads();
