@@ -11,8 +11,8 @@ src = sys.argv[1]
 names = {  # rocprof kernel name -> bench.py roofline label
     "cca::weight_strip_kernel<8, false>": "weight_strip_kernel ca_map_backward.dA[dy.v]",
     "cca::weight_strip_kernel<8, true>": "weight_strip_kernel ca_forward[q.k]",
-    "cca::map_strip_kernel<8, false, false, 2>": "map_strip_kernel<col> ca_map_forward[A.v]",
-    "cca::map_strip_kernel<8, true, false, 1>": "map_strip_kernel<row> ca_map_forward[A.v]",
+    "cca::map_strip_kernel<8, false, false, 2, false>": "map_strip_kernel<col> ca_map_forward[A.v]",
+    "cca::map_strip_kernel<8, true, false, 1, false>": "map_strip_kernel<row> ca_map_forward[A.v]",
 }
 d = json.load(open(src))
 out = {}
