@@ -85,8 +85,8 @@ def shard_seed(base_seed, rank):
 
 
 def max_over_ranks(seconds, device, world):
-    """MAX-reduce a local wall time over all ranks (identity for world == 1)."""
-    if world <= 1 or not dist.is_initialized():
+    """MAX-reduce a local wall time over all ranks (identity when no process group is up)."""
+    if not dist.is_initialized():
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -324,7 +324,8 @@ def main():
         sys.exit("bench.py needs a HIP device (the product has no CPU path)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"     # (the latter: exercise the RCCL path on 1 GPU)
+    if use_dist:
         dist.init_process_group("nccl", device_id=device)     # backend "nccl" is RCCL on ROCm
 
     from ccnet_amd import _lib
@@ -335,14 +336,14 @@ def main():
     for _ in range(args.warmup):
         wl.step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     local_s = time.perf_counter() - t0
@@ -381,11 +382,11 @@ def main():
             out["module_ms_per_step"] = f"failed: {e}"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, H, W, args.cpu_budget)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
