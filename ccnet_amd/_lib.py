@@ -24,6 +24,7 @@ CCNET_IMPL_DIRECT = 1
 CCNET_IMPL_MFMA = 2
 CCNET_PRECISION_F32 = 0
 CCNET_PRECISION_BF16X3 = 1
+CCNET_PRECISION_DEFAULT = 2
 
 _P = c_void_p  # every tensor argument is a raw device pointer
 

@@ -200,12 +200,21 @@ int launch_map_pair(const float *T, const float *F, const float *resid, const fl
 }
 
 // both branches in ONE launch (column workgroups first, then row workgroups)
-template <int NS, bool MASK>
+// arithmetic of the K = C weight kernel (ca_map_backward's dA, 15 GFLOP, matrix-pipe bound in f32):
+// 1 (default) = packed split-bf16 x3 (one bf16 MFMA per tile and 8-channel chunk), 0 = exact f32.
+// The affinity kernel (ca_forward, K = C/8) always runs exact f32: its energies feed exp().
+int g_weight_bf16 = -1;
+bool weight_bf16() {
+    if (g_weight_bf16 < 0) g_weight_bf16 = env_int("CCNET_CCA_WEIGHT_BF16", 1) ? 1 : 0;
+    return g_weight_bf16 == 1;
+}
+
+template <int NS, bool MASK, bool BF>
 int launch_weight_ns(const float *X, const float *Y, float *T, int B, int Cx, int H, int W,
                      ccnet_stream_t stream, const char *what) {
     const int tc = (g_branch_mask & CCNET_BRANCH_COL) ? (W + NS - 1) / NS : 0;
     const int tr = (g_branch_mask & CCNET_BRANCH_ROW) ? (H + NS - 1) / NS : 0;
-    CCA_LAUNCH((cca::weight_strip_kernel<NS, MASK>), dim3((tc + tr) * B), dim3(cca::kWave * NS), stream,
+    CCA_LAUNCH((cca::weight_strip_kernel<NS, MASK, BF>), dim3((tc + tr) * B), dim3(cca::kWave * NS), stream,
                X, Y, T, Cx, H, W, tc, tr);
     return launch_status(what);
 }
@@ -213,8 +222,10 @@ int launch_weight_ns(const float *X, const float *Y, float *T, int B, int Cx, in
 template <bool MASK>
 int launch_weight_pair(const float *X, const float *Y, float *T, int B, int Cx, int H, int W,
                        ccnet_stream_t stream, const char *what) {
-    return weight_strips() == 4 ? launch_weight_ns<4, MASK>(X, Y, T, B, Cx, H, W, stream, what)
-                                : launch_weight_ns<8, MASK>(X, Y, T, B, Cx, H, W, stream, what);
+    if (!MASK && weight_bf16() && weight_strips() == 8)
+        return launch_weight_ns<8, false, true>(X, Y, T, B, Cx, H, W, stream, what);
+    return weight_strips() == 4 ? launch_weight_ns<4, MASK, false>(X, Y, T, B, Cx, H, W, stream, what)
+                                : launch_weight_ns<8, MASK, false>(X, Y, T, B, Cx, H, W, stream, what);
 }
 
 int softmax_forward(const float *E, float *A, int B, int H, int W, ccnet_stream_t stream) {
@@ -240,8 +251,12 @@ int ccnet_cca_set_impl(int impl) {
 }
 int ccnet_cca_get_impl(void) { return g_impl; }
 int ccnet_cca_set_precision(int precision) {
-    const int prev = g_map_bf16 < 0 ? (env_int("CCNET_CCA_MAP_BF16", 0) ? 1 : 0) : g_map_bf16;
-    if (precision == CCNET_PRECISION_F32 || precision == CCNET_PRECISION_BF16X3) g_map_bf16 = precision;
+    if (g_map_bf16 < 0) g_map_bf16 = env_int("CCNET_CCA_MAP_BF16", 0) ? 1 : 0;
+    if (g_weight_bf16 < 0) g_weight_bf16 = env_int("CCNET_CCA_WEIGHT_BF16", 1) ? 1 : 0;
+    const int prev = g_map_bf16 ? CCNET_PRECISION_BF16X3 : (g_weight_bf16 ? CCNET_PRECISION_DEFAULT : CCNET_PRECISION_F32);
+    if (precision == CCNET_PRECISION_F32)     { g_map_bf16 = 0; g_weight_bf16 = 0; }
+    if (precision == CCNET_PRECISION_DEFAULT) { g_map_bf16 = 0; g_weight_bf16 = 1; }
+    if (precision == CCNET_PRECISION_BF16X3)  { g_map_bf16 = 1; g_weight_bf16 = 1; }
     return prev;
 }
 int ccnet_cca_set_branch_mask(int mask) {

@@ -33,7 +33,9 @@ __host__ __device__ constexpr int w_op(int ns) { return W_KC * w_cpmax(ns); }   
 __host__ __device__ constexpr int w_lds_floats(int ns) { return 6 * w_op(ns); }  // 2 operands x 3 buffers (162,816 B at NS = 8)
 
 // FULL: the strip needs all 7x7 tiles (97..100 long) -> no per-tile guards in the hot loop
-template <int NS, bool ROW, bool MASK, bool FULL>
+// BF: packed split-bf16 (one v_mfma_f32_16x16x32_bf16 per tile and 8-channel chunk, see bf16_pack_a/b) instead
+//     of two exact f32 k-steps
+template <int NS, bool ROW, bool MASK, bool FULL, bool BF>
 __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, const float *__restrict__ X,
                                                   const float *__restrict__ Y, float *__restrict__ T,
                                                   int Cx, int H, int W) {
@@ -109,6 +111,30 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
         if (active) {
             const float *xs = lds + (bcur * 2 + 0) * OP + fr;
             const float *ys = lds + (bcur * 2 + 1) * OP + fr;
+            if constexpr (BF) {
+                // lane (position l & 15, k group l >> 4) carries channels 2 (l >> 4) and 2 (l >> 4) + 1 of the chunk
+                const int cpair = (2 * lk - lk) * CP;                    // fr already holds lk * CP
+                const bool kin0 = n * W_KC + 2 * lk < Cx, kin1 = n * W_KC + 2 * lk + 1 < Cx;
+                u32x4 af[kMaxTiles];
+#pragma unroll
+                for (int t = 0; t < kMaxTiles; ++t)
+                    if (CCA_TILE_ON(t)) {
+                        const float x0 = CCA_LDS_LD(xs + cpair + t * tstep), x1 = CCA_LDS_LD(xs + cpair + CP + t * tstep);
+                        af[t] = bf16_pack_a(kin0 ? x0 : 0.f, kin1 ? x1 : 0.f);
+                    }
+#pragma unroll
+                for (int rn = 0; rn < kMaxTiles; ++rn) {
+#pragma unroll
+                    for (int q = rn * QT / kMaxTiles; q < (rn + 1) * QT / kMaxTiles; ++q) dma_piece(q, c1, bnext);
+                    if (CCA_TILE_ON(rn)) {
+                        const float y0 = CCA_LDS_LD(ys + cpair + rn * tstep), y1 = CCA_LDS_LD(ys + cpair + CP + rn * tstep);
+                        const u32x4 bb = bf16_pack_b(y0, y1);
+#pragma unroll
+                        for (int rm = 0; rm < kMaxTiles; ++rm)
+                            if (CCA_TILE_ON(rm)) acc[rm][rn] = mfma_bf16_16x16x32(af[rm], bb, acc[rm][rn]);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int ks = 0; ks < W_KC / 4; ++ks) {
                 const bool kin = n * W_KC + ks * 4 + lk < Cx;        // channels beyond Cx hold clamped data: zero A
@@ -142,6 +168,7 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
                     }
                 }
             }
+            }
         } else {
             issue(c1, bnext);                 // strips outside the image still own DMA channels
         }
@@ -171,7 +198,7 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
 
 // One launch covers BOTH branches and all images: 1-D grid of B * (tiles_col + tiles_row) workgroups in
 // XCD-aware order, image-major, then column tiles, then row tiles.
-template <int NS, bool MASK>
+template <int NS, bool MASK, bool BF>
 __global__ __launch_bounds__(kWave * NS, 2) void weight_strip_kernel(const float *__restrict__ X,
                                                                       const float *__restrict__ Y,
                                                                       float *__restrict__ T, int Cx, int H, int W,
@@ -186,11 +213,11 @@ __global__ __launch_bounds__(kWave * NS, 2) void weight_strip_kernel(const float
     const int L = row ? W : H;
     const bool full = L > (kMaxTiles - 1) * kTile;
     if (row) {
-        if (full) weight_strip_body<NS, true, MASK, true>(lds, b, tile, X, Y, T, Cx, H, W);
-        else      weight_strip_body<NS, true, MASK, false>(lds, b, tile, X, Y, T, Cx, H, W);
+        if (full) weight_strip_body<NS, true, MASK, true, BF>(lds, b, tile, X, Y, T, Cx, H, W);
+        else      weight_strip_body<NS, true, MASK, false, BF>(lds, b, tile, X, Y, T, Cx, H, W);
     } else {
-        if (full) weight_strip_body<NS, false, MASK, true>(lds, b, tile, X, Y, T, Cx, H, W);
-        else      weight_strip_body<NS, false, MASK, false>(lds, b, tile, X, Y, T, Cx, H, W);
+        if (full) weight_strip_body<NS, false, MASK, true, BF>(lds, b, tile, X, Y, T, Cx, H, W);
+        else      weight_strip_body<NS, false, MASK, false, BF>(lds, b, tile, X, Y, T, Cx, H, W);
     }
 }
 

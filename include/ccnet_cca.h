@@ -54,8 +54,9 @@ extern "C" {
  * fmaf chain).  BF16X3: every fp32 operand is split into bf16 hi + lo and a product is
  * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix pipe with fp32 accumulation (relative error ~2^-16 per
  * product, far inside the 1e-3 fp32 parity bar); it applies when both H and W are in 97..100. */
-#define CCNET_PRECISION_F32     0
-#define CCNET_PRECISION_BF16X3  1
+#define CCNET_PRECISION_F32     0      /* exact f32 MFMA in every kernel */
+#define CCNET_PRECISION_BF16X3  1      /* split-bf16 x3 in the map kernels and in ca_map_backward's dA kernel */
+#define CCNET_PRECISION_DEFAULT 2      /* split-bf16 x3 only in ca_map_backward's dA kernel (the matrix-pipe-bound one) */
 
 /* profiling aid: restrict the strip-kernel launches of every entry point to one branch so a single
  * kernel can be timed in isolation (results are then partial).  Default CCNET_BRANCH_BOTH. */

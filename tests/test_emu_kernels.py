@@ -31,9 +31,13 @@ SHAPES = [
 
 @pytest.fixture(scope="module")
 def ops():
+    """Emulated library pinned to the EXACT-f32 arithmetic (tight tolerances below); the split-bf16 modes
+    (the default one included) have their own test with their own tolerances."""
     o = EmuOps()
+    o.lib.ccnet_cca_set_precision(0)
     yield o
     o.set_impl(0)
+    o.lib.ccnet_cca_set_precision(2)
 
 
 def T(a):
@@ -148,17 +152,22 @@ def test_split_bf16_option_at_97(ops):
     """Optional split-bf16 x3 arithmetic of the map kernels (3 k-steps of 32 on the bf16 MFMA + one exact f32
     k-step for k = 96..99): inside a few 1e-5 of the oracle on O(1) data."""
     ops.set_impl(MFMA)
-    prev = ops.lib.ccnet_cca_set_precision(1)
+    prev = 0
     try:
-        for shape, seed in (((1, 32, 97, 97), 3), ((1, 16, 100, 98), 4)):
+      for prec in (2, 1):        # 2 = default (packed split-bf16 in the dA kernel only), 1 = split-bf16 everywhere it exists
+        ops.lib.ccnet_cca_set_precision(prec)
+        for shape, seed in (((1, 32, 97, 97), 3), ((1, 16, 100, 98), 4), ((2, 24, 17, 20), 5)):
             c = rand_case(*shape, seed=seed)
             y, A = ops.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
             yo, Ao = O.cca_core_forward(*(T(c[n]) for n in ("q", "k", "v", "x", "gamma")))
-            assert maxerr(A, Ao.numpy()) < TOL and 0 < maxerr(y, yo.numpy()) < 2e-4
+            assert maxerr(A, Ao.numpy()) < TOL and maxerr(y, yo.numpy()) < 2e-4
             dq, dk, dv, dg = ops.cca_backward(c["dy"], c["q"], c["k"], c["v"], A, c["gamma"])
             g = O.cca_core_backward(T(c["dy"]), T(c["q"]), T(c["k"]), T(c["v"]), Ao, T(c["gamma"]))
             assert maxerr(dq, g["dq"].numpy()) < 5e-4 and maxerr(dk, g["dk"].numpy()) < 5e-4
             assert maxerr(dv, g["dv"].numpy()) < 2e-4
+            dA, _ = ops.ca_map_backward(c["dy"], Ao.numpy(), c["v"], None)
+            dAo, _ = O.ca_map_backward(T(c["dy"]), Ao, T(c["v"]))
+            assert maxerr(dA, dAo.numpy()) < 1e-3 * max(1.0, float(dAo.abs().max()))
     finally:
         ops.lib.ccnet_cca_set_precision(prev)
 
@@ -233,6 +242,17 @@ def test_argument_errors(ops):
     assert lib.ccnet_ca_softmax_backward_f32(a.ctypes.data, a.ctypes.data, None, a.ctypes.data, a.ctypes.data,
                                              None, 0, 1, 1, 2, None) == -4
     assert "workspace" in lib.last_error()
+
+
+def test_default_precision_is_packed_bf16_for_dA_only(ops):
+    """ccnet_cca_set_precision returns the previous mode; F32 pins every kernel to the exact arithmetic."""
+    assert ops.lib.ccnet_cca_set_precision(0) == 0                # the module fixture pinned F32
+    c = rand_case(1, 16, 20, 12, seed=12)
+    y0, A0 = ops.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
+    ops.lib.ccnet_cca_set_precision(2)
+    y2, A2 = ops.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
+    ops.lib.ccnet_cca_set_precision(0)
+    assert np.array_equal(y0, y2) and np.array_equal(A0, A2)     # the forward pass is exact f32 in both modes
 
 
 def test_lds_layouts_stay_near_conflict_free():

@@ -24,9 +24,11 @@ DIRECT, MFMA = 1, 2
 def lib():
     from ccnet_amd import _lib
     L = _lib.get_lib()          # raises if libccnet_cca.so is missing: there is no fallback to hide behind
+    L.ccnet_cca_set_precision(_lib.CCNET_PRECISION_DEFAULT)      # what a user gets: exact f32 except the dA kernel
     yield L
     L.ccnet_cca_set_impl(0)
     L.ccnet_cca_set_branch_mask(3)
+    L.ccnet_cca_set_precision(_lib.CCNET_PRECISION_DEFAULT)
 
 
 @pytest.fixture(scope="module")
@@ -151,7 +153,7 @@ def test_headline_shape_against_oracle_and_direct_kernels(lib, dev):
     assert lib.ccnet_cca_shape_uses_mfma(B, C, H, W) == 1
     cross = {n: err(res[MFMA][n], res[DIRECT][n]) for n in ("y", "dq", "dk", "dv")}
     print("headline strip-vs-direct kernels:", cross)
-    assert all(e < 2e-4 for e in cross.values()), cross
+    assert all(e < 5e-4 for e in cross.values()), cross      # (dq/dk inherit the split-bf16 rounding of the dA kernel)
     yo, Ao = O.cca_core_forward(q, k, v, x, gamma)
     go = O.cca_core_backward(dy, q, k, v, Ao, gamma)
     report = {n: err(res[MFMA][n], t) for n, t in (("y", yo), ("dq", go["dq"]), ("dk", go["dk"]), ("dv", go["dv"]))}
