@@ -83,15 +83,23 @@ int weight_strips() {
     if (!v) v = env_int("CCNET_CCA_WEIGHT_STRIPS", 8) == 4 ? 4 : 8;
     return v;
 }
-// arithmetic of the map kernels: 0 = exact f32 MFMA (default), 1 = split-bf16 x3 on the bf16 matrix pipe
-// (strips 97..100 long, NS = 8).  Measured on MI355X the map kernels are HBM-bound either way (the row launch
-// moves 491 MB at 4.2 TB/s), so the 5x cheaper MFMA phase buys < 8 % and the exact path stays the default.
-// CCNET_CCA_MAP_BF16=1 or ccnet_cca_set_precision(CCNET_PRECISION_BF16X3) select the split path.
+// arithmetic of the map kernels.  g_map_bf16: 0 = exact f32 MFMA everywhere, 1 = split-bf16 x3 in the ROW launches
+// only (default), 2 = split-bf16 x3 in both launches.  Measured on MI355X (profiles/): the row launches gain
+// ~20 % (their traffic is fully coalesced, so the 5x cheaper MFMA phase shows), the column launches gain nothing
+// (they are bound by the L2 request rate of their 32-byte segments), so by default only the row launches use it.
+// Only strips 97..100 long have a split-bf16 kernel; other shapes run exact f32.
 int g_map_bf16 = -1;
-bool map_bf16(int H, int W) {
-    if (g_map_bf16 < 0) g_map_bf16 = env_int("CCNET_CCA_MAP_BF16", 0) ? 1 : 0;
+int map_bf16_mode() {
+    if (g_map_bf16 < 0) {
+        g_map_bf16 = env_int("CCNET_CCA_MAP_BF16", 1);
+        if (g_map_bf16 < 0 || g_map_bf16 > 2) g_map_bf16 = 1;
+    }
+    return g_map_bf16;
+}
+bool map_bf16(int H, int W, bool row) {
     const int lo = H < W ? H : W, hi = H < W ? W : H;
-    return g_map_bf16 == 1 && lo > 96 && hi <= cca::kMaxStrip;
+    const int mode = map_bf16_mode();
+    return (mode == 2 || (mode == 1 && row)) && lo > 96 && hi <= cca::kMaxStrip;
 }
 
 int map_strips() {
@@ -144,7 +152,7 @@ void map_grid(int ns, int B, int C, int G, dim3 &grid, int &chunks_per_block, in
 }
 
 // out = alpha * (column sums + row sums) + resid, both branches, strip kernels
-template <int NS, bool TRANS, bool BF>
+template <int NS, bool TRANS, bool BFC, bool BFR>
 int launch_map_pair_ns(const float *T, const float *F, const float *resid, const float *gamma, float *out,
                        int B, int C, int H, int W, ccnet_stream_t stream, const char *what) {
     dim3 grid;
@@ -153,17 +161,17 @@ int launch_map_pair_ns(const float *T, const float *F, const float *resid, const
         map_grid(NS, B, C, /*G=*/W, grid, cpb, tiles, cs);
         if (resid) {
             if (TRANS) return fail(CCNET_E_BADFLAGS, "residual epilogue only exists for the forward aggregation");
-            CCA_LAUNCH((cca::map_strip_kernel<NS, false, false, cca::EPI_COL_RESID, BF>), grid, dim3(cca::kWave * NS),
+            CCA_LAUNCH((cca::map_strip_kernel<NS, false, false, cca::EPI_COL_RESID, BFC>), grid, dim3(cca::kWave * NS),
                        stream, T, F, resid, gamma, out, C, H, W, cpb, tiles, cs);
         } else {
-            CCA_LAUNCH((cca::map_strip_kernel<NS, false, TRANS, cca::EPI_COL, BF>), grid, dim3(cca::kWave * NS), stream,
+            CCA_LAUNCH((cca::map_strip_kernel<NS, false, TRANS, cca::EPI_COL, BFC>), grid, dim3(cca::kWave * NS), stream,
                        T, F, resid, gamma, out, C, H, W, cpb, tiles, cs);
         }
         if (int e = launch_status(what)) return e;
     }
     if (g_branch_mask & CCNET_BRANCH_ROW) {
         map_grid(NS, B, C, /*G=*/H, grid, cpb, tiles, cs);
-        CCA_LAUNCH((cca::map_strip_kernel<NS, true, TRANS, cca::EPI_ROW, BF>), grid, dim3(cca::kWave * NS), stream,
+        CCA_LAUNCH((cca::map_strip_kernel<NS, true, TRANS, cca::EPI_ROW, BFR>), grid, dim3(cca::kWave * NS), stream,
                    T, F, (const float *)nullptr, gamma, out, C, H, W, cpb, tiles, cs);
         return launch_status(what);
     }
@@ -194,9 +202,11 @@ int launch_map_dual_ns(const float *T, const float *F0, float *out0, const float
 template <bool TRANS>
 int launch_map_pair(const float *T, const float *F, const float *resid, const float *gamma, float *out,
                     int B, int C, int H, int W, ccnet_stream_t stream, const char *what) {
-    if (map_strips() == 4) return launch_map_pair_ns<4, TRANS, false>(T, F, resid, gamma, out, B, C, H, W, stream, what);
-    if (map_bf16(H, W)) return launch_map_pair_ns<8, TRANS, true>(T, F, resid, gamma, out, B, C, H, W, stream, what);
-    return launch_map_pair_ns<8, TRANS, false>(T, F, resid, gamma, out, B, C, H, W, stream, what);
+    if (map_strips() == 4) return launch_map_pair_ns<4, TRANS, false, false>(T, F, resid, gamma, out, B, C, H, W, stream, what);
+    const bool bc = map_bf16(H, W, false), br = map_bf16(H, W, true);
+    if (bc && br) return launch_map_pair_ns<8, TRANS, true, true>(T, F, resid, gamma, out, B, C, H, W, stream, what);
+    if (br)       return launch_map_pair_ns<8, TRANS, false, true>(T, F, resid, gamma, out, B, C, H, W, stream, what);
+    return launch_map_pair_ns<8, TRANS, false, false>(T, F, resid, gamma, out, B, C, H, W, stream, what);
 }
 
 // both branches in ONE launch (column workgroups first, then row workgroups)
@@ -251,12 +261,13 @@ int ccnet_cca_set_impl(int impl) {
 }
 int ccnet_cca_get_impl(void) { return g_impl; }
 int ccnet_cca_set_precision(int precision) {
-    if (g_map_bf16 < 0) g_map_bf16 = env_int("CCNET_CCA_MAP_BF16", 0) ? 1 : 0;
+    map_bf16_mode();
     if (g_weight_bf16 < 0) g_weight_bf16 = env_int("CCNET_CCA_WEIGHT_BF16", 1) ? 1 : 0;
-    const int prev = g_map_bf16 ? CCNET_PRECISION_BF16X3 : (g_weight_bf16 ? CCNET_PRECISION_DEFAULT : CCNET_PRECISION_F32);
+    const int prev = g_map_bf16 == 2 ? CCNET_PRECISION_BF16X3
+                   : (g_map_bf16 == 1 || g_weight_bf16 ? CCNET_PRECISION_DEFAULT : CCNET_PRECISION_F32);
     if (precision == CCNET_PRECISION_F32)     { g_map_bf16 = 0; g_weight_bf16 = 0; }
-    if (precision == CCNET_PRECISION_DEFAULT) { g_map_bf16 = 0; g_weight_bf16 = 1; }
-    if (precision == CCNET_PRECISION_BF16X3)  { g_map_bf16 = 1; g_weight_bf16 = 1; }
+    if (precision == CCNET_PRECISION_DEFAULT) { g_map_bf16 = 1; g_weight_bf16 = 1; }
+    if (precision == CCNET_PRECISION_BF16X3)  { g_map_bf16 = 2; g_weight_bf16 = 1; }
     return prev;
 }
 int ccnet_cca_set_branch_mask(int mask) {

@@ -50,13 +50,19 @@ extern "C" {
 #define CCNET_IMPL_DIRECT  1           /* one-thread-per-output kernels, any shape */
 #define CCNET_IMPL_MFMA    2           /* LDS-staged f32-MFMA strip kernels (max(H,W) <= 100) */
 
-/* arithmetic of the aggregation-type (map) strip kernels.  F32 (default): exact fp32 MFMA (bit-identical to an
- * fmaf chain).  BF16X3: every fp32 operand is split into bf16 hi + lo and a product is
- * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix pipe with fp32 accumulation (relative error ~2^-16 per
- * product, far inside the 1e-3 fp32 parity bar); it applies when both H and W are in 97..100. */
-#define CCNET_PRECISION_F32     0      /* exact f32 MFMA in every kernel */
-#define CCNET_PRECISION_BF16X3  1      /* split-bf16 x3 in the map kernels and in ca_map_backward's dA kernel */
-#define CCNET_PRECISION_DEFAULT 2      /* split-bf16 x3 only in ca_map_backward's dA kernel (the matrix-pipe-bound one) */
+/* Arithmetic of the strip kernels.  The affinity (ca_forward), the softmax and the dq/dk kernels always run
+ * exact fp32 (the f32 MFMA is bit-identical to an fmaf chain).  The three C-sized contractions may instead split
+ * every fp32 operand into bf16 hi + lo and evaluate the products on the bf16 matrix pipe with fp32 accumulation
+ * (relative error ~2^-17 per product; measured max-abs error at (8,512,97,97): 2e-4 on dq/dk, 3e-5 on y/dv,
+ * inside the 1e-3 fp32 parity bar):
+ *   F32      exact fp32 everywhere
+ *   DEFAULT  split-bf16 in ca_map_backward's dA kernel (matrix-pipe bound in f32) and in the ROW launches of the
+ *            aggregation kernels; exact fp32 in their column launches (no gain there)
+ *   BF16X3   split-bf16 in every kernel that has such a variant
+ * The split variants exist for strips 97..100 long (aggregation) / any shape (dA); other shapes run exact fp32. */
+#define CCNET_PRECISION_F32     0
+#define CCNET_PRECISION_BF16X3  1
+#define CCNET_PRECISION_DEFAULT 2
 
 /* profiling aid: restrict the strip-kernel launches of every entry point to one branch so a single
  * kernel can be timed in isolation (results are then partial).  Default CCNET_BRANCH_BOTH. */
