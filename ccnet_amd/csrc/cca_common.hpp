@@ -160,6 +160,14 @@ __device__ inline void fbuf_store(const FBuf &b, float v, int voff_bytes, int so
     if ((uint32_t)voff_bytes >= b.bytes || (size_t)o + 4 > b.bytes) return;      // out-of-range stores are dropped
     memcpy(const_cast<char *>(b.base) + o, &v, 4);
 }
+__device__ inline void fbuf_store_x4(const FBuf &b, f32x4 v, int voff_bytes, int soff_bytes) {
+    for (int e = 0; e < 4; ++e) fbuf_store(b, v[e], voff_bytes + 4 * e, soff_bytes);
+}
+__device__ inline f32x4 lds_load_x4(const float *p) {
+    f32x4 v;
+    memcpy(&v, p, 16);
+    return v;
+}
 // LDS-DMA: every lane fetches one dword and the wave deposits the 64 dwords CONTIGUOUSLY at
 // lds_wave_base + lane (buffer_load_dword ... lds).  The emulator completes it synchronously.
 __device__ inline void fbuf_load_to_lds(const FBuf &b, float *lds_wave_base, int voff_bytes, int soff_bytes) {
@@ -215,6 +223,12 @@ __device__ __forceinline__ float fbuf_load(const FBuf &b, int voff_bytes, int so
 __device__ __forceinline__ void fbuf_store(const FBuf &b, float v, int voff_bytes, int soff_bytes) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), b, voff_bytes, soff_bytes, 0);
 }
+// 16-byte store (global address needs only 4-byte alignment, like the 16-byte loads)
+__device__ __forceinline__ void fbuf_store_x4(const FBuf &b, f32x4 v, int voff_bytes, int soff_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), b, voff_bytes, soff_bytes, 0);
+}
+// ds_read_b128: p must be 16-byte aligned
+__device__ __forceinline__ f32x4 lds_load_x4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 // LDS-DMA (buffer_load_dword ... lds): no staging VGPRs, no ds_write pass; the 64 dwords of the wave land
 // contiguously at the wave-uniform LDS address (M0) + lane * 4.  Completion is tracked by vmcnt; the
 // compiler drains it before the next __syncthreads(), which is exactly the double-buffer hand-over.

@@ -25,7 +25,7 @@
 //   row launch    (EPI_ROW)   out = alpha * row_sum + out        (re-read by the thread that rewrites it)
 // The tile of ``resid`` / ``out`` a workgroup needs at the end of a chunk is fetched by LDS-DMA into a third
 // LDS image BEFORE the chunk's MFMAs, so its latency hides under them and costs no registers
-// (3 images x 16 channels x 849 floats = 163,008 B of the 163,840 B LDS at NS = 8).
+// (3 images x 16 channels x 852 floats = 163,584 B of the 163,840 B LDS at NS = 8).
 #pragma once
 #include "cca_common.hpp"
 
@@ -35,12 +35,13 @@ constexpr int M_MC = 16;                          // channels per chunk = one MF
 constexpr int M_KS = kMaxStrip / 4;               // 25 k-steps
 constexpr int M_BKS = 3;                          // bf16 path: 3 k-steps of 32 cover k < 96
 constexpr int EPI_COL = 0, EPI_ROW = 1, EPI_COL_RESID = 2;    // column launch without / row launch / column launch with residual
-// channel pitch of the LDS image: pieces * 64 + 17 (odd: see strip geometry in cca_common.hpp; >= NS*L + 3)
-__host__ __device__ constexpr int m_cp(int ns) { return strip_pieces_c(ns) * 64 + 17; }
+// channel pitch of the LDS image: pieces * 64 + 20 (a multiple of 4 so that 16-byte LDS reads of the tile-store
+// phase stay aligned; >= NS*L + 3 for the K-padding reads)
+__host__ __device__ constexpr int m_cp(int ns) { return strip_pieces_c(ns) * 64 + 20; }
 // prologue images of the attention blocks: 4 strips x 100 rows x pitch 102 (>= 100, == 2 mod 4: the
 // stride-pitch fragment reads of the non-transposed orientation are bank-conflict-free)
 constexpr int M_PP = kMaxStrip + 2, M_SIMG = kMaxStrip * M_PP, M_SPP = 4;
-// LDS: max(2 feature buffers + addend image, prologue images) = 40,800 floats = 163,200 B of 163,840 B
+// LDS: max(2 feature buffers + addend image, prologue images) = 40,896 floats = 163,584 B of 163,840 B
 __host__ __device__ constexpr int m_lds_floats(int ns) {
     return 3 * M_MC * m_cp(ns) > M_SPP * M_SIMG ? 3 * M_MC * m_cp(ns) : M_SPP * M_SIMG;
 }
@@ -289,6 +290,28 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
             for (int q = 0; q < QT; ++q) dma_piece(q, ch, chn, buf);   // strips outside the image still own channels
         }
         __syncthreads();                 // output tile complete; addend tile and chunk ch+1 landed (vmcnt drained)
+        if (FULL && gvalid == NS) {
+            // full tile: 16-byte tile stores mirroring the 16-byte DMA pieces (ds_read_b128 + buffer_store_dwordx4)
+#pragma unroll
+            for (int pr = 0; pr < M_MC / NS; ++pr) {
+                const int cc = wv + pr * NS, c = ch * M_MC + cc;
+                if (c < C) {
+                    const int soff = c * HW * 4;
+                    const float *src = img + cc * CP;
+#pragma unroll
+                    for (int m = 0; m < PIECES4; ++m)
+                        if (sl4.valid(m)) {
+                            f32x4 val = lds_load_x4(&src[m * 256 + 4 * lane]);
+                            val = alpha * val;
+#ifdef CCA_ABL_NOSTORE
+                            if (val[0] != 123.456f) continue;
+#endif
+                            if (has_add) val += lds_load_x4(&lds[2 * BUF + cc * CP + m * 256 + 4 * lane]);
+                            fbuf_store_x4(Ob, val, sl4.vb, soff + sl4.piece_soff(m, W));
+                        }
+                }
+            }
+        } else {
 #pragma unroll
         for (int pr = 0; pr < M_MC / NS; ++pr) {
             const int cc = wv + pr * NS, c = ch * M_MC + cc;
@@ -308,6 +331,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                     }
             }
         }
+        }
         barrier_lds_only();              // images free for the next iteration; the tile stores stay in flight
     }
 }
@@ -319,7 +343,7 @@ __global__ __launch_bounds__(kWave * NS, 2) void map_strip_kernel(const float *_
                                                                    const float *__restrict__ gamma,
                                                                    float *out, int C, int H, int W,
                                                                    int chunks_per_block, int tiles, int nsplit) {
-    __shared__ float lds[m_lds_floats(NS)];
+    __shared__ __attribute__((aligned(16))) float lds[m_lds_floats(NS)];
     CCA_LDS_REGISTER(lds);
     const int L = ROW ? W : H;
     const int wg_linear = blockIdx.x, wg_count = gridDim.x;
@@ -343,7 +367,7 @@ __global__ __launch_bounds__(kWave * NS, 2) void map_strip_dual_kernel(const flo
                                                                         const float *__restrict__ gamma,
                                                                         int C, int H, int W,
                                                                         int chunks_per_block, int tiles, int nsplit) {
-    __shared__ float lds[m_lds_floats(NS)];
+    __shared__ __attribute__((aligned(16))) float lds[m_lds_floats(NS)];
     CCA_LDS_REGISTER(lds);
     const int L = ROW ? W : H;
     const int half = gridDim.x / 2;
