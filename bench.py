@@ -315,6 +315,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline/module/cpu legs (timed region only)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--prewarm-s", type=float, default=0.5, help="untimed pre-run (seconds) before the warm-up steps")
     args = ap.parse_args()
 
     rank, world, local = dist_env()
@@ -333,6 +334,12 @@ def main():
     B, C, H, W = args.batch, args.channels, args.height, args.width
     wl = CoreWorkload(lib, B, C, H, W, device, shard_seed(1234, rank))
 
+    # clocks ramp with load: a short untimed pre-run settles DVFS before the contract's own W warm-up steps
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm_s:
+        for _ in range(10):
+            wl.step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         wl.step()
     torch.cuda.synchronize()
