@@ -195,23 +195,27 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
 
     // DMA work of one chunk iteration, cut into single pieces so that it can be interleaved with the MFMAs
     // (a piece costs ~60-100 issue cycles; 52 of them in front of the MFMAs would add ~40 % to a chunk):
-    //   q in [0, QF)        feature chunk ch+1 -> the other buffer   (channel pr of this wave, piece m)
-    //   q in [QF, QF + QA)  addend tile of chunk ch -> third image
-    constexpr int QF = CPW * PIECES4, QA = CPW * PIECES4, QT = QF + QA;
+    //   q in [0, QA)        addend tile of chunk ch -> third image        (channel pr of this wave, piece m)
+    //   q in [QA, QA + QF)  feature chunk ch+1 -> the other buffer
+    // The addend pieces come FIRST: the barrier in front of the tile stores then only has to wait for them
+    // (counted vmcnt) and the feature pieces of the next chunk keep flying through the store phase.
+    constexpr int QA = (EPI != EPI_COL) ? CPW * PIECES4 : 0, QF = CPW * PIECES4, QT = QA + QF;
+    constexpr int NSTORE4 = CPW * PIECES4;        // 16-byte tile stores per wave and chunk (full tiles)
     // Branch-free in the FULL path: channels beyond C are clamped (they are output rows that are never
     // stored), and when there is no next chunk the current one is simply fetched again into the idle buffer.
     auto dma_piece = [&](int q, int ch, int chn, int buf) {
-        const bool feat = q < QF;
-        const int rem = feat ? q : q - QF;
+        const bool feat = q >= QA;
+        const int rem = feat ? q - QA : q;
         const int pr = rem / PIECES4, m = rem % PIECES4;
         if (!(FULL || m < npieces4)) return;
-        if (!feat && !has_add) return;
         const int cc = wv + pr * NS;
         const int c = (feat ? chn : ch) * M_MC + cc;
         float *dst = lds + (feat ? (buf ^ 1) : 2) * BUF + cc * CP + m * 256;
         if (sl4.valid(m))
             fbuf_load_to_lds_x4(feat ? Fb : Ab, dst, sl4.vb, (c < C ? c : C - 1) * HW * 4 + sl4.piece_soff(m, W));
     };
+    // counted waits need every wave to issue exactly QA + QF pieces and NSTORE4 stores per chunk
+    const bool counted = FULL && gvalid == NS && (C % M_MC == 0);
 
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int buf = (ch - ch_begin) & 1;
@@ -289,7 +293,9 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
 #pragma unroll
             for (int q = 0; q < QT; ++q) dma_piece(q, ch, chn, buf);   // strips outside the image still own channels
         }
-        __syncthreads();                 // output tile complete; addend tile and chunk ch+1 landed (vmcnt drained)
+        // output tile complete and addend tile landed; the QF feature pieces of chunk ch+1 may still be in flight
+        if (counted) barrier_dma_keep<QF>();
+        else         __syncthreads();
         if (FULL && gvalid == NS) {
             // full tile: 16-byte tile stores mirroring the 16-byte DMA pieces (ds_read_b128 + buffer_store_dwordx4)
 #pragma unroll
@@ -332,7 +338,9 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
             }
         }
         }
-        barrier_lds_only();              // images free for the next iteration; the tile stores stay in flight
+        // images free for the next iteration and chunk ch+1 landed; the tile stores stay in flight
+        if (counted) barrier_dma_keep<NSTORE4>();
+        else         barrier_lds_only();
     }
 }
 
