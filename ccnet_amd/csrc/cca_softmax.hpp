@@ -96,10 +96,8 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_kernel(const float *A, c
         }
         wsum += rsum;
     }
-    const bool active = true;
-    const float rsum = wsum;
     if (partials) {
-        if (lane == 0) red[wv] = active ? rsum : 0.f;
+        if (lane == 0) red[wv] = wsum;
         __syncthreads();
         if (threadIdx.x == 0) {
             float t = 0.f;
@@ -127,10 +125,8 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_generic_kernel(const flo
         for (int s = lane; s < S; s += kWave) o[s] = g * a[s] * (d[s] - rsum);
         wsum += rsum;
     }
-    const bool active = true;
-    const float rsum = wsum;
     if (partials) {
-        if (lane == 0) red[wv] = active ? rsum : 0.f;
+        if (lane == 0) red[wv] = wsum;
         __syncthreads();
         if (threadIdx.x == 0) {
             float t = 0.f;
