@@ -52,8 +52,8 @@ def kernel_accounting(kind, B, K, H, W, row):
     """Algorithmic bytes / flops of ONE strip-kernel launch (one branch).
 
     weight kernel: reads X and Y (B,K,H,W) once, writes its half of the (B,H,W,H+W) attention tensor.
-    map kernel   : reads its half of the attention tensor and F (B,K,H,W), writes out (B,K,H,W); the row
-                   launch also re-reads the column partial (and the residual when there is one).
+    map kernel   : reads its half of the attention tensor and F (B,K,H,W), writes out (B,K,H,W); the column
+                   launch also reads the residual when there is one, the row launch re-reads the column partial.
     """
     L = W if row else H
     feat = 4 * B * K * H * W
@@ -64,8 +64,8 @@ def kernel_accounting(kind, B, K, H, W, row):
     nbytes = att + 2 * feat
     if row:
         nbytes += feat                      # column partial re-read
-        if kind == "map_resid":
-            nbytes += feat                  # residual x
+    elif kind == "map_resid":
+        nbytes += feat                      # residual x (added by the column launch)
     return nbytes, flops
 
 

@@ -9,8 +9,12 @@ import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]
 names = {  # rocprof kernel name -> bench.py roofline label
-    "cca::weight_strip_kernel<8, false>": "weight_strip_kernel ca_map_backward.dA[dy.v]",
-    "cca::weight_strip_kernel<8, true>": "weight_strip_kernel ca_forward[q.k]",
+    "cca::weight_strip_kernel<8, false, true>": "weight_strip_kernel ca_map_backward.dA[dy.v]",
+    "cca::weight_strip_kernel<8, false, false>": "weight_strip_kernel ca_map_backward.dA[dy.v]",
+    "cca::weight_strip_kernel<8, true, false>": "weight_strip_kernel ca_forward[q.k]",
+    "cca::map_strip_kernel<8, true, false, 1, true>": "map_strip_kernel<row> ca_map_forward[A.v]",
+    "cca::map_strip_kernel<8, false, true, 0, false>": "map_strip_kernel<col> ca_map_backward.dv[A^T.dy]",
+    "cca::map_strip_kernel<8, true, true, 1, true>": "map_strip_kernel<row> ca_map_backward.dv[A^T.dy]",
     "cca::map_strip_kernel<8, false, false, 2, false>": "map_strip_kernel<col> ca_map_forward[A.v]",
     "cca::map_strip_kernel<8, true, false, 1, false>": "map_strip_kernel<row> ca_map_forward[A.v]",
 }
