@@ -282,11 +282,13 @@ def cpu_baseline(C, H, W, budget_s=20.0):
             "ms_per_image": round(el / n / B * 1e3, 1)}
 
 
-def module_level_ms(B, C, H, W, device, iters=10):
-    """fwd+bwd of the whole CrissCrossAttention module (adds the three torch 1x1 convs + autograd)."""
+def module_level_ms(B, C, H, W, device, iters=10, fuse=True):
+    """fwd+bwd of the whole CrissCrossAttention module (adds the 1x1 projections + autograd); ``fuse`` False
+    runs the three projections as separate convolutions exactly as functions.py:29-35."""
     from ccnet_amd import CrissCrossAttention
     torch.manual_seed(0)
     m = CrissCrossAttention(C).to(device)
+    m.fuse_projections = fuse
     with torch.no_grad():
         m.gamma.fill_(0.5)
     x = torch.randn(B, C, H, W, device=device, requires_grad=True)
@@ -385,6 +387,7 @@ def main():
         out["stages_ms"] = {k: round(v, 4) for k, v in roofline_object.stages.items()}
         try:
             out["module_ms_per_step"] = round(module_level_ms(B, C, H, W, device), 4)
+            out["module_ms_per_step_unfused_projections"] = round(module_level_ms(B, C, H, W, device, fuse=False), 4)
         except Exception as e:          # the metric does not depend on it
             out["module_ms_per_step"] = f"failed: {e}"
         if world == 1 and not args.no_cpu_baseline:

@@ -10,7 +10,7 @@ from __future__ import annotations
 import ctypes
 import os
 import re
-from ctypes import c_char_p, c_int, c_size_t, c_void_p
+from ctypes import c_char_p, c_int, c_long, c_size_t, c_void_p
 from typing import List, Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -47,6 +47,11 @@ _PROTOTYPES = {
     "ccnet_cca_forward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ccnet_cca_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t,
                                        c_int, c_int, c_int, c_int, c_int, _P]),
+    "ccnet_cca_forward_strided_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
+                                              c_long, c_long, c_long, _P]),
+    "ccnet_cca_backward_strided_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t,
+                                               c_int, c_int, c_int, c_int, c_int,
+                                               c_long, c_long, c_long, c_long, c_long, c_long, _P]),
     "ccnet_cca_shape_uses_mfma": (c_int, [c_int, c_int, c_int, c_int]),
     "ccnet_cca_mfma_selftest": (c_int, [_P, _P]),
 }

@@ -154,7 +154,8 @@ void map_grid(int ns, int B, int C, int G, dim3 &grid, int &chunks_per_block, in
 // out = alpha * (column sums + row sums) + resid, both branches, strip kernels
 template <int NS, bool TRANS, bool BFC, bool BFR>
 int launch_map_pair_ns(const float *T, const float *F, const float *resid, const float *gamma, float *out,
-                       int B, int C, int H, int W, ccnet_stream_t stream, const char *what) {
+                       int B, int C, int H, int W, ccnet_stream_t stream, const char *what,
+                       long fbs, long rbs, long obs) {
     dim3 grid;
     int cpb, tiles, cs;
     if (g_branch_mask & CCNET_BRANCH_COL) {
@@ -162,17 +163,17 @@ int launch_map_pair_ns(const float *T, const float *F, const float *resid, const
         if (resid) {
             if (TRANS) return fail(CCNET_E_BADFLAGS, "residual epilogue only exists for the forward aggregation");
             CCA_LAUNCH((cca::map_strip_kernel<NS, false, false, cca::EPI_COL_RESID, BFC>), grid, dim3(cca::kWave * NS),
-                       stream, T, F, resid, gamma, out, C, H, W, cpb, tiles, cs);
+                       stream, T, F, resid, gamma, out, C, H, W, cpb, tiles, cs, fbs, rbs, obs);
         } else {
             CCA_LAUNCH((cca::map_strip_kernel<NS, false, TRANS, cca::EPI_COL, BFC>), grid, dim3(cca::kWave * NS), stream,
-                       T, F, resid, gamma, out, C, H, W, cpb, tiles, cs);
+                       T, F, resid, gamma, out, C, H, W, cpb, tiles, cs, fbs, rbs, obs);
         }
         if (int e = launch_status(what)) return e;
     }
     if (g_branch_mask & CCNET_BRANCH_ROW) {
         map_grid(NS, B, C, /*G=*/H, grid, cpb, tiles, cs);
         CCA_LAUNCH((cca::map_strip_kernel<NS, true, TRANS, cca::EPI_ROW, BFR>), grid, dim3(cca::kWave * NS), stream,
-                   T, F, (const float *)nullptr, gamma, out, C, H, W, cpb, tiles, cs);
+                   T, F, (const float *)nullptr, gamma, out, C, H, W, cpb, tiles, cs, fbs, rbs, obs);
         return launch_status(what);
     }
     return 0;
@@ -181,19 +182,20 @@ int launch_map_pair_ns(const float *T, const float *F, const float *resid, const
 // dq (non-transposed, F0 = k) and dk (transposed, F1 = q) in one launch per branch
 template <int NS>
 int launch_map_dual_ns(const float *T, const float *F0, float *out0, const float *F1, float *out1,
-                       int B, int C, int H, int W, ccnet_stream_t stream, const char *what) {
+                       int B, int C, int H, int W, ccnet_stream_t stream, const char *what,
+                       long fbs0, long obs0, long fbs1, long obs1) {
     dim3 grid;
     int cpb, tiles, cs;
     if (g_branch_mask & CCNET_BRANCH_COL) {
         map_grid(NS, B, C, /*G=*/W, grid, cpb, tiles, cs, 2);
         CCA_LAUNCH((cca::map_strip_dual_kernel<NS, false, cca::EPI_COL>), grid, dim3(cca::kWave * NS), stream,
-                   T, F0, out0, F1, out1, (const float *)nullptr, C, H, W, cpb, tiles, cs);
+                   T, F0, out0, F1, out1, (const float *)nullptr, C, H, W, cpb, tiles, cs, fbs0, obs0, fbs1, obs1);
         if (int e = launch_status(what)) return e;
     }
     if (g_branch_mask & CCNET_BRANCH_ROW) {
         map_grid(NS, B, C, /*G=*/H, grid, cpb, tiles, cs, 2);
         CCA_LAUNCH((cca::map_strip_dual_kernel<NS, true, cca::EPI_ROW>), grid, dim3(cca::kWave * NS), stream,
-                   T, F0, out0, F1, out1, (const float *)nullptr, C, H, W, cpb, tiles, cs);
+                   T, F0, out0, F1, out1, (const float *)nullptr, C, H, W, cpb, tiles, cs, fbs0, obs0, fbs1, obs1);
         return launch_status(what);
     }
     return 0;
@@ -201,12 +203,14 @@ int launch_map_dual_ns(const float *T, const float *F0, float *out0, const float
 
 template <bool TRANS>
 int launch_map_pair(const float *T, const float *F, const float *resid, const float *gamma, float *out,
-                    int B, int C, int H, int W, ccnet_stream_t stream, const char *what) {
-    if (map_strips() == 4) return launch_map_pair_ns<4, TRANS, false, false>(T, F, resid, gamma, out, B, C, H, W, stream, what);
+                    int B, int C, int H, int W, ccnet_stream_t stream, const char *what,
+                    long fbs, long rbs, long obs) {
+    if (map_strips() == 4)
+        return launch_map_pair_ns<4, TRANS, false, false>(T, F, resid, gamma, out, B, C, H, W, stream, what, fbs, rbs, obs);
     const bool bc = map_bf16(H, W, false), br = map_bf16(H, W, true);
-    if (bc && br) return launch_map_pair_ns<8, TRANS, true, true>(T, F, resid, gamma, out, B, C, H, W, stream, what);
-    if (br)       return launch_map_pair_ns<8, TRANS, false, true>(T, F, resid, gamma, out, B, C, H, W, stream, what);
-    return launch_map_pair_ns<8, TRANS, false, false>(T, F, resid, gamma, out, B, C, H, W, stream, what);
+    if (bc && br) return launch_map_pair_ns<8, TRANS, true, true>(T, F, resid, gamma, out, B, C, H, W, stream, what, fbs, rbs, obs);
+    if (br)       return launch_map_pair_ns<8, TRANS, false, true>(T, F, resid, gamma, out, B, C, H, W, stream, what, fbs, rbs, obs);
+    return launch_map_pair_ns<8, TRANS, false, false>(T, F, resid, gamma, out, B, C, H, W, stream, what, fbs, rbs, obs);
 }
 
 // both branches in ONE launch (column workgroups first, then row workgroups)
@@ -221,21 +225,21 @@ bool weight_bf16() {
 
 template <int NS, bool MASK, bool BF>
 int launch_weight_ns(const float *X, const float *Y, float *T, int B, int Cx, int H, int W,
-                     ccnet_stream_t stream, const char *what) {
+                     ccnet_stream_t stream, const char *what, long xbs, long ybs) {
     const int tc = (g_branch_mask & CCNET_BRANCH_COL) ? (W + NS - 1) / NS : 0;
     const int tr = (g_branch_mask & CCNET_BRANCH_ROW) ? (H + NS - 1) / NS : 0;
     CCA_LAUNCH((cca::weight_strip_kernel<NS, MASK, BF>), dim3((tc + tr) * B), dim3(cca::kWave * NS), stream,
-               X, Y, T, Cx, H, W, tc, tr);
+               X, Y, T, Cx, H, W, tc, tr, xbs, ybs);
     return launch_status(what);
 }
 
 template <bool MASK>
 int launch_weight_pair(const float *X, const float *Y, float *T, int B, int Cx, int H, int W,
-                       ccnet_stream_t stream, const char *what) {
+                       ccnet_stream_t stream, const char *what, long xbs, long ybs) {
     if (!MASK && weight_bf16() && weight_strips() == 8)
-        return launch_weight_ns<8, false, true>(X, Y, T, B, Cx, H, W, stream, what);
-    return weight_strips() == 4 ? launch_weight_ns<4, MASK, false>(X, Y, T, B, Cx, H, W, stream, what)
-                                : launch_weight_ns<8, MASK, false>(X, Y, T, B, Cx, H, W, stream, what);
+        return launch_weight_ns<8, false, true>(X, Y, T, B, Cx, H, W, stream, what, xbs, ybs);
+    return weight_strips() == 4 ? launch_weight_ns<4, MASK, false>(X, Y, T, B, Cx, H, W, stream, what, xbs, ybs)
+                                : launch_weight_ns<8, MASK, false>(X, Y, T, B, Cx, H, W, stream, what, xbs, ybs);
 }
 
 int softmax_forward(const float *E, float *A, int B, int H, int W, ccnet_stream_t stream) {
@@ -245,6 +249,104 @@ int softmax_forward(const float *E, float *A, int B, int H, int W, ccnet_stream_
     else if (S <= 512) CCA_LAUNCH((cca::softmax_fwd_kernel<8>), grid, block, stream, E, A, npix, S);
     else               CCA_LAUNCH(cca::softmax_fwd_generic_kernel, grid, block, stream, E, A, npix, S);
     return launch_status("softmax_fwd");
+}
+
+
+// ---- strided internals: every feature tensor is (B, C, H, W) with a dense (C, H, W) image per batch and a
+// ---- caller-given batch stride in elements (dense = C*H*W), so q/k/v may be channel slices of one projection.
+int ca_forward_impl(const float *q, const float *k, float *out, int B, int Cq, int H, int W, int flags,
+                    ccnet_stream_t stream, long qbs, long kbs) {
+    if (int e = check_shape(B, Cq, H, W)) return e;
+    if (!q || !k || !out) return fail(CCNET_E_NULLPTR, "ca_forward: null tensor");
+    if (flags != CCNET_CA_ENERGY && flags != CCNET_CA_SOFTMAX) return fail(CCNET_E_BADFLAGS, "ca_forward: bad flags");
+    const int impl = pick_impl(H, W);
+    if (impl < 0) return impl;
+    if (impl == 1) {
+        if (int e = launch_weight_pair<true>(q, k, out, B, Cq, H, W, stream, "ca_forward", qbs, kbs)) return e;
+    } else {
+        const size_t total = (size_t)B * H * W * (H + W);
+        CCA_LAUNCH((cca::direct_weight_kernel<true>), dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
+                   q, k, out, Cq, H, W, total, qbs, kbs);
+        if (int e = launch_status("ca_forward(direct)")) return e;
+    }
+    if (flags == CCNET_CA_SOFTMAX) return softmax_forward(out, out, B, H, W, stream);
+    return 0;
+}
+
+int ca_backward_impl(const float *dE, const float *q, const float *k, float *dq, float *dk,
+                     int B, int Cq, int H, int W, ccnet_stream_t stream, long qbs, long kbs, long dqbs, long dkbs) {
+    if (int e = check_shape(B, Cq, H, W)) return e;
+    if (!dE || !q || !k || !dq || !dk) return fail(CCNET_E_NULLPTR, "ca_backward: null tensor");
+    const int impl = pick_impl(H, W);
+    if (impl < 0) return impl;
+    if (impl == 1) {
+        static const int dual = env_int("CCNET_CCA_DUAL_QK", 1);
+        if (dual)
+            return map_strips() == 4
+                       ? launch_map_dual_ns<4>(dE, k, dq, q, dk, B, Cq, H, W, stream, "ca_backward(dq,dk)", kbs, dqbs, qbs, dkbs)
+                       : launch_map_dual_ns<8>(dE, k, dq, q, dk, B, Cq, H, W, stream, "ca_backward(dq,dk)", kbs, dqbs, qbs, dkbs);
+        if (int e = launch_map_pair<false>(dE, k, nullptr, nullptr, dq, B, Cq, H, W, stream, "ca_backward(dq)", kbs, 0, dqbs))
+            return e;
+        return launch_map_pair<true>(dE, q, nullptr, nullptr, dk, B, Cq, H, W, stream, "ca_backward(dk)", qbs, 0, dkbs);
+    }
+    const size_t total = (size_t)B * Cq * H * W;
+    CCA_LAUNCH(cca::direct_map_kernel, dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
+               dE, k, (const float *)nullptr, (const float *)nullptr, dq, Cq, H, W, total, kbs, 0L, dqbs);
+    if (int e = launch_status("ca_backward(dq,direct)")) return e;
+    CCA_LAUNCH(cca::direct_mapT_kernel, dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
+               dE, q, (const float *)nullptr, dk, Cq, H, W, total, qbs, dkbs);
+    return launch_status("ca_backward(dk,direct)");
+}
+
+int ca_map_forward_impl(const float *A, const float *v, const float *x, const float *gamma, float *out,
+                        int B, int C, int H, int W, ccnet_stream_t stream, long vbs, long xbs, long obs) {
+    if (int e = check_shape(B, C, H, W)) return e;
+    if (!A || !v || !out) return fail(CCNET_E_NULLPTR, "ca_map_forward: null tensor");
+    const int impl = pick_impl(H, W);
+    if (impl < 0) return impl;
+    if (impl == 1) return launch_map_pair<false>(A, v, x, gamma, out, B, C, H, W, stream, "ca_map_forward", vbs, xbs, obs);
+    const size_t total = (size_t)B * C * H * W;
+    CCA_LAUNCH(cca::direct_map_kernel, dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
+               A, v, x, gamma, out, C, H, W, total, vbs, xbs, obs);
+    return launch_status("ca_map_forward(direct)");
+}
+
+int ca_map_backward_impl(const float *dout, const float *A, const float *v, const float *gamma,
+                         float *dA, float *dv, int B, int C, int H, int W, ccnet_stream_t stream,
+                         long dobs, long vbs, long dvbs) {
+    if (int e = check_shape(B, C, H, W)) return e;
+    if (!dout || !A || !v) return fail(CCNET_E_NULLPTR, "ca_map_backward: null tensor");
+    const int impl = pick_impl(H, W);
+    if (impl < 0) return impl;
+    if (dA) {
+        if (impl == 1) {
+            if (int e = launch_weight_pair<false>(dout, v, dA, B, C, H, W, stream, "ca_map_backward(dA)", dobs, vbs)) return e;
+        } else {
+            const size_t total = (size_t)B * H * W * (H + W);
+            CCA_LAUNCH((cca::direct_weight_kernel<false>), dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
+                       dout, v, dA, C, H, W, total, dobs, vbs);
+            if (int e = launch_status("ca_map_backward(dA,direct)")) return e;
+        }
+    }
+    if (dv) {
+        if (impl == 1)
+            return launch_map_pair<true>(A, dout, nullptr, gamma, dv, B, C, H, W, stream, "ca_map_backward(dv)", dobs, 0, dvbs);
+        const size_t total = (size_t)B * C * H * W;
+        CCA_LAUNCH(cca::direct_mapT_kernel, dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
+                   A, dout, gamma, dv, C, H, W, total, dobs, dvbs);
+        return launch_status("ca_map_backward(dv,direct)");
+    }
+    return 0;
+}
+
+// a batch stride must hold one dense image and keep 4-byte-element addressing inside 32-bit buffer offsets
+int check_stride(long bs, int C, int H, int W, const char *what) {
+    if (bs < (long)C * H * W) {
+        static thread_local std::string msg;
+        msg = std::string(what) + ": batch stride smaller than C*H*W";
+        return fail(CCNET_E_BADSHAPE, msg.c_str());
+    }
+    return 0;
 }
 
 }  // namespace
@@ -289,44 +391,14 @@ int ccnet_ca_softmax_forward_f32(const float *energy, float *out, int B, int H, 
 
 int ccnet_ca_forward_f32(const float *q, const float *k, float *out, int B, int Cq, int H, int W, int flags,
                          ccnet_stream_t stream) {
-    if (int e = check_shape(B, Cq, H, W)) return e;
-    if (!q || !k || !out) return fail(CCNET_E_NULLPTR, "ca_forward: null tensor");
-    if (flags != CCNET_CA_ENERGY && flags != CCNET_CA_SOFTMAX) return fail(CCNET_E_BADFLAGS, "ca_forward: bad flags");
-    const int impl = pick_impl(H, W);
-    if (impl < 0) return impl;
-    if (impl == 1) {
-        if (int e = launch_weight_pair<true>(q, k, out, B, Cq, H, W, stream, "ca_forward")) return e;
-    } else {
-        const size_t total = (size_t)B * H * W * (H + W);
-        CCA_LAUNCH((cca::direct_weight_kernel<true>), dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
-                   q, k, out, Cq, H, W, total);
-        if (int e = launch_status("ca_forward(direct)")) return e;
-    }
-    if (flags == CCNET_CA_SOFTMAX) return softmax_forward(out, out, B, H, W, stream);
-    return 0;
+    const long d = (long)Cq * H * W;
+    return ca_forward_impl(q, k, out, B, Cq, H, W, flags, stream, d, d);
 }
 
 int ccnet_ca_backward_f32(const float *dE, const float *q, const float *k, float *dq, float *dk,
                           int B, int Cq, int H, int W, ccnet_stream_t stream) {
-    if (int e = check_shape(B, Cq, H, W)) return e;
-    if (!dE || !q || !k || !dq || !dk) return fail(CCNET_E_NULLPTR, "ca_backward: null tensor");
-    const int impl = pick_impl(H, W);
-    if (impl < 0) return impl;
-    if (impl == 1) {
-        static const int dual = env_int("CCNET_CCA_DUAL_QK", 1);
-        if (dual)
-            return map_strips() == 4 ? launch_map_dual_ns<4>(dE, k, dq, q, dk, B, Cq, H, W, stream, "ca_backward(dq,dk)")
-                                     : launch_map_dual_ns<8>(dE, k, dq, q, dk, B, Cq, H, W, stream, "ca_backward(dq,dk)");
-        if (int e = launch_map_pair<false>(dE, k, nullptr, nullptr, dq, B, Cq, H, W, stream, "ca_backward(dq)")) return e;
-        return launch_map_pair<true>(dE, q, nullptr, nullptr, dk, B, Cq, H, W, stream, "ca_backward(dk)");
-    }
-    const size_t total = (size_t)B * Cq * H * W;
-    CCA_LAUNCH(cca::direct_map_kernel, dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
-               dE, k, (const float *)nullptr, (const float *)nullptr, dq, Cq, H, W, total);
-    if (int e = launch_status("ca_backward(dq,direct)")) return e;
-    CCA_LAUNCH(cca::direct_mapT_kernel, dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
-               dE, q, (const float *)nullptr, dk, Cq, H, W, total);
-    return launch_status("ca_backward(dk,direct)");
+    const long d = (long)Cq * H * W;
+    return ca_backward_impl(dE, q, k, dq, dk, B, Cq, H, W, stream, d, d, d, d);
 }
 
 size_t ccnet_ca_softmax_backward_workspace_bytes(int B, int H, int W) {
@@ -363,62 +435,67 @@ int ccnet_ca_softmax_backward_f32(const float *A, const float *dA, const float *
 
 int ccnet_ca_map_forward_f32(const float *A, const float *v, const float *x, const float *gamma, float *out,
                              int B, int C, int H, int W, ccnet_stream_t stream) {
-    if (int e = check_shape(B, C, H, W)) return e;
-    if (!A || !v || !out) return fail(CCNET_E_NULLPTR, "ca_map_forward: null tensor");
-    const int impl = pick_impl(H, W);
-    if (impl < 0) return impl;
-    if (impl == 1) return launch_map_pair<false>(A, v, x, gamma, out, B, C, H, W, stream, "ca_map_forward");
-    const size_t total = (size_t)B * C * H * W;
-    CCA_LAUNCH(cca::direct_map_kernel, dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
-               A, v, x, gamma, out, C, H, W, total);
-    return launch_status("ca_map_forward(direct)");
+    const long d = (long)C * H * W;
+    return ca_map_forward_impl(A, v, x, gamma, out, B, C, H, W, stream, d, d, d);
 }
 
 int ccnet_ca_map_backward_f32(const float *dout, const float *A, const float *v, const float *gamma,
                               float *dA, float *dv, int B, int C, int H, int W, ccnet_stream_t stream) {
+    const long d = (long)C * H * W;
+    return ca_map_backward_impl(dout, A, v, gamma, dA, dv, B, C, H, W, stream, d, d, d);
+}
+
+int ccnet_cca_forward_strided_f32(const float *q, const float *k, const float *v, const float *x, const float *gamma,
+                                  float *y, float *A, int B, int C, int Cq, int H, int W,
+                                  long q_bs, long k_bs, long v_bs, ccnet_stream_t stream) {
+    if (!q || !k || !v || !x || !gamma || !y || !A) return fail(CCNET_E_NULLPTR, "cca_forward: null tensor");
     if (int e = check_shape(B, C, H, W)) return e;
-    if (!dout || !A || !v) return fail(CCNET_E_NULLPTR, "ca_map_backward: null tensor");
-    const int impl = pick_impl(H, W);
-    if (impl < 0) return impl;
-    if (dA) {
-        if (impl == 1) {
-            if (int e = launch_weight_pair<false>(dout, v, dA, B, C, H, W, stream, "ca_map_backward(dA)")) return e;
-        } else {
-            const size_t total = (size_t)B * H * W * (H + W);
-            CCA_LAUNCH((cca::direct_weight_kernel<false>), dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
-                       dout, v, dA, C, H, W, total);
-            if (int e = launch_status("ca_map_backward(dA,direct)")) return e;
-        }
-    }
-    if (dv) {
-        if (impl == 1) return launch_map_pair<true>(A, dout, nullptr, gamma, dv, B, C, H, W, stream, "ca_map_backward(dv)");
-        const size_t total = (size_t)B * C * H * W;
-        CCA_LAUNCH(cca::direct_mapT_kernel, dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
-                   A, dout, gamma, dv, C, H, W, total);
-        return launch_status("ca_map_backward(dv,direct)");
-    }
-    return 0;
+    if (int e = check_shape(B, Cq, H, W)) return e;
+    if (int e = check_stride(q_bs, Cq, H, W, "cca_forward(q)")) return e;
+    if (int e = check_stride(k_bs, Cq, H, W, "cca_forward(k)")) return e;
+    if (int e = check_stride(v_bs, C, H, W, "cca_forward(v)")) return e;
+    if (int e = ca_forward_impl(q, k, A, B, Cq, H, W, CCNET_CA_SOFTMAX, stream, q_bs, k_bs)) return e;
+    const long d = (long)C * H * W;
+    return ca_map_forward_impl(A, v, x, gamma, y, B, C, H, W, stream, v_bs, d, d);
 }
 
 int ccnet_cca_forward_f32(const float *q, const float *k, const float *v, const float *x, const float *gamma,
                           float *y, float *A, int B, int C, int Cq, int H, int W, ccnet_stream_t stream) {
-    if (!q || !k || !v || !x || !gamma || !y || !A) return fail(CCNET_E_NULLPTR, "cca_forward: null tensor");
-    if (int e = ccnet_ca_forward_f32(q, k, A, B, Cq, H, W, CCNET_CA_SOFTMAX, stream)) return e;
-    return ccnet_ca_map_forward_f32(A, v, x, gamma, y, B, C, H, W, stream);
+    return ccnet_cca_forward_strided_f32(q, k, v, x, gamma, y, A, B, C, Cq, H, W,
+                                         (long)Cq * H * W, (long)Cq * H * W, (long)C * H * W, stream);
+}
+
+int ccnet_cca_backward_strided_f32(const float *dy, const float *q, const float *k, const float *v, const float *A,
+                                   const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
+                                   void *workspace, size_t workspace_bytes, int B, int C, int Cq, int H, int W,
+                                   long q_bs, long k_bs, long v_bs, long dq_bs, long dk_bs, long dv_bs,
+                                   ccnet_stream_t stream) {
+    if (!dy || !q || !k || !v || !A || !gamma || !dq || !dk || !dv || !dgamma || !scratch)
+        return fail(CCNET_E_NULLPTR, "cca_backward: null tensor");
+    if (int e = check_shape(B, C, H, W)) return e;
+    if (int e = check_shape(B, Cq, H, W)) return e;
+    if (int e = check_stride(q_bs, Cq, H, W, "cca_backward(q)")) return e;
+    if (int e = check_stride(k_bs, Cq, H, W, "cca_backward(k)")) return e;
+    if (int e = check_stride(v_bs, C, H, W, "cca_backward(v)")) return e;
+    if (int e = check_stride(dq_bs, Cq, H, W, "cca_backward(dq)")) return e;
+    if (int e = check_stride(dk_bs, Cq, H, W, "cca_backward(dk)")) return e;
+    if (int e = check_stride(dv_bs, C, H, W, "cca_backward(dv)")) return e;
+    // t = un-scaled dA into scratch, dv = gamma * (A^T-weighted sums of dy)
+    if (int e = ca_map_backward_impl(dy, A, v, gamma, scratch, dv, B, C, H, W, stream, (long)C * H * W, v_bs, dv_bs))
+        return e;
+    // dgamma = sum A*t ; dE = gamma * A * (t - sum_s A t), in place
+    if (int e = ccnet_ca_softmax_backward_f32(A, scratch, gamma, scratch, dgamma, workspace, workspace_bytes,
+                                              B, H, W, stream)) return e;
+    return ca_backward_impl(scratch, q, k, dq, dk, B, Cq, H, W, stream, q_bs, k_bs, dq_bs, dk_bs);
 }
 
 int ccnet_cca_backward_f32(const float *dy, const float *q, const float *k, const float *v, const float *A,
                            const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
                            void *workspace, size_t workspace_bytes, int B, int C, int Cq, int H, int W,
                            ccnet_stream_t stream) {
-    if (!dy || !q || !k || !v || !A || !gamma || !dq || !dk || !dv || !dgamma || !scratch)
-        return fail(CCNET_E_NULLPTR, "cca_backward: null tensor");
-    // t = un-scaled dA into scratch, dv = gamma * (A^T-weighted sums of dy)
-    if (int e = ccnet_ca_map_backward_f32(dy, A, v, gamma, scratch, dv, B, C, H, W, stream)) return e;
-    // dgamma = sum A*t ; dE = gamma * A * (t - sum_s A t), in place
-    if (int e = ccnet_ca_softmax_backward_f32(A, scratch, gamma, scratch, dgamma, workspace, workspace_bytes,
-                                              B, H, W, stream)) return e;
-    return ccnet_ca_backward_f32(scratch, q, k, dq, dk, B, Cq, H, W, stream);
+    const long dq_ = (long)Cq * H * W, dc = (long)C * H * W;
+    return ccnet_cca_backward_strided_f32(dy, q, k, v, A, gamma, dq, dk, dv, dgamma, scratch, workspace,
+                                          workspace_bytes, B, C, Cq, H, W, dq_, dq_, dc, dq_, dq_, dc, stream);
 }
 
 int ccnet_cca_mfma_selftest(float *scratch, ccnet_stream_t stream) {

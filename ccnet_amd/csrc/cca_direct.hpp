@@ -15,7 +15,7 @@ constexpr int D_BLOCK = 256;
 // T[b,h,w,s] = sum_c X[b,c,h,w] * Y[b,c,src(s)];   column self slot -> -inf when MASK
 template <bool MASK>
 __global__ __launch_bounds__(D_BLOCK) void direct_weight_kernel(const float *X, const float *Y, float *T,
-                                                                int Cx, int H, int W, size_t total) {
+                                                                int Cx, int H, int W, size_t total, long xbs, long ybs) {
     const int S = H + W, HW = H * W;
     for (size_t idx = (size_t)blockIdx.x * D_BLOCK + threadIdx.x; idx < total; idx += (size_t)gridDim.x * D_BLOCK) {
         // idx enumerates (b, h, s, w) with w fastest so that a wave reads contiguous w
@@ -26,8 +26,8 @@ __global__ __launch_bounds__(D_BLOCK) void direct_weight_kernel(const float *X, 
         const int h = int(rest % H);
         const int b = int(rest / H);
         const int sh = (s < H) ? s : h, sw = (s < H) ? w : s - H;
-        const float *xp = X + (size_t)b * Cx * HW + (size_t)h * W + w;
-        const float *yp = Y + (size_t)b * Cx * HW + (size_t)sh * W + sw;
+        const float *xp = X + (size_t)b * xbs + (size_t)h * W + w;
+        const float *yp = Y + (size_t)b * ybs + (size_t)sh * W + sw;
         float acc = 0.f;
         for (int c = 0; c < Cx; ++c) acc = fmaf(xp[(size_t)c * HW], yp[(size_t)c * HW], acc);
         if (MASK && s == h) acc = -INFINITY;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(D_BLOCK) void direct_weight_kernel(const float *X, 
 // out[b,c,h,w] = alpha * sum_s T[b,h,w,s] * F[b,c,src(s)] + resid
 __global__ __launch_bounds__(D_BLOCK) void direct_map_kernel(const float *T, const float *F, const float *resid,
                                                              const float *gamma, float *out,
-                                                             int C, int H, int W, size_t total) {
+                                                             int C, int H, int W, size_t total, long fbs, long rbs, long obs) {
     const int S = H + W, HW = H * W;
     const float alpha = gamma ? gamma[0] : 1.f;
     for (size_t idx = (size_t)blockIdx.x * D_BLOCK + threadIdx.x; idx < total; idx += (size_t)gridDim.x * D_BLOCK) {
@@ -49,19 +49,21 @@ __global__ __launch_bounds__(D_BLOCK) void direct_map_kernel(const float *T, con
         const int c = int(rest % C);
         const int b = int(rest / C);
         const float *t = T + (((size_t)b * H + h) * W + w) * S;
-        const float *f = F + ((size_t)b * C + c) * HW;
+        const float *f = F + (size_t)b * fbs + (size_t)c * HW;
         float acc = 0.f;
         for (int j = 0; j < H; ++j) acc = fmaf(t[j], f[(size_t)j * W + w], acc);
         for (int j = 0; j < W; ++j) acc = fmaf(t[H + j], f[(size_t)h * W + j], acc);
         float val = alpha * acc;
-        if (resid) val += resid[idx];
-        out[idx] = val;
+        const size_t in_image = (size_t)c * HW + (size_t)h * W + w;
+        if (resid) val += resid[(size_t)b * rbs + in_image];
+        out[(size_t)b * obs + in_image] = val;
     }
 }
 
 // out[b,c,j,w] = alpha * ( sum_h T[b,h,w,j] * F[b,c,h,w]  +  sum_w' T[b,j,w',H+w] * F[b,c,j,w'] )
 __global__ __launch_bounds__(D_BLOCK) void direct_mapT_kernel(const float *T, const float *F, const float *gamma,
-                                                              float *out, int C, int H, int W, size_t total) {
+                                                              float *out, int C, int H, int W, size_t total,
+                                                              long fbs, long obs) {
     const int S = H + W, HW = H * W;
     const float alpha = gamma ? gamma[0] : 1.f;
     for (size_t idx = (size_t)blockIdx.x * D_BLOCK + threadIdx.x; idx < total; idx += (size_t)gridDim.x * D_BLOCK) {
@@ -72,11 +74,11 @@ __global__ __launch_bounds__(D_BLOCK) void direct_mapT_kernel(const float *T, co
         const int c = int(rest % C);
         const int b = int(rest / C);
         const float *tb = T + (size_t)b * HW * S;
-        const float *f = F + ((size_t)b * C + c) * HW;
+        const float *f = F + (size_t)b * fbs + (size_t)c * HW;
         float acc = 0.f;
         for (int h = 0; h < H; ++h) acc = fmaf(tb[((size_t)h * W + w) * S + j], f[(size_t)h * W + w], acc);
         for (int w2 = 0; w2 < W; ++w2) acc = fmaf(tb[((size_t)j * W + w2) * S + H + w], f[(size_t)j * W + w2], acc);
-        out[idx] = alpha * acc;
+        out[(size_t)b * obs + (size_t)c * HW + (size_t)j * W + w] = alpha * acc;
     }
 }
 

@@ -54,7 +54,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                                                const float *__restrict__ F, const float *__restrict__ resid,
                                                const float *__restrict__ gamma, float *out,
                                                int C, int H, int W, int chunks_per_block, int tiles, int nsplit,
-                                               int wg_linear, int wg_count) {
+                                               int wg_linear, int wg_count, long fbs, long rbs, long obs) {
     constexpr int CP = m_cp(NS), BUF = M_MC * CP, kBlock = kWave * NS, PIECES = strip_pieces_c(NS);
     constexpr int CPW = M_MC / NS;                // channels per wave in the DMA / tile-store phases
     constexpr int PIECES4 = strip_pieces4_c(NS);
@@ -82,11 +82,11 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
     sl4.init(lane, L, W, g0, gvalid);
     const int npieces4 = FULL ? strip_pieces4_c(NS) : (NS * L + 255) / 256;
 
-    const FBuf Fb = make_fbuf(F + (size_t)b * C * HW, (size_t)C * HW * sizeof(float));
-    const FBuf Ob = make_fbuf(out + (size_t)b * C * HW, (size_t)C * HW * sizeof(float));
+    const FBuf Fb = make_fbuf(F + (size_t)b * fbs, (size_t)C * HW * sizeof(float));        // fbs/rbs/obs: batch strides (elements)
+    const FBuf Ob = make_fbuf(out + (size_t)b * obs, (size_t)C * HW * sizeof(float));
     // the tensor added in the epilogue: the residual (column launch, optional) or the column partial (row launch)
     constexpr bool has_add = EPI != EPI_COL;
-    const FBuf Ab = make_fbuf((EPI == EPI_COL_RESID ? resid : out) + (size_t)b * C * HW, (size_t)C * HW * sizeof(float));
+    const FBuf Ab = make_fbuf(EPI == EPI_COL_RESID ? resid + (size_t)b * rbs : out + (size_t)b * obs, (size_t)C * HW * sizeof(float));
     const float alpha = gamma ? gamma[0] : 1.f;
 
     // channels of a chunk are dealt round-robin to the NS waves, for the DMA and for the tile stores
@@ -350,18 +350,19 @@ __global__ __launch_bounds__(kWave * NS, 2) void map_strip_kernel(const float *_
                                                                    const float *__restrict__ resid,
                                                                    const float *__restrict__ gamma,
                                                                    float *out, int C, int H, int W,
-                                                                   int chunks_per_block, int tiles, int nsplit) {
+                                                                   int chunks_per_block, int tiles, int nsplit,
+                                                                   long fbs, long rbs, long obs) {
     __shared__ __attribute__((aligned(16))) float lds[m_lds_floats(NS)];
     CCA_LDS_REGISTER(lds);
     const int L = ROW ? W : H;
     const int wg_linear = blockIdx.x, wg_count = gridDim.x;
     if constexpr (BF) {           // the host only selects BF for strips 97..100 long
-        map_strip_body<NS, ROW, TRANS, EPI, true, true>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count);
+        map_strip_body<NS, ROW, TRANS, EPI, true, true>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs, rbs, obs);
     } else {
         if (L > (M_KS - 1) * 4)
-            map_strip_body<NS, ROW, TRANS, EPI, true, false>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count);
+            map_strip_body<NS, ROW, TRANS, EPI, true, false>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs, rbs, obs);
         else
-            map_strip_body<NS, ROW, TRANS, EPI, false, false>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count);
+            map_strip_body<NS, ROW, TRANS, EPI, false, false>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs, rbs, obs);
     }
 }
 
@@ -374,7 +375,8 @@ __global__ __launch_bounds__(kWave * NS, 2) void map_strip_dual_kernel(const flo
                                                                         const float *__restrict__ F1, float *out1,
                                                                         const float *__restrict__ gamma,
                                                                         int C, int H, int W,
-                                                                        int chunks_per_block, int tiles, int nsplit) {
+                                                                        int chunks_per_block, int tiles, int nsplit,
+                                                                        long fbs0, long obs0, long fbs1, long obs1) {
     __shared__ __attribute__((aligned(16))) float lds[m_lds_floats(NS)];
     CCA_LDS_REGISTER(lds);
     const int L = ROW ? W : H;
@@ -383,11 +385,11 @@ __global__ __launch_bounds__(kWave * NS, 2) void map_strip_dual_kernel(const flo
     const int wg_linear = second ? blockIdx.x - half : blockIdx.x, wg_count = half;
     const bool full = L > (M_KS - 1) * 4;
     if (!second) {
-        if (full) map_strip_body<NS, ROW, false, EPI, true, false>(lds, T, F0, nullptr, gamma, out0, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count);
-        else      map_strip_body<NS, ROW, false, EPI, false, false>(lds, T, F0, nullptr, gamma, out0, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count);
+        if (full) map_strip_body<NS, ROW, false, EPI, true, false>(lds, T, F0, nullptr, gamma, out0, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs0, 0, obs0);
+        else      map_strip_body<NS, ROW, false, EPI, false, false>(lds, T, F0, nullptr, gamma, out0, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs0, 0, obs0);
     } else {
-        if (full) map_strip_body<NS, ROW, true, EPI, true, false>(lds, T, F1, nullptr, gamma, out1, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count);
-        else      map_strip_body<NS, ROW, true, EPI, false, false>(lds, T, F1, nullptr, gamma, out1, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count);
+        if (full) map_strip_body<NS, ROW, true, EPI, true, false>(lds, T, F1, nullptr, gamma, out1, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs1, 0, obs1);
+        else      map_strip_body<NS, ROW, true, EPI, false, false>(lds, T, F1, nullptr, gamma, out1, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs1, 0, obs1);
     }
 }
 

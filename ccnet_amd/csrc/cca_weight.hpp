@@ -38,7 +38,7 @@ __host__ __device__ constexpr int w_lds_floats(int ns) { return 6 * w_op(ns); } 
 template <int NS, bool ROW, bool MASK, bool FULL, bool BF>
 __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, const float *__restrict__ X,
                                                   const float *__restrict__ Y, float *__restrict__ T,
-                                                  int Cx, int H, int W) {
+                                                  int Cx, int H, int W, long xbs, long ybs) {
     constexpr int CP = w_cp(NS, ROW), OP = w_op(NS);
     const Branch br = make_branch(ROW, H, W);
     const int L = br.L, HW = H * W, S = H + W;
@@ -54,8 +54,8 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
     StripLanes4<NS, ROW> sl;
     sl.init(lane, L, W, g0, gvalid);
 
-    const FBuf Xb = make_fbuf(X + (size_t)b * Cx * HW, (size_t)Cx * HW * sizeof(float));
-    const FBuf Yb = make_fbuf(Y + (size_t)b * Cx * HW, (size_t)Cx * HW * sizeof(float));
+    const FBuf Xb = make_fbuf(X + (size_t)b * xbs, (size_t)Cx * HW * sizeof(float));   // xbs: batch stride (elements)
+    const FBuf Yb = make_fbuf(Y + (size_t)b * ybs, (size_t)Cx * HW * sizeof(float));
 
     // DMA of chunk c0 into buffer `buf`: (operand, channel) pairs are dealt round-robin to the NS waves
     auto issue = [&](int c0, int buf) {
@@ -202,7 +202,7 @@ template <int NS, bool MASK, bool BF>
 __global__ __launch_bounds__(kWave * NS, 2) void weight_strip_kernel(const float *__restrict__ X,
                                                                       const float *__restrict__ Y,
                                                                       float *__restrict__ T, int Cx, int H, int W,
-                                                                      int tiles_col, int tiles_row) {
+                                                                      int tiles_col, int tiles_row, long xbs, long ybs) {
     __shared__ float lds[w_lds_floats(NS)];
     CCA_LDS_REGISTER(lds);
     const int per_image = tiles_col + tiles_row;
@@ -213,11 +213,11 @@ __global__ __launch_bounds__(kWave * NS, 2) void weight_strip_kernel(const float
     const int L = row ? W : H;
     const bool full = L > (kMaxTiles - 1) * kTile;
     if (row) {
-        if (full) weight_strip_body<NS, true, MASK, true, BF>(lds, b, tile, X, Y, T, Cx, H, W);
-        else      weight_strip_body<NS, true, MASK, false, BF>(lds, b, tile, X, Y, T, Cx, H, W);
+        if (full) weight_strip_body<NS, true, MASK, true, BF>(lds, b, tile, X, Y, T, Cx, H, W, xbs, ybs);
+        else      weight_strip_body<NS, true, MASK, false, BF>(lds, b, tile, X, Y, T, Cx, H, W, xbs, ybs);
     } else {
-        if (full) weight_strip_body<NS, false, MASK, true, BF>(lds, b, tile, X, Y, T, Cx, H, W);
-        else      weight_strip_body<NS, false, MASK, false, BF>(lds, b, tile, X, Y, T, Cx, H, W);
+        if (full) weight_strip_body<NS, false, MASK, true, BF>(lds, b, tile, X, Y, T, Cx, H, W, xbs, ybs);
+        else      weight_strip_body<NS, false, MASK, false, BF>(lds, b, tile, X, Y, T, Cx, H, W, xbs, ybs);
     }
 }
 

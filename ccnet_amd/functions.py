@@ -28,7 +28,7 @@ from torch.nn import Softmax
 from . import _lib
 from ._lib import CCNET_CA_ENERGY, CCNET_CA_SOFTMAX
 
-__all__ = ["INF", "CA_Weight", "CA_Map", "CrissCrossFunction", "ca_weight", "ca_map", "ca_softmax",
+__all__ = ["INF", "CA_Weight", "CA_Map", "CrissCrossFunction", "CrissCrossPackedFunction", "ca_weight", "ca_map", "ca_softmax",
            "criss_cross_attention", "CrissCrossAttention"]
 
 
@@ -238,6 +238,62 @@ class CrissCrossFunction(torch.autograd.Function):
         return dq, dk, dv, dy, dgamma.view_as(gamma)
 
 
+class CrissCrossPackedFunction(torch.autograd.Function):
+    """Fused core on a PACKED projection: ``qkv`` is the (B, 2*Cq + C, H, W) output of one 1x1 convolution whose
+    weight is the row-wise concatenation of query_conv / key_conv / value_conv (functions.py:29,32,35).  The
+    kernels read q, k, v as channel slices of it through the batch-stride arguments of
+    ``ccnet_cca_forward_strided_f32`` (include/ccnet_cca.h) -- no split copies -- and the backward writes dq, dk,
+    dv straight into the slices of one ``dqkv`` tensor, which is what the fused convolution's backward consumes."""
+
+    @staticmethod
+    def forward(ctx, qkv, x, gamma, cq):
+        qkv, x = _dev_f32("qkv", qkv), _dev_f32("x", x)
+        gamma = _dev_f32("gamma", gamma)
+        _same_device(qkv, x, gamma)
+        B, C, H, W = x.shape
+        cq = int(cq)
+        if qkv.dim() != 4 or tuple(qkv.shape) != (B, 2 * cq + C, H, W):
+            raise RuntimeError(f"qkv must be (B, 2*Cq+C, H, W) = {(B, 2 * cq + C, H, W)}; got {tuple(qkv.shape)}")
+        if gamma.numel() != 1:
+            raise RuntimeError("gamma must hold exactly one element")
+        lib = _lib.get_lib()
+        y = torch.empty_like(x)
+        A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
+        hw, bs = H * W * 4, (2 * cq + C) * H * W
+        base = qkv.data_ptr()
+        with torch.cuda.device(x.device):
+            lib.check(lib.ccnet_cca_forward_strided_f32(base, base + cq * hw, base + 2 * cq * hw, x.data_ptr(),
+                                                        gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
+                                                        B, C, cq, H, W, bs, bs, bs, _stream()), "cca_forward")
+        ctx.save_for_backward(qkv, A, gamma)
+        ctx.cq = cq
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        qkv, A, gamma = ctx.saved_tensors
+        cq = ctx.cq
+        dy = _dev_f32("grad_output", dy)
+        B, C, H, W = dy.shape
+        lib = _lib.get_lib()
+        dqkv = torch.empty_like(qkv)
+        dgamma = torch.empty_like(gamma)
+        scratch = torch.empty_like(A)
+        nbytes = lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
+        ws = torch.empty((nbytes + 3) // 4, device=dy.device, dtype=torch.float32)
+        hw, bs = H * W * 4, (2 * cq + C) * H * W
+        p, g = qkv.data_ptr(), dqkv.data_ptr()
+        with torch.cuda.device(dy.device):
+            lib.check(lib.ccnet_cca_backward_strided_f32(dy.data_ptr(), p, p + cq * hw, p + 2 * cq * hw,
+                                                         A.data_ptr(), gamma.data_ptr(),
+                                                         g, g + cq * hw, g + 2 * cq * hw,
+                                                         dgamma.data_ptr(), scratch.data_ptr(), ws.data_ptr(), nbytes,
+                                                         B, C, cq, H, W, bs, bs, bs, bs, bs, bs, _stream()),
+                      "cca_backward")
+        return dqkv, dy, dgamma.view_as(gamma), None
+
+
 def criss_cross_attention(q, k, v, x, gamma):
     """Functional form of the fused core."""
     return CrissCrossFunction.apply(q, k, v, x, gamma)
@@ -259,11 +315,25 @@ class CrissCrossAttention(nn.Module):
         self.INF = INF
         self.gamma = nn.Parameter(torch.zeros(1))
 
+    #: run query/key/value as ONE 1x1 convolution (stacked weights) feeding the kernels through channel-slice
+    #: strides; set False (class or instance) for three separate convolutions exactly as functions.py:29-35.
+    fuse_projections = True
+
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError(
                 "CrissCrossAttention (ccnet_amd): input is on the CPU. This module runs its attention core as HIP "
                 "kernels on an AMD GPU and has no CPU fallback; move the module and its input to the device.")
+        if self.fuse_projections and self._fusable():
+            # one GEMM for functions.py:29,32,35: the three 1x1 convolutions share their input, so their
+            # weights are stacked row-wise (parameters and state_dict keys stay the reference's three convs)
+            w = torch.cat([self.query_conv.weight, self.key_conv.weight, self.value_conv.weight], 0)
+            b = torch.cat([self.query_conv.bias, self.key_conv.bias, self.value_conv.bias], 0)
+            qkv = torch.nn.functional.conv2d(x, w, b)
+            cq = self.query_conv.out_channels
+            if x.dtype != torch.float32:   # autocast / half inputs: the kernels compute in fp32
+                return CrissCrossPackedFunction.apply(qkv.float(), x.float(), self.gamma.float(), cq).to(x.dtype)
+            return CrissCrossPackedFunction.apply(qkv, x, self.gamma, cq)
         proj_query = self.query_conv(x)
         proj_key = self.key_conv(x)
         proj_value = self.value_conv(x)
@@ -272,3 +342,11 @@ class CrissCrossAttention(nn.Module):
                                            x.float(), self.gamma.float())
             return out.to(x.dtype)
         return CrissCrossFunction.apply(proj_query, proj_key, proj_value, x, self.gamma)
+
+    def _fusable(self):
+        """The packed path needs the three projections to still be the plain biased 1x1 convolutions the
+        constructor made (a user may have swapped one out or hooked it)."""
+        convs = (self.query_conv, self.key_conv, self.value_conv)
+        return all(type(c) is nn.Conv2d and c.kernel_size == (1, 1) and c.bias is not None and c.groups == 1
+                   and not c._forward_hooks and not c._forward_pre_hooks and not c._backward_hooks
+                   for c in convs)

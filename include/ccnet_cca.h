@@ -127,6 +127,23 @@ int ccnet_cca_backward_f32(const float *dy, const float *q, const float *k, cons
                            float *dgamma, float *scratch, void *workspace, size_t workspace_bytes,
                            int B, int C, int Cq, int H, int W, ccnet_stream_t stream);
 
+/* Strided forms of the fused core: q, k, v (and dq, dk, dv) may be channel slices of ONE (B, 2*Cq+C, H, W)
+ * projection -- the output of a single fused 1x1 convolution that replaces functions.py:29,32,35 -- so no
+ * copy is needed to make them contiguous.  Each still is a dense (C, H, W) image per batch element; the
+ * ``*_bs`` arguments are the distance between consecutive batch elements in ELEMENTS (dense tensor: C*H*W;
+ * a slice of the fused projection: (2*Cq+C)*H*W).  Base pointers must be 4-byte aligned.  x, y, dy, A and
+ * scratch stay dense.  A stride below C*H*W returns CCNET_E_BADSHAPE. */
+int ccnet_cca_forward_strided_f32(const float *q, const float *k, const float *v, const float *x,
+                                  const float *gamma, float *y, float *A,
+                                  int B, int C, int Cq, int H, int W,
+                                  long q_bs, long k_bs, long v_bs, ccnet_stream_t stream);
+int ccnet_cca_backward_strided_f32(const float *dy, const float *q, const float *k, const float *v,
+                                   const float *A, const float *gamma, float *dq, float *dk, float *dv,
+                                   float *dgamma, float *scratch, void *workspace, size_t workspace_bytes,
+                                   int B, int C, int Cq, int H, int W,
+                                   long q_bs, long k_bs, long v_bs, long dq_bs, long dk_bs, long dv_bs,
+                                   ccnet_stream_t stream);
+
 /* 1 if the MFMA strip kernels serve this shape under CCNET_IMPL_AUTO, else 0 (direct kernels). */
 int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W);
 

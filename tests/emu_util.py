@@ -114,6 +114,32 @@ class EmuOps:
                                                        B, C, q.shape[1], H, W, None))
         return dq, dk, dv, dgamma
 
+    def cca_forward_packed(self, qkv, x, gamma, cq):
+        """q, k, v are channel slices of one (B, 2*cq+C, H, W) array (the strided entry point)."""
+        B, C, H, W = x.shape
+        y = np.full_like(x, np.nan)
+        A = np.full((B, H, W, H + W), np.nan, np.float32)
+        hw, bs = H * W * 4, (2 * cq + C) * H * W
+        base = qkv.ctypes.data
+        self.lib.check(self.lib.ccnet_cca_forward_strided_f32(base, base + cq * hw, base + 2 * cq * hw, _p(x), _p(gamma),
+                                                              _p(y), _p(A), B, C, cq, H, W, bs, bs, bs, None))
+        return y, A
+
+    def cca_backward_packed(self, dy, qkv, A, gamma, cq):
+        B, C, H, W = dy.shape
+        dqkv = np.full_like(qkv, np.nan)
+        dgamma = np.full(1, np.nan, np.float32)
+        scratch = np.full_like(A, np.nan)
+        nbytes = self.lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
+        ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
+        hw, bs = H * W * 4, (2 * cq + C) * H * W
+        p, g = qkv.ctypes.data, dqkv.ctypes.data
+        self.lib.check(self.lib.ccnet_cca_backward_strided_f32(_p(dy), p, p + cq * hw, p + 2 * cq * hw, _p(A), _p(gamma),
+                                                               g, g + cq * hw, g + 2 * cq * hw, _p(dgamma), _p(scratch),
+                                                               _p(ws), nbytes, B, C, cq, H, W,
+                                                               bs, bs, bs, bs, bs, bs, None))
+        return dqkv, dgamma
+
     def mfma_selftest(self):
         scratch = np.zeros(16, np.float32)
         return self.lib.ccnet_cca_mfma_selftest(_p(scratch), None)

@@ -244,6 +244,48 @@ def test_argument_errors(ops):
     assert "workspace" in lib.last_error()
 
 
+@pytest.mark.parametrize("impl", [DIRECT, MFMA])
+@pytest.mark.parametrize("shape", [(2, 16, 5, 6), (1, 24, 17, 20), (2, 40, 33, 18)])
+def test_packed_projection_slices_are_bit_identical_to_dense(ops, impl, shape):
+    """ccnet_cca_{forward,backward}_strided_f32 on channel slices of one (B, 2Cq+C, H, W) array (what a fused
+    query/key/value convolution produces) == the dense entry points on copies of the slices, bit for bit; the
+    gaps between the written slices of dqkv stay untouched."""
+    ops.set_impl(impl)
+    B, C, H, W = shape
+    c = rand_case(*shape, seed=21)
+    cq = c["q"].shape[1]
+    qkv = np.ascontiguousarray(np.concatenate([c["q"], c["k"], c["v"]], axis=1))
+    y0, A0 = ops.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
+    y1, A1 = ops.cca_forward_packed(qkv, c["x"], c["gamma"], cq)
+    assert np.array_equal(A0, A1, equal_nan=True) and np.array_equal(y0, y1)
+    dq, dk, dv, dg = ops.cca_backward(c["dy"], c["q"], c["k"], c["v"], A0, c["gamma"])
+    dqkv, dg1 = ops.cca_backward_packed(c["dy"], qkv, A0, c["gamma"], cq)
+    assert np.array_equal(dqkv, np.concatenate([dq, dk, dv], axis=1))
+    assert np.array_equal(dg, dg1)
+    # strides larger than the packed layout (padding channels between batches) also work
+    pad = np.full((B, 2 * cq + C + 3, H, W), np.nan, np.float32)
+    pad[:, :2 * cq + C] = qkv
+    hw, bs = H * W * 4, (2 * cq + C + 3) * H * W
+    y2, A2 = np.full_like(y0, np.nan), np.full_like(A0, np.nan)
+    base = pad.ctypes.data
+    P = lambda a: a.ctypes.data  # noqa: E731
+    ops.lib.check(ops.lib.ccnet_cca_forward_strided_f32(base, base + cq * hw, base + 2 * cq * hw, P(c["x"]),
+                                                        P(c["gamma"]), P(y2), P(A2), B, C, cq, H, W, bs, bs, bs, None))
+    assert np.array_equal(y0, y2) and np.array_equal(A0, A2, equal_nan=True)
+    ops.set_impl(0)
+
+
+def test_strided_entry_points_reject_overlapping_strides(ops):
+    a = np.zeros(256, np.float32)
+    p = a.ctypes.data
+    lib = ops.lib
+    rc = lib.ccnet_cca_forward_strided_f32(p, p, p, p, p, p, p, 2, 8, 1, 2, 2, 3, 4, 32, None)   # q stride 3 < 1*2*2
+    assert rc == -1 and "stride" in lib.last_error()
+    rc = lib.ccnet_cca_backward_strided_f32(p, p, p, p, p, p, p, p, p, p, p, p, 64, 2, 8, 1, 2, 2,
+                                            4, 4, 32, 4, 4, 31, None)                           # dv stride 31 < 8*2*2
+    assert rc == -1 and "stride" in lib.last_error()
+
+
 def test_precision_modes_leave_short_strips_exact(ops):
     """ccnet_cca_set_precision returns the previous mode; below 97-long strips the forward pass is exact f32 in
     every mode (the split-bf16 aggregation kernels only exist for strips 97..100 long)."""

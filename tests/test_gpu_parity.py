@@ -239,6 +239,53 @@ def test_determinism_full_overwrite_and_no_out_of_bounds(lib, dev, impl):
             assert torch.equal(runs[0][n], runs[1][n]), f"{n}: run-to-run difference"
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 20, 24), (1, 24, 17, 20), (2, 512, 97, 97), (1, 64, 120, 40)])
+def test_fused_projection_matches_three_separate_convolutions(lib, dev, shape):
+    """The module's default path runs functions.py:29,32,35 as ONE stacked 1x1 convolution and hands the kernels
+    channel slices of its output (ccnet_cca_*_strided_f32).  It must agree with three separate convolutions +
+    the dense entry points: the criss-cross kernels are bit-identical on the same q/k/v (checked directly below),
+    only the GEMM library's summation order for the projections may differ."""
+    from ccnet_amd import CrissCrossAttention
+    from ccnet_amd.functions import CrissCrossFunction, CrissCrossPackedFunction
+    lib.ccnet_cca_set_impl(0)
+    B, C, H, W = shape
+    torch.manual_seed(5)
+    m = CrissCrossAttention(C).to(dev)
+    with torch.no_grad():
+        m.gamma.fill_(0.7)
+    assert m.fuse_projections and m._fusable()
+    x = torch.randn(B, C, H, W, device=dev)
+    dy = torch.randn(B, C, H, W, device=dev)
+    outs = {}
+    for fused in (True, False):
+        m.fuse_projections = fused
+        m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        y = m(xi)
+        y.backward(dy)
+        outs[fused] = (y.detach(), xi.grad, {n: p.grad.clone() for n, p in m.named_parameters()})
+    m.fuse_projections = True
+    scale = float(outs[False][1].abs().max())
+    assert err(outs[True][0], outs[False][0]) < TIGHT * 4
+    assert err(outs[True][1], outs[False][1]) < TIGHT * 4 * max(scale, 1.0)
+    for n in outs[True][2]:
+        ref = outs[False][2][n]
+        assert err(outs[True][2][n], ref) < 1e-4 * max(float(ref.abs().max()), 1.0), n
+    # same q/k/v bits through the dense and the strided entry points -> identical bits out
+    cq = m.query_conv.out_channels
+    qkv = torch.randn(B, 2 * cq + C, H, W, device=dev)
+    q, k, v = (t.contiguous() for t in qkv.split([cq, cq, C], dim=1))
+    leaf = lambda t: t.clone().requires_grad_(True)  # noqa: E731
+    q1, k1, v1, x1, g1, p2, x2, g2 = leaf(q), leaf(k), leaf(v), leaf(x), leaf(m.gamma.detach()), leaf(qkv), leaf(x), \
+        leaf(m.gamma.detach())
+    y1 = CrissCrossFunction.apply(q1, k1, v1, x1, g1)
+    y1.backward(dy)
+    y2 = CrissCrossPackedFunction.apply(p2, x2, g2, cq)
+    y2.backward(dy)
+    assert torch.equal(y1, y2) and torch.equal(g1.grad, g2.grad) and torch.equal(x1.grad, x2.grad)
+    assert torch.equal(torch.cat([q1.grad, k1.grad, v1.grad], 1), p2.grad)
+
+
 def test_gamma_zero_identity_and_zero_init_module(lib, dev):
     """functions.py:24 zero-initialises gamma: step-0 output must equal x bit-exactly and q/k/v grads vanish."""
     from ccnet_amd import CrissCrossAttention
