@@ -270,7 +270,9 @@ def test_fused_projection_matches_three_separate_convolutions(lib, dev, shape):
     assert err(outs[True][1], outs[False][1]) < TIGHT * 4 * max(scale, 1.0)
     for n in outs[True][2]:
         ref = outs[False][2][n]
-        assert err(outs[True][2][n], ref) < 1e-4 * max(float(ref.abs().max()), 1.0), n
+        # key_conv.bias has a mathematically ZERO gradient (softmax is shift-invariant per pixel): what is compared
+        # there is the rounding residue of an 18818-term cancelling sum, hence the absolute floor
+        assert err(outs[True][2][n], ref) < max(1e-4 * float(ref.abs().max()), TOL), n
     # same q/k/v bits through the dense and the strided entry points -> identical bits out
     cq = m.query_conv.out_channels
     qkv = torch.randn(B, 2 * cq + C, H, W, device=dev)
