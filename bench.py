@@ -282,6 +282,48 @@ def cpu_baseline(C, H, W, budget_s=20.0):
             "ms_per_image": round(el / n / B * 1e3, 1)}
 
 
+def stock_pytorch_core(B, C, H, W, device, iters=10):
+    """What stock PyTorch gives on the same device for the same core: the reference's op sequence for
+    functions.py:30-49 (permuted contiguous copies, four torch.bmm, the -inf diagonal, cat, softmax, the gamma /
+    residual epilogue) restated with torch ops -> rocBLAS + elementwise kernels, autograd backward.  Reported
+    beside ``value`` with the same algorithmic-byte numerator; it is a baseline, never the product path."""
+    torch.manual_seed(0)
+    Cq = C // 8
+    q, k = (torch.randn(B, Cq, H, W, device=device, requires_grad=True) for _ in range(2))
+    v, x = (torch.randn(B, C, H, W, device=device, requires_grad=True) for _ in range(2))
+    gamma = torch.full((1,), 0.5, device=device, requires_grad=True)
+    dy = torch.randn(B, C, H, W, device=device)
+
+    def cols(t):       # (B, c, H, W) -> (B*W, c, H): one matrix per image column
+        return t.permute(0, 3, 1, 2).contiguous().view(B * W, -1, H)
+
+    def rows(t):       # (B, c, H, W) -> (B*H, c, W): one matrix per image row
+        return t.permute(0, 2, 1, 3).contiguous().view(B * H, -1, W)
+
+    def fwd():
+        ninf = -torch.diag(torch.full((H,), float("inf"), device=device)).unsqueeze(0).repeat(B * W, 1, 1)
+        e_col = (torch.bmm(cols(q).permute(0, 2, 1), cols(k)) + ninf).view(B, W, H, H).permute(0, 2, 1, 3)
+        e_row = torch.bmm(rows(q).permute(0, 2, 1), rows(k)).view(B, H, W, W)
+        att = torch.softmax(torch.cat([e_col, e_row], 3), dim=3)
+        a_col = att[:, :, :, 0:H].permute(0, 2, 1, 3).contiguous().view(B * W, H, H)
+        a_row = att[:, :, :, H:H + W].contiguous().view(B * H, W, W)
+        o_col = torch.bmm(cols(v), a_col.permute(0, 2, 1)).view(B, W, -1, H).permute(0, 2, 3, 1)
+        o_row = torch.bmm(rows(v), a_row.permute(0, 2, 1)).view(B, H, -1, W).permute(0, 2, 1, 3)
+        return gamma * (o_col + o_row) + x
+
+    def one():
+        for t in (q, k, v, x, gamma):
+            t.grad = None
+        fwd().backward(dy)
+
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    ms = time_region(one, iters)
+    return {"ms_per_step": round(ms, 4), "GB/s": round(core_bytes(B, C, H, W) / (ms * 1e-3) / 1e9, 1),
+            "what": "torch.bmm / cat / softmax formulation of functions.py:30-49 + autograd on this GPU"}
+
+
 def module_level_ms(B, C, H, W, device, iters=10, fuse=True):
     """fwd+bwd of the whole CrissCrossAttention module (adds the 1x1 projections + autograd); ``fuse`` False
     runs the three projections as separate convolutions exactly as functions.py:29-35."""
@@ -390,6 +432,11 @@ def main():
             out["module_ms_per_step_unfused_projections"] = round(module_level_ms(B, C, H, W, device, fuse=False), 4)
         except Exception as e:          # the metric does not depend on it
             out["module_ms_per_step"] = f"failed: {e}"
+        try:
+            out["stock_pytorch_core"] = stock_pytorch_core(B, C, H, W, device)
+            out["speedup_vs_stock_pytorch"] = round(out["stock_pytorch_core"]["ms_per_step"] / out["ms_per_step"], 2)
+        except Exception as e:          # the metric does not depend on it
+            out["stock_pytorch_core"] = f"failed: {e}"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, H, W, args.cpu_budget)
     if use_dist:

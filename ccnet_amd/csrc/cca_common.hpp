@@ -97,6 +97,7 @@ __device__ inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
 }
 
 __device__ inline int uniform(int v) { return v; }
+__device__ inline int recompute_here(int v) { return v; }
 
 // round-to-nearest-even fp32 -> bf16 (as the device's v_cvt_pk_bf16_f32), two values into one dword
 __device__ inline uint32_t emu_bf16_rne(float x) {
@@ -208,6 +209,14 @@ __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
 
 // tell the compiler a value is wave-uniform (it is: derived from the wave id) so it lives in SGPRs
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Opaque copy of a per-lane value: everything computed from the result is recomputed where it is used instead of
+// being hoisted out of the surrounding loop (loop-invariant address arithmetic of the tile-store phase would
+// otherwise occupy VGPRs across the MFMA phase, where every register is spoken for).
+__device__ __forceinline__ int recompute_here(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
 
 // Buffer-resource view of one image's worth of a tensor: buffer_load_dword v, voff, s[rsrc], soff offen
 // keeps ONE 32-bit VGPR offset per lane plus a scalar offset per load, instead of a 64-bit VGPR
@@ -424,6 +433,25 @@ struct StripLanes4 {
         return ROW ? (m * 256 + li < lim) : (okg && m * (256 / NS) + li < lim);
     }
 };
+
+// ---------------------------------------------------------------------------------------------
+// Layout of the column -> row PARTIAL SUM of the map kernels (cca_map.hpp).  The column launch owns NS adjacent
+// columns, the row launch NS adjacent rows; in the tensor's natural layout the column launch would write 4*NS-byte
+// segments (32 B: measured 2.7 TB/s for a copy against ~5 TB/s for whole rows, tools/probes/seg_bw_probe.hip).
+// The partial sums are internal -- the row launch rewrites the same memory with the final values -- so they are
+// stored PERMUTED inside each band of NS rows [k*NS, k*NS + nr), which is exactly the memory a row workgroup
+// owns:   (h, w) -> k*NS*W + (w/4)*4*nr + (h - k*NS)*nw + w%4,   nr = rows in the band, nw = min(4, W - 4*(w/4)).
+// 16-byte granules are 4 consecutive w of one row (what the row launch stores), and the 4*NS granules of a
+// (band, NS columns) tile are contiguous (NS*NS*4 = 256 B at NS = 8) -- what the column launch stores.
+// ---------------------------------------------------------------------------------------------
+template <int NS>
+__device__ __forceinline__ int blocked_offset(int h, int w, int H, int W) {
+    const int k = h / NS, hh = h - k * NS;
+    const int nr = (H - k * NS < NS) ? H - k * NS : NS;
+    const int g = w >> 2;
+    const int nw = (W - 4 * g < 4) ? W - 4 * g : 4;
+    return k * NS * W + g * 4 * nr + hh * nw + (w & 3);
+}
 
 // LDS-DMA of one channel plane slice into its image (FULL: npieces4 is the compile-time maximum)
 template <int NS, bool ROW, bool FULL>

@@ -64,7 +64,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
     const int id = xcd_logical_id(wg_linear, wg_count);
     const int b = id / (tiles * nsplit), rem = id - b * (tiles * nsplit);
     const int split = rem / tiles, g0 = (rem - split * tiles) * NS;
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), lane_ = lane, wv = uniform(tid >> 6);
     const int g = g0 + wv;
     const bool active = g < br.G;
     const int nt = FULL ? kMaxTiles : (L + kTile - 1) / kTile;
@@ -76,8 +76,6 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
     const int ch_end = (ch_begin + chunks_per_block < nchunks) ? ch_begin + chunks_per_block : nchunks;
     const int ln = lane & 15, lk = lane >> 4;
 
-    StripLanes<NS, ROW> sl;                       // 4-byte pieces: tile stores
-    sl.init(lane, L, W, g0, gvalid);
     StripLanes4<NS, ROW> sl4;                     // 16-byte pieces: LDS-DMA
     sl4.init(lane, L, W, g0, gvalid);
     const int npieces4 = FULL ? strip_pieces4_c(NS) : (NS * L + 255) / 256;
@@ -200,7 +198,6 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
     // The addend pieces come FIRST: the barrier in front of the tile stores then only has to wait for them
     // (counted vmcnt) and the feature pieces of the next chunk keep flying through the store phase.
     constexpr int QA = (EPI != EPI_COL) ? CPW * PIECES4 : 0, QF = CPW * PIECES4, QT = QA + QF;
-    constexpr int NSTORE4 = CPW * PIECES4;        // 16-byte tile stores per wave and chunk (full tiles)
     // Branch-free in the FULL path: channels beyond C are clamped (they are output rows that are never
     // stored), and when there is no next chunk the current one is simply fetched again into the idle buffer.
     auto dma_piece = [&](int q, int ch, int chn, int buf) {
@@ -208,21 +205,31 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
         const int rem = feat ? q - QA : q;
         const int pr = rem / PIECES4, m = rem % PIECES4;
         if (!(FULL || m < npieces4)) return;
+#ifdef CCA_ABL_NOFEAT
+        if (feat) return;
+#endif
+#ifdef CCA_ABL_NOADD
+        if (!feat) return;
+#endif
         const int cc = wv + pr * NS;
         const int c = (feat ? chn : ch) * M_MC + cc;
         float *dst = lds + (feat ? (buf ^ 1) : 2) * BUF + cc * CP + m * 256;
         if (sl4.valid(m))
             fbuf_load_to_lds_x4(feat ? Fb : Ab, dst, sl4.vb, (c < C ? c : C - 1) * HW * 4 + sl4.piece_soff(m, W));
     };
-    // counted waits need every wave to issue exactly QA + QF pieces and NSTORE4 stores per chunk
-    const bool counted = FULL && gvalid == NS && (C % M_MC == 0);
+    // counted waits need every wave to issue exactly QA + QF pieces and at least NSTORE_MIN stores per chunk
+    const bool fast = FULL && gvalid == NS;       // full tile of 97..100-long strips: 16-byte granule stores
+    const bool counted = fast && (C % M_MC == 0);
+    // guaranteed number of 16-byte tile stores per wave and chunk on the fast path (counted vmcnt): the column
+    // launch stores PIECES4 granule pieces per channel, the row launch one piece per 64 granules of NS * 24
+    constexpr int NSTORE_MIN = ROW ? CPW * ((NS * 24 + 63) / 64) : CPW * PIECES4;
 
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int buf = (ch - ch_begin) & 1;
         const int chn = (ch + 1 < ch_end) ? ch + 1 : ch;
         float *img = lds + buf * BUF;
+        f32x4 acc[kMaxTiles];
         if (active) {
-            f32x4 acc[kMaxTiles];
 #pragma unroll
             for (int t = 0; t < kMaxTiles; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float *ab = as + buf * BUF;
@@ -278,46 +285,119 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                 }
             }
             }
-            // D[m = channel 4*(l>>4)+r][n = position t*16 + (l&15)] -> this strip's slots of the image
-#pragma unroll
-            for (int t = 0; t < kMaxTiles; ++t)
-                if (FULL || t < nt) {
-                    const int pos = t * kTile + ln;
-                    if (pos < L) {
-                        float *d = img + (4 * lk) * CP + strip_lds_index<NS, ROW>(pos, wv, L);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) CCA_LDS_ST(&d[r * CP], acc[t][r]);
-                    }
-                }
         } else {
 #pragma unroll
             for (int q = 0; q < QT; ++q) dma_piece(q, ch, chn, buf);   // strips outside the image still own channels
         }
-        // output tile complete and addend tile landed; the QF feature pieces of chunk ch+1 may still be in flight
-        if (counted) barrier_dma_keep<QF>();
-        else         __syncthreads();
-        if (FULL && gvalid == NS) {
-            // full tile: 16-byte tile stores mirroring the 16-byte DMA pieces (ds_read_b128 + buffer_store_dwordx4)
+        // D[m = channel 4*(l>>4)+r][n = position t*16 + (l&15)] -> LDS -> tile stores
+        if (fast && !ROW) {
+            // Column launch, full tile: the results go to LDS in the band-permuted layout of the partial sums
+            // (blocked_offset), alpha applied, so that the store phase is a linear copy of 16-byte granules.
+            // They land in the idle third image; with a residual that image holds the residual tile, which is
+            // added here, and the results overwrite this chunk's feature image instead -- after one more
+            // barrier, because other strips' slots of it are still being read as MFMA operands.
+            float *dimg = (EPI == EPI_COL_RESID) ? img : lds + 2 * BUF;
+            if constexpr (EPI == EPI_COL_RESID) {
+                if (counted) barrier_dma_keep<QF>();      // residual tile landed, feature image dead
+                else         __syncthreads();
+            }
+            const int ln = recompute_here(lane_) & 15;    // LDS addresses below are rebuilt per chunk
+#pragma unroll
+            for (int t = 0; t < kMaxTiles; ++t) {
+                const int pos = t * kTile + ln;
+                if (pos < L) {
+                    const int k = pos / NS, hh = pos - k * NS;
+                    const int nr = (L - k * NS < NS) ? L - k * NS : NS;
+                    float *d = dimg + (4 * lk) * CP + k * NS * NS + (wv >> 2) * 4 * nr + hh * 4 + (wv & 3);
+                    const float *xr = lds + 2 * BUF + (4 * lk) * CP + strip_lds_index<NS, ROW>(pos, wv, L);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float val = alpha * acc[t][r];
+                        if constexpr (EPI == EPI_COL_RESID) val += CCA_LDS_LD(&xr[r * CP]);
+                        CCA_LDS_ST(&d[r * CP], val);
+                    }
+                }
+            }
+            if (EPI == EPI_COL_RESID || !counted) { if (counted) barrier_lds_only(); else __syncthreads(); }
+            else                                  barrier_dma_keep<QF>();
+        } else {
+            if (active) {
+#pragma unroll
+                for (int t = 0; t < kMaxTiles; ++t)
+                    if (FULL || t < nt) {
+                        const int pos = t * kTile + ln;
+                        if (pos < L) {
+                            float *d = img + (4 * lk) * CP + strip_lds_index<NS, ROW>(pos, wv, L);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) CCA_LDS_ST(&d[r * CP], acc[t][r]);
+                        }
+                    }
+            }
+            // output tile complete and addend tile landed; the QF feature pieces of chunk ch+1 may still be in flight
+            if (counted) barrier_dma_keep<QF>();
+            else         __syncthreads();
+        }
+        if (fast) {
+            const int lane = recompute_here(lane_);       // store-phase addresses are rebuilt per chunk, not kept live
 #pragma unroll
             for (int pr = 0; pr < M_MC / NS; ++pr) {
                 const int cc = wv + pr * NS, c = ch * M_MC + cc;
                 if (c < C) {
                     const int soff = c * HW * 4;
-                    const float *src = img + cc * CP;
+                    if constexpr (!ROW) {
+                        // column launch: linear copy of the band-permuted image (alpha / residual already applied);
+                        // granule e0 = 256 m + 4 lane lies in band k = e0 / NS^2 at r = e0 % NS^2, valid while r < NS * nr
+                        const float *src = ((EPI == EPI_COL_RESID) ? img : lds + 2 * BUF) + cc * CP;
 #pragma unroll
-                    for (int m = 0; m < PIECES4; ++m)
-                        if (sl4.valid(m)) {
-                            f32x4 val = lds_load_x4(&src[m * 256 + 4 * lane]);
-                            val = alpha * val;
+                        for (int m = 0; m < PIECES4; ++m) {
+                            const int e0 = m * 256 + 4 * lane;
+                            const int k = e0 / (NS * NS), r = e0 - k * NS * NS;
+                            const int rem = L - k * NS, nr = rem < NS ? rem : NS;      // rem <= 0 beyond the last band
+                            if (r < NS * nr) {
+                                const f32x4 val = lds_load_x4(&src[e0]);
 #ifdef CCA_ABL_NOSTORE
-                            if (val[0] != 123.456f) continue;
+                                if (val[0] != 123.456f) continue;
 #endif
-                            if (has_add) val += lds_load_x4(&lds[2 * BUF + cc * CP + m * 256 + 4 * lane]);
-                            fbuf_store_x4(Ob, val, sl4.vb, soff + sl4.piece_soff(m, W));
+                                fbuf_store_x4(Ob, val, 4 * (k * NS * W + g0 * nr + r), soff);
+                            }
                         }
+                    } else {
+                        // row launch: granule p = 64 m + lane is (row p % NS, columns 4 (p / NS) .. + 3); the column
+                        // partial sums of the same granule sit at 4 p of the addend image (band-permuted layout)
+                        const float *res = img + cc * CP;
+                        const float *add = lds + 2 * BUF + cc * CP;
+                        const int ngr = L >> 2;                    // full granules per row
+#pragma unroll
+                        for (int m = 0; m < PIECES4; ++m) {
+                            const int pidx = m * 64 + lane;
+                            const int s4 = pidx % NS, w4 = pidx / NS;
+                            if (w4 < ngr) {
+                                f32x4 val;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) val[i] = alpha * CCA_LDS_LD(&res[s4 * L + 4 * w4 + i]);
+#ifdef CCA_ABL_NOSTORE
+                                if (val[0] != 123.456f) continue;
+#endif
+                                if (has_add) val += lds_load_x4(&add[4 * pidx]);
+                                fbuf_store_x4(Ob, val, 4 * ((g0 + s4) * W + 4 * w4), soff);
+                            }
+                        }
+                        const int nwt = L & 3;                     // columns of the last, partial granule
+                        if (nwt) {
+                            const int mul = nwt == 1 ? 32 : nwt == 2 ? 16 : 11;     // lane / nwt for lane < 24
+                            const int s4 = (lane * mul) >> 5, wi = lane - s4 * nwt;
+                            if (lane < NS * nwt) {
+                                const int w = 4 * ngr + wi;
+                                float val = alpha * CCA_LDS_LD(&res[s4 * L + w]);
+                                if (has_add) val += CCA_LDS_LD(&add[4 * ngr * NS + lane]);
+                                fbuf_store(Ob, val, 4 * ((g0 + s4) * W + w), soff);
+                            }
+                        }
+                    }
                 }
             }
         } else {
+        const int lane = recompute_here(lane_);
 #pragma unroll
         for (int pr = 0; pr < M_MC / NS; ++pr) {
             const int cc = wv + pr * NS, c = ch * M_MC + cc;
@@ -327,19 +407,31 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
 #pragma unroll
                 for (int m = 0; m < strip_pieces_c(NS); ++m)
                     if (FULL || m < npieces) {
-                        const int voff = sl.valid(m) ? sl.vb[m & 1] : kOobOffset;     // invalid lanes: store dropped
-                        float val = alpha * CCA_LDS_LD(&src[m * 64 + lane]);
+                        // natural image order; the column launch scatters into the band-permuted layout, the row
+                        // launch gathers its addend from it (slow path: per-element index arithmetic)
+                        const int e = m * 64 + lane;
+                        float val = alpha * CCA_LDS_LD(&src[e]);
 #ifdef CCA_ABL_NOSTORE
                         if (val != 123.456f) continue;
 #endif
-                        if (has_add) val += CCA_LDS_LD(&lds[2 * BUF + cc * CP + m * 64 + lane]);
-                        fbuf_store(Ob, val, voff, soff + sl.piece_soff(m, W));
+                        if constexpr (!ROW) {
+                            const int pos = e / NS, gg = (e % NS) ^ col_swizzle<NS>(pos);
+                            const bool ok = pos < L && gg < gvalid;
+                            if (has_add) val += CCA_LDS_LD(&lds[2 * BUF + cc * CP + e]);
+                            fbuf_store(Ob, val, ok ? 4 * blocked_offset<NS>(pos, g0 + gg, H, W) : kOobOffset, soff);
+                        } else {
+                            const int s4 = e / L, w = e - s4 * L;
+                            const bool ok = s4 < gvalid;
+                            if (has_add && ok)
+                                val += CCA_LDS_LD(&lds[2 * BUF + cc * CP + blocked_offset<NS>(g0 + s4, w, H, W) - g0 * W]);
+                            fbuf_store(Ob, val, ok ? 4 * ((g0 + s4) * W + w) : kOobOffset, soff);
+                        }
                     }
             }
         }
         }
         // images free for the next iteration and chunk ch+1 landed; the tile stores stay in flight
-        if (counted) barrier_dma_keep<NSTORE4>();
+        if (counted) barrier_dma_keep<NSTORE_MIN>();
         else         barrier_lds_only();
     }
 }

@@ -148,6 +148,24 @@ def test_full_length_strips_97(ops):
     assert maxerr(dv, g["dv"].numpy()) < TOL
 
 
+@pytest.mark.parametrize("shape", [(1, 16, 8, 99), (1, 24, 99, 9), (1, 16, 16, 100), (1, 32, 98, 16)])
+def test_band_permuted_partial_sums_at_every_full_strip_length(ops, shape):
+    """The column launch hands its partial sums to the row launch in the band-permuted layout (cca_common.hpp,
+    blocked_offset); the 16-byte fast paths exist for strips 97..100 long: cover the tail granule widths
+    (L % 4 = 0..3), a short last band (99 = 12 * 8 + 3), a partial strip tile next to a full one and a channel
+    count that is not a multiple of 16 (no counted waits)."""
+    ops.set_impl(MFMA)
+    c = rand_case(*shape, seed=31)
+    y, A = ops.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
+    yo, Ao = O.cca_core_forward(*(T(c[n]) for n in ("q", "k", "v", "x", "gamma")))
+    assert maxerr(y, yo.numpy()) < TOL and maxerr(A, Ao.numpy()) < TOL
+    dq, dk, dv, dg = ops.cca_backward(c["dy"], c["q"], c["k"], c["v"], A, c["gamma"])
+    g = O.cca_core_backward(T(c["dy"]), T(c["q"]), T(c["k"]), T(c["v"]), Ao, T(c["gamma"]))
+    assert maxerr(dq, g["dq"].numpy()) < 1e-4 and maxerr(dk, g["dk"].numpy()) < 1e-4
+    assert maxerr(dv, g["dv"].numpy()) < TOL
+    ops.set_impl(0)
+
+
 def test_split_bf16_option_at_97(ops):
     """Optional split-bf16 x3 arithmetic of the map kernels (3 k-steps of 32 on the bf16 MFMA + one exact f32
     k-step for k = 96..99): inside a few 1e-5 of the oracle on O(1) data."""

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time every strip kernel of several builds of the library (ablation / A-B variants) in ONE process.
-usage: python tools/ablate.py name=path.so [name=path.so ...]   (first is the baseline)"""
+usage: python tools/ablate.py name=path.so[:precision][,ENV=value...] ...   (first is the baseline)
+The environment knobs of a variant are set around every use of its library (the library reads them lazily, once)."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,15 +15,30 @@ def main():
     res = {}
     rounds = int(os.environ.get("ABL_ROUNDS", "3"))
     libs = []
+    envs = {}
     for spec in sys.argv[1:]:
-        name, path = spec.split("=")
-        libs.append((name, _lib.CcaLibrary(os.path.join(ROOT, path))))
+        name, rest = spec.split("=", 1)
+        parts = rest.split(",")
+        path, prec = (parts[0].split(":") + [None])[:2]
+        lib = _lib.CcaLibrary(os.path.join(ROOT, path))
+        if prec is not None:
+            lib.ccnet_cca_set_precision(int(prec))
+        envs[name] = dict(kv.split("=") for kv in parts[1:])
+        libs.append((name, lib))
+
+    def use(name):
+        for k in [k for e in envs.values() for k in e]:
+            os.environ.pop(k, None)
+        os.environ.update(envs[name])
+
     wls = {name: bench.CoreWorkload(lib, B, C, H, W, dev, 1234) for name, lib in libs}
     for name, lib in libs:
-        wls[name].forward()          # A must be a valid attention for later stages
+        use(name)
+        wls[name].step()             # A must be a valid attention for later stages; initialises the lazy knobs
     torch.cuda.synchronize()
     for r in range(rounds):
         for name, lib in libs:
+            use(name)
             wl = wls[name]
             _, rows = bench.roofline_object(wl, iters=10)
             step = bench.time_region(wl.step, 10)
