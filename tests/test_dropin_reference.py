@@ -21,7 +21,7 @@ def ref_networks():
     saved_mods = {k: v for k, v in sys.modules.items() if k.split(".")[0] in ("networks", "utils", "inplace_abn")}
     for k in saved_mods:
         del sys.modules[k]
-    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests", "shims"), REF]     # ours first, then the shim, then the reference
+    sys.path[:0] = [ROOT, REF]     # ours first (cc_attention AND the inplace_abn restatement), then the reference
     try:
         yield importlib.import_module("networks.ccnet")
     finally:

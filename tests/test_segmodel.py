@@ -1,0 +1,245 @@
+"""The callers around the hot path: ``inplace_abn`` restatement, RCCAModule / ResNet-101
+mirror (``ccnet_amd/segmodel.py``) and the synthetic DDP train driver (``ccnet_amd/train_synthetic.py``).
+
+CPU tests compare against the UNMODIFIED reference network code where /root/reference is mounted (the build
+container); the device attention has no CPU path, so on the CPU a test-only module built on the oracle stands in
+for it on OUR side while the reference side runs its own pure-python CrissCrossAttention.  GPU tests (``-m gpu``)
+run the real HIP module inside RCCAModule against the stock-PyTorch formulation on the same device."""
+import importlib
+import json
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import ROOT
+from oracle import cca_oracle as O
+
+REF = "/root/reference"
+needs_ref = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted (GPU box)")
+
+
+class OracleCCA(nn.Module):
+    """Test-only stand-in with the module's parameters; forward = the oracle's torch restatement (any device)."""
+
+    def __init__(self, in_dim):
+        super().__init__()
+        self.query_conv = nn.Conv2d(in_dim, in_dim // 8, 1)
+        self.key_conv = nn.Conv2d(in_dim, in_dim // 8, 1)
+        self.value_conv = nn.Conv2d(in_dim, in_dim, 1)
+        self.gamma = nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        y, _ = O.cca_core_forward(self.query_conv(x), self.key_conv(x), self.value_conv(x), x, self.gamma)
+        return y
+
+
+def swap_cca(model, cls=OracleCCA):
+    """Replace every CrissCrossAttention in ``model`` by ``cls`` carrying the same parameters."""
+    from ccnet_amd import CrissCrossAttention
+    for parent in model.modules():
+        for name, child in list(parent.named_children()):
+            if isinstance(child, CrissCrossAttention):
+                new = cls(child.value_conv.in_channels)
+                new.load_state_dict(child.state_dict())
+                setattr(parent, name, new)
+    return model
+
+
+@pytest.fixture()
+def ref_networks():
+    saved = list(sys.path)
+    mine = ("networks", "utils", "inplace_abn", "cc_attention", "loss")
+    saved_mods = {k: v for k, v in sys.modules.items() if k.split(".")[0] in mine}
+    for k in saved_mods:
+        del sys.modules[k]
+    sys.path[:0] = [REF]                    # the reference's cc_attention AND networks; inplace_abn from this repo
+    sys.path.insert(1, ROOT)
+    try:
+        yield importlib.import_module("networks.ccnet")
+    finally:
+        sys.path[:] = saved
+        for k in [k for k in sys.modules if k.split(".")[0] in mine]:
+            del sys.modules[k]
+        sys.modules.update(saved_mods)
+
+
+def test_abn_is_batchnorm_plus_leaky_relu_and_has_the_real_packages_state_dict_keys():
+    from inplace_abn import InPlaceABN, InPlaceABNSync
+    torch.manual_seed(0)
+    x = torch.randn(4, 6, 5, 7)
+    for cls in (InPlaceABN, InPlaceABNSync):
+        m = cls(6)
+        assert sorted(m.state_dict()) == ["bias", "running_mean", "running_var", "weight"]
+        with torch.no_grad():
+            m.weight.uniform_(0.5, 1.5), m.bias.uniform_(-1, 1)
+        bn = nn.BatchNorm2d(6)
+        bn.load_state_dict(m.state_dict(), strict=False)
+        assert torch.allclose(m(x), nn.functional.leaky_relu(bn(x), 0.01), atol=1e-6)         # training statistics
+        assert torch.allclose(m.running_mean, bn.running_mean) and torch.allclose(m.running_var, bn.running_var)
+        m.eval(), bn.eval()
+        assert torch.allclose(m(x), nn.functional.leaky_relu(bn(x), 0.01), atol=1e-6)         # running statistics
+    ident = InPlaceABNSync(6, activation="identity")
+    assert torch.allclose(ident(x), nn.BatchNorm2d(6)(x), atol=1e-6)
+    with pytest.raises(ValueError):
+        InPlaceABN(6, activation="swish")
+
+
+@needs_ref
+def test_state_dict_table_equals_the_reference_networks(ref_networks):
+    """Same keys, same shapes as ``Seg_Model`` of the unmodified networks/ccnet.py (built on this repository's
+    inplace_abn) -> reference checkpoints load strictly."""
+    from ccnet_amd.segmodel import Seg_Model
+    theirs = ref_networks.Seg_Model(19, recurrence=2)
+    ours = Seg_Model(19, recurrence=2)
+    t_ref = {k: tuple(v.shape) for k, v in theirs.state_dict().items()}
+    t_our = {k: tuple(v.shape) for k, v in ours.state_dict().items()}
+    assert t_our == t_ref
+    res = ours.load_state_dict(theirs.state_dict(), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert sum(p.numel() for p in ours.parameters()) == sum(p.numel() for p in theirs.parameters())
+
+
+@needs_ref
+def test_forward_and_loss_match_the_reference_network_on_cpu(ref_networks):
+    """Whole network, eval mode (running statistics, no dropout), 65x65 input -> 9x9 attention maps, R = 2:
+    the reference runs its own pure-python CrissCrossAttention (INF override: functions.py:12 hard-codes .cuda()),
+    ours runs the oracle stand-in.  Then the DSN loss on the same logits."""
+    from ccnet_amd.segmodel import CriterionDSN, Seg_Model
+    torch.manual_seed(0)
+    theirs = ref_networks.Seg_Model(19, recurrence=2).eval()
+    for m in theirs.modules():
+        if type(m).__name__ == "CrissCrossAttention":
+            m.INF = lambda B, H, W: -torch.diag(torch.tensor(float("inf")).repeat(H), 0).unsqueeze(0).repeat(B * W, 1, 1)
+            with torch.no_grad():
+                m.gamma.fill_(0.6)
+    with torch.no_grad():                    # non-trivial running statistics
+        for m in theirs.modules():
+            if hasattr(m, "running_var"):
+                m.running_mean.normal_(0, 0.1), m.running_var.uniform_(0.8, 1.2)
+    ours = Seg_Model(19, recurrence=2)
+    ours.load_state_dict(theirs.state_dict(), strict=True)
+    ours = swap_cca(ours).eval()
+    x = torch.randn(1, 3, 65, 65)
+    with torch.no_grad():
+        a, b = theirs(x), ours(x)
+    assert a[0].shape == b[0].shape == (1, 19, 9, 9) and a[1].shape == b[1].shape
+    scale = float(a[0].abs().max())
+    assert float((a[0] - b[0]).abs().max()) < 1e-4 * max(scale, 1.0)
+    assert float((a[1] - b[1]).abs().max()) < 1e-4 * max(float(a[1].abs().max()), 1.0)
+    labels = torch.randint(0, 19, (1, 65, 65))
+    labels[0, :5] = 255
+    crit_ref = importlib.import_module("loss.criterion").CriterionDSN() if os.path.isdir(os.path.join(REF, "loss")) else None
+    if crit_ref is not None:
+        assert float(CriterionDSN()(b, labels)) == pytest.approx(float(crit_ref(a, labels)), rel=1e-4)
+
+
+def _tiny_factory():
+    """A two-stage toy network with the real head / loss structure, oracle attention: for the CPU driver test."""
+    from ccnet_amd.segmodel import CriterionDSN, ResNetCCNet
+    stages = ((8, 1, 1, 1), (8, 1, 2, 1), (8, 1, 1, 2), (16, 1, 1, 4))
+    return swap_cca(ResNetCCNet(5, CriterionDSN(), recurrence=2, stages=stages))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _driver_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from ccnet_amd import train_synthetic as T
+    import test_segmodel as me
+    args = T.build_parser().parse_args(["--cpu", "--steps", "2", "--warmup", "1", "--size", "33", "--num-classes", "5",
+                                        "--batch-per-gpu", "2"])
+    res = T.run(args, model_factory=me._tiny_factory)
+    out.put((rank, res))
+
+
+def test_train_driver_world2_gloo():
+    """DDP + poly LR + SGD + DSN loss on two CPU ranks (gloo): rank 0 reports whole-job images/s."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_driver_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(out.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    res = got[0]
+    assert got[1] is None and res["n_gpus"] == 2 and res["config"]["global_batch"] == 4
+    assert res["value"] > 0 and res["final_loss"] == res["final_loss"]          # finite
+    json.dumps(res)
+
+
+def test_train_driver_single_process_and_poly_lr():
+    from ccnet_amd import train_synthetic as T
+    assert T.lr_poly(1e-2, 0, 100) == pytest.approx(1e-2)
+    assert T.lr_poly(1e-2, 50, 100) == pytest.approx(1e-2 * 0.5 ** 0.9)
+    args = T.build_parser().parse_args(["--cpu", "--steps", "1", "--warmup", "0", "--size", "33", "--num-classes", "5"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    res = T.run(args, model_factory=_tiny_factory)
+    assert res["n_gpus"] == 1 and res["value"] > 0
+    img, lab = T.synthetic_batch(2, 17, 5, torch.device("cpu"), torch.Generator().manual_seed(0))
+    assert img.shape == (2, 3, 17, 17) and set(lab.unique().tolist()) <= set(range(5)) | {255}
+
+
+# ----------------------------------------------------------------------------------------------
+# GPU
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 256, 33, 40), (1, 2048, 97, 97)])
+def test_rcca_head_r2_hip_attention_vs_stock_formulation(shape):
+    """BASELINE configs[2]: RCCAModule with R = 2 (ccnet.py:116-123).  The HIP attention inside the head against
+    the same head with the attention computed by torch ops on the same device (shared parameters), forward and
+    all gradients."""
+    from ccnet_amd.segmodel import RCCAModule
+    dev = torch.device("cuda:0")
+    B, C, H, W = shape
+    torch.manual_seed(7)
+    head = RCCAModule(C, 512, 19).to(dev)
+    with torch.no_grad():
+        head.cca.gamma.fill_(0.5)
+    twin = RCCAModule(C, 512, 19).to(dev)
+    twin.load_state_dict(head.state_dict())
+    twin = swap_cca(twin).to(dev)
+    head.eval(), twin.eval()                      # no dropout; running statistics
+    x = torch.randn(B, C, H, W, device=dev)
+    dy = torch.randn(B, 19, H, W, device=dev)
+    outs = []
+    for m in (head, twin):
+        xi = x.clone().requires_grad_(True)
+        y = m(xi, 2)
+        y.backward(dy)
+        outs.append((y.detach(), xi.grad, dict((n, p.grad) for n, p in m.named_parameters())))
+    (y0, dx0, g0), (y1, dx1, g1) = outs
+    tol = lambda ref: 2e-3 * max(float(ref.abs().max()), 1.0)  # noqa: E731  (two fp32 GEMM libraries + 1e-3 attention bar)
+    assert float((y0 - y1).abs().max()) < tol(y1)
+    assert float((dx0 - dx1).abs().max()) < tol(dx1)
+    for n in g1:
+        assert float((g0[n] - g1[n]).abs().max()) < tol(g1[n]), n
+
+
+@pytest.mark.gpu
+def test_train_driver_one_gpu_small_crop():
+    """BASELINE configs[3] on one GPU at a reduced crop (the full 769x769 run is `python -m
+    ccnet_amd.train_synthetic`): the real ResNet-101 + RCCA R=2 with the HIP attention takes optimiser steps."""
+    from ccnet_amd import train_synthetic as T
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    args = T.build_parser().parse_args(["--steps", "2", "--warmup", "1", "--size", "257"])
+    res = T.run(args)
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["final_loss"] == res["final_loss"]
+    with open("/proc/self/maps") as f:
+        assert "libccnet_cca.so" in f.read()
