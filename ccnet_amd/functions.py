@@ -331,17 +331,14 @@ class CrissCrossAttention(nn.Module):
             b = torch.cat([self.query_conv.bias, self.key_conv.bias, self.value_conv.bias], 0)
             qkv = torch.nn.functional.conv2d(x, w, b)
             cq = self.query_conv.out_channels
-            if x.dtype != torch.float32:   # autocast / half inputs: the kernels compute in fp32
-                return CrissCrossPackedFunction.apply(qkv.float(), x.float(), self.gamma.float(), cq).to(x.dtype)
-            return CrissCrossPackedFunction.apply(qkv, x, self.gamma, cq)
+            # half inputs, or fp32 inputs whose projections autocast turned into bf16: the kernels compute in fp32
+            return CrissCrossPackedFunction.apply(qkv.float(), x.float(), self.gamma.float(), cq).to(x.dtype)
         proj_query = self.query_conv(x)
         proj_key = self.key_conv(x)
         proj_value = self.value_conv(x)
-        if x.dtype != torch.float32:       # autocast / half inputs: the kernels compute in fp32
-            out = CrissCrossFunction.apply(proj_query.float(), proj_key.float(), proj_value.float(),
-                                           x.float(), self.gamma.float())
-            return out.to(x.dtype)
-        return CrissCrossFunction.apply(proj_query, proj_key, proj_value, x, self.gamma)
+        out = CrissCrossFunction.apply(proj_query.float(), proj_key.float(), proj_value.float(),
+                                       x.float(), self.gamma.float())
+        return out.to(x.dtype)
 
     def _fusable(self):
         """The packed path needs the three projections to still be the plain biased 1x1 convolutions the

@@ -58,8 +58,6 @@ def run(args, model_factory=None):
     else:
         model = model_factory()
     model = model.to(device).train()
-    if args.channels_last:
-        model = model.to(memory_format=torch.channels_last)
     net = model
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local] if use_cuda else None,
@@ -73,8 +71,6 @@ def run(args, model_factory=None):
         for g in opt.param_groups:
             g["lr"] = lr_poly(args.lr, it, max(total, 1))
         images, labels = synthetic_batch(args.batch_per_gpu, args.size, args.num_classes, device, gen)
-        if args.channels_last:
-            images = images.contiguous(memory_format=torch.channels_last)
         opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.bf16 and use_cuda):
             loss = net(images, labels)
@@ -132,7 +128,6 @@ def build_parser():
     ap.add_argument("--weight-decay", type=float, default=1e-4)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--bf16", action="store_true", help="autocast convolutions to bf16 (the attention core stays fp32)")
-    ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--cpu", action="store_true", help="tests only: gloo on CPU with an injected model")
     ap.add_argument("--no-destroy-group", dest="destroy_group", action="store_false")
     return ap

@@ -288,6 +288,34 @@ def test_fused_projection_matches_three_separate_convolutions(lib, dev, shape):
     assert torch.equal(torch.cat([q1.grad, k1.grad, v1.grad], 1), p2.grad)
 
 
+def test_channels_last_and_autocast_inputs_are_accepted(lib, dev):
+    """NHWC-strided (channels_last) tensors and bf16 autocast activations reach the module in real training
+    scripts (``train_synthetic --bf16``, NHWC pipelines): the host layer makes them NCHW-contiguous fp32, results
+    equal the plain call."""
+    from ccnet_amd import CrissCrossAttention
+    lib.ccnet_cca_set_impl(0)
+    torch.manual_seed(9)
+    m = CrissCrossAttention(64).to(dev)
+    with torch.no_grad():
+        m.gamma.fill_(0.5)
+    x = torch.randn(2, 64, 24, 31, device=dev)
+    dy = torch.randn_like(x)
+    ref_in = x.clone().requires_grad_(True)
+    y_ref = m(ref_in)
+    y_ref.backward(dy)
+    g_ref = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    cl_in = x.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y_cl = m(cl_in)
+    y_cl.backward(dy.contiguous(memory_format=torch.channels_last))
+    assert err(y_cl, y_ref) < TIGHT and err(cl_in.grad, ref_in.grad) < TIGHT * 4
+    for n, p in m.named_parameters():
+        assert err(p.grad, g_ref[n]) < 1e-4 * max(float(g_ref[n].abs().max()), 1.0), n
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y_ac = m(x)
+    assert y_ac.dtype == torch.float32 and err(y_ac, y_ref) < 0.1       # bf16 projections, fp32 attention core
+
+
 def test_gamma_zero_identity_and_zero_init_module(lib, dev):
     """functions.py:24 zero-initialises gamma: step-0 output must equal x bit-exactly and q/k/v grads vanish."""
     from ccnet_amd import CrissCrossAttention
