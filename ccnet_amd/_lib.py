@@ -52,6 +52,9 @@ _PROTOTYPES = {
     "ccnet_cca_backward_strided_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t,
                                                c_int, c_int, c_int, c_int, c_int,
                                                c_long, c_long, c_long, c_long, c_long, c_long, _P]),
+    "ccnet_cca_forward_bf16": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "ccnet_cca_backward_bf16": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t,
+                                        c_int, c_int, c_int, c_int, c_int, _P]),
     "ccnet_cca_shape_uses_mfma": (c_int, [c_int, c_int, c_int, c_int]),
     "ccnet_cca_mfma_selftest": (c_int, [_P, _P]),
 }

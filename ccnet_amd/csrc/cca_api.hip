@@ -290,10 +290,10 @@ int ca_backward_impl(const float *dE, const float *q, const float *k, float *dq,
         return launch_map_pair<true>(dE, q, nullptr, nullptr, dk, B, Cq, H, W, stream, "ca_backward(dk)", qbs, 0, dkbs);
     }
     const size_t total = (size_t)B * Cq * H * W;
-    CCA_LAUNCH(cca::direct_map_kernel, dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
+    CCA_LAUNCH((cca::direct_map_kernel<float>), dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
                dE, k, (const float *)nullptr, (const float *)nullptr, dq, Cq, H, W, total, kbs, 0L, dqbs);
     if (int e = launch_status("ca_backward(dq,direct)")) return e;
-    CCA_LAUNCH(cca::direct_mapT_kernel, dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
+    CCA_LAUNCH((cca::direct_mapT_kernel<float>), dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
                dE, q, (const float *)nullptr, dk, Cq, H, W, total, qbs, dkbs);
     return launch_status("ca_backward(dk,direct)");
 }
@@ -306,7 +306,7 @@ int ca_map_forward_impl(const float *A, const float *v, const float *x, const fl
     if (impl < 0) return impl;
     if (impl == 1) return launch_map_pair<false>(A, v, x, gamma, out, B, C, H, W, stream, "ca_map_forward", vbs, xbs, obs);
     const size_t total = (size_t)B * C * H * W;
-    CCA_LAUNCH(cca::direct_map_kernel, dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
+    CCA_LAUNCH((cca::direct_map_kernel<float>), dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
                A, v, x, gamma, out, C, H, W, total, vbs, xbs, obs);
     return launch_status("ca_map_forward(direct)");
 }
@@ -332,7 +332,7 @@ int ca_map_backward_impl(const float *dout, const float *A, const float *v, cons
         if (impl == 1)
             return launch_map_pair<true>(A, dout, nullptr, gamma, dv, B, C, H, W, stream, "ca_map_backward(dv)", dobs, 0, dvbs);
         const size_t total = (size_t)B * C * H * W;
-        CCA_LAUNCH(cca::direct_mapT_kernel, dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
+        CCA_LAUNCH((cca::direct_mapT_kernel<float>), dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
                    A, dout, gamma, dv, C, H, W, total, dobs, dvbs);
         return launch_status("ca_map_backward(dv,direct)");
     }
@@ -497,6 +497,60 @@ int ccnet_cca_backward_f32(const float *dy, const float *q, const float *k, cons
     return ccnet_cca_backward_strided_f32(dy, q, k, v, A, gamma, dq, dk, dv, dgamma, scratch, workspace,
                                           workspace_bytes, B, C, Cq, H, W, dq_, dq_, dc, dq_, dq_, dc, stream);
 }
+
+/* ---- bf16 feature I/O (BASELINE configs[4]): bf16 q, k, v, x, y, dy, dq, dk, dv; fp32 attention, softmax,
+ * ---- accumulation, gamma.  Served by the any-shape kernels (one thread per output). ---- */
+int ccnet_cca_forward_bf16(const uint16_t *q_, const uint16_t *k_, const uint16_t *v_, const uint16_t *x_,
+                           const float *gamma, uint16_t *y_, float *A, int B, int C, int Cq, int H, int W,
+                           ccnet_stream_t stream) {
+    if (!q_ || !k_ || !v_ || !x_ || !gamma || !y_ || !A) return fail(CCNET_E_NULLPTR, "cca_forward_bf16: null tensor");
+    if (int e = check_shape(B, C, H, W)) return e;
+    if (int e = check_shape(B, Cq, H, W)) return e;
+    using cca::bf16_t;
+    const bf16_t *q = (const bf16_t *)q_, *k = (const bf16_t *)k_, *v = (const bf16_t *)v_, *x = (const bf16_t *)x_;
+    bf16_t *y = (bf16_t *)y_;
+    const long dq_ = (long)Cq * H * W, dc = (long)C * H * W;
+    const size_t na = (size_t)B * H * W * (H + W), nf = (size_t)B * C * H * W;
+    CCA_LAUNCH((cca::direct_weight_kernel<true, bf16_t>), dim3(direct_grid(na)), dim3(cca::D_BLOCK), stream,
+               q, k, A, Cq, H, W, na, dq_, dq_);
+    if (int e = launch_status("cca_forward_bf16(energy)")) return e;
+    if (int e = softmax_forward(A, A, B, H, W, stream)) return e;
+    CCA_LAUNCH((cca::direct_map_kernel<bf16_t>), dim3(direct_grid(nf)), dim3(cca::D_BLOCK), stream,
+               (const float *)A, v, x, gamma, y, C, H, W, nf, dc, dc, dc);
+    return launch_status("cca_forward_bf16(aggregate)");
+}
+
+int ccnet_cca_backward_bf16(const uint16_t *dy_, const uint16_t *q_, const uint16_t *k_, const uint16_t *v_,
+                            const float *A, const float *gamma, uint16_t *dq_, uint16_t *dk_, uint16_t *dv_,
+                            float *dgamma, float *scratch, void *workspace, size_t workspace_bytes,
+                            int B, int C, int Cq, int H, int W, ccnet_stream_t stream) {
+    if (!dy_ || !q_ || !k_ || !v_ || !A || !gamma || !dq_ || !dk_ || !dv_ || !dgamma || !scratch)
+        return fail(CCNET_E_NULLPTR, "cca_backward_bf16: null tensor");
+    if (int e = check_shape(B, C, H, W)) return e;
+    if (int e = check_shape(B, Cq, H, W)) return e;
+    using cca::bf16_t;
+    const bf16_t *dy = (const bf16_t *)dy_, *q = (const bf16_t *)q_, *k = (const bf16_t *)k_, *v = (const bf16_t *)v_;
+    bf16_t *dq = (bf16_t *)dq_, *dk = (bf16_t *)dk_, *dv = (bf16_t *)dv_;
+    const long sq = (long)Cq * H * W, sc = (long)C * H * W;
+    const size_t na = (size_t)B * H * W * (H + W), nf = (size_t)B * C * H * W, nq = (size_t)B * Cq * H * W;
+    // t = un-scaled dA into scratch, dv = gamma * (A^T-weighted sums of dy)
+    CCA_LAUNCH((cca::direct_weight_kernel<false, bf16_t>), dim3(direct_grid(na)), dim3(cca::D_BLOCK), stream,
+               dy, v, scratch, C, H, W, na, sc, sc);
+    if (int e = launch_status("cca_backward_bf16(dA)")) return e;
+    CCA_LAUNCH((cca::direct_mapT_kernel<bf16_t>), dim3(direct_grid(nf)), dim3(cca::D_BLOCK), stream,
+               A, dy, gamma, dv, C, H, W, nf, sc, sc);
+    if (int e = launch_status("cca_backward_bf16(dv)")) return e;
+    // dgamma = sum A*t ; dE = gamma * A * (t - sum_s A t), in place
+    if (int e = ccnet_ca_softmax_backward_f32(A, scratch, gamma, scratch, dgamma, workspace, workspace_bytes,
+                                              B, H, W, stream)) return e;
+    CCA_LAUNCH((cca::direct_map_kernel<bf16_t>), dim3(direct_grid(nq)), dim3(cca::D_BLOCK), stream,
+               (const float *)scratch, k, (const bf16_t *)nullptr, (const float *)nullptr, dq, Cq, H, W, nq, sq, 0L, sq);
+    if (int e = launch_status("cca_backward_bf16(dq)")) return e;
+    CCA_LAUNCH((cca::direct_mapT_kernel<bf16_t>), dim3(direct_grid(nq)), dim3(cca::D_BLOCK), stream,
+               (const float *)scratch, q, (const float *)nullptr, dk, Cq, H, W, nq, sq, sq);
+    return launch_status("cca_backward_bf16(dk)");
+}
+
 
 int ccnet_cca_mfma_selftest(float *scratch, ccnet_stream_t stream) {
     if (!scratch) return fail(CCNET_E_NULLPTR, "mfma_selftest: null scratch");

@@ -341,6 +341,26 @@ __device__ __forceinline__ int xcd_logical_id(int linear, int nwg) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Storage types of the feature tensors.  Arithmetic is fp32 everywhere; bf16 tensors (BASELINE configs[4]) are
+// raw 16-bit patterns widened on load and rounded to nearest-even on store (NaN stays NaN), the same rounding as
+// v_cvt_pk_bf16_f32 and torch's float -> bfloat16 conversion.
+// ---------------------------------------------------------------------------------------------
+struct bf16_t { uint16_t bits; };
+__host__ __device__ inline float load_f32(const float *p) { return *p; }
+__host__ __device__ inline void store_f32(float *p, float v) { *p = v; }
+__host__ __device__ inline float load_f32(const bf16_t *p) {
+    const uint32_t u = (uint32_t)p->bits << 16;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+__host__ __device__ inline void store_f32(bf16_t *p, float v) {
+    uint32_t u;
+    __builtin_memcpy(&u, &v, 4);
+    p->bits = (uint16_t)(((u & 0x7fffffffu) > 0x7f800000u) ? ((u >> 16) | 0x40u) : ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16));
+}
+
+// ---------------------------------------------------------------------------------------------
 // Strip-tile geometry shared by the strip kernels: the NS strips x L positions of ONE channel form a
 // linear LDS image, element (position i, strip gg) at index p:
 //   column branch  p = i * NS + (gg ^ swz(i))    NS consecutive w per position; the swizzle only swaps the two

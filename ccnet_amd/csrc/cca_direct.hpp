@@ -4,7 +4,9 @@
 // straight from the index definitions of /root/reference/cc_attention/functions.py:38-47 and its
 // autograd.  They serve shapes the strip kernels do not cover (a strip longer than 100) and are the
 // on-device cross-check of the MFMA path (tests/test_gpu_parity.py runs both).  Threads are laid out
-// with w fastest so feature reads coalesce; accumulation is a plain fmaf chain in slot order.
+// with w fastest so feature reads coalesce; accumulation is a plain fmaf chain in slot order.  The feature element
+// type FT is float or bf16_t (bf16 storage, fp32 arithmetic: BASELINE configs[4]); attention-shaped tensors and
+// gamma are always fp32.
 #pragma once
 #include "cca_common.hpp"
 
@@ -13,8 +15,8 @@ namespace cca {
 constexpr int D_BLOCK = 256;
 
 // T[b,h,w,s] = sum_c X[b,c,h,w] * Y[b,c,src(s)];   column self slot -> -inf when MASK
-template <bool MASK>
-__global__ __launch_bounds__(D_BLOCK) void direct_weight_kernel(const float *X, const float *Y, float *T,
+template <bool MASK, typename FT = float>
+__global__ __launch_bounds__(D_BLOCK) void direct_weight_kernel(const FT *X, const FT *Y, float *T,
                                                                 int Cx, int H, int W, size_t total, long xbs, long ybs) {
     const int S = H + W, HW = H * W;
     for (size_t idx = (size_t)blockIdx.x * D_BLOCK + threadIdx.x; idx < total; idx += (size_t)gridDim.x * D_BLOCK) {
@@ -26,18 +28,19 @@ __global__ __launch_bounds__(D_BLOCK) void direct_weight_kernel(const float *X, 
         const int h = int(rest % H);
         const int b = int(rest / H);
         const int sh = (s < H) ? s : h, sw = (s < H) ? w : s - H;
-        const float *xp = X + (size_t)b * xbs + (size_t)h * W + w;
-        const float *yp = Y + (size_t)b * ybs + (size_t)sh * W + sw;
+        const FT *xp = X + (size_t)b * xbs + (size_t)h * W + w;
+        const FT *yp = Y + (size_t)b * ybs + (size_t)sh * W + sw;
         float acc = 0.f;
-        for (int c = 0; c < Cx; ++c) acc = fmaf(xp[(size_t)c * HW], yp[(size_t)c * HW], acc);
+        for (int c = 0; c < Cx; ++c) acc = fmaf(load_f32(xp + (size_t)c * HW), load_f32(yp + (size_t)c * HW), acc);
         if (MASK && s == h) acc = -INFINITY;
         T[(((size_t)b * H + h) * W + w) * S + s] = acc;
     }
 }
 
 // out[b,c,h,w] = alpha * sum_s T[b,h,w,s] * F[b,c,src(s)] + resid
-__global__ __launch_bounds__(D_BLOCK) void direct_map_kernel(const float *T, const float *F, const float *resid,
-                                                             const float *gamma, float *out,
+template <typename FT = float>
+__global__ __launch_bounds__(D_BLOCK) void direct_map_kernel(const float *T, const FT *F, const FT *resid,
+                                                             const float *gamma, FT *out,
                                                              int C, int H, int W, size_t total, long fbs, long rbs, long obs) {
     const int S = H + W, HW = H * W;
     const float alpha = gamma ? gamma[0] : 1.f;
@@ -49,20 +52,21 @@ __global__ __launch_bounds__(D_BLOCK) void direct_map_kernel(const float *T, con
         const int c = int(rest % C);
         const int b = int(rest / C);
         const float *t = T + (((size_t)b * H + h) * W + w) * S;
-        const float *f = F + (size_t)b * fbs + (size_t)c * HW;
+        const FT *f = F + (size_t)b * fbs + (size_t)c * HW;
         float acc = 0.f;
-        for (int j = 0; j < H; ++j) acc = fmaf(t[j], f[(size_t)j * W + w], acc);
-        for (int j = 0; j < W; ++j) acc = fmaf(t[H + j], f[(size_t)h * W + j], acc);
+        for (int j = 0; j < H; ++j) acc = fmaf(t[j], load_f32(f + (size_t)j * W + w), acc);
+        for (int j = 0; j < W; ++j) acc = fmaf(t[H + j], load_f32(f + (size_t)h * W + j), acc);
         float val = alpha * acc;
         const size_t in_image = (size_t)c * HW + (size_t)h * W + w;
-        if (resid) val += resid[(size_t)b * rbs + in_image];
-        out[(size_t)b * obs + in_image] = val;
+        if (resid) val += load_f32(resid + (size_t)b * rbs + in_image);
+        store_f32(out + (size_t)b * obs + in_image, val);
     }
 }
 
 // out[b,c,j,w] = alpha * ( sum_h T[b,h,w,j] * F[b,c,h,w]  +  sum_w' T[b,j,w',H+w] * F[b,c,j,w'] )
-__global__ __launch_bounds__(D_BLOCK) void direct_mapT_kernel(const float *T, const float *F, const float *gamma,
-                                                              float *out, int C, int H, int W, size_t total,
+template <typename FT = float>
+__global__ __launch_bounds__(D_BLOCK) void direct_mapT_kernel(const float *T, const FT *F, const float *gamma,
+                                                              FT *out, int C, int H, int W, size_t total,
                                                               long fbs, long obs) {
     const int S = H + W, HW = H * W;
     const float alpha = gamma ? gamma[0] : 1.f;
@@ -74,11 +78,12 @@ __global__ __launch_bounds__(D_BLOCK) void direct_mapT_kernel(const float *T, co
         const int c = int(rest % C);
         const int b = int(rest / C);
         const float *tb = T + (size_t)b * HW * S;
-        const float *f = F + (size_t)b * fbs + (size_t)c * HW;
+        const FT *f = F + (size_t)b * fbs + (size_t)c * HW;
         float acc = 0.f;
-        for (int h = 0; h < H; ++h) acc = fmaf(tb[((size_t)h * W + w) * S + j], f[(size_t)h * W + w], acc);
-        for (int w2 = 0; w2 < W; ++w2) acc = fmaf(tb[((size_t)j * W + w2) * S + H + w], f[(size_t)j * W + w2], acc);
-        out[(size_t)b * obs + (size_t)c * HW + (size_t)j * W + w] = alpha * acc;
+        for (int h = 0; h < H; ++h) acc = fmaf(tb[((size_t)h * W + w) * S + j], load_f32(f + (size_t)h * W + w), acc);
+        for (int w2 = 0; w2 < W; ++w2)
+            acc = fmaf(tb[((size_t)j * W + w2) * S + H + w], load_f32(f + (size_t)j * W + w2), acc);
+        store_f32(out + (size_t)b * obs + (size_t)c * HW + (size_t)j * W + w, alpha * acc);
     }
 }
 

@@ -28,7 +28,7 @@ from torch.nn import Softmax
 from . import _lib
 from ._lib import CCNET_CA_ENERGY, CCNET_CA_SOFTMAX
 
-__all__ = ["INF", "CA_Weight", "CA_Map", "CrissCrossFunction", "CrissCrossPackedFunction", "ca_weight", "ca_map", "ca_softmax",
+__all__ = ["INF", "CA_Weight", "CA_Map", "CrissCrossFunction", "CrissCrossPackedFunction", "CrissCrossBF16Function", "ca_weight", "ca_map", "ca_softmax",
            "criss_cross_attention", "CrissCrossAttention"]
 
 
@@ -294,6 +294,58 @@ class CrissCrossPackedFunction(torch.autograd.Function):
         return dqkv, dy, dgamma.view_as(gamma), None
 
 
+def _dev_bf16(name: str, t: torch.Tensor) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a bfloat16 tensor on an AMD GPU (there is no CPU fallback)")
+    if t.dtype != torch.bfloat16:
+        raise RuntimeError(f"{name}: expected bfloat16, got {t.dtype}")
+    return t.contiguous()
+
+
+class CrissCrossBF16Function(torch.autograd.Function):
+    """Fused core with bf16 feature tensors (BASELINE configs[4]): q, k, v, x -> y in bf16, the attention, its
+    softmax, every accumulation and gamma in fp32 (``ccnet_cca_forward_bf16`` / ``ccnet_cca_backward_bf16``)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, x, gamma):
+        q, k, v, x = _dev_bf16("query", q), _dev_bf16("key", k), _dev_bf16("value", v), _dev_bf16("x", x)
+        gamma = _dev_f32("gamma", gamma)
+        _check_qk(q, k)
+        _same_device(q, k, v, x, gamma)
+        B, C, H, W = v.shape
+        if x.shape != v.shape or q.shape[0] != B or tuple(q.shape[2:]) != (H, W):
+            raise RuntimeError(f"shape mismatch: q {tuple(q.shape)}, v {tuple(v.shape)}, x {tuple(x.shape)}")
+        lib = _lib.get_lib()
+        y = torch.empty_like(x)
+        A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            lib.check(lib.ccnet_cca_forward_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), x.data_ptr(),
+                                                 gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
+                                                 B, C, q.shape[1], H, W, _stream()), "cca_forward_bf16")
+        ctx.save_for_backward(q, k, v, A, gamma)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        q, k, v, A, gamma = ctx.saved_tensors
+        dy = _dev_bf16("grad_output", dy)
+        B, C, H, W = v.shape
+        lib = _lib.get_lib()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dgamma = torch.empty_like(gamma)
+        scratch = torch.empty_like(A)
+        nbytes = lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
+        ws = torch.empty((nbytes + 3) // 4, device=v.device, dtype=torch.float32)
+        with torch.cuda.device(v.device):
+            lib.check(lib.ccnet_cca_backward_bf16(dy.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                                  A.data_ptr(), gamma.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                                  dv.data_ptr(), dgamma.data_ptr(), scratch.data_ptr(),
+                                                  ws.data_ptr(), nbytes, B, C, q.shape[1], H, W, _stream()),
+                      "cca_backward_bf16")
+        return dq, dk, dv, dy, dgamma.view_as(gamma)
+
+
 def criss_cross_attention(q, k, v, x, gamma):
     """Functional form of the fused core."""
     return CrissCrossFunction.apply(q, k, v, x, gamma)
@@ -319,11 +371,21 @@ class CrissCrossAttention(nn.Module):
     #: strides; set False (class or instance) for three separate convolutions exactly as functions.py:29-35.
     fuse_projections = True
 
+    #: bf16 inputs at geometries outside the fp32 strip kernels (strips longer than 100) use the bf16-I/O entry
+    #: points; everything else is computed through fp32 copies on the MFMA kernels.
+    native_bf16 = True
+
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError(
                 "CrissCrossAttention (ccnet_amd): input is on the CPU. This module runs its attention core as HIP "
                 "kernels on an AMD GPU and has no CPU fallback; move the module and its input to the device.")
+        if x.dtype == torch.bfloat16 and self.native_bf16 and not self._strip_kernels_cover(x):
+            # bf16 activations at a geometry the fp32 MFMA strip kernels do not cover: run the bf16-I/O entry points
+            # (fp32 attention / softmax / accumulation inside) instead of materialising fp32 copies of every tensor
+            q, k, v = self.query_conv(x), self.key_conv(x), self.value_conv(x)
+            return CrissCrossBF16Function.apply(q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16),
+                                                x, self.gamma.float())
         if self.fuse_projections and self._fusable():
             # one GEMM for functions.py:29,32,35: the three 1x1 convolutions share their input, so their
             # weights are stacked row-wise (parameters and state_dict keys stay the reference's three convs)
@@ -339,6 +401,11 @@ class CrissCrossAttention(nn.Module):
         out = CrissCrossFunction.apply(proj_query.float(), proj_key.float(), proj_value.float(),
                                        x.float(), self.gamma.float())
         return out.to(x.dtype)
+
+    @staticmethod
+    def _strip_kernels_cover(x):
+        B, C, H, W = x.shape
+        return bool(_lib.get_lib().ccnet_cca_shape_uses_mfma(B, C, H, W))
 
     def _fusable(self):
         """The packed path needs the three projections to still be the plain biased 1x1 convolutions the

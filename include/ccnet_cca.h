@@ -29,6 +29,7 @@
 #define CCNET_CCA_H
 
 #include <stddef.h>
+#include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -143,6 +144,19 @@ int ccnet_cca_backward_strided_f32(const float *dy, const float *q, const float 
                                    int B, int C, int Cq, int H, int W,
                                    long q_bs, long k_bs, long v_bs, long dq_bs, long dk_bs, long dv_bs,
                                    ccnet_stream_t stream);
+
+/* bf16 feature I/O (BASELINE.json configs[4]: "bf16 mixed-precision CrissCrossAttention with fp32 softmax
+ * accumulate"): q, k, v, x, y, dy, dq, dk, dv are bf16 (raw 16-bit patterns, NCHW contiguous); the attention
+ * tensor A, the scratch buffer, gamma, dgamma and every accumulation stay fp32; outputs are rounded to nearest
+ * even once, on store.  Same semantics and argument order as ccnet_cca_forward_f32 / ccnet_cca_backward_f32.
+ * This round they run on the any-shape kernels (correct for every H, W; the MFMA strip kernels are fp32-only). */
+int ccnet_cca_forward_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v, const uint16_t *x,
+                           const float *gamma, uint16_t *y, float *A,
+                           int B, int C, int Cq, int H, int W, ccnet_stream_t stream);
+int ccnet_cca_backward_bf16(const uint16_t *dy, const uint16_t *q, const uint16_t *k, const uint16_t *v,
+                            const float *A, const float *gamma, uint16_t *dq, uint16_t *dk, uint16_t *dv,
+                            float *dgamma, float *scratch, void *workspace, size_t workspace_bytes,
+                            int B, int C, int Cq, int H, int W, ccnet_stream_t stream);
 
 /* 1 if the MFMA strip kernels serve this shape under CCNET_IMPL_AUTO, else 0 (direct kernels). */
 int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W);

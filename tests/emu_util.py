@@ -140,6 +140,27 @@ class EmuOps:
                                                                bs, bs, bs, bs, bs, bs, None))
         return dqkv, dgamma
 
+    def cca_forward_bf16(self, q, k, v, x, gamma):
+        """q, k, v, x: uint16 arrays holding bf16 bit patterns; returns (y bits, A fp32)."""
+        B, C, H, W = v.shape
+        y = np.zeros_like(v)
+        A = np.full((B, H, W, H + W), np.nan, np.float32)
+        self.lib.check(self.lib.ccnet_cca_forward_bf16(_p(q), _p(k), _p(v), _p(x), _p(gamma), _p(y), _p(A),
+                                                       B, C, q.shape[1], H, W, None))
+        return y, A
+
+    def cca_backward_bf16(self, dy, q, k, v, A, gamma):
+        B, C, H, W = v.shape
+        dq, dk, dv = np.zeros_like(q), np.zeros_like(k), np.zeros_like(v)
+        dgamma = np.full(1, np.nan, np.float32)
+        scratch = np.full_like(A, np.nan)
+        nbytes = self.lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
+        ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
+        self.lib.check(self.lib.ccnet_cca_backward_bf16(_p(dy), _p(q), _p(k), _p(v), _p(A), _p(gamma), _p(dq), _p(dk),
+                                                        _p(dv), _p(dgamma), _p(scratch), _p(ws), nbytes,
+                                                        B, C, q.shape[1], H, W, None))
+        return dq, dk, dv, dgamma
+
     def mfma_selftest(self):
         scratch = np.zeros(16, np.float32)
         return self.lib.ccnet_cca_mfma_selftest(_p(scratch), None)

@@ -304,6 +304,43 @@ def test_strided_entry_points_reject_overlapping_strides(ops):
     assert rc == -1 and "stride" in lib.last_error()
 
 
+def _bf16_bits(a):
+    """fp32 numpy -> (uint16 bit patterns, the bf16-rounded values as fp32) with torch's round-to-nearest-even."""
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16)
+    return t.view(torch.int16).numpy().view(np.uint16).copy(), t.float()
+
+
+def _from_bits(bits):
+    return torch.from_numpy(bits.view(np.int16).copy()).view(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 5, 6), (1, 24, 17, 20), (1, 16, 9, 1)])
+def test_bf16_io_entry_points_round_once_on_store(ops, shape):
+    """BASELINE configs[4] restated: bf16 q/k/v/x/dy in, bf16 y/dq/dk/dv out, fp32 attention / softmax / accumulate.
+    Oracle = the fp32 restatement fed the SAME bf16-rounded inputs; the only extra error allowed is the final
+    rounding of each output to bf16 (half an ulp = 2^-9 relative) on top of the fp32 path's own tolerance."""
+    c = rand_case(*shape, seed=41)
+    bits, vals = {}, {}
+    for n in ("q", "k", "v", "x", "dy"):
+        bits[n], vals[n] = _bf16_bits(c[n])
+    g = T(c["gamma"])
+    y, A = ops.cca_forward_bf16(bits["q"], bits["k"], bits["v"], bits["x"], c["gamma"])
+    yo, Ao = O.cca_core_forward(vals["q"], vals["k"], vals["v"], vals["x"], g)
+    assert maxerr(A, Ao.numpy()) < TOL                                        # the attention itself is fp32
+    rnd = lambda ref: 2.0 ** -8 * ref.abs() + 1e-4                            # noqa: E731
+    assert bool(((_from_bits(y) - yo).abs() <= rnd(yo)).all())
+    assert torch.equal(_from_bits(y), yo.to(torch.bfloat16).float()) or \
+        float(((_from_bits(y) - yo.to(torch.bfloat16).float()).abs() > 0).float().mean()) < 0.02   # ties / 1-ulp flips only
+    dq, dk, dv, dg = ops.cca_backward_bf16(bits["dy"], bits["q"], bits["k"], bits["v"], A, c["gamma"])
+    go = O.cca_core_backward(vals["dy"], vals["q"], vals["k"], vals["v"], Ao, g)
+    for name, got in (("dq", dq), ("dk", dk), ("dv", dv)):
+        assert bool(((_from_bits(got) - go[name]).abs() <= rnd(go[name])).all()), name
+    assert abs(float(dg[0]) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
+    # gamma = 0: y must be x bit for bit
+    y0, _ = ops.cca_forward_bf16(bits["q"], bits["k"], bits["v"], bits["x"], np.zeros(1, np.float32))
+    assert np.array_equal(y0, bits["x"])
+
+
 def test_precision_modes_leave_short_strips_exact(ops):
     """ccnet_cca_set_precision returns the previous mode; below 97-long strips the forward pass is exact f32 in
     every mode (the split-bf16 aggregation kernels only exist for strips 97..100 long)."""

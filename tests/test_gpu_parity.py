@@ -316,6 +316,68 @@ def test_channels_last_and_autocast_inputs_are_accepted(lib, dev):
     assert y_ac.dtype == torch.float32 and err(y_ac, y_ref) < 0.1       # bf16 projections, fp32 attention core
 
 
+def _bf16_core_inputs(B, C, H, W, dev, seed):
+    q, k, v, x, dy = (t.to(dev).to(torch.bfloat16) for t in make_core_inputs(B, C, H, W, seed=seed))
+    return q, k, v, x, dy
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 5, 6), (1, 24, 17, 20), (2, 64, 40, 33), (1, 32, 129, 70)])
+def test_bf16_io_matches_oracle_on_the_same_rounded_inputs(lib, dev, shape):
+    """BASELINE configs[4] at oracle-sized shapes: bf16 q/k/v/x/dy -> bf16 y/dq/dk/dv, fp32 inside.  Oracle: the
+    fp32 restatement on the same bf16-rounded inputs.  Tolerance re-stated: the fp32 path's 1e-3 before the final
+    rounding, plus one rounding of the output to bf16 (<= 2^-8 relative)."""
+    from ccnet_amd.functions import CrissCrossBF16Function
+    B, C, H, W = shape
+    q, k, v, x, dy = _bf16_core_inputs(B, C, H, W, dev, seed=51)
+    gamma = torch.tensor([0.5], device=dev)
+    leaves = [t.clone().requires_grad_(True) for t in (q, k, v, x)] + [gamma.clone().requires_grad_(True)]
+    y = CrissCrossBF16Function.apply(*leaves)
+    assert y.dtype == torch.bfloat16
+    y.backward(dy)
+    f = lambda t: t.detach().float().cpu()                                  # noqa: E731
+    yo, Ao = O.cca_core_forward(f(q), f(k), f(v), f(x), f(gamma))
+    go = O.cca_core_backward(f(dy), f(q), f(k), f(v), Ao, f(gamma))
+    tol = lambda ref: 2.0 ** -8 * ref.abs() + TOL                           # noqa: E731
+    assert bool(((f(y) - yo).abs() <= tol(yo)).all())
+    for got, name in zip(leaves[:3], ("dq", "dk", "dv")):
+        assert bool(((f(got.grad) - go[name]).abs() <= tol(go[name])).all()), name
+    assert torch.equal(leaves[3].grad, dy)                                  # dx of the core is dy (functions.py:49)
+    assert abs(float(leaves[4].grad) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
+
+
+def test_bf16_config5_full_size_against_the_fp32_path(lib, dev):
+    """BASELINE configs[4] at its full size (16,512,129,129): too large for the CPU oracle, so the bf16-I/O entry
+    points are compared with the fp32 entry points (checked against the oracle elsewhere) on the same bf16-rounded
+    inputs; they must agree to one bf16 rounding of each output.  Also the module picks the native path here."""
+    from ccnet_amd import CrissCrossAttention, criss_cross_attention
+    from ccnet_amd.functions import CrissCrossBF16Function
+    lib.ccnet_cca_set_impl(0)
+    B, C, H, W = 16, 512, 129, 129
+    q, k, v, x, dy = _bf16_core_inputs(B, C, H, W, dev, seed=61)
+    q, k = q * 0.35, k * 0.35                                               # keep the softmax from saturating
+    gamma = torch.tensor([0.5], device=dev)
+    a = [t.clone().requires_grad_(True) for t in (q, k, v, x)] + [gamma.clone().requires_grad_(True)]
+    ya = CrissCrossBF16Function.apply(*a)
+    ya.backward(dy)
+    b = [t.float().requires_grad_(True) for t in (q, k, v, x)] + [gamma.clone().requires_grad_(True)]
+    yb = criss_cross_attention(*b)
+    yb.backward(dy.float())
+    tol = lambda ref: 2.0 ** -8 * ref.abs() + 2e-4                          # noqa: E731
+    assert bool(((ya.float() - yb).abs() <= tol(yb)).all())
+    for i, name in enumerate(("dq", "dk", "dv")):
+        assert bool(((a[i].grad.float() - b[i].grad).abs() <= tol(b[i].grad)).all()), name
+    assert abs(float(a[4].grad) - float(b[4].grad)) < 2e-3 * max(1.0, abs(float(b[4].grad)))
+    del a, b, ya, yb
+    m = CrissCrossAttention(64).to(dev).to(torch.bfloat16)
+    assert not m._strip_kernels_cover(torch.empty(1, 64, 129, 129)) and m._strip_kernels_cover(torch.empty(1, 64, 97, 97))
+    with torch.no_grad():
+        m.gamma.fill_(0.5)
+    xm = torch.randn(1, 64, 129, 40, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    ym = m(xm)
+    ym.sum().backward()
+    assert ym.dtype == torch.bfloat16 and m.gamma.grad is not None and xm.grad is not None
+
+
 def test_gamma_zero_identity_and_zero_init_module(lib, dev):
     """functions.py:24 zero-initialises gamma: step-0 output must equal x bit-exactly and q/k/v grads vanish."""
     from ccnet_amd import CrissCrossAttention
