@@ -179,8 +179,10 @@ int launch_map_pair_ns(const float *T, const float *F, const float *resid, const
     return 0;
 }
 
-// dq (non-transposed, F0 = k) and dk (transposed, F1 = q) in one launch per branch
-template <int NS>
+// dq (non-transposed, F0 = k) and dk (transposed, F1 = q) in one launch per branch.  These launches have only
+// C/8 channels (4 chunks per workgroup at the headline shape) and are bound by the prologue + the matrix pipe; BF
+// selects the split-bf16 x3 arithmetic for both branches (isolated stage 94 -> 76 us; opt-in, see ca_backward_impl).
+template <int NS, bool BF>
 int launch_map_dual_ns(const float *T, const float *F0, float *out0, const float *F1, float *out1,
                        int B, int C, int H, int W, ccnet_stream_t stream, const char *what,
                        long fbs0, long obs0, long fbs1, long obs1) {
@@ -188,13 +190,13 @@ int launch_map_dual_ns(const float *T, const float *F0, float *out0, const float
     int cpb, tiles, cs;
     if (g_branch_mask & CCNET_BRANCH_COL) {
         map_grid(NS, B, C, /*G=*/W, grid, cpb, tiles, cs, 2);
-        CCA_LAUNCH((cca::map_strip_dual_kernel<NS, false, cca::EPI_COL>), grid, dim3(cca::kWave * NS), stream,
+        CCA_LAUNCH((cca::map_strip_dual_kernel<NS, false, cca::EPI_COL, BF>), grid, dim3(cca::kWave * NS), stream,
                    T, F0, out0, F1, out1, (const float *)nullptr, C, H, W, cpb, tiles, cs, fbs0, obs0, fbs1, obs1);
         if (int e = launch_status(what)) return e;
     }
     if (g_branch_mask & CCNET_BRANCH_ROW) {
         map_grid(NS, B, C, /*G=*/H, grid, cpb, tiles, cs, 2);
-        CCA_LAUNCH((cca::map_strip_dual_kernel<NS, true, cca::EPI_ROW>), grid, dim3(cca::kWave * NS), stream,
+        CCA_LAUNCH((cca::map_strip_dual_kernel<NS, true, cca::EPI_ROW, BF>), grid, dim3(cca::kWave * NS), stream,
                    T, F0, out0, F1, out1, (const float *)nullptr, C, H, W, cpb, tiles, cs, fbs0, obs0, fbs1, obs1);
         return launch_status(what);
     }
@@ -281,10 +283,17 @@ int ca_backward_impl(const float *dE, const float *q, const float *k, float *dq,
     if (impl < 0) return impl;
     if (impl == 1) {
         static const int dual = env_int("CCNET_CCA_DUAL_QK", 1);
-        if (dual)
-            return map_strips() == 4
-                       ? launch_map_dual_ns<4>(dE, k, dq, q, dk, B, Cq, H, W, stream, "ca_backward(dq,dk)", kbs, dqbs, qbs, dkbs)
-                       : launch_map_dual_ns<8>(dE, k, dq, q, dk, B, Cq, H, W, stream, "ca_backward(dq,dk)", kbs, dqbs, qbs, dkbs);
+        if (dual) {
+            if (map_strips() == 4)
+                return launch_map_dual_ns<4, false>(dE, k, dq, q, dk, B, Cq, H, W, stream, "ca_backward(dq,dk)", kbs, dqbs, qbs, dkbs);
+            // split-bf16 here costs accuracy where it is scarcest (dq/dk reach |50| at the headline shape: 6-8e-4
+            // max-abs against the 1e-3 bar, measured) and bought nothing inside the step, so it is opt-in:
+            // CCNET_PRECISION_BF16X3 or CCNET_CCA_DUAL_BF16=1
+            static const int dual_bf = env_int("CCNET_CCA_DUAL_BF16", 0);
+            if ((dual_bf || map_bf16_mode() == 2) && map_bf16(H, W, true))
+                return launch_map_dual_ns<8, true>(dE, k, dq, q, dk, B, Cq, H, W, stream, "ca_backward(dq,dk)", kbs, dqbs, qbs, dkbs);
+            return launch_map_dual_ns<8, false>(dE, k, dq, q, dk, B, Cq, H, W, stream, "ca_backward(dq,dk)", kbs, dqbs, qbs, dkbs);
+        }
         if (int e = launch_map_pair<false>(dE, k, nullptr, nullptr, dq, B, Cq, H, W, stream, "ca_backward(dq)", kbs, 0, dqbs))
             return e;
         return launch_map_pair<true>(dE, q, nullptr, nullptr, dk, B, Cq, H, W, stream, "ca_backward(dk)", qbs, 0, dkbs);

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(kWave * NS, 2) void map_strip_kernel(const float *_
 // Two independent map problems that share the attention-shaped operand T in ONE launch: workgroups
 // [0, n) run the non-transposed problem (F0 -> out0), workgroups [n, 2n) the transposed one (F1 -> out1).
 // Used for ca_backward (dq from k, dk from q): each half alone would leave most CUs idle.
-template <int NS, bool ROW, int EPI>
+template <int NS, bool ROW, int EPI, bool BF>
 __global__ __launch_bounds__(kWave * NS, 2) void map_strip_dual_kernel(const float *__restrict__ T,
                                                                         const float *__restrict__ F0, float *out0,
                                                                         const float *__restrict__ F1, float *out1,
@@ -475,13 +475,18 @@ __global__ __launch_bounds__(kWave * NS, 2) void map_strip_dual_kernel(const flo
     const int half = gridDim.x / 2;
     const bool second = (int)blockIdx.x >= half;
     const int wg_linear = second ? blockIdx.x - half : blockIdx.x, wg_count = half;
-    const bool full = L > (M_KS - 1) * 4;
-    if (!second) {
-        if (full) map_strip_body<NS, ROW, false, EPI, true, false>(lds, T, F0, nullptr, gamma, out0, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs0, 0, obs0);
-        else      map_strip_body<NS, ROW, false, EPI, false, false>(lds, T, F0, nullptr, gamma, out0, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs0, 0, obs0);
+    if constexpr (BF) {           // the host only selects BF for strips 97..100 long
+        if (!second) map_strip_body<NS, ROW, false, EPI, true, true>(lds, T, F0, nullptr, gamma, out0, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs0, 0, obs0);
+        else         map_strip_body<NS, ROW, true, EPI, true, true>(lds, T, F1, nullptr, gamma, out1, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs1, 0, obs1);
     } else {
-        if (full) map_strip_body<NS, ROW, true, EPI, true, false>(lds, T, F1, nullptr, gamma, out1, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs1, 0, obs1);
-        else      map_strip_body<NS, ROW, true, EPI, false, false>(lds, T, F1, nullptr, gamma, out1, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs1, 0, obs1);
+        const bool full = L > (M_KS - 1) * 4;
+        if (!second) {
+            if (full) map_strip_body<NS, ROW, false, EPI, true, false>(lds, T, F0, nullptr, gamma, out0, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs0, 0, obs0);
+            else      map_strip_body<NS, ROW, false, EPI, false, false>(lds, T, F0, nullptr, gamma, out0, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs0, 0, obs0);
+        } else {
+            if (full) map_strip_body<NS, ROW, true, EPI, true, false>(lds, T, F1, nullptr, gamma, out1, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs1, 0, obs1);
+            else      map_strip_body<NS, ROW, true, EPI, false, false>(lds, T, F1, nullptr, gamma, out1, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs1, 0, obs1);
+        }
     }
 }
 
