@@ -8,6 +8,7 @@
 #include "cca_common.hpp"
 #include "cca_direct.hpp"
 #include "cca_map.hpp"
+#include "cca_long.hpp"
 #include "cca_softmax.hpp"
 #include "cca_weight.hpp"
 
@@ -57,13 +58,15 @@ int check_shape(int B, int C, int H, int W) {
     return 0;
 }
 
-// 1 = MFMA strip kernels, 0 = direct kernels, <0 = error
+// 1 = stationary MFMA strip kernels (strips <= 100), 2 = windowed MFMA strip kernels for long strips (<= 320),
+// 0 = direct kernels, <0 = error
 int pick_impl(int H, int W) {
-    const bool fits = H <= cca::kMaxStrip && W <= cca::kMaxStrip;
+    const int longest = H > W ? H : W;
     if (g_impl == CCNET_IMPL_DIRECT) return 0;
-    if (g_impl == CCNET_IMPL_MFMA)
-        return fits ? 1 : fail(CCNET_E_BADSHAPE, "CCNET_IMPL_MFMA forced but max(H,W) > 100");
-    return fits ? 1 : 0;
+    if (longest <= cca::kMaxStrip) return 1;
+    if (longest <= cca::kLongMaxStrip) return 2;
+    if (g_impl == CCNET_IMPL_MFMA) return fail(CCNET_E_BADSHAPE, "CCNET_IMPL_MFMA forced but max(H,W) > 320");
+    return 0;
 }
 
 unsigned direct_grid(size_t total) {
@@ -254,6 +257,84 @@ int softmax_forward(const float *E, float *A, int B, int H, int W, ccnet_stream_
 }
 
 
+// ---- long strips (101 .. 320): windowed MFMA strip kernels of cca_long.hpp --------------------------------------
+// grid = images x channel splits x windows x strip tiles; the channel split only has to top the grid up to a few
+// workgroups per CU (windows and the 4- or 2-strip tiles already make many)
+template <int NS>
+void long_map_grid(int B, int C, int L, int G, dim3 &grid, int &cpb, int &tiles, int &cs, int &nwin) {
+    tiles = (G + NS - 1) / NS;
+    nwin = (L + cca::long_window_tiles(NS) * cca::kTile - 1) / (cca::long_window_tiles(NS) * cca::kTile);
+    const int nchunks = (C + cca::LG_MC - 1) / cca::LG_MC;
+    const long base = (long)B * tiles * nwin, want = 4L * num_cus();
+    int s = (int)((want + base - 1) / base);
+    if (s < 1) s = 1;
+    if (s > nchunks) s = nchunks;
+    cpb = (nchunks + s - 1) / s;
+    cs = (nchunks + cpb - 1) / cpb;
+    grid = dim3((unsigned)(base * cs));
+}
+
+template <int NS, bool TRANS>
+int launch_long_map_pair_ns(const float *T, const float *F, const float *resid, const float *gamma, float *out,
+                            int B, int C, int H, int W, ccnet_stream_t stream, const char *what,
+                            long fbs, long rbs, long obs, bool ns_col, bool ns_row) {
+    dim3 grid;
+    int cpb, tiles, cs, nwin;
+    if ((g_branch_mask & CCNET_BRANCH_COL) && ns_col) {
+        long_map_grid<NS>(B, C, /*L=*/H, /*G=*/W, grid, cpb, tiles, cs, nwin);
+        if (resid) {
+            if (TRANS) return fail(CCNET_E_BADFLAGS, "residual epilogue only exists for the forward aggregation");
+            CCA_LAUNCH((cca::map_long_kernel<NS, false, false, cca::EPI_COL_RESID>), grid, dim3(cca::kWave * NS), stream,
+                       T, F, resid, gamma, out, C, H, W, cpb, tiles, cs, nwin, fbs, rbs, obs);
+        } else {
+            CCA_LAUNCH((cca::map_long_kernel<NS, false, TRANS, cca::EPI_COL>), grid, dim3(cca::kWave * NS), stream,
+                       T, F, resid, gamma, out, C, H, W, cpb, tiles, cs, nwin, fbs, rbs, obs);
+        }
+        if (int e = launch_status(what)) return e;
+    }
+    if ((g_branch_mask & CCNET_BRANCH_ROW) && ns_row) {
+        long_map_grid<NS>(B, C, /*L=*/W, /*G=*/H, grid, cpb, tiles, cs, nwin);
+        CCA_LAUNCH((cca::map_long_kernel<NS, true, TRANS, cca::EPI_ROW>), grid, dim3(cca::kWave * NS), stream,
+                   T, F, (const float *)nullptr, gamma, out, C, H, W, cpb, tiles, cs, nwin, fbs, rbs, obs);
+        return launch_status(what);
+    }
+    return 0;
+}
+
+// the two launches of a pair may need different configurations (H = 129, W = 257: column strips 129 long -> 4 strips
+// per workgroup, row strips 257 long -> 2): the partial sums are in the natural layout, so they combine freely
+template <bool TRANS>
+int launch_long_map_pair(const float *T, const float *F, const float *resid, const float *gamma, float *out,
+                         int B, int C, int H, int W, ccnet_stream_t stream, const char *what,
+                         long fbs, long rbs, long obs) {
+    const bool col4 = H <= cca::long_maxl(4), row4 = W <= cca::long_maxl(4);
+    if (int e = launch_long_map_pair_ns<4, TRANS>(T, F, resid, gamma, out, B, C, H, W, stream, what, fbs, rbs, obs, col4, false)) return e;
+    if (int e = launch_long_map_pair_ns<2, TRANS>(T, F, resid, gamma, out, B, C, H, W, stream, what, fbs, rbs, obs, !col4, false)) return e;
+    if (int e = launch_long_map_pair_ns<4, TRANS>(T, F, resid, gamma, out, B, C, H, W, stream, what, fbs, rbs, obs, false, row4)) return e;
+    return launch_long_map_pair_ns<2, TRANS>(T, F, resid, gamma, out, B, C, H, W, stream, what, fbs, rbs, obs, false, !row4);
+}
+
+template <int NS, bool MASK>
+int launch_long_weight_ns(const float *X, const float *Y, float *T, int B, int Cx, int H, int W,
+                          ccnet_stream_t stream, const char *what, long xbs, long ybs, bool do_col, bool do_row) {
+    const int wt = cca::long_window_tiles(NS) * cca::kTile;
+    const int tc = do_col ? (W + NS - 1) / NS : 0, wc = (H + wt - 1) / wt;
+    const int tr = do_row ? (H + NS - 1) / NS : 0, wr = (W + wt - 1) / wt;
+    if (tc * wc + tr * wr == 0) return 0;
+    CCA_LAUNCH((cca::weight_long_kernel<NS, MASK>), dim3((unsigned)((tc * wc + tr * wr) * B)), dim3(cca::kWave * NS), stream,
+               X, Y, T, Cx, H, W, tc, wc, tr, wr, xbs, ybs);
+    return launch_status(what);
+}
+
+template <bool MASK>
+int launch_long_weight_pair(const float *X, const float *Y, float *T, int B, int Cx, int H, int W,
+                            ccnet_stream_t stream, const char *what, long xbs, long ybs) {
+    const bool col = g_branch_mask & CCNET_BRANCH_COL, row = g_branch_mask & CCNET_BRANCH_ROW;
+    const bool col4 = H <= cca::long_maxl(4), row4 = W <= cca::long_maxl(4);
+    if (int e = launch_long_weight_ns<4, MASK>(X, Y, T, B, Cx, H, W, stream, what, xbs, ybs, col && col4, row && row4)) return e;
+    return launch_long_weight_ns<2, MASK>(X, Y, T, B, Cx, H, W, stream, what, xbs, ybs, col && !col4, row && !row4);
+}
+
 // ---- strided internals: every feature tensor is (B, C, H, W) with a dense (C, H, W) image per batch and a
 // ---- caller-given batch stride in elements (dense = C*H*W), so q/k/v may be channel slices of one projection.
 int ca_forward_impl(const float *q, const float *k, float *out, int B, int Cq, int H, int W, int flags,
@@ -265,6 +346,8 @@ int ca_forward_impl(const float *q, const float *k, float *out, int B, int Cq, i
     if (impl < 0) return impl;
     if (impl == 1) {
         if (int e = launch_weight_pair<true>(q, k, out, B, Cq, H, W, stream, "ca_forward", qbs, kbs)) return e;
+    } else if (impl == 2) {
+        if (int e = launch_long_weight_pair<true>(q, k, out, B, Cq, H, W, stream, "ca_forward(long)", qbs, kbs)) return e;
     } else {
         const size_t total = (size_t)B * H * W * (H + W);
         CCA_LAUNCH((cca::direct_weight_kernel<true>), dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
@@ -298,6 +381,11 @@ int ca_backward_impl(const float *dE, const float *q, const float *k, float *dq,
             return e;
         return launch_map_pair<true>(dE, q, nullptr, nullptr, dk, B, Cq, H, W, stream, "ca_backward(dk)", qbs, 0, dkbs);
     }
+    if (impl == 2) {
+        if (int e = launch_long_map_pair<false>(dE, k, nullptr, nullptr, dq, B, Cq, H, W, stream, "ca_backward(dq,long)", kbs, 0, dqbs))
+            return e;
+        return launch_long_map_pair<true>(dE, q, nullptr, nullptr, dk, B, Cq, H, W, stream, "ca_backward(dk,long)", qbs, 0, dkbs);
+    }
     const size_t total = (size_t)B * Cq * H * W;
     CCA_LAUNCH((cca::direct_map_kernel<float>), dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
                dE, k, (const float *)nullptr, (const float *)nullptr, dq, Cq, H, W, total, kbs, 0L, dqbs);
@@ -314,6 +402,7 @@ int ca_map_forward_impl(const float *A, const float *v, const float *x, const fl
     const int impl = pick_impl(H, W);
     if (impl < 0) return impl;
     if (impl == 1) return launch_map_pair<false>(A, v, x, gamma, out, B, C, H, W, stream, "ca_map_forward", vbs, xbs, obs);
+    if (impl == 2) return launch_long_map_pair<false>(A, v, x, gamma, out, B, C, H, W, stream, "ca_map_forward(long)", vbs, xbs, obs);
     const size_t total = (size_t)B * C * H * W;
     CCA_LAUNCH((cca::direct_map_kernel<float>), dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
                A, v, x, gamma, out, C, H, W, total, vbs, xbs, obs);
@@ -330,6 +419,8 @@ int ca_map_backward_impl(const float *dout, const float *A, const float *v, cons
     if (dA) {
         if (impl == 1) {
             if (int e = launch_weight_pair<false>(dout, v, dA, B, C, H, W, stream, "ca_map_backward(dA)", dobs, vbs)) return e;
+        } else if (impl == 2) {
+            if (int e = launch_long_weight_pair<false>(dout, v, dA, B, C, H, W, stream, "ca_map_backward(dA,long)", dobs, vbs)) return e;
         } else {
             const size_t total = (size_t)B * H * W * (H + W);
             CCA_LAUNCH((cca::direct_weight_kernel<false>), dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
@@ -340,6 +431,8 @@ int ca_map_backward_impl(const float *dout, const float *A, const float *v, cons
     if (dv) {
         if (impl == 1)
             return launch_map_pair<true>(A, dout, nullptr, gamma, dv, B, C, H, W, stream, "ca_map_backward(dv)", dobs, 0, dvbs);
+        if (impl == 2)
+            return launch_long_map_pair<true>(A, dout, nullptr, gamma, dv, B, C, H, W, stream, "ca_map_backward(dv,long)", dobs, 0, dvbs);
         const size_t total = (size_t)B * C * H * W;
         CCA_LAUNCH((cca::direct_mapT_kernel<float>), dim3(direct_grid(total)), dim3(cca::D_BLOCK), stream,
                    A, dout, gamma, dv, C, H, W, total, dobs, dvbs);
@@ -389,7 +482,9 @@ int ccnet_cca_set_branch_mask(int mask) {
 
 int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W) {
     (void)B; (void)C;
-    return (g_impl != CCNET_IMPL_DIRECT && H <= cca::kMaxStrip && W <= cca::kMaxStrip) ? 1 : 0;
+    if (g_impl == CCNET_IMPL_DIRECT || H <= 0 || W <= 0) return 0;
+    const int longest = H > W ? H : W;
+    return longest <= cca::kMaxStrip ? 1 : longest <= cca::kLongMaxStrip ? 2 : 0;
 }
 
 int ccnet_ca_softmax_forward_f32(const float *energy, float *out, int B, int H, int W, ccnet_stream_t stream) {

@@ -1,0 +1,280 @@
+// cca_long.hpp -- strip kernels for LONG strips (101 .. 320 positions): the same six contractions as
+// cca_weight.hpp / cca_map.hpp on shapes whose attention block no longer fits a wavefront's registers
+// (129 x 129 of BASELINE configs[4], the 129 x 257 whole-image evaluation map of evaluate.py --whole).
+//
+// Same decomposition -- one workgroup = NS adjacent strips, one wavefront per strip, exact-fp32
+// v_mfma_f32_16x16x4_f32, feature chunks through LDS by LDS-DMA -- with the output positions of a strip cut into
+// WINDOWS that become an extra grid dimension:
+//   map kernels     a workgroup produces the outputs of a window of NTW position tiles; its wavefronts keep only the
+//                   L x (16 NTW) slice of the attention block they need as MFMA B fragments (<= 160 VGPRs)
+//   weight kernel   a workgroup produces the rows of a window of NTI query tiles of the L x L result (<= 40 tiles
+//                   of accumulators); the channel contraction streams through LDS
+// Every window re-streams the features of its strips (from L2 / Infinity Cache: the tensors of these shapes are
+// small or re-used at once), which is what the register file costs at these lengths.
+//
+//   configuration      strips / workgroup   longest strip   map window   weight window
+//   NS = 4             4 (16-byte column segments)   160    4 tiles      4 query tiles
+//   NS = 2             2                             320    2 tiles      2 query tiles
+//
+// The column -> row partial sums of a map launch pair stay in the NATURAL layout here (windows of one row band are
+// different workgroups, so the band permutation of cca_map.hpp would race); the addend is read from global memory
+// in the store phase.  These kernels are deliberately simple (no counted waits, no split-bf16): they exist so that
+// no shape up to 320 x 320 falls back to the one-thread-per-output kernels.
+#pragma once
+#include "cca_common.hpp"
+#include "cca_map.hpp"      // EPI_COL / EPI_ROW / EPI_COL_RESID
+
+namespace cca {
+
+constexpr int kLongMaxStrip = 320;
+__host__ __device__ constexpr int long_maxl(int ns) { return ns == 4 ? 160 : 320; }
+__host__ __device__ constexpr int long_window_tiles(int ns) { return ns == 4 ? 4 : 2; }
+__host__ __device__ constexpr int long_cp(int ns) { return ns * long_maxl(ns) + 20; }      // channel pitch of an image
+constexpr int LG_MC = 16;                         // channels per chunk of the map kernel = one MFMA M tile
+constexpr int LG_KC = 8;                          // channels per chunk of the weight kernel = 2 MFMA k-steps
+
+// global element offset (inside one channel plane) of position `pos` of strip `strip`
+template <bool ROW>
+__device__ __forceinline__ int long_plane_offset(int pos, int strip, int W) {
+    return ROW ? strip * W + pos : pos * W + strip;
+}
+
+// LDS-DMA of the NS strips x L positions of one channel plane into an image: column image index pos * NS + s,
+// row image index s * L + pos (a linear copy of the NS rows).  Lanes outside the tile are masked; their LDS slots
+// keep the zeros the image was initialised with.
+template <int NS, bool ROW>
+__device__ __forceinline__ void long_dma_plane(const FBuf &src, float *dst, int soff, int lane, int L, int W,
+                                               int g0, int gvalid) {
+    const int total = ROW ? gvalid * L : NS * L;
+    for (int e0 = 0; e0 < total; e0 += kWave) {               // wave-uniform trip count
+        const int e = e0 + lane;
+        int voff;
+        bool ok;
+        if (ROW) {
+            ok = e < total;
+            voff = 4 * (g0 * W + e);
+        } else {
+            const int pos = e / NS, s = e % NS;
+            ok = pos < L && s < gvalid;
+            voff = 4 * (pos * W + g0 + s);
+        }
+        if (ok) fbuf_load_to_lds(src, dst + e0, voff, soff);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// map type:  TRANS = false  out[c, pos(i)] (+)= sum_j P[i][j] F[c, pos(j)]     TRANS = true  sum_i P[i][j] F[c, pos(i)]
+// ---------------------------------------------------------------------------------------------
+template <int NS, bool ROW, bool TRANS, int EPI>
+__global__ __launch_bounds__(kWave * NS) void map_long_kernel(const float *__restrict__ T, const float *__restrict__ F,
+                                                              const float *__restrict__ resid,
+                                                              const float *__restrict__ gamma, float *out,
+                                                              int C, int H, int W, int chunks_per_block, int tiles,
+                                                              int nsplit, int nwin, long fbs, long rbs, long obs) {
+    constexpr int MAXL = long_maxl(NS), NTW = long_window_tiles(NS), MAXKS = MAXL / 4, CP = long_cp(NS);
+    constexpr int WIN = NTW * kTile, RP = WIN * NS;           // window positions; floats per channel of the result image
+    __shared__ float lds[LG_MC * CP + LG_MC * RP];
+    CCA_LDS_REGISTER(lds);
+    float *img = lds, *res = lds + LG_MC * CP;
+    const Branch br = make_branch(ROW, H, W);
+    const int L = br.L, HW = H * W, S = H + W;
+    // logical id -> (image, channel split, window, tile), tile fastest
+    const int id = xcd_logical_id(blockIdx.x, gridDim.x);
+    const int per_image = nsplit * nwin * tiles;
+    const int b = id / per_image, r0 = id - b * per_image;
+    const int split = r0 / (nwin * tiles), r1 = r0 - split * nwin * tiles;
+    const int win = r1 / tiles, g0 = (r1 - win * tiles) * NS;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
+    const int ln = lane & 15, lk = lane >> 4;
+    const int g = g0 + wv;
+    const bool active = g < br.G;
+    const int gvalid = (br.G - g0 < NS) ? br.G - g0 : NS;
+    const int p0 = win * WIN;                                 // first output position of this window
+    const int nks = (L + 3) / 4;
+    const int nchunks = (C + LG_MC - 1) / LG_MC;
+    const int ch_begin = split * chunks_per_block;
+    const int ch_end = (ch_begin + chunks_per_block < nchunks) ? ch_begin + chunks_per_block : nchunks;
+
+    const FBuf Tb = make_fbuf(T + (size_t)b * HW * S, (size_t)HW * S * sizeof(float));
+    const FBuf Fb = make_fbuf(F + (size_t)b * fbs, (size_t)C * HW * sizeof(float));
+    const FBuf Ob = make_fbuf(out + (size_t)b * obs, (size_t)C * HW * sizeof(float));
+    const FBuf Rb = make_fbuf(EPI == EPI_COL_RESID ? resid + (size_t)b * rbs : out + (size_t)b * obs,
+                              (size_t)C * HW * sizeof(float));
+    const float alpha = gamma ? gamma[0] : 1.f;
+
+    // stationary slice of the attention block as MFMA B fragments B[k][n]: k = contraction position 4 ks + (l >> 4),
+    // n = output position p0 + 16 t + (l & 15); gathered straight from global memory (prologue only)
+    float bf[MAXKS][NTW];
+#pragma unroll
+    for (int ks = 0; ks < MAXKS; ++ks)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int kidx = ks * 4 + lk, nidx = p0 + t * kTile + ln;
+            const int iq = TRANS ? kidx : nidx, j = TRANS ? nidx : kidx;
+            const bool ok = active && iq < L && j < L;
+            const float v = fbuf_load(Tb, ok ? 4 * (iq * br.as_q + g * br.as_g + br.a_off + j) : 0, 0);
+            bf[ks][t] = ok ? v : 0.f;
+        }
+
+    for (int idx = tid; idx < LG_MC * CP; idx += kWave * NS) CCA_LDS_ST(&img[idx], 0.f);
+    __syncthreads();
+
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        // feature chunk -> LDS (channels dealt round-robin to the wavefronts; clamped channels are never stored)
+#pragma unroll
+        for (int pr = 0; pr < LG_MC / NS; ++pr) {
+            const int cc = wv + pr * NS, c = ch * LG_MC + cc;
+            long_dma_plane<NS, ROW>(Fb, img + cc * CP, (c < C ? c : C - 1) * HW * 4, lane, L, W, g0, gvalid);
+        }
+        __syncthreads();
+        if (active) {
+            f32x4 acc[NTW];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float *ab = img + ln * CP;                  // A fragment: channel = l & 15
+#pragma unroll
+            for (int ks = 0; ks < MAXKS; ++ks)
+                if (ks < nks) {
+                    const int k = ks * 4 + lk;
+                    const float av = CCA_LDS_LD(&ab[k < L ? (ROW ? wv * L + k : k * NS + wv) : 0]);
+                    const float a = k < L ? av : 0.f;         // never multiply a zero fragment by foreign data
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) acc[t] = mfma_16x16x4(a, bf[ks][t], acc[t]);
+                }
+            // D[m = channel 4 (l >> 4) + r][n = window position 16 t + (l & 15)] -> result image
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int wp = t * kTile + ln;
+                float *d = res + (4 * lk) * RP + (ROW ? wv * WIN + wp : wp * NS + wv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) CCA_LDS_ST(&d[r * RP], acc[t][r]);
+            }
+        }
+        __syncthreads();
+        // window of the output tile -> global memory (+ the other branch's partial sums / the residual)
+#pragma unroll
+        for (int pr = 0; pr < LG_MC / NS; ++pr) {
+            const int cc = wv + pr * NS, c = ch * LG_MC + cc;
+            if (c < C) {
+                const int soff = c * HW * 4;
+                for (int e0 = 0; e0 < RP; e0 += kWave) {
+                    const int e = e0 + lane;
+                    const int wp = ROW ? e % WIN : e / NS, s = ROW ? e / WIN : e % NS;
+                    const int pos = p0 + wp;
+                    if (pos < L && s < gvalid) {
+                        const int voff = 4 * long_plane_offset<ROW>(pos, g0 + s, W);
+                        float val = alpha * CCA_LDS_LD(&res[cc * RP + e]);
+                        if (EPI != EPI_COL) val += fbuf_load(Rb, voff, soff);
+                        fbuf_store(Ob, val, voff, soff);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight type:  T[b, pixel(i, g), a_off + j] = sum_c X[b, c, pos(i, g)] * Y[b, c, pos(j, g)]
+// ---------------------------------------------------------------------------------------------
+template <int NS, bool ROW, bool MASK>
+__device__ __forceinline__ void weight_long_body(float *lds, int b, int tile, int win, const float *__restrict__ X,
+                                                 const float *__restrict__ Y, float *__restrict__ T,
+                                                 int Cx, int H, int W, long xbs, long ybs) {
+    constexpr int MAXL = long_maxl(NS), NTI = long_window_tiles(NS), NTJ = MAXL / kTile, CP = long_cp(NS);
+    float *xi = lds, *yi = lds + LG_KC * CP;
+    const Branch br = make_branch(ROW, H, W);
+    const int L = br.L, HW = H * W, S = H + W;
+    const int g0 = tile * NS;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
+    const int ln = lane & 15, lk = lane >> 4;
+    const int g = g0 + wv;
+    const bool active = g < br.G;
+    const int gvalid = (br.G - g0 < NS) ? br.G - g0 : NS;
+    const int i0 = win * NTI * kTile;                         // first query position of this window
+    const int ntj = (L + kTile - 1) / kTile;
+
+    const FBuf Xb = make_fbuf(X + (size_t)b * xbs, (size_t)Cx * HW * sizeof(float));
+    const FBuf Yb = make_fbuf(Y + (size_t)b * ybs, (size_t)Cx * HW * sizeof(float));
+
+    f32x4 acc[NTI][NTJ];
+#pragma unroll
+    for (int ti = 0; ti < NTI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NTJ; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int idx = tid; idx < 2 * LG_KC * CP; idx += kWave * NS) CCA_LDS_ST(&lds[idx], 0.f);
+    __syncthreads();
+
+    const int nchunks = (Cx + LG_KC - 1) / LG_KC;
+    for (int n = 0; n < nchunks; ++n) {
+        // 2 operands x 8 channels dealt round-robin to the wavefronts
+#pragma unroll
+        for (int pr = 0; pr < 2 * LG_KC / NS; ++pr) {
+            const int pair = wv + pr * NS, op = pair / LG_KC, cc = pair % LG_KC;
+            const int c = (n * LG_KC + cc < Cx) ? n * LG_KC + cc : Cx - 1;      // K padding is zeroed at fragment read
+            long_dma_plane<NS, ROW>(op ? Yb : Xb, (op ? yi : xi) + cc * CP, c * HW * 4, lane, L, W, g0, gvalid);
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int ks = 0; ks < LG_KC / 4; ++ks) {
+                const bool kin = n * LG_KC + ks * 4 + lk < Cx;
+                const float *xs = xi + (ks * 4 + lk) * CP, *ys = yi + (ks * 4 + lk) * CP;
+                float a[NTI];
+#pragma unroll
+                for (int ti = 0; ti < NTI; ++ti) {
+                    const int p = i0 + ti * kTile + ln;
+                    const float v = CCA_LDS_LD(&xs[p < L ? (ROW ? wv * L + p : p * NS + wv) : 0]);
+                    a[ti] = (kin && p < L) ? v : 0.f;
+                }
+#pragma unroll
+                for (int tj = 0; tj < NTJ; ++tj)
+                    if (tj < ntj) {
+                        const int p = tj * kTile + ln;
+                        const float v = CCA_LDS_LD(&ys[p < L ? (ROW ? wv * L + p : p * NS + wv) : 0]);
+                        const float bb = p < L ? v : 0.f;
+#pragma unroll
+                        for (int ti = 0; ti < NTI; ++ti) acc[ti][tj] = mfma_16x16x4(a[ti], bb, acc[ti][tj]);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (!active) return;
+    float *Tg = T + (size_t)b * HW * S + (size_t)g * br.as_g + br.a_off;
+#pragma unroll
+    for (int ti = 0; ti < NTI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NTJ; ++tj)
+            if (tj < ntj) {
+                const int j = tj * kTile + ln;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int iq = i0 + ti * kTile + 4 * lk + r;
+                    if (iq < L && j < L) {
+                        float val = acc[ti][tj][r];
+                        if (MASK && !ROW && iq == j) val = -INFINITY;      // functions.py:11-12 (column self slot)
+                        Tg[(size_t)iq * br.as_q + j] = val;
+                    }
+                }
+            }
+}
+
+// one launch covers both branches: per image, column (tile, window) workgroups first, then the row ones
+template <int NS, bool MASK>
+__global__ __launch_bounds__(kWave * NS) void weight_long_kernel(const float *__restrict__ X, const float *__restrict__ Y,
+                                                                 float *__restrict__ T, int Cx, int H, int W,
+                                                                 int tiles_col, int win_col, int tiles_row, int win_row,
+                                                                 long xbs, long ybs) {
+    __shared__ float lds[2 * LG_KC * long_cp(NS)];
+    CCA_LDS_REGISTER(lds);
+    const int ncol = tiles_col * win_col, per_image = ncol + tiles_row * win_row;
+    const int id = xcd_logical_id(blockIdx.x, gridDim.x);
+    const int b = id / per_image, t = id - b * per_image;
+    if (t < ncol) weight_long_body<NS, false, MASK>(lds, b, t % tiles_col, t / tiles_col, X, Y, T, Cx, H, W, xbs, ybs);
+    else          weight_long_body<NS, true, MASK>(lds, b, (t - ncol) % tiles_row, (t - ncol) / tiles_row, X, Y, T, Cx, H, W, xbs, ybs);
+}
+
+}  // namespace cca

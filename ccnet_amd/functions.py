@@ -371,7 +371,7 @@ class CrissCrossAttention(nn.Module):
     #: strides; set False (class or instance) for three separate convolutions exactly as functions.py:29-35.
     fuse_projections = True
 
-    #: bf16 inputs at geometries outside the fp32 strip kernels (strips longer than 100) use the bf16-I/O entry
+    #: bf16 inputs at geometries outside the fp32 strip kernels (strips longer than 320) use the bf16-I/O entry
     #: points; everything else is computed through fp32 copies on the MFMA kernels.
     native_bf16 = True
 

@@ -166,6 +166,39 @@ def test_band_permuted_partial_sums_at_every_full_strip_length(ops, shape):
     ops.set_impl(0)
 
 
+@pytest.mark.parametrize("shape", [(1, 16, 129, 12), (1, 24, 9, 170), (2, 16, 101, 103), (1, 8, 161, 5), (1, 16, 6, 257)])
+def test_long_strips_use_the_windowed_mfma_kernels(ops, shape):
+    """Strips 101 .. 320 long (129 x 129 of BASELINE configs[4], 129 x 257 of evaluate.py --whole) run on the
+    windowed strip kernels of cca_long.hpp: 4 strips per workgroup up to 160, 2 up to 320, the two launches of a
+    pair choosing independently (9 x 170: column strips 9 long, row strips 170 long).  Exact fp32 MFMA: tight
+    tolerances; every entry point, partial strip tiles, partial windows, C not a multiple of 16."""
+    ops.set_impl(MFMA)
+    B, C, H, W = shape
+    assert ops.lib.ccnet_cca_shape_uses_mfma(B, C, H, W) == 2
+    c = rand_case(*shape, seed=71)
+    c["q"] *= 0.5
+    q, k, v, x, g = (T(c[n]) for n in ("q", "k", "v", "x", "gamma"))
+    e = ops.ca_forward(c["q"], c["k"])
+    eo = O.ca_forward(q, k)
+    fin = np.isfinite(eo.numpy())
+    assert np.array_equal(np.isneginf(e), np.isneginf(eo.numpy())) and maxerr(e[fin], eo.numpy()[fin]) < TOL
+    y, A = ops.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
+    yo, Ao = O.cca_core_forward(q, k, v, x, g)
+    assert maxerr(A, Ao.numpy()) < TOL and maxerr(y, yo.numpy()) < TOL
+    o2 = ops.ca_map_forward(Ao.numpy(), c["v"])                                  # no residual, alpha = 1
+    assert maxerr(o2, O.ca_map_forward(Ao, v).numpy()) < TOL
+    dq, dk, dv, dg = ops.cca_backward(c["dy"], c["q"], c["k"], c["v"], A, c["gamma"])
+    go = O.cca_core_backward(T(c["dy"]), q, k, v, Ao, g)
+    assert maxerr(dq, go["dq"].numpy()) < 1e-4 and maxerr(dk, go["dk"].numpy()) < 1e-4
+    assert maxerr(dv, go["dv"].numpy()) < TOL
+    assert abs(float(dg[0]) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
+    # same results as the any-shape kernels
+    ops.set_impl(DIRECT)
+    y_d, _ = ops.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
+    assert maxerr(y, y_d) < TOL
+    ops.set_impl(0)
+
+
 def test_split_bf16_option_at_97(ops):
     """Optional split-bf16 x3 arithmetic of the map kernels (3 k-steps of 32 on the bf16 MFMA + one exact f32
     k-step for k = 96..99): inside a few 1e-5 of the oracle on O(1) data."""
@@ -202,18 +235,22 @@ def test_rectangular_100_by_40(ops):
     assert maxerr(dv, g["dv"].numpy()) < TOL
 
 
-def test_auto_dispatch_falls_back_to_direct_kernels_beyond_100(ops):
+def test_auto_dispatch_by_strip_length(ops):
+    """<= 100: stationary strip kernels (1); 101..320: windowed strip kernels (2); beyond: any-shape kernels (0)."""
     ops.set_impl(0)
     assert ops.lib.ccnet_cca_shape_uses_mfma(1, 8, 97, 97) == 1
-    assert ops.lib.ccnet_cca_shape_uses_mfma(1, 8, 101, 20) == 0
-    c = rand_case(1, 8, 101, 3, seed=5)
+    assert ops.lib.ccnet_cca_shape_uses_mfma(1, 8, 101, 20) == 2
+    assert ops.lib.ccnet_cca_shape_uses_mfma(1, 8, 20, 320) == 2
+    assert ops.lib.ccnet_cca_shape_uses_mfma(1, 8, 321, 20) == 0
+    c = rand_case(1, 8, 321, 2, seed=5)
     y, A = ops.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
     yo, _ = O.cca_core_forward(*(T(c[n]) for n in ("q", "k", "v", "x", "gamma")))
     assert maxerr(y, yo.numpy()) < TOL
     ops.set_impl(MFMA)
-    e = np.empty((1, 101, 3, 104), np.float32)
-    rc = ops.lib.ccnet_ca_forward_f32(c["q"].ctypes.data, c["k"].ctypes.data, e.ctypes.data, 1, 1, 101, 3, 0, None)
-    assert rc == -1 and "100" in ops.lib.last_error()
+    e = np.empty((1, 321, 2, 323), np.float32)
+    rc = ops.lib.ccnet_ca_forward_f32(c["q"].ctypes.data, c["k"].ctypes.data, e.ctypes.data, 1, 1, 321, 2, 0, None)
+    assert rc == -1 and "320" in ops.lib.last_error()
+    ops.set_impl(0)
 
 
 @pytest.mark.parametrize("impl", [DIRECT, MFMA])

@@ -347,8 +347,9 @@ def test_bf16_io_matches_oracle_on_the_same_rounded_inputs(lib, dev, shape):
 
 def test_bf16_config5_full_size_against_the_fp32_path(lib, dev):
     """BASELINE configs[4] at its full size (16,512,129,129): too large for the CPU oracle, so the bf16-I/O entry
-    points are compared with the fp32 entry points (checked against the oracle elsewhere) on the same bf16-rounded
-    inputs; they must agree to one bf16 rounding of each output.  Also the module picks the native path here."""
+    points are compared with the fp32 entry points (checked against the oracle elsewhere; at this size the windowed
+    long-strip kernels) on the same bf16-rounded inputs; they must agree to one bf16 rounding of each output.  The
+    module uses the native bf16 path only where no strip kernel covers the geometry."""
     from ccnet_amd import CrissCrossAttention, criss_cross_attention
     from ccnet_amd.functions import CrissCrossBF16Function
     lib.ccnet_cca_set_impl(0)
@@ -369,13 +370,41 @@ def test_bf16_config5_full_size_against_the_fp32_path(lib, dev):
     assert abs(float(a[4].grad) - float(b[4].grad)) < 2e-3 * max(1.0, abs(float(b[4].grad)))
     del a, b, ya, yb
     m = CrissCrossAttention(64).to(dev).to(torch.bfloat16)
-    assert not m._strip_kernels_cover(torch.empty(1, 64, 129, 129)) and m._strip_kernels_cover(torch.empty(1, 64, 97, 97))
+    assert m._strip_kernels_cover(torch.empty(1, 64, 129, 129)) and not m._strip_kernels_cover(torch.empty(1, 64, 321, 20))
     with torch.no_grad():
         m.gamma.fill_(0.5)
-    xm = torch.randn(1, 64, 129, 40, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    xm = torch.randn(1, 64, 330, 9, device=dev, dtype=torch.bfloat16, requires_grad=True)     # beyond every strip kernel
     ym = m(xm)
     ym.sum().backward()
     assert ym.dtype == torch.bfloat16 and m.gamma.grad is not None and xm.grad is not None
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 129, 129), (2, 24, 101, 160), (1, 64, 129, 257), (1, 16, 320, 33)])
+def test_long_strip_kernels_match_oracle(lib, dev, shape):
+    """Strips 101..320 long on the windowed MFMA kernels (cca_long.hpp): 129 x 129 (BASELINE configs[4] geometry),
+    129 x 257 (evaluate.py --whole), the 160 / 320 limits; fused core forward + backward against the oracle."""
+    from ccnet_amd import criss_cross_attention
+    lib.ccnet_cca_set_impl(0)
+    B, C, H, W = shape
+    assert lib.ccnet_cca_shape_uses_mfma(B, C, H, W) == 2
+    q, k, v, x, dy = make_core_inputs(B, C, H, W, seed=81)
+    q, k = q * 0.5, k * 0.5
+    gamma = torch.tensor([0.5])
+    yo, Ao = O.cca_core_forward(q, k, v, x, gamma)
+    go = O.cca_core_backward(dy, q, k, v, Ao, gamma)
+    leaves = [t.to(dev).requires_grad_(True) for t in (q, k, v, x, gamma)]
+    y = criss_cross_attention(*leaves)
+    y.backward(dy.to(dev))
+    assert err(y, yo) < TIGHT * 2
+    assert err(leaves[0].grad, go["dq"]) < 2e-4 and err(leaves[1].grad, go["dk"]) < 2e-4
+    assert err(leaves[2].grad, go["dv"]) < TIGHT * 2
+    assert abs(float(leaves[4].grad) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
+    # and the any-shape kernels agree (they are what served these shapes before)
+    lib.ccnet_cca_set_impl(DIRECT)
+    with torch.no_grad():
+        y_d = criss_cross_attention(*[t.detach() for t in leaves])
+    lib.ccnet_cca_set_impl(0)
+    assert err(y, y_d) < TIGHT * 2
 
 
 def test_gamma_zero_identity_and_zero_init_module(lib, dev):
