@@ -260,10 +260,18 @@ int softmax_forward(const float *E, float *A, int B, int H, int W, ccnet_stream_
 // ---- long strips (101 .. 320): windowed MFMA strip kernels of cca_long.hpp --------------------------------------
 // grid = images x channel splits x windows x strip tiles; the channel split only has to top the grid up to a few
 // workgroups per CU (windows and the 4- or 2-strip tiles already make many)
+// windows of a strip: as few as the register file allows, evened out (129 positions = 9 tiles -> 3 + 3 + 3)
 template <int NS>
-void long_map_grid(int B, int C, int L, int G, dim3 &grid, int &cpb, int &tiles, int &cs, int &nwin) {
+void long_windows(int L, int &nwin, int &wtiles) {
+    const int ntiles = (L + cca::kTile - 1) / cca::kTile, cap = cca::long_window_tiles(NS);
+    nwin = (ntiles + cap - 1) / cap;
+    wtiles = (ntiles + nwin - 1) / nwin;
+}
+
+template <int NS>
+void long_map_grid(int B, int C, int L, int G, dim3 &grid, int &cpb, int &tiles, int &cs, int &nwin, int &wtiles) {
     tiles = (G + NS - 1) / NS;
-    nwin = (L + cca::long_window_tiles(NS) * cca::kTile - 1) / (cca::long_window_tiles(NS) * cca::kTile);
+    long_windows<NS>(L, nwin, wtiles);
     const int nchunks = (C + cca::LG_MC - 1) / cca::LG_MC;
     const long base = (long)B * tiles * nwin, want = 4L * num_cus();
     int s = (int)((want + base - 1) / base);
@@ -279,23 +287,23 @@ int launch_long_map_pair_ns(const float *T, const float *F, const float *resid, 
                             int B, int C, int H, int W, ccnet_stream_t stream, const char *what,
                             long fbs, long rbs, long obs, bool ns_col, bool ns_row) {
     dim3 grid;
-    int cpb, tiles, cs, nwin;
+    int cpb, tiles, cs, nwin, wt;
     if ((g_branch_mask & CCNET_BRANCH_COL) && ns_col) {
-        long_map_grid<NS>(B, C, /*L=*/H, /*G=*/W, grid, cpb, tiles, cs, nwin);
+        long_map_grid<NS>(B, C, /*L=*/H, /*G=*/W, grid, cpb, tiles, cs, nwin, wt);
         if (resid) {
             if (TRANS) return fail(CCNET_E_BADFLAGS, "residual epilogue only exists for the forward aggregation");
             CCA_LAUNCH((cca::map_long_kernel<NS, false, false, cca::EPI_COL_RESID>), grid, dim3(cca::kWave * NS), stream,
-                       T, F, resid, gamma, out, C, H, W, cpb, tiles, cs, nwin, fbs, rbs, obs);
+                       T, F, resid, gamma, out, C, H, W, cpb, tiles, cs, nwin, wt, fbs, rbs, obs);
         } else {
             CCA_LAUNCH((cca::map_long_kernel<NS, false, TRANS, cca::EPI_COL>), grid, dim3(cca::kWave * NS), stream,
-                       T, F, resid, gamma, out, C, H, W, cpb, tiles, cs, nwin, fbs, rbs, obs);
+                       T, F, resid, gamma, out, C, H, W, cpb, tiles, cs, nwin, wt, fbs, rbs, obs);
         }
         if (int e = launch_status(what)) return e;
     }
     if ((g_branch_mask & CCNET_BRANCH_ROW) && ns_row) {
-        long_map_grid<NS>(B, C, /*L=*/W, /*G=*/H, grid, cpb, tiles, cs, nwin);
+        long_map_grid<NS>(B, C, /*L=*/W, /*G=*/H, grid, cpb, tiles, cs, nwin, wt);
         CCA_LAUNCH((cca::map_long_kernel<NS, true, TRANS, cca::EPI_ROW>), grid, dim3(cca::kWave * NS), stream,
-                   T, F, (const float *)nullptr, gamma, out, C, H, W, cpb, tiles, cs, nwin, fbs, rbs, obs);
+                   T, F, (const float *)nullptr, gamma, out, C, H, W, cpb, tiles, cs, nwin, wt, fbs, rbs, obs);
         return launch_status(what);
     }
     return 0;
@@ -317,12 +325,13 @@ int launch_long_map_pair(const float *T, const float *F, const float *resid, con
 template <int NS, bool MASK>
 int launch_long_weight_ns(const float *X, const float *Y, float *T, int B, int Cx, int H, int W,
                           ccnet_stream_t stream, const char *what, long xbs, long ybs, bool do_col, bool do_row) {
-    const int wt = cca::long_window_tiles(NS) * cca::kTile;
-    const int tc = do_col ? (W + NS - 1) / NS : 0, wc = (H + wt - 1) / wt;
-    const int tr = do_row ? (H + NS - 1) / NS : 0, wr = (W + wt - 1) / wt;
+    int wc, wtc, wr, wtr;
+    long_windows<NS>(H, wc, wtc);
+    long_windows<NS>(W, wr, wtr);
+    const int tc = do_col ? (W + NS - 1) / NS : 0, tr = do_row ? (H + NS - 1) / NS : 0;
     if (tc * wc + tr * wr == 0) return 0;
     CCA_LAUNCH((cca::weight_long_kernel<NS, MASK>), dim3((unsigned)((tc * wc + tr * wr) * B)), dim3(cca::kWave * NS), stream,
-               X, Y, T, Cx, H, W, tc, wc, tr, wr, xbs, ybs);
+               X, Y, T, Cx, H, W, tc, wc, wtc, tr, wr, wtr, xbs, ybs);
     return launch_status(what);
 }
 

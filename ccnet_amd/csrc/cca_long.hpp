@@ -24,6 +24,8 @@
 #include "cca_common.hpp"
 #include "cca_map.hpp"      // EPI_COL / EPI_ROW / EPI_COL_RESID
 
+#include <type_traits>
+
 namespace cca {
 
 constexpr int kLongMaxStrip = 320;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(kWave * NS) void map_long_kernel(const float *__res
                                                               const float *__restrict__ resid,
                                                               const float *__restrict__ gamma, float *out,
                                                               int C, int H, int W, int chunks_per_block, int tiles,
-                                                              int nsplit, int nwin, long fbs, long rbs, long obs) {
+                                                              int nsplit, int nwin, int wtiles, long fbs, long rbs, long obs) {
     constexpr int MAXL = long_maxl(NS), NTW = long_window_tiles(NS), MAXKS = MAXL / 4, CP = long_cp(NS);
     constexpr int WIN = NTW * kTile, RP = WIN * NS;           // window positions; floats per channel of the result image
     __shared__ float lds[LG_MC * CP + LG_MC * RP];
@@ -89,7 +91,9 @@ __global__ __launch_bounds__(kWave * NS) void map_long_kernel(const float *__res
     const int g = g0 + wv;
     const bool active = g < br.G;
     const int gvalid = (br.G - g0 < NS) ? br.G - g0 : NS;
-    const int p0 = win * WIN;                                 // first output position of this window
+    // windows are evened out by the host: wtiles <= NTW position tiles each (129 -> 3 + 3 + 3 tiles, not 4 + 4 + 1)
+    const int p0 = win * wtiles * kTile;                      // first output position of this window
+    const int pend = (p0 + wtiles * kTile < L) ? p0 + wtiles * kTile : L;
     const int nks = (L + 3) / 4;
     const int nchunks = (C + LG_MC - 1) / LG_MC;
     const int ch_begin = split * chunks_per_block;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(kWave * NS) void map_long_kernel(const float *__res
         for (int t = 0; t < NTW; ++t) {
             const int kidx = ks * 4 + lk, nidx = p0 + t * kTile + ln;
             const int iq = TRANS ? kidx : nidx, j = TRANS ? nidx : kidx;
-            const bool ok = active && iq < L && j < L;
+            const bool ok = active && t < wtiles && iq < L && j < L;
             const float v = fbuf_load(Tb, ok ? 4 * (iq * br.as_q + g * br.as_g + br.a_off + j) : 0, 0);
             bf[ks][t] = ok ? v : 0.f;
         }
@@ -128,27 +132,36 @@ __global__ __launch_bounds__(kWave * NS) void map_long_kernel(const float *__res
         }
         __syncthreads();
         if (active) {
-            f32x4 acc[NTW];
+            // the number of position tiles of this window is wave-uniform but only known at run time: dispatch once
+            // per chunk to a body with a compile-time tile count (a guard around every MFMA would serialise them)
+            auto compute = [&](auto nt_tag) {
+                constexpr int NT = decltype(nt_tag)::value;
+                f32x4 acc[NT];
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float *ab = img + ln * CP;                  // A fragment: channel = l & 15
+                for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float *ab = img + ln * CP;              // A fragment: channel = l & 15
 #pragma unroll
-            for (int ks = 0; ks < MAXKS; ++ks)
-                if (ks < nks) {
-                    const int k = ks * 4 + lk;
-                    const float av = CCA_LDS_LD(&ab[k < L ? (ROW ? wv * L + k : k * NS + wv) : 0]);
-                    const float a = k < L ? av : 0.f;         // never multiply a zero fragment by foreign data
+                for (int ks = 0; ks < MAXKS; ++ks)
+                    if (ks < nks) {
+                        const int k = ks * 4 + lk;
+                        const float av = CCA_LDS_LD(&ab[k < L ? (ROW ? wv * L + k : k * NS + wv) : 0]);
+                        const float a = k < L ? av : 0.f;     // never multiply a zero fragment by foreign data
 #pragma unroll
-                    for (int t = 0; t < NTW; ++t) acc[t] = mfma_16x16x4(a, bf[ks][t], acc[t]);
+                        for (int t = 0; t < NT; ++t) acc[t] = mfma_16x16x4(a, bf[ks][t], acc[t]);
+                    }
+                // D[m = channel 4 (l >> 4) + r][n = window position 16 t + (l & 15)] -> result image
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int wp = t * kTile + ln;
+                    float *d = res + (4 * lk) * RP + (ROW ? wv * WIN + wp : wp * NS + wv);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) CCA_LDS_ST(&d[r * RP], acc[t][r]);
                 }
-            // D[m = channel 4 (l >> 4) + r][n = window position 16 t + (l & 15)] -> result image
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-                const int wp = t * kTile + ln;
-                float *d = res + (4 * lk) * RP + (ROW ? wv * WIN + wp : wp * NS + wv);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) CCA_LDS_ST(&d[r * RP], acc[t][r]);
-            }
+            };
+            if (wtiles >= NTW)                  compute(std::integral_constant<int, NTW>{});
+            else if (NTW > 2 && wtiles == 3)    compute(std::integral_constant<int, (NTW > 2 ? 3 : 1)>{});
+            else if (wtiles == 2)               compute(std::integral_constant<int, 2>{});
+            else                                compute(std::integral_constant<int, 1>{});
         }
         __syncthreads();
         // window of the output tile -> global memory (+ the other branch's partial sums / the residual)
@@ -159,9 +172,9 @@ __global__ __launch_bounds__(kWave * NS) void map_long_kernel(const float *__res
                 const int soff = c * HW * 4;
                 for (int e0 = 0; e0 < RP; e0 += kWave) {
                     const int e = e0 + lane;
-                    const int wp = ROW ? e % WIN : e / NS, s = ROW ? e / WIN : e % NS;
+                    const int wp = ROW ? e % WIN : e / NS, s = ROW ? e / WIN : e % NS;     // (positions beyond pend are masked)
                     const int pos = p0 + wp;
-                    if (pos < L && s < gvalid) {
+                    if (pos < pend && s < gvalid) {
                         const int voff = 4 * long_plane_offset<ROW>(pos, g0 + s, W);
                         float val = alpha * CCA_LDS_LD(&res[cc * RP + e]);
                         if (EPI != EPI_COL) val += fbuf_load(Rb, voff, soff);
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(kWave * NS) void map_long_kernel(const float *__res
 // weight type:  T[b, pixel(i, g), a_off + j] = sum_c X[b, c, pos(i, g)] * Y[b, c, pos(j, g)]
 // ---------------------------------------------------------------------------------------------
 template <int NS, bool ROW, bool MASK>
-__device__ __forceinline__ void weight_long_body(float *lds, int b, int tile, int win, const float *__restrict__ X,
+__device__ __forceinline__ void weight_long_body(float *lds, int b, int tile, int win, int wtiles, const float *__restrict__ X,
                                                  const float *__restrict__ Y, float *__restrict__ T,
                                                  int Cx, int H, int W, long xbs, long ybs) {
     constexpr int MAXL = long_maxl(NS), NTI = long_window_tiles(NS), NTJ = MAXL / kTile, CP = long_cp(NS);
@@ -191,7 +204,7 @@ __device__ __forceinline__ void weight_long_body(float *lds, int b, int tile, in
     const int g = g0 + wv;
     const bool active = g < br.G;
     const int gvalid = (br.G - g0 < NS) ? br.G - g0 : NS;
-    const int i0 = win * NTI * kTile;                         // first query position of this window
+    const int i0 = win * wtiles * kTile;                      // first query position of this (evened-out) window
     const int ntj = (L + kTile - 1) / kTile;
 
     const FBuf Xb = make_fbuf(X + (size_t)b * xbs, (size_t)Cx * HW * sizeof(float));
@@ -217,27 +230,34 @@ __device__ __forceinline__ void weight_long_body(float *lds, int b, int tile, in
         }
         __syncthreads();
         if (active) {
+            auto compute = [&](auto nt_tag) {
+                constexpr int NT = decltype(nt_tag)::value;   // query tiles of this window (compile time, see above)
 #pragma unroll
-            for (int ks = 0; ks < LG_KC / 4; ++ks) {
-                const bool kin = n * LG_KC + ks * 4 + lk < Cx;
-                const float *xs = xi + (ks * 4 + lk) * CP, *ys = yi + (ks * 4 + lk) * CP;
-                float a[NTI];
+                for (int ks = 0; ks < LG_KC / 4; ++ks) {
+                    const bool kin = n * LG_KC + ks * 4 + lk < Cx;
+                    const float *xs = xi + (ks * 4 + lk) * CP, *ys = yi + (ks * 4 + lk) * CP;
+                    float a[NT];
 #pragma unroll
-                for (int ti = 0; ti < NTI; ++ti) {
-                    const int p = i0 + ti * kTile + ln;
-                    const float v = CCA_LDS_LD(&xs[p < L ? (ROW ? wv * L + p : p * NS + wv) : 0]);
-                    a[ti] = (kin && p < L) ? v : 0.f;
-                }
-#pragma unroll
-                for (int tj = 0; tj < NTJ; ++tj)
-                    if (tj < ntj) {
-                        const int p = tj * kTile + ln;
-                        const float v = CCA_LDS_LD(&ys[p < L ? (ROW ? wv * L + p : p * NS + wv) : 0]);
-                        const float bb = p < L ? v : 0.f;
-#pragma unroll
-                        for (int ti = 0; ti < NTI; ++ti) acc[ti][tj] = mfma_16x16x4(a[ti], bb, acc[ti][tj]);
+                    for (int ti = 0; ti < NT; ++ti) {
+                        const int p = i0 + ti * kTile + ln;
+                        const float v = CCA_LDS_LD(&xs[p < L ? (ROW ? wv * L + p : p * NS + wv) : 0]);
+                        a[ti] = (kin && p < L) ? v : 0.f;
                     }
-            }
+#pragma unroll
+                    for (int tj = 0; tj < NTJ; ++tj)
+                        if (tj < ntj) {
+                            const int p = tj * kTile + ln;
+                            const float v = CCA_LDS_LD(&ys[p < L ? (ROW ? wv * L + p : p * NS + wv) : 0]);
+                            const float bb = p < L ? v : 0.f;
+#pragma unroll
+                            for (int ti = 0; ti < NT; ++ti) acc[ti][tj] = mfma_16x16x4(a[ti], bb, acc[ti][tj]);
+                        }
+                }
+            };
+            if (wtiles >= NTI)                  compute(std::integral_constant<int, NTI>{});
+            else if (NTI > 2 && wtiles == 3)    compute(std::integral_constant<int, (NTI > 2 ? 3 : 1)>{});
+            else if (wtiles == 2)               compute(std::integral_constant<int, 2>{});
+            else                                compute(std::integral_constant<int, 1>{});
         }
         __syncthreads();
     }
@@ -253,7 +273,7 @@ __device__ __forceinline__ void weight_long_body(float *lds, int b, int tile, in
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int iq = i0 + ti * kTile + 4 * lk + r;
-                    if (iq < L && j < L) {
+                    if (ti < wtiles && iq < L && j < L) {
                         float val = acc[ti][tj][r];
                         if (MASK && !ROW && iq == j) val = -INFINITY;      // functions.py:11-12 (column self slot)
                         Tg[(size_t)iq * br.as_q + j] = val;
@@ -266,15 +286,15 @@ __device__ __forceinline__ void weight_long_body(float *lds, int b, int tile, in
 template <int NS, bool MASK>
 __global__ __launch_bounds__(kWave * NS) void weight_long_kernel(const float *__restrict__ X, const float *__restrict__ Y,
                                                                  float *__restrict__ T, int Cx, int H, int W,
-                                                                 int tiles_col, int win_col, int tiles_row, int win_row,
-                                                                 long xbs, long ybs) {
+                                                                 int tiles_col, int win_col, int wt_col, int tiles_row,
+                                                                 int win_row, int wt_row, long xbs, long ybs) {
     __shared__ float lds[2 * LG_KC * long_cp(NS)];
     CCA_LDS_REGISTER(lds);
     const int ncol = tiles_col * win_col, per_image = ncol + tiles_row * win_row;
     const int id = xcd_logical_id(blockIdx.x, gridDim.x);
     const int b = id / per_image, t = id - b * per_image;
-    if (t < ncol) weight_long_body<NS, false, MASK>(lds, b, t % tiles_col, t / tiles_col, X, Y, T, Cx, H, W, xbs, ybs);
-    else          weight_long_body<NS, true, MASK>(lds, b, (t - ncol) % tiles_row, (t - ncol) / tiles_row, X, Y, T, Cx, H, W, xbs, ybs);
+    if (t < ncol) weight_long_body<NS, false, MASK>(lds, b, t % tiles_col, t / tiles_col, wt_col, X, Y, T, Cx, H, W, xbs, ybs);
+    else          weight_long_body<NS, true, MASK>(lds, b, (t - ncol) % tiles_row, (t - ncol) / tiles_row, wt_row, X, Y, T, Cx, H, W, xbs, ybs);
 }
 
 }  // namespace cca
