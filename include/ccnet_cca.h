@@ -49,7 +49,7 @@ extern "C" {
 /* kernel family selection (debug / A-B testing; default AUTO picks MFMA when the shape fits) */
 #define CCNET_IMPL_AUTO    0
 #define CCNET_IMPL_DIRECT  1           /* one-thread-per-output kernels, any shape */
-#define CCNET_IMPL_MFMA    2           /* LDS-staged f32-MFMA strip kernels (max(H,W) <= 100) */
+#define CCNET_IMPL_MFMA    2           /* MFMA strip kernels only (max(H,W) <= 320), error beyond */
 
 /* Arithmetic of the strip kernels.  The affinity (ca_forward), the softmax and the dq/dk kernels always run
  * exact fp32 (the f32 MFMA is bit-identical to an fmaf chain).  The three C-sized contractions may instead split
@@ -158,7 +158,8 @@ int ccnet_cca_backward_bf16(const uint16_t *dy, const uint16_t *q, const uint16_
                             float *dgamma, float *scratch, void *workspace, size_t workspace_bytes,
                             int B, int C, int Cq, int H, int W, ccnet_stream_t stream);
 
-/* 1 if the MFMA strip kernels serve this shape under CCNET_IMPL_AUTO, else 0 (direct kernels). */
+/* Which kernel family serves this shape under the current impl setting: 1 = stationary MFMA strip kernels
+ * (max(H,W) <= 100), 2 = windowed MFMA strip kernels (101 .. 320), 0 = any-shape kernels. */
 int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W);
 
 /* Device self-test of the MFMA fragment layout the kernels assume (asymmetric operands).

@@ -31,3 +31,5 @@ ms = bench.time_region(step, iters)
 nbytes = bench.core_bytes(B, C, H, W) * (2 if dt == torch.bfloat16 else 4) // 4
 print(f"({B},{C},{H},{W}) {dt}: {ms:.3f} ms per fwd+bwd, {nbytes / ms / 1e6:.1f} GB/s algorithmic, "
       f"mfma strip kernels: {bool(lib.ccnet_cca_shape_uses_mfma(B, C, H, W))}")
+if len(sys.argv) > 7 and sys.argv[7] == "stock" and dt == torch.float32:
+    print("stock PyTorch formulation:", bench.stock_pytorch_core(B, C, H, W, dev, iters=3))
