@@ -184,7 +184,18 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
     // (multiplied by zero fragments): start from an all-zero LDS so that they can never hold a NaN
     for (int idx = tid; idx < 3 * BUF; idx += kBlock) CCA_LDS_ST(&lds[idx], 0.f);
     __syncthreads();
-    if (ch_begin < ch_end) issue(ch_begin, 0);
+    // Chunk order.  The column launch of a pair walks its channel chunks upwards, the row launch (which runs right
+    // after it) DOWNWARDS: the column launch's last chunks -- features, and the partial sums it has just written --
+    // are what the 256 MB Infinity Cache still holds, so the row launch starts on cache-resident data instead of
+    // evicting it before it gets there.  CCA_ROW_ASCENDING restores the ascending order (A/B builds).
+#ifdef CCA_ROW_ASCENDING
+    constexpr bool kDescending = false;
+#else
+    constexpr bool kDescending = ROW;
+#endif
+    const int nmine = ch_end - ch_begin;
+    const int ch_first = kDescending ? ch_end - 1 : ch_begin, ch_step = kDescending ? -1 : 1;
+    if (nmine > 0) issue(ch_first, 0);
     __syncthreads();                     // first chunk landed (the compiler drains vmcnt before the barrier)
 
     // A fragment: channel = l & 15 (pitch CP), contraction position k = 4 ks + (l >> 4)
@@ -224,9 +235,10 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
     // launch stores PIECES4 granule pieces per channel, the row launch one piece per 64 granules of NS * 24
     constexpr int NSTORE_MIN = ROW ? CPW * ((NS * 24 + 63) / 64) : CPW * PIECES4;
 
-    for (int ch = ch_begin; ch < ch_end; ++ch) {
-        const int buf = (ch - ch_begin) & 1;
-        const int chn = (ch + 1 < ch_end) ? ch + 1 : ch;
+    for (int it = 0; it < nmine; ++it) {
+        const int ch = ch_first + it * ch_step;
+        const int buf = it & 1;
+        const int chn = (it + 1 < nmine) ? ch + ch_step : ch;
         float *img = lds + buf * BUF;
         f32x4 acc[kMaxTiles];
         if (active) {
