@@ -324,13 +324,14 @@ def stock_pytorch_core(B, C, H, W, device, iters=10):
             "what": "torch.bmm / cat / softmax formulation of functions.py:30-49 + autograd on this GPU"}
 
 
-def module_level_ms(B, C, H, W, device, iters=10, fuse=True):
+def module_level_ms(B, C, H, W, device, iters=10, fuse=True, one_node=True):
     """fwd+bwd of the whole CrissCrossAttention module (adds the 1x1 projections + autograd); ``fuse`` False
     runs the three projections as separate convolutions exactly as functions.py:29-35."""
     from ccnet_amd import CrissCrossAttention
     torch.manual_seed(0)
     m = CrissCrossAttention(C).to(device)
     m.fuse_projections = fuse
+    m.fuse_module_backward = one_node
     with torch.no_grad():
         m.gamma.fill_(0.5)
     x = torch.randn(B, C, H, W, device=device, requires_grad=True)
@@ -429,6 +430,7 @@ def main():
         out["stages_ms"] = {k: round(v, 4) for k, v in roofline_object.stages.items()}
         try:
             out["module_ms_per_step"] = round(module_level_ms(B, C, H, W, device), 4)
+            out["module_ms_per_step_conv2d_autograd"] = round(module_level_ms(B, C, H, W, device, one_node=False), 4)
             out["module_ms_per_step_unfused_projections"] = round(module_level_ms(B, C, H, W, device, fuse=False), 4)
         except Exception as e:          # the metric does not depend on it
             out["module_ms_per_step"] = f"failed: {e}"

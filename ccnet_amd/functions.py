@@ -28,7 +28,7 @@ from torch.nn import Softmax
 from . import _lib
 from ._lib import CCNET_CA_ENERGY, CCNET_CA_SOFTMAX
 
-__all__ = ["INF", "CA_Weight", "CA_Map", "CrissCrossFunction", "CrissCrossPackedFunction", "CrissCrossBF16Function", "ca_weight", "ca_map", "ca_softmax",
+__all__ = ["INF", "CA_Weight", "CA_Map", "CrissCrossFunction", "CrissCrossPackedFunction", "CrissCrossBF16Function", "CrissCrossModuleFunction", "ca_weight", "ca_map", "ca_softmax",
            "criss_cross_attention", "CrissCrossAttention"]
 
 
@@ -346,6 +346,67 @@ class CrissCrossBF16Function(torch.autograd.Function):
         return dq, dk, dv, dy, dgamma.view_as(gamma)
 
 
+class CrissCrossModuleFunction(torch.autograd.Function):
+    """The whole module of functions.py:27-49 as ONE autograd node (fp32, no autocast): stacked projection GEMM ->
+    fused criss-cross core -> hand-written backward in which the input gradient of the projection is a GEMM with
+    ``beta = 1`` on ``dy`` (``dx = dy + W^T dqkv``: the residual's gradient is accumulated by the GEMM epilogue
+    instead of a separate 154 MB elementwise add), and the weight / bias gradients are one batched GEMM + reductions.
+    The GEMMs are torch ops (hipBLASLt); only their composition is ours."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma):
+        x, gamma = _dev_f32("x", x), _dev_f32("gamma", gamma)
+        B, C, H, W = x.shape
+        cq, hw = wq.shape[0], H * W
+        w = torch.cat([wq.reshape(cq, C), wk.reshape(cq, C), wv.reshape(C, C)], 0)          # (2Cq + C, C)
+        b = torch.cat([bq, bk, bv], 0)
+        xm = x.view(B, C, hw)
+        qkv = torch.baddbmm(b.view(1, -1, 1), w.unsqueeze(0).expand(B, -1, -1), xm)          # (B, 2Cq + C, HW)
+        lib = _lib.get_lib()
+        y = torch.empty_like(x)
+        A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
+        esz, bs = hw * 4, (2 * cq + C) * hw
+        base = qkv.data_ptr()
+        with torch.cuda.device(x.device):
+            lib.check(lib.ccnet_cca_forward_strided_f32(base, base + cq * esz, base + 2 * cq * esz, x.data_ptr(),
+                                                        gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
+                                                        B, C, cq, H, W, bs, bs, bs, _stream()), "cca_forward")
+        ctx.save_for_backward(x, w, qkv, A, gamma)
+        ctx.cq = cq
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w, qkv, A, gamma = ctx.saved_tensors
+        cq = ctx.cq
+        dy = _dev_f32("grad_output", dy)
+        B, C, H, W = x.shape
+        hw = H * W
+        lib = _lib.get_lib()
+        dqkv = torch.empty_like(qkv)
+        dgamma = torch.empty_like(gamma)
+        scratch = torch.empty_like(A)
+        nbytes = lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
+        ws = torch.empty((nbytes + 3) // 4, device=dy.device, dtype=torch.float32)
+        esz, bs = hw * 4, (2 * cq + C) * hw
+        p, g = qkv.data_ptr(), dqkv.data_ptr()
+        with torch.cuda.device(dy.device):
+            lib.check(lib.ccnet_cca_backward_strided_f32(dy.data_ptr(), p, p + cq * esz, p + 2 * cq * esz,
+                                                         A.data_ptr(), gamma.data_ptr(),
+                                                         g, g + cq * esz, g + 2 * cq * esz,
+                                                         dgamma.data_ptr(), scratch.data_ptr(), ws.data_ptr(), nbytes,
+                                                         B, C, cq, H, W, bs, bs, bs, bs, bs, bs, _stream()),
+                      "cca_backward")
+        xm = x.view(B, C, hw)
+        dx = torch.baddbmm(dy.view(B, C, hw), w.t().unsqueeze(0).expand(B, -1, -1), dqkv)     # dy + W^T dqkv
+        dw = torch.bmm(dqkv, xm.transpose(1, 2)).sum(0)                                       # (2Cq + C, C)
+        db = dqkv.sum(dim=(0, 2))
+        dwq, dwk, dwv = dw[:cq], dw[cq:2 * cq], dw[2 * cq:]
+        return (dx.view(B, C, H, W), dwq.reshape(cq, C, 1, 1), db[:cq], dwk.reshape(cq, C, 1, 1), db[cq:2 * cq],
+                dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma))
+
+
 def criss_cross_attention(q, k, v, x, gamma):
     """Functional form of the fused core."""
     return CrissCrossFunction.apply(q, k, v, x, gamma)
@@ -371,6 +432,10 @@ class CrissCrossAttention(nn.Module):
     #: strides; set False (class or instance) for three separate convolutions exactly as functions.py:29-35.
     fuse_projections = True
 
+    #: fp32, no autocast: run projection + core + their backward as one autograd node (``CrissCrossModuleFunction``:
+    #: the input gradient ``dy + W^T dqkv`` is a single GEMM with beta = 1); False keeps torch's conv2d autograd.
+    fuse_module_backward = True
+
     #: bf16 inputs at geometries outside the fp32 strip kernels (strips longer than 320) use the bf16-I/O entry
     #: points; everything else is computed through fp32 copies on the MFMA kernels.
     native_bf16 = True
@@ -386,6 +451,11 @@ class CrissCrossAttention(nn.Module):
             q, k, v = self.query_conv(x), self.key_conv(x), self.value_conv(x)
             return CrissCrossBF16Function.apply(q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16),
                                                 x, self.gamma.float())
+        if (self.fuse_projections and self.fuse_module_backward and self._fusable() and x.dtype == torch.float32
+                and not torch.is_autocast_enabled()):
+            return CrissCrossModuleFunction.apply(x, self.query_conv.weight, self.query_conv.bias,
+                                                  self.key_conv.weight, self.key_conv.bias,
+                                                  self.value_conv.weight, self.value_conv.bias, self.gamma)
         if self.fuse_projections and self._fusable():
             # one GEMM for functions.py:29,32,35: the three 1x1 convolutions share their input, so their
             # weights are stacked row-wise (parameters and state_dict keys stay the reference's three convs)

@@ -257,22 +257,26 @@ def test_fused_projection_matches_three_separate_convolutions(lib, dev, shape):
     x = torch.randn(B, C, H, W, device=dev)
     dy = torch.randn(B, C, H, W, device=dev)
     outs = {}
-    for fused in (True, False):
-        m.fuse_projections = fused
+    # "node": projection + core + backward as one autograd node (the default); "conv": stacked conv2d with torch's
+    # autograd around the packed core; False: three separate convolutions (functions.py:29-35 literally)
+    for variant in ("node", "conv", False):
+        m.fuse_projections = bool(variant)
+        m.fuse_module_backward = variant == "node"
         m.zero_grad(set_to_none=True)
         xi = x.clone().requires_grad_(True)
         y = m(xi)
         y.backward(dy)
-        outs[fused] = (y.detach(), xi.grad, {n: p.grad.clone() for n, p in m.named_parameters()})
-    m.fuse_projections = True
+        outs[variant] = (y.detach(), xi.grad, {n: p.grad.clone() for n, p in m.named_parameters()})
+    m.fuse_projections = m.fuse_module_backward = True
     scale = float(outs[False][1].abs().max())
-    assert err(outs[True][0], outs[False][0]) < TIGHT * 4
-    assert err(outs[True][1], outs[False][1]) < TIGHT * 4 * max(scale, 1.0)
-    for n in outs[True][2]:
-        ref = outs[False][2][n]
-        # key_conv.bias has a mathematically ZERO gradient (softmax is shift-invariant per pixel): what is compared
-        # there is the rounding residue of an 18818-term cancelling sum, hence the absolute floor
-        assert err(outs[True][2][n], ref) < max(1e-4 * float(ref.abs().max()), TOL), n
+    for variant in ("node", "conv"):
+        assert err(outs[variant][0], outs[False][0]) < TIGHT * 4
+        assert err(outs[variant][1], outs[False][1]) < TIGHT * 4 * max(scale, 1.0)
+        for n in outs[variant][2]:
+            ref = outs[False][2][n]
+            # key_conv.bias has a mathematically ZERO gradient (softmax is shift-invariant per pixel): what is compared
+            # there is the rounding residue of an 18818-term cancelling sum, hence the absolute floor
+            assert err(outs[variant][2][n], ref) < max(1e-4 * float(ref.abs().max()), TOL), n
     # same q/k/v bits through the dense and the strided entry points -> identical bits out
     cq = m.query_conv.out_channels
     qkv = torch.randn(B, 2 * cq + C, H, W, device=dev)
