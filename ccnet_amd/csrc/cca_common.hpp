@@ -368,8 +368,8 @@ __host__ __device__ inline void store_f32(bf16_t *p, float v) {
 //                  in memory while the stride-NS fragment reads spread over more banks
 //   row branch     p = gg * L + i                the NS rows are contiguous in memory
 // The image is filled by 16-byte LDS-DMA pieces of 256 floats (lane l moves p = 256 m + 4 l .. + 3: 16 B of one
-// (c, i) position in the column branch, 16 B of a row in the row branch) and drained, in the map kernel, by
-// 4-byte tile stores over 64-float pieces.  Lanes whose data would lie outside the strip tile are masked.
+// (c, i) position in the column branch, 16 B of a row in the row branch).  Lanes whose data would lie outside the
+// strip tile are masked.  (How the map kernel drains its result images is described in cca_map.hpp.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kOobOffset = 0x7ffffff0;            // per-lane byte offset that is out of range for every view
 
@@ -386,38 +386,6 @@ template <int NS, bool ROW>
 __device__ __forceinline__ int strip_lds_index(int i, int gg, int L) {
     return ROW ? gg * L + i : i * NS + (gg ^ col_swizzle<NS>(i));
 }
-
-// Per-lane addressing of the 4-byte pieces (tile stores).  Piece m covers LDS indices [64 m, 64 m + 64); the
-// element a lane moves is plane[vb + piece_soff(m)] when valid(m).
-template <int NS, bool ROW>
-struct StripLanes {
-    int vb[2];
-    bool okg[2];
-    int li;
-    int lim;
-
-    __device__ __forceinline__ void init(int lane, int L, int W, int g0, int gvalid) {
-        if (ROW) {
-            li = lane;
-            lim = gvalid * L;
-            vb[0] = vb[1] = 4 * (g0 * W + lane);
-            okg[0] = okg[1] = true;
-        } else {
-            li = lane / NS;
-            lim = L;
-#pragma unroll
-            for (int par = 0; par < 2; ++par) {
-                const int gg = (lane % NS) ^ col_swizzle<NS>(par * (64 / NS) + li);
-                okg[par] = gg < gvalid;
-                vb[par] = 4 * (li * W + g0 + gg);
-            }
-        }
-    }
-    __device__ __forceinline__ int piece_soff(int m, int W) const { return ROW ? m * 256 : m * (64 / NS) * W * 4; }
-    __device__ __forceinline__ bool valid(int m) const {
-        return ROW ? (m * 64 + li < lim) : (okg[m & 1] && m * (64 / NS) + li < lim);
-    }
-};
 
 // Per-lane addressing of the 16-byte DMA pieces.  Piece m covers LDS indices [256 m, 256 m + 256); lane l moves
 // the 4 consecutive elements starting at plane[vb + piece_soff(m)] when valid(m).  A valid lane may fetch up to
