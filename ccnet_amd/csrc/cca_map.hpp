@@ -180,8 +180,8 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
     }
 #endif
 
-    // masked DMA lanes leave their LDS slots untouched, and slots just past a strip are read as K padding
-    // (multiplied by zero fragments): start from an all-zero LDS so that they can never hold a NaN
+    // masked DMA lanes leave their LDS slots untouched, and slots just past a strip are read as K padding (and then
+    // discarded): start from an all-zero LDS so that what is read there is at least defined
     for (int idx = tid; idx < 3 * BUF; idx += kBlock) CCA_LDS_ST(&lds[idx], 0.f);
     __syncthreads();
     // Chunk order.  The column launch of a pair walks its channel chunks upwards, the row launch (which runs right
@@ -269,7 +269,10 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                 }
                 {
                     const int koff = ROW ? 96 : 96 * NS + (wv ^ col_swizzle<NS>(96));
-                    const float a = CCA_LDS_LD(ab + koff);
+                    const float araw = CCA_LDS_LD(ab + koff);
+                    // K padding (positions L .. 99): in the row image those slots hold the NEXT row's first values; their
+                    // B fragments are zero, but 0 * inf would still poison this row, so the A operand is zeroed too
+                    const float a = (96 + lk < L) ? araw : 0.f;
 #pragma unroll
                     for (int t = 0; t < kMaxTiles; ++t) {
                         const int sidx = M_BKS * kMaxTiles + t;
@@ -290,7 +293,10 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                 if (FULL || ks < nks) {
 #endif
                     const int koff = ROW ? ks * 4 : ks * 4 * NS + (wv ^ col_swizzle<NS>(ks * 4));
-                    const float a = CCA_LDS_LD(ab + koff);
+                    const float araw = CCA_LDS_LD(ab + koff);
+                    // K padding: zero the A operand as well as the B fragment (see the bf16 path); only the last
+                    // k-step of a full strip can hold padding
+                    const float a = (FULL && ks < M_KS - 1) ? araw : ((ks * 4 + lk < L) ? araw : 0.f);
 #pragma unroll
                     for (int t = 0; t < kMaxTiles; ++t)
                         if (FULL || t < nt) acc[t] = mfma_16x16x4(a, bf[ks][t], acc[t]);

@@ -378,6 +378,24 @@ def test_bf16_io_entry_points_round_once_on_store(ops, shape):
     assert np.array_equal(y0, bits["x"])
 
 
+@pytest.mark.parametrize("shape", [(1, 16, 3, 97), (1, 16, 4, 21), (1, 16, 3, 129)])
+def test_non_finite_values_do_not_leak_through_k_padding(ops, shape):
+    """An inf in v at (row 1, column 0) may only reach the pixels that attend to it: row 1 (row branch) and column 0
+    (column branch).  The row strips are padded to a multiple of 4 positions with the NEXT row's first values; a zero
+    attention fragment is not enough to keep 0 * inf = nan out of row 0."""
+    B, C, H, W = shape
+    for prec in (0, 2):
+        ops.lib.ccnet_cca_set_precision(prec)
+        ops.set_impl(MFMA)
+        c = rand_case(*shape, seed=91)
+        c["v"][0, 5, 1, 0] = np.inf
+        y, _ = ops.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
+        assert np.isfinite(y[0, :, 0, 1:]).all() and np.isfinite(y[0, :, 2:, 1:]).all()
+        assert not np.isfinite(y[0, 5, 1, 1:]).all()                        # the pixels that do attend to it
+    ops.lib.ccnet_cca_set_precision(0)
+    ops.set_impl(0)
+
+
 def test_precision_modes_leave_short_strips_exact(ops):
     """ccnet_cca_set_precision returns the previous mode; below 97-long strips the forward pass is exact f32 in
     every mode (the split-bf16 aggregation kernels only exist for strips 97..100 long)."""
