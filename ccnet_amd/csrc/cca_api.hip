@@ -268,12 +268,17 @@ void long_windows(int L, int &nwin, int &wtiles) {
     wtiles = (ntiles + nwin - 1) / nwin;
 }
 
-template <int NS>
+template <int NS, int WPS>
 void long_map_grid(int B, int C, int L, int G, dim3 &grid, int &cpb, int &tiles, int &cs, int &nwin, int &wtiles) {
     tiles = (G + NS - 1) / NS;
-    long_windows<NS>(L, nwin, wtiles);
+    if (WPS == 2) {                 // the two windows of a strip are the two wavefronts that own it
+        nwin = 1;
+        wtiles = ((L + cca::kTile - 1) / cca::kTile + 1) / 2;
+    } else {
+        long_windows<NS>(L, nwin, wtiles);
+    }
     const int nchunks = (C + cca::LG_MC - 1) / cca::LG_MC;
-    const long base = (long)B * tiles * nwin, want = 4L * num_cus();
+    const long base = (long)B * tiles * nwin, want = (WPS == 2 ? 2L : 4L) * num_cus();
     int s = (int)((want + base - 1) / base);
     if (s < 1) s = 1;
     if (s > nchunks) s = nchunks;
@@ -282,66 +287,86 @@ void long_map_grid(int B, int C, int L, int G, dim3 &grid, int &cpb, int &tiles,
     grid = dim3((unsigned)(base * cs));
 }
 
-template <int NS, bool TRANS>
-int launch_long_map_pair_ns(const float *T, const float *F, const float *resid, const float *gamma, float *out,
-                            int B, int C, int H, int W, ccnet_stream_t stream, const char *what,
-                            long fbs, long rbs, long obs, bool ns_col, bool ns_row) {
+// one launch of a pair: the column launch (row == false) or the row launch of configuration <NS, WPS>
+template <int NS, int WPS, bool TRANS>
+int launch_long_map_one(bool row, const float *T, const float *F, const float *resid, const float *gamma, float *out,
+                        int B, int C, int H, int W, ccnet_stream_t stream, const char *what,
+                        long fbs, long rbs, long obs) {
     dim3 grid;
     int cpb, tiles, cs, nwin, wt;
-    if ((g_branch_mask & CCNET_BRANCH_COL) && ns_col) {
-        long_map_grid<NS>(B, C, /*L=*/H, /*G=*/W, grid, cpb, tiles, cs, nwin, wt);
+    const dim3 block(cca::kWave * NS * WPS);
+    if (!row) {
+        long_map_grid<NS, WPS>(B, C, /*L=*/H, /*G=*/W, grid, cpb, tiles, cs, nwin, wt);
         if (resid) {
             if (TRANS) return fail(CCNET_E_BADFLAGS, "residual epilogue only exists for the forward aggregation");
-            CCA_LAUNCH((cca::map_long_kernel<NS, false, false, cca::EPI_COL_RESID>), grid, dim3(cca::kWave * NS), stream,
+            CCA_LAUNCH((cca::map_long_kernel<NS, WPS, false, false, cca::EPI_COL_RESID>), grid, block, stream,
                        T, F, resid, gamma, out, C, H, W, cpb, tiles, cs, nwin, wt, fbs, rbs, obs);
         } else {
-            CCA_LAUNCH((cca::map_long_kernel<NS, false, TRANS, cca::EPI_COL>), grid, dim3(cca::kWave * NS), stream,
+            CCA_LAUNCH((cca::map_long_kernel<NS, WPS, false, TRANS, cca::EPI_COL>), grid, block, stream,
                        T, F, resid, gamma, out, C, H, W, cpb, tiles, cs, nwin, wt, fbs, rbs, obs);
         }
-        if (int e = launch_status(what)) return e;
-    }
-    if ((g_branch_mask & CCNET_BRANCH_ROW) && ns_row) {
-        long_map_grid<NS>(B, C, /*L=*/W, /*G=*/H, grid, cpb, tiles, cs, nwin, wt);
-        CCA_LAUNCH((cca::map_long_kernel<NS, true, TRANS, cca::EPI_ROW>), grid, dim3(cca::kWave * NS), stream,
+    } else {
+        long_map_grid<NS, WPS>(B, C, /*L=*/W, /*G=*/H, grid, cpb, tiles, cs, nwin, wt);
+        CCA_LAUNCH((cca::map_long_kernel<NS, WPS, true, TRANS, cca::EPI_ROW>), grid, block, stream,
                    T, F, (const float *)nullptr, gamma, out, C, H, W, cpb, tiles, cs, nwin, wt, fbs, rbs, obs);
-        return launch_status(what);
     }
-    return 0;
+    return launch_status(what);
 }
 
-// the two launches of a pair may need different configurations (H = 129, W = 257: column strips 129 long -> 4 strips
-// per workgroup, row strips 257 long -> 2): the partial sums are in the natural layout, so they combine freely
+// the two launches of a pair choose their configuration independently from the length of THEIR strips (H = 129,
+// W = 257: column strips 129 long -> 4 strips x 2 wavefronts, row strips 257 long -> 2 strips): the partial sums are
+// in the natural layout, so they combine freely
 template <bool TRANS>
 int launch_long_map_pair(const float *T, const float *F, const float *resid, const float *gamma, float *out,
                          int B, int C, int H, int W, ccnet_stream_t stream, const char *what,
                          long fbs, long rbs, long obs) {
-    const bool col4 = H <= cca::long_maxl(4), row4 = W <= cca::long_maxl(4);
-    if (int e = launch_long_map_pair_ns<4, TRANS>(T, F, resid, gamma, out, B, C, H, W, stream, what, fbs, rbs, obs, col4, false)) return e;
-    if (int e = launch_long_map_pair_ns<2, TRANS>(T, F, resid, gamma, out, B, C, H, W, stream, what, fbs, rbs, obs, !col4, false)) return e;
-    if (int e = launch_long_map_pair_ns<4, TRANS>(T, F, resid, gamma, out, B, C, H, W, stream, what, fbs, rbs, obs, false, row4)) return e;
-    return launch_long_map_pair_ns<2, TRANS>(T, F, resid, gamma, out, B, C, H, W, stream, what, fbs, rbs, obs, false, !row4);
+    static const int two_waves = env_int("CCNET_CCA_LONG_TWO_WAVES", 1);
+    for (int row = 0; row < 2; ++row) {
+        if (!(g_branch_mask & (row ? CCNET_BRANCH_ROW : CCNET_BRANCH_COL))) continue;
+        const int L = row ? W : H;
+        int e;
+        if (two_waves && L <= cca::LongMapCfg<4, 2>::MAXL)
+            e = launch_long_map_one<4, 2, TRANS>(row, T, F, resid, gamma, out, B, C, H, W, stream, what, fbs, rbs, obs);
+        else if (L <= cca::long_maxl(4))
+            e = launch_long_map_one<4, 1, TRANS>(row, T, F, resid, gamma, out, B, C, H, W, stream, what, fbs, rbs, obs);
+        else
+            e = launch_long_map_one<2, 1, TRANS>(row, T, F, resid, gamma, out, B, C, H, W, stream, what, fbs, rbs, obs);
+        if (e) return e;
+    }
+    return 0;
 }
 
-template <int NS, bool MASK>
+template <int NS, int WPS, bool MASK>
 int launch_long_weight_ns(const float *X, const float *Y, float *T, int B, int Cx, int H, int W,
                           ccnet_stream_t stream, const char *what, long xbs, long ybs, bool do_col, bool do_row) {
     int wc, wtc, wr, wtr;
-    long_windows<NS>(H, wc, wtc);
-    long_windows<NS>(W, wr, wtr);
+    if (WPS == 2) {                 // the two query windows of a strip are the two wavefronts that own it
+        wc = wr = 1;
+        wtc = ((H + cca::kTile - 1) / cca::kTile + 1) / 2;
+        wtr = ((W + cca::kTile - 1) / cca::kTile + 1) / 2;
+    } else {
+        long_windows<NS>(H, wc, wtc);
+        long_windows<NS>(W, wr, wtr);
+    }
     const int tc = do_col ? (W + NS - 1) / NS : 0, tr = do_row ? (H + NS - 1) / NS : 0;
     if (tc * wc + tr * wr == 0) return 0;
-    CCA_LAUNCH((cca::weight_long_kernel<NS, MASK>), dim3((unsigned)((tc * wc + tr * wr) * B)), dim3(cca::kWave * NS), stream,
-               X, Y, T, Cx, H, W, tc, wc, wtc, tr, wr, wtr, xbs, ybs);
+    CCA_LAUNCH((cca::weight_long_kernel<NS, WPS, MASK>), dim3((unsigned)((tc * wc + tr * wr) * B)),
+               dim3(cca::kWave * NS * WPS), stream, X, Y, T, Cx, H, W, tc, wc, wtc, tr, wr, wtr, xbs, ybs);
     return launch_status(what);
 }
 
+// per branch: strips up to 144 -> 4 strips x 2 wavefronts (one pass over the channels), up to 160 -> 4 strips with
+// query windows, up to 320 -> 2 strips with query windows
 template <bool MASK>
 int launch_long_weight_pair(const float *X, const float *Y, float *T, int B, int Cx, int H, int W,
                             ccnet_stream_t stream, const char *what, long xbs, long ybs) {
+    static const int two_waves = env_int("CCNET_CCA_LONG_TWO_WAVES", 1);
     const bool col = g_branch_mask & CCNET_BRANCH_COL, row = g_branch_mask & CCNET_BRANCH_ROW;
-    const bool col4 = H <= cca::long_maxl(4), row4 = W <= cca::long_maxl(4);
-    if (int e = launch_long_weight_ns<4, MASK>(X, Y, T, B, Cx, H, W, stream, what, xbs, ybs, col && col4, row && row4)) return e;
-    return launch_long_weight_ns<2, MASK>(X, Y, T, B, Cx, H, W, stream, what, xbs, ybs, col && !col4, row && !row4);
+    const int lim2 = two_waves ? cca::LongWeightCfg<4, 2>::MAXL : 0, lim4 = cca::long_maxl(4);
+    const bool c2 = H <= lim2, r2 = W <= lim2, c4 = !c2 && H <= lim4, r4 = !r2 && W <= lim4;
+    if (int e = launch_long_weight_ns<4, 2, MASK>(X, Y, T, B, Cx, H, W, stream, what, xbs, ybs, col && c2, row && r2)) return e;
+    if (int e = launch_long_weight_ns<4, 1, MASK>(X, Y, T, B, Cx, H, W, stream, what, xbs, ybs, col && c4, row && r4)) return e;
+    return launch_long_weight_ns<2, 1, MASK>(X, Y, T, B, Cx, H, W, stream, what, xbs, ybs, col && !c2 && !c4, row && !r2 && !r4);
 }
 
 // ---- strided internals: every feature tensor is (B, C, H, W) with a dense (C, H, W) image per batch and a

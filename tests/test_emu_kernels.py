@@ -166,7 +166,8 @@ def test_band_permuted_partial_sums_at_every_full_strip_length(ops, shape):
     ops.set_impl(0)
 
 
-@pytest.mark.parametrize("shape", [(1, 16, 129, 12), (1, 24, 9, 170), (2, 16, 101, 103), (1, 8, 161, 5), (1, 16, 6, 257)])
+@pytest.mark.parametrize("shape", [(1, 16, 129, 12), (1, 24, 9, 170), (2, 16, 101, 103), (1, 8, 161, 5), (1, 16, 6, 257),
+                                   (1, 16, 150, 7)])
 def test_long_strips_use_the_windowed_mfma_kernels(ops, shape):
     """Strips 101 .. 320 long (129 x 129 of BASELINE configs[4], 129 x 257 of evaluate.py --whole) run on the
     windowed strip kernels of cca_long.hpp: 4 strips per workgroup up to 160, 2 up to 320, the two launches of a
