@@ -295,20 +295,28 @@ int launch_long_map_one(bool row, const float *T, const float *F, const float *r
     dim3 grid;
     int cpb, tiles, cs, nwin, wt;
     const dim3 block(cca::kWave * NS * WPS);
+    if (resid && TRANS) return fail(CCNET_E_BADFLAGS, "residual epilogue only exists for the forward aggregation");
     if (!row) {
+        // the residual is added by the ROW launch of this family (whole-row addend loads); a column-only run (profiling
+        // mask) keeps it here
+        const bool resid_here = resid && !(g_branch_mask & CCNET_BRANCH_ROW);
         long_map_grid<NS, WPS>(B, C, /*L=*/H, /*G=*/W, grid, cpb, tiles, cs, nwin, wt);
-        if (resid) {
-            if (TRANS) return fail(CCNET_E_BADFLAGS, "residual epilogue only exists for the forward aggregation");
+        if (resid_here) {
             CCA_LAUNCH((cca::map_long_kernel<NS, WPS, false, false, cca::EPI_COL_RESID>), grid, block, stream,
                        T, F, resid, gamma, out, C, H, W, cpb, tiles, cs, nwin, wt, fbs, rbs, obs);
         } else {
             CCA_LAUNCH((cca::map_long_kernel<NS, WPS, false, TRANS, cca::EPI_COL>), grid, block, stream,
-                       T, F, resid, gamma, out, C, H, W, cpb, tiles, cs, nwin, wt, fbs, rbs, obs);
+                       T, F, (const float *)nullptr, gamma, out, C, H, W, cpb, tiles, cs, nwin, wt, fbs, rbs, obs);
         }
     } else {
         long_map_grid<NS, WPS>(B, C, /*L=*/W, /*G=*/H, grid, cpb, tiles, cs, nwin, wt);
-        CCA_LAUNCH((cca::map_long_kernel<NS, WPS, true, TRANS, cca::EPI_ROW>), grid, block, stream,
-                   T, F, (const float *)nullptr, gamma, out, C, H, W, cpb, tiles, cs, nwin, wt, fbs, rbs, obs);
+        if (resid && !TRANS) {
+            CCA_LAUNCH((cca::map_long_kernel<NS, WPS, true, false, cca::EPI_ROW_RESID>), grid, block, stream,
+                       T, F, resid, gamma, out, C, H, W, cpb, tiles, cs, nwin, wt, fbs, rbs, obs);
+        } else {
+            CCA_LAUNCH((cca::map_long_kernel<NS, WPS, true, TRANS, cca::EPI_ROW>), grid, block, stream,
+                       T, F, (const float *)nullptr, gamma, out, C, H, W, cpb, tiles, cs, nwin, wt, fbs, rbs, obs);
+        }
     }
     return launch_status(what);
 }

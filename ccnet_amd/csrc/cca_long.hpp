@@ -34,6 +34,10 @@ __host__ __device__ constexpr int long_maxl(int ns) { return ns == 4 ? 160 : 320
 __host__ __device__ constexpr int long_window_tiles(int ns) { return ns == 4 ? 4 : 2; }
 __host__ __device__ constexpr int long_cp(int ns) { return ns * long_maxl(ns) + 20; }      // channel pitch of an image
 constexpr int LG_MC = 16;                         // channels per chunk of the map kernel = one MFMA M tile
+// Epilogue of the long family's ROW launch when the op has a residual: out = alpha * row + partial + resid.  Here the
+// residual belongs to the row launch (its addend loads are whole rows; in the column launch they would be 4-byte
+// gathers) -- the stationary family keeps it in the column launch because its row launch has no LDS image to spare.
+constexpr int EPI_ROW_RESID = 3;
 constexpr int LG_KC = 8;                          // channels per chunk of the weight kernel = 2 MFMA k-steps
 
 // global element offset (inside one channel plane) of position `pos` of strip `strip`
@@ -123,6 +127,8 @@ __global__ __launch_bounds__(kWave * NS * WPS) void map_long_kernel(const float 
     const FBuf Ob = make_fbuf(out + (size_t)b * obs, (size_t)C * HW * sizeof(float));
     const FBuf Rb = make_fbuf(EPI == EPI_COL_RESID ? resid + (size_t)b * rbs : out + (size_t)b * obs,
                               (size_t)C * HW * sizeof(float));
+    const FBuf Xb = make_fbuf(EPI == EPI_ROW_RESID ? resid + (size_t)b * rbs : out + (size_t)b * obs,
+                              (size_t)C * HW * sizeof(float));
     const float alpha = gamma ? gamma[0] : 1.f;
 
     // stationary slice of the attention block as MFMA B fragments B[k][n]: k = contraction position 4 ks + (l >> 4),
@@ -177,7 +183,9 @@ __global__ __launch_bounds__(kWave * NS * WPS) void map_long_kernel(const float 
                 bool ok;
                 decode((q % NPC) * kWave + recompute_here(lane), pos, s, ok);
                 ok = ok && c < C;
-                addend[q] = fbuf_load(Rb, ok ? 4 * long_plane_offset<ROW>(pos, g0 + s, W) : kOobOffset, (c < C ? c : 0) * HW * 4);
+                const int voff = ok ? 4 * long_plane_offset<ROW>(pos, g0 + s, W) : kOobOffset, soff = (c < C ? c : 0) * HW * 4;
+                addend[q] = fbuf_load(Rb, voff, soff);
+                if (EPI == EPI_ROW_RESID) addend[q] += fbuf_load(Xb, voff, soff);
             }
         };
         // (with two wavefronts per strip the registers are needed for the attention fragments during the MFMAs: there

@@ -106,7 +106,8 @@ int ccnet_ca_softmax_backward_f32(const float *A, const float *dA, const float *
 
 /* Aggregation: replaces functions.py:36-37,42,45 (layout shuffles), :46-47 (bmm x2), :49 (epilogue).
  * out = g * (out_H + out_W) + x, with g = *gamma (1 if NULL) and x optional (NULL -> no residual).
- * With gamma == NULL and x == NULL this is the plain ca_map_forward of the extension API. */
+ * With gamma == NULL and x == NULL this is the plain ca_map_forward of the extension API.
+ * out must not alias x or v (the two launches of the pair pass partial sums through out). */
 int ccnet_ca_map_forward_f32(const float *A, const float *v, const float *x, const float *gamma,
                              float *out, int B, int C, int H, int W, ccnet_stream_t stream);
 
