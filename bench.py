@@ -2,25 +2,40 @@
 """bench.py -- criss-cross attention fwd+bwd throughput on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus 8 --steps 50 --warmup 10          # self-spawns 8 ranks (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch: forward (q,k,v,x,gamma -> y, A) and backward
 (dy -> dq, dk, dv, dgamma) of the attention core at BASELINE.json configs[1], (8,512,97,97) fp32, R=1,
-issued through the C ABI (include/ccnet_cca.h) with every buffer already resident in HBM.  The three
-1x1 convolutions around the core stay torch ops and are reported separately (``module_ms_per_step``),
-not in ``value``.
+issued through the C ABI (include/ccnet_cca.h) with every buffer already resident in HBM.  The 1x1
+projections around the core stay torch ops and are reported separately (``module_ms_per_step``), not in
+``value``.
 
-Multi-GPU: the path shards along the batch with no exchange inside the op, so every
-rank runs the same per-GPU batch on its own shard ("weak" scaling, no data-path collective); the
-timed region is bracketed by barrier + synchronize and the maximum over ranks is used.
+Multi-GPU (reference: run_local.sh:18, engine.py:52-57,85-88): the path shards along the batch with no exchange
+inside the op, so every rank runs the same per-GPU batch on its own shard ("weak" scaling, no
+data-path collective); the timed region is bracketed by barrier + synchronize and the maximum over ranks is used.
+``--gpus N`` with no WORLD_SIZE in the environment re-executes this file under ``torch.distributed.run`` with N
+ranks; a WORLD_SIZE that disagrees with ``--gpus`` is an error.  ``--allreduce-grads`` adds the all-reduce of the
+seven CrissCrossAttention parameter gradients (328,321 floats, what DDP moves for this module: engine.py:75) to
+every step.
 
-Rank 0 prints ONE JSON line: the driver contract plus ``roofline`` (dominant kernel, live HIP-event
-timing) and ``cpu_baseline`` (the CPU oracle timed on a bounded sample on this box's host cores).
+Rank 0 prints ONE JSON line: the driver contract plus
+  ``roofline``      op-level: SURVEY 8(d) algorithmic bytes of one step / the step time, against 8 TB/s; the
+                    slowest single launch is described under ``roofline.dominant_kernel`` (live HIP events);
+  ``cpu_baseline``  the CPU oracle timed on a bounded sample on this box's host cores;
+  ``imgs_per_s``    the other half of BASELINE.json's metric: ResNet-101 + RCCA(R=2) synthetic 769x769 train
+                    step (ccnet_amd.train_synthetic, DDP over RCCL when N > 1), whole-job images/s;
+  ``step_ms_stats`` median / p10 / p90 of per-step HIP-event times, warm (back to back) and cold (a 512 MiB
+                    buffer rewritten between steps, so nothing of the step's tensors survives in the 256 MiB
+                    Infinity Cache).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,6 +49,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0          # measured float4-copy ceiling, same table
 F32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_16x16x4_f32 = fp32 vector rate
+CCA_PARAM_FLOATS = lambda C: 2 * ((C // 8) * C + C // 8) + C * C + C + 1      # noqa: E731  (7 tensors)
 
 
 # --------------------------------------------------------------------------------------------
@@ -69,6 +85,10 @@ def kernel_accounting(kind, B, K, H, W, row):
     return nbytes, flops
 
 
+def metric_label(C, H, W):
+    return f"CrissCrossAttention core fwd+bwd algorithmic GB/s at (B,{C},{H},{W})"
+
+
 # --------------------------------------------------------------------------------------------
 # distributed helpers (pure host logic; covered by tests/test_dist_gloo.py on the gloo backend)
 # --------------------------------------------------------------------------------------------
@@ -96,6 +116,34 @@ def max_over_ranks(seconds, device, world):
 def aggregate_value(bytes_per_step_per_rank, steps, world, seconds):
     """Whole-job GB/s: all ranks' bytes over the slowest rank's time."""
     return world * bytes_per_step_per_rank * steps / seconds / 1e9
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv, backend="nccl"):
+    """``--gpus N`` without a launcher: re-execute this file as N ranks of one node (the reference's
+    ``python -m torch.distributed.launch --nproc_per_node=N`` of run_local.sh:18).  Returns (rc, parsed JSON line)."""
+    if backend == "nccl":
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            sys.exit(f"bench.py: --gpus {n} requested but this node exposes {have} HIP device(s); refusing to "
+                     f"report a {n}-GPU number from fewer devices")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    print("[bench] spawning:", " ".join(cmd), file=sys.stderr, flush=True)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if line is not None:
+        print(line, flush=True)
+    return p.returncode, (json.loads(line) if line else None)
 
 
 # --------------------------------------------------------------------------------------------
@@ -191,12 +239,55 @@ def time_region(fn, iters):
     return e0.elapsed_time(e1) / iters        # ms
 
 
-def roofline_object(wl, iters=20):
-    """Time every strip-kernel launch of a step alone and describe the slowest one.
+def quantiles(xs):
+    s = sorted(xs)
+    pick = lambda p: s[min(len(s) - 1, max(0, int(round(p * (len(s) - 1)))))]  # noqa: E731
+    return {"median": round(pick(0.5), 4), "p10": round(pick(0.1), 4), "p90": round(pick(0.9), 4),
+            "min": round(s[0], 4), "n": len(s)}
 
-    A step issues the weight kernel ONCE for both branches (column and row workgroups of one launch) and
-    the map kernel once per branch, so those are the units timed here (branch mask 3 for the weight
-    stages, 1 / 2 for the map stages); the single-branch weight timings are kept as extra rows."""
+
+def per_step_stats(fn, iters, flush=None):
+    """One HIP-event pair per step (median & p10/p90).  ``flush`` (a > 256 MiB tensor) is rewritten
+    before every step, outside the event pair: the step then starts with none of its tensors in the Infinity Cache."""
+    pairs = []
+    for _ in range(iters):
+        if flush is not None:
+            flush.add_(1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    return quantiles([a.elapsed_time(b) for a, b in pairs])
+
+
+def lib_sha16(lib):
+    with open(lib.path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def measured_traffic(lib):
+    """Per-launch HBM bytes from the PMC passes (tools/pmc.sh -> tools/traffic_from_pmc.py), accepted only when
+    they were taken on the library that is being benched (sha recorded next to them); otherwise None."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(tpath) as f:
+            t = json.load(f)
+        if t.get("_lib_sha16") == lib_sha16(lib):
+            return t
+    except Exception:
+        pass
+    return None
+
+
+def roofline_object(wl, step_ms, iters=20):
+    """Op-level roofline (algorithmic bytes of one fwd+bwd / step time, against 8 TB/s) plus the
+    slowest single launch, timed alone with HIP events.
+
+    A step issues the weight kernel ONCE for both branches (column and row workgroups of one launch) and the map
+    kernel once per branch, so those are the units timed here (branch mask 3 for the weight stages, 1 / 2 for the
+    map stages)."""
     B, C, H, W = wl.shape
     lib = wl.lib
     rows, stages = [], {}
@@ -229,28 +320,21 @@ def roofline_object(wl, iters=20):
     finally:
         lib.ccnet_cca_set_branch_mask(3)
     roofline_object.stages = stages
-    dom = max(rows, key=lambda r: r["ms"])
-    t_hbm = dom["bytes"] / (HBM_PEAK_GBS * 1e9)
-    t_mfma = dom["flops"] / (F32_MFMA_PEAK_TF * 1e12)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
-        try:
-            with open(tpath) as f:
-                traffic = json.load(f).get(dom["kernel"])
-        except Exception:
-            traffic = None
-    if t_mfma >= t_hbm:
-        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        obj = {"bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-               "frac": round(ach / F32_MFMA_PEAK_TF, 4)}
-    else:
-        ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-        obj = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": round(ach / HBM_PEAK_GBS, 4)}
-    obj.update({"traffic": traffic, "kernel": dom["kernel"], "kernel_ms": round(dom["ms"], 4),
-                "algorithmic_bytes": dom["bytes"], "algorithmic_flops": dom["flops"],
-                "hbm_gbs_equiv": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1)})
+    nbytes = core_bytes(B, C, H, W)
+    ach = nbytes / (step_ms * 1e-3) / 1e9
+    traffic = measured_traffic(lib)
+    obj = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(ach / HBM_COPY_GBS, 4),
+           "level": "op (one core fwd+bwd)", "algorithmic_bytes": nbytes, "step_ms": round(step_ms, 4),
+           "traffic": (traffic or {}).get("_step_total_bytes")}
+    if rows:
+        dom = max(rows, key=lambda r: r["ms"])
+        obj["dominant_kernel"] = {
+            "kernel": dom["kernel"], "kernel_ms": round(dom["ms"], 4), "algorithmic_bytes": dom["bytes"],
+            "algorithmic_flops": dom["flops"],
+            "achieved_gbs": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
+            "frac": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic": (traffic or {}).get(dom["kernel"])}
     return obj, rows
 
 
@@ -348,7 +432,55 @@ def module_level_ms(B, C, H, W, device, iters=10, fuse=True, one_node=True):
     return time_region(one, iters)
 
 
-def main():
+def rcca_head_ms(device, batches=(1, 2), iters=5):
+    """BASELINE.json configs[2] (networks/ccnet.py:116-123): RCCAModule(2048, 512, 19), recurrence 2, fwd+bwd on a
+    (B,2048,97,97) input -- the layer4 output of a 769x769 crop -- B in {1, 2}."""
+    from ccnet_amd.segmodel import RCCAModule
+    out = {}
+    torch.manual_seed(0)
+    head = RCCAModule(2048, 512, 19).to(device).train()
+    with torch.no_grad():
+        head.cca.gamma.fill_(0.5)
+    for b in batches:
+        x = torch.randn(b, 2048, 97, 97, device=device, requires_grad=True)
+
+        def one():
+            head.zero_grad(set_to_none=True)
+            x.grad = None
+            y = head(x, 2)
+            y.backward(torch.ones_like(y))
+
+        for _ in range(2):
+            one()
+        torch.cuda.synchronize()
+        out[f"B{b}_ms"] = round(time_region(one, iters), 3)
+    out["what"] = "RCCAModule(2048,512,19) R=2 fwd+bwd, input (B,2048,97,97) fp32 (BASELINE configs[2])"
+    return out
+
+
+def small_batch_ms(lib, C, H, W, device, batches=(1, 2), iters=30):
+    """The reference trains at 1-2 images per GPU (README.md:97, engine.py:88): core fwd+bwd at those batches."""
+    out = {}
+    for b in batches:
+        wl = CoreWorkload(lib, b, C, H, W, device, 99 + b)
+        for _ in range(5):
+            wl.step()
+        torch.cuda.synchronize()
+        out[f"B{b}_ms"] = round(time_region(wl.step, iters), 4)
+    return out
+
+
+def train_imgs_per_s(steps, warmup, batch_per_gpu, bf16=False, size=769):
+    """The imgs/s half of the metric (engine.py:85-88 global batch / world; train.py:160-183 step): every rank of the
+    job runs ccnet_amd.train_synthetic.run (DDP over the already initialised process group when world > 1)."""
+    from ccnet_amd import train_synthetic as TS
+    argv = ["--steps", str(steps), "--warmup", str(warmup), "--batch-per-gpu", str(batch_per_gpu),
+            "--size", str(size), "--no-destroy-group"] + (["--bf16"] if bf16 else [])
+    return TS.run(TS.build_parser().parse_args(argv), quiet=True)
+
+
+def main(argv=None, workload_factory=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -357,96 +489,160 @@ def main():
     ap.add_argument("--channels", type=int, default=512)
     ap.add_argument("--height", type=int, default=97)
     ap.add_argument("--width", type=int, default=97)
+    ap.add_argument("--allreduce-grads", action="store_true",
+                    help="all-reduce the module's 7 parameter gradients after every step (engine.py:75)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip roofline/module/cpu legs (timed region only)")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline/module/cpu/train legs (timed region only)")
+    ap.add_argument("--no-train", action="store_true", help="skip the synthetic train-step leg (imgs_per_s)")
+    ap.add_argument("--train-steps", type=int, default=4)
+    ap.add_argument("--train-batch", type=int, default=1, help="images per GPU in the train leg (engine.py:88: 8/world)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--prewarm-s", type=float, default=0.5, help="untimed pre-run (seconds) before the warm-up steps")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="gloo = host-logic tests on CPU with an injected workload (the product has no CPU path)")
+    ap.add_argument("--workload-factory", default=None,
+                    help="tests only: 'module:callable' returning an object with .step() (used with --backend gloo)")
+    args = ap.parse_args(argv)
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        rc, parsed = spawn_ranks(args.gpus, argv, args.backend)
+        if rc != 0:
+            sys.exit(rc)
+        return parsed
     rank, world, local = dist_env()
-    if world != args.gpus and world > 1:
-        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a HIP device (the product has no CPU path)")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    if world != args.gpus:
+        sys.exit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}; refusing to mislabel the run")
+    on_gpu = args.backend == "nccl"
+    if on_gpu:
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs a HIP device (the product has no CPU path)")
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    else:
+        device = torch.device("cpu")
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"     # (the latter: exercise the RCCL path on 1 GPU)
     if use_dist:
-        dist.init_process_group("nccl", device_id=device)     # backend "nccl" is RCCL on ROCm
+        if on_gpu:
+            dist.init_process_group("nccl", device_id=device)     # backend "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
-    from ccnet_amd import _lib
-    lib = _lib.get_lib()
     B, C, H, W = args.batch, args.channels, args.height, args.width
-    wl = CoreWorkload(lib, B, C, H, W, device, shard_seed(1234, rank))
+    lib = None
+    if workload_factory is None and args.workload_factory:
+        mod, attr = args.workload_factory.split(":")
+        workload_factory = getattr(__import__(mod, fromlist=[attr]), attr)
+    if workload_factory is not None:
+        wl = workload_factory(B, C, H, W, device, shard_seed(1234, rank))
+    else:
+        if not on_gpu:
+            sys.exit("bench.py: --backend gloo needs --workload-factory (tests); the product path is HIP-only")
+        from ccnet_amd import _lib
+        lib = _lib.get_lib()
+        wl = CoreWorkload(lib, B, C, H, W, device, shard_seed(1234, rank))
+
+    grads = torch.zeros(CCA_PARAM_FLOATS(C), device=device) if args.allreduce_grads else None
+
+    def step():
+        wl.step()
+        if grads is not None and dist.is_initialized():
+            dist.all_reduce(grads)
 
     # clocks ramp with load: a short untimed pre-run settles DVFS before the contract's own W warm-up steps
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < args.prewarm_s:
         for _ in range(10):
-            wl.step()
-        torch.cuda.synchronize()
+            step()
+        sync()
     for _ in range(args.warmup):
-        wl.step()
-    torch.cuda.synchronize()
+        step()
+    sync()
     if use_dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        wl.step()
-    torch.cuda.synchronize()
+        step()
+    sync()
     if use_dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     local_s = time.perf_counter() - t0
     secs = max_over_ranks(local_s, device, world)
 
     nbytes = core_bytes(B, C, H, W)
     value = aggregate_value(nbytes, args.steps, world, secs)
     ms = secs / args.steps * 1e3
+    impl = "injected" if lib is None else ("mfma-strip" if lib.ccnet_cca_shape_uses_mfma(B, C, H, W) else "direct")
     out = {
-        "metric": "CrissCrossAttention core fwd+bwd algorithmic GB/s at (B,512,97,97)",
+        "metric": metric_label(C, H, W),
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[1]: single-op CrissCrossAttention core fwd+bwd, "
                                f"({B},{C},{H},{W}) fp32 per GPU, R=1",
                    "per_gpu_batch": B, "global_batch": B * world, "shape": [B, C, H, W],
-                   "parallelism": f"batch-sharded x{world} (no data-path collective)",
-                   "impl": "mfma-strip" if lib.ccnet_cca_shape_uses_mfma(B, C, H, W) else "direct"},
+                   "parallelism": f"batch-sharded x{world} (no data-path collective"
+                                  + (", + all-reduce of the 7 parameter gradients per step)" if grads is not None else ")"),
+                   "impl": impl},
         "algorithmic_bytes_per_step_per_gpu": nbytes,
         "frac_of_hbm_roofline": round(value / world / HBM_PEAK_GBS, 4),
         "frac_of_hbm_copy_ceiling": round(value / world / HBM_COPY_GBS, 4),
         "tflops": round(core_flops(B, C, H, W) * world / (ms * 1e-3) / 1e12, 2),
     }
 
-    if rank == 0 and not args.no_extras:
+    extras = on_gpu and lib is not None and not args.no_extras
+    if extras and rank == 0:
+        out["step_ms_stats"] = {"warm": per_step_stats(wl.step, 100)}
+        flush = torch.zeros(128 * 1024 * 1024, device=device)                 # 512 MiB > the 256 MiB Infinity Cache
+        out["step_ms_stats"]["cold"] = per_step_stats(wl.step, 30, flush)
+        out["step_ms_stats"]["cold"]["flush"] = "512 MiB read-modify-write before every step, outside the event pair"
+        del flush
         fwd_ms = time_region(wl.forward, 10)
         bwd_ms = time_region(wl.backward, 10)
         out["fwd_ms"], out["bwd_ms"] = round(fwd_ms, 4), round(bwd_ms, 4)
-        roof, rows = roofline_object(wl)
+        roof, rows = roofline_object(wl, ms)
         out["roofline"] = roof
         out["kernels_ms"] = {r["kernel"]: round(r["ms"], 4) for r in rows}
         out["stages_ms"] = {k: round(v, 4) for k, v in roofline_object.stages.items()}
+        for key, fn in (("small_batch_core_ms", lambda: small_batch_ms(lib, C, H, W, device)),
+                        ("rcca_head_R2_2048x97x97", lambda: rcca_head_ms(device)),
+                        ("stock_pytorch_core", lambda: stock_pytorch_core(B, C, H, W, device))):
+            try:
+                out[key] = fn()
+            except Exception as e:          # the metric does not depend on it
+                out[key] = f"failed: {e}"
         try:
             out["module_ms_per_step"] = round(module_level_ms(B, C, H, W, device), 4)
             out["module_ms_per_step_conv2d_autograd"] = round(module_level_ms(B, C, H, W, device, one_node=False), 4)
             out["module_ms_per_step_unfused_projections"] = round(module_level_ms(B, C, H, W, device, fuse=False), 4)
-        except Exception as e:          # the metric does not depend on it
+        except Exception as e:
             out["module_ms_per_step"] = f"failed: {e}"
-        try:
-            out["stock_pytorch_core"] = stock_pytorch_core(B, C, H, W, device)
+        if isinstance(out.get("stock_pytorch_core"), dict):
             out["speedup_vs_stock_pytorch"] = round(out["stock_pytorch_core"]["ms_per_step"] / out["ms_per_step"], 2)
-        except Exception as e:          # the metric does not depend on it
-            out["stock_pytorch_core"] = f"failed: {e}"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, H, W, args.cpu_budget)
+    if extras and not args.no_train:
+        # every rank takes part (DDP + SyncBN collectives); rank 0 keeps the result
+        del wl
+        torch.cuda.empty_cache()
+        try:
+            r = train_imgs_per_s(args.train_steps, 2, args.train_batch)
+            if rank == 0:
+                out["imgs_per_s"] = r["value"]
+                out["train_step"] = {k: r[k] for k in ("metric", "ms_per_step", "dtype", "config", "final_loss")}
+        except Exception as e:
+            if rank == 0:
+                out["imgs_per_s"] = None
+                out["train_step"] = f"failed: {e}"
     if use_dist:
         dist.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":

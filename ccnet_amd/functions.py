@@ -33,11 +33,15 @@ __all__ = ["INF", "CA_Weight", "CA_Map", "CrissCrossFunction", "CrissCrossPacked
 
 
 def INF(B, H, W, device=None):
-    """Same values as the reference's ``INF`` (functions.py:11-12) without the hard-coded ``.cuda()``.
+    """Same values as the reference's ``INF`` (functions.py:11-12).  Like the reference it returns a tensor on the
+    current HIP device (``.cuda()``) when one exists -- on a host without a GPU it stays on the CPU instead of
+    raising; ``device=`` overrides.
 
     The kernels never materialise this (B*W, H, H) tensor -- the mask is the predicate ``j == h`` --
     it exists so that code poking at ``module.INF`` keeps working.
     """
+    if device is None and torch.cuda.is_available():
+        device = torch.device("cuda", torch.cuda.current_device())
     return -torch.diag(torch.tensor(float("inf"), device=device).repeat(H), 0).unsqueeze(0).repeat(B * W, 1, 1)
 
 
@@ -451,7 +455,7 @@ class CrissCrossAttention(nn.Module):
             q, k, v = self.query_conv(x), self.key_conv(x), self.value_conv(x)
             return CrissCrossBF16Function.apply(q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16),
                                                 x, self.gamma.float())
-        if (self.fuse_projections and self.fuse_module_backward and self._fusable() and x.dtype == torch.float32
+        if (self.fuse_projections and self.fuse_module_backward and self._fusable(x) and x.dtype == torch.float32
                 and not torch.is_autocast_enabled()):
             return CrissCrossModuleFunction.apply(x, self.query_conv.weight, self.query_conv.bias,
                                                   self.key_conv.weight, self.key_conv.bias,
@@ -477,10 +481,25 @@ class CrissCrossAttention(nn.Module):
         B, C, H, W = x.shape
         return bool(_lib.get_lib().ccnet_cca_shape_uses_mfma(B, C, H, W))
 
-    def _fusable(self):
-        """The packed path needs the three projections to still be the plain biased 1x1 convolutions the
-        constructor made (a user may have swapped one out or hooked it)."""
+    def _fusable(self, x=None):
+        """The packed path bypasses ``nn.Conv2d.forward``: it needs the three projections to still be the plain dense
+        biased 1x1 convolutions the constructor made (a user may have swapped one out, changed its geometry, cast it
+        or hooked it) and, when ``x`` is given, their weights to live where and as what ``x`` does."""
         convs = (self.query_conv, self.key_conv, self.value_conv)
-        return all(type(c) is nn.Conv2d and c.kernel_size == (1, 1) and c.bias is not None and c.groups == 1
-                   and not c._forward_hooks and not c._forward_pre_hooks and not c._backward_hooks
-                   for c in convs)
+        cin = convs[0].in_channels
+
+        def plain(c):
+            return (type(c) is nn.Conv2d and c.kernel_size == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0)
+                    and c.dilation == (1, 1) and c.groups == 1 and c.bias is not None and c.in_channels == cin
+                    and c.padding_mode == "zeros" and tuple(c.weight.shape) == (c.out_channels, cin, 1, 1)
+                    and not c._forward_hooks and not c._forward_pre_hooks and not c._backward_hooks
+                    and not getattr(c, "_backward_pre_hooks", None)
+                    and c.weight.dtype == c.bias.dtype and c.weight.device == c.bias.device)
+
+        if not all(plain(c) for c in convs):
+            return False
+        if self.value_conv.out_channels != cin or self.query_conv.out_channels != self.key_conv.out_channels:
+            return False
+        if x is not None:
+            return all(c.weight.device == x.device and c.weight.dtype == x.dtype for c in convs) and x.shape[1] == cin
+        return len({(c.weight.device, c.weight.dtype) for c in convs}) == 1

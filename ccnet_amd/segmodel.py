@@ -25,7 +25,7 @@ from inplace_abn import InPlaceABNSync
 
 from .functions import CrissCrossAttention
 
-__all__ = ["RCCAModule", "ResNetCCNet", "Seg_Model", "CriterionDSN"]
+__all__ = ["RCCAModule", "ResNetCCNet", "Seg_Model", "CriterionDSN", "load_model"]
 
 # (planes, blocks, stride, dilation) of the four residual stages -- ccnet.py:142-145, 195
 _RESNET101_STAGES = ((64, 3, 1, 1), (128, 4, 2, 1), (256, 23, 1, 2), (512, 3, 1, 4))
@@ -130,12 +130,40 @@ class ResNetCCNet(nn.Module):
         return outs
 
 
+def load_model(model, model_file):
+    """Checkpoint loading with the semantics of the reference's ``utils/pyt_utils.py:47-85`` (what ccnet.py:198-199
+    calls): unwrap a ``{'model': ...}`` (or ``{'state_dict': ...}``) wrapper, strip a DataParallel ``module.`` prefix,
+    load non-strictly, WARN about missing / unexpected keys and refuse a checkpoint none of whose keys match
+    (the reference would silently train from random init)."""
+    import logging
+    log = logging.getLogger("ccnet_amd.segmodel")
+    state = torch.load(model_file, map_location="cpu") if isinstance(model_file, (str, bytes)) or hasattr(model_file, "read") else model_file
+    if isinstance(state, dict):
+        for wrapper in ("model", "state_dict"):
+            if wrapper in state and isinstance(state[wrapper], dict):
+                state = state[wrapper]
+                break
+    own = set(model.state_dict().keys())
+    if state and all(k.startswith("module.") for k in state) and not any(k.startswith("module.") for k in own):
+        state = {k[len("module."):]: v for k, v in state.items()}
+    ckpt = set(state.keys())
+    if own and ckpt and not (own & ckpt):
+        raise RuntimeError(f"checkpoint shares no key with the model ({len(ckpt)} keys, e.g. {sorted(ckpt)[:3]}); "
+                           "refusing to continue from random initialisation")
+    model.load_state_dict(state, strict=False)
+    missing, unexpected = sorted(own - ckpt), sorted(ckpt - own)
+    if missing:
+        log.warning("Missing key(s) in state_dict: %s", ", ".join(missing))
+    if unexpected:
+        log.warning("Unexpected key(s) in state_dict: %s", ", ".join(unexpected))
+    return model
+
+
 def Seg_Model(num_classes, criterion=None, pretrained_model=None, recurrence=0, **kwargs):
-    """Same call as ccnet.py:195-201 (``pretrained_model``: path of a ``state_dict`` to load non-strictly)."""
+    """Same call as ccnet.py:195-201 (``pretrained_model``: checkpoint path, loaded by :func:`load_model`)."""
     model = ResNetCCNet(num_classes, criterion, recurrence)
     if pretrained_model is not None:
-        state = torch.load(pretrained_model, map_location="cpu")
-        model.load_state_dict(state.get("state_dict", state) if isinstance(state, dict) else state, strict=False)
+        load_model(model, pretrained_model)
     return model
 
 

@@ -39,8 +39,9 @@ def synthetic_batch(batch, size, num_classes, device, generator):
     return images, labels.masked_fill(ignore, 255)
 
 
-def run(args, model_factory=None):
-    """One training job on the calling rank; returns the result dict (rank 0) or None."""
+def run(args, model_factory=None, quiet=False):
+    """One training job on the calling rank; returns the result dict (rank 0) or None.  ``quiet`` suppresses the
+    JSON line (bench.py embeds the result in its own line)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -110,7 +111,8 @@ def run(args, model_factory=None):
                        "optimizer": "sgd+poly"},
             "final_loss": round(float(loss.detach().float().item()), 4) if loss is not None else None,
         }
-        print(json.dumps(result), flush=True)
+        if not quiet:
+            print(json.dumps(result), flush=True)
     if world > 1 and args.destroy_group:
         dist.destroy_process_group()
     return result

@@ -123,3 +123,32 @@ def test_bench_accounting_matches_survey():
     nbytes, flops = bench.kernel_accounting("weight", 8, 512, 97, 97, row=False)
     assert nbytes == 2 * 4 * 8 * 512 * 97 * 97 + 4 * 8 * 97 * 97 * 97
     assert flops == 2 * 8 * 97 * 97 * 97 * 512
+
+
+def test_fusable_rejects_modified_projections():
+    """the one-node path bypasses nn.Conv2d.forward, so anything but the constructor's plain dense 1x1
+    convolutions (geometry, dtype, device, hooks) must fall back to torch's own conv2d."""
+    import torch
+    from ccnet_amd import CrissCrossAttention
+    m = CrissCrossAttention(16)
+    x = torch.zeros(1, 16, 3, 3)
+    assert m._fusable() and m._fusable(x)
+    assert not m._fusable(x.double())
+    m.key_conv.stride = (2, 2)
+    assert not m._fusable()
+    m.key_conv.stride = (1, 1)
+    m.value_conv.half()
+    assert not m._fusable() and not m._fusable(x)
+    m.value_conv.float()
+    h = m.query_conv.register_full_backward_pre_hook(lambda mod, g: None)
+    assert not m._fusable()
+    h.remove()
+    assert m._fusable(x)
+
+
+def test_inf_matches_reference_values():
+    import torch
+    from ccnet_amd.functions import INF
+    t = INF(2, 3, 4, device="cpu")
+    assert t.shape == (2 * 4, 3, 3) and torch.isneginf(t.diagonal(dim1=1, dim2=2)).all()
+    assert (t[~torch.isinf(t)] == 0).all()

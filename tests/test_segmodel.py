@@ -243,3 +243,27 @@ def test_train_driver_one_gpu_small_crop():
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["final_loss"] == res["final_loss"]
     with open("/proc/self/maps") as f:
         assert "libccnet_cca.so" in f.read()
+
+
+def test_load_model_follows_the_reference_loader(tmp_path, caplog):
+    """same unwrapping / reporting as utils/pyt_utils.py:47-85 (+ 'module.' prefixes), and a checkpoint
+    that matches nothing is an error instead of a silent random init."""
+    import logging
+    from ccnet_amd.segmodel import load_model
+    net = torch.nn.Sequential(torch.nn.Conv2d(2, 3, 1), torch.nn.Conv2d(3, 1, 1))
+    ref = {k: torch.randn_like(v) for k, v in net.state_dict().items()}
+    for wrapped in ({"model": ref}, {"state_dict": ref}, ref, {"model": {"module." + k: v for k, v in ref.items()}}):
+        path = tmp_path / "ckpt.pth"
+        torch.save(wrapped, path)
+        fresh = torch.nn.Sequential(torch.nn.Conv2d(2, 3, 1), torch.nn.Conv2d(3, 1, 1))
+        load_model(fresh, str(path))
+        for k, v in fresh.state_dict().items():
+            assert torch.equal(v, ref[k]), k
+    partial = dict(ref)
+    partial.pop("1.bias")
+    partial["extra.weight"] = torch.zeros(1)
+    with caplog.at_level(logging.WARNING, logger="ccnet_amd.segmodel"):
+        load_model(net, partial)
+    assert "Missing key(s)" in caplog.text and "1.bias" in caplog.text and "extra.weight" in caplog.text
+    with pytest.raises(RuntimeError, match="shares no key"):
+        load_model(net, {"model": {"foo": torch.zeros(1)}})
