@@ -9,21 +9,18 @@
 //             slot H + j <-> source pixel (h, j).
 #pragma once
 
-#ifdef CCNET_EMU
-#include "hip_emu.hpp"
-#else
-#include <hip/hip_runtime.h>
-#endif
+// The device primitives (wave shuffles, MFMA wrappers, buffer resources, LDS-DMA, counted barriers, the launch
+// macro) live in <cca_platform.hpp>.  The product build finds ccnet_amd/csrc/cca_platform.hpp (gfx950 intrinsics);
+// the CPU test-suite puts tests/emu/ first on the include path and gets the SIMT-emulator implementations of the
+// same names -- nothing emulator-related lives in this directory.
+#include <cca_platform.hpp>
 
 #include <math.h>
 #include <stdint.h>
 
 namespace cca {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // 8 packed bf16 (element e in dword e/2, low half = even e)
-
-constexpr int kWave = 64;                 // CDNA wavefront
+// f32x4 / u32x4 (8 packed bf16: element e in dword e/2, low half = even e) and kWave = 64 come from the platform header
 // Strip kernels are templated on NS = strips per workgroup (one wavefront per strip, NS adjacent w or h):
 //   NS = 8: 512 threads, one workgroup per CU;  NS = 4: 256 threads, two independent workgroups per CU
 constexpr int kMaxStripsPerBlock = 8;
@@ -49,235 +46,6 @@ __host__ __device__ inline Branch make_branch(bool row, int H, int W) {
     else     { g.L = H; g.G = W; g.fs_i = W; g.fs_g = 1; g.as_q = W * S; g.as_g = S; g.a_off = 0; }
     return g;
 }
-
-// ---------------------------------------------------------------------------------------------
-// wave-level primitives.  On the device these are single instructions; under CCNET_EMU they are
-// rendez-vous points of the fiber scheduler (tests/emu/hip_emu.cpp).
-// ---------------------------------------------------------------------------------------------
-#ifdef CCNET_EMU
-
-__device__ inline int lane_id() { return emu::lane_id(); }
-
-__device__ inline float shfl_xor(float v, int mask) {
-    uint32_t bits;
-    memcpy(&bits, &v, 4);
-    const uint64_t *s = emu::wave_exchange(bits);
-    uint32_t o = uint32_t(s[emu::lane_id() ^ mask]);
-    float r;
-    memcpy(&r, &o, 4);
-    return r;
-}
-
-// D = A(16x4) * B(4x16) + C, v_mfma_f32_16x16x4_f32 layout (cdna_hip_programming.md section 3):
-//   a: lane l holds A[i = l & 15][k = l >> 4];  b: lane l holds B[k = l >> 4][j = l & 15]
-//   c/d: lane l, reg r holds D[row = 4 * (l >> 4) + r][col = l & 15]
-// bit-for-bit a k-ordered fmaf chain.
-__device__ inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
-    uint32_t ab[2];
-    memcpy(&ab[0], &a, 4);
-    memcpy(&ab[1], &b, 4);
-    uint64_t payload = uint64_t(ab[0]) | (uint64_t(ab[1]) << 32);
-    const uint64_t *s = emu::wave_exchange(payload);
-    const int l = emu::lane_id(), col = l & 15, rg = l >> 4;
-    f32x4 d = c;
-    for (int r = 0; r < 4; ++r) {
-        const int row = 4 * rg + r;
-        float acc = c[r];
-        for (int k = 0; k < 4; ++k) {
-            uint32_t ua = uint32_t(s[k * 16 + row]), ub = uint32_t(s[k * 16 + col] >> 32);
-            float fa, fb;
-            memcpy(&fa, &ua, 4);
-            memcpy(&fb, &ub, 4);
-            acc = fmaf(fa, fb, acc);
-        }
-        d[r] = acc;
-    }
-    emu::stats().mfma++;
-    return d;
-}
-
-__device__ inline int uniform(int v) { return v; }
-__device__ inline int recompute_here(int v) { return v; }
-
-// round-to-nearest-even fp32 -> bf16 (as the device's v_cvt_pk_bf16_f32), two values into one dword
-__device__ inline uint32_t emu_bf16_rne(float x) {
-    uint32_t u;
-    memcpy(&u, &x, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;     // NaN stays NaN
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ inline uint32_t cvt_pk_bf16(float lo_elem, float hi_elem) {
-    return emu_bf16_rne(lo_elem) | (emu_bf16_rne(hi_elem) << 16);
-}
-__device__ inline float emu_bf16_to_f32(uint32_t h) {
-    uint32_t u = h << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-// D = A(16x32) * B(32x16) + C for v_mfma_f32_16x16x32_bf16:
-//   a: lane l holds A[i = l & 15][k = 8 (l >> 4) + e], e = 0..7;   b: lane l holds B[k = 8 (l >> 4) + e][j = l & 15]
-//   c/d as the f32 16x16 forms.  Products are exact in fp32; the emulator sums them in double.
-__device__ inline f32x4 mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
-    uint32_t mine[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    const unsigned char *s = emu::wave_exchange_bytes(mine, 32);
-    const int l = emu::lane_id(), col = l & 15, rg = l >> 4;
-    f32x4 d = c;
-    for (int r = 0; r < 4; ++r) {
-        const int row = 4 * rg + r;
-        double acc = c[r];
-        for (int kg = 0; kg < 4; ++kg) {
-            uint32_t wa[8], wb[8];
-            memcpy(wa, s + size_t(kg * 16 + row) * 32, 32);
-            memcpy(wb, s + size_t(kg * 16 + col) * 32, 32);
-            for (int e = 0; e < 8; ++e) {
-                const uint32_t ha = (wa[e / 2] >> (16 * (e & 1))) & 0xffffu;
-                const uint32_t hb = (wb[4 + e / 2] >> (16 * (e & 1))) & 0xffffu;
-                acc += (double)emu_bf16_to_f32(ha) * (double)emu_bf16_to_f32(hb);
-            }
-        }
-        d[r] = (float)acc;
-    }
-    emu::stats().mfma++;
-    return d;
-}
-
-// Read-only view of one image's worth of a tensor, addressed by (per-lane byte offset) +
-// (wave-uniform byte offset).  Out-of-range reads return 0 like a raw buffer resource.
-struct FBuf {
-    const char *base;
-    uint32_t bytes;
-};
-__device__ inline FBuf make_fbuf(const float *p, size_t bytes) { return FBuf{(const char *)p, (uint32_t)bytes}; }
-__device__ inline float fbuf_load(const FBuf &b, int voff_bytes, int soff_bytes) {
-    const uint32_t o = (uint32_t)voff_bytes + (uint32_t)soff_bytes;
-    if ((uint32_t)voff_bytes >= b.bytes || (size_t)o + 4 > b.bytes) return 0.f;
-    float r;
-    memcpy(&r, b.base + o, 4);
-    return r;
-}
-__device__ inline void fbuf_store(const FBuf &b, float v, int voff_bytes, int soff_bytes) {
-    const uint32_t o = (uint32_t)voff_bytes + (uint32_t)soff_bytes;
-    if ((uint32_t)voff_bytes >= b.bytes || (size_t)o + 4 > b.bytes) return;      // out-of-range stores are dropped
-    memcpy(const_cast<char *>(b.base) + o, &v, 4);
-}
-__device__ inline void fbuf_store_x4(const FBuf &b, f32x4 v, int voff_bytes, int soff_bytes) {
-    for (int e = 0; e < 4; ++e) fbuf_store(b, v[e], voff_bytes + 4 * e, soff_bytes);
-}
-__device__ inline f32x4 lds_load_x4(const float *p) {
-    f32x4 v;
-    memcpy(&v, p, 16);
-    return v;
-}
-// LDS-DMA: every lane fetches one dword and the wave deposits the 64 dwords CONTIGUOUSLY at
-// lds_wave_base + lane (buffer_load_dword ... lds).  The emulator completes it synchronously.
-__device__ inline void fbuf_load_to_lds(const FBuf &b, float *lds_wave_base, int voff_bytes, int soff_bytes) {
-    lds_wave_base[emu::lane_id()] = fbuf_load(b, voff_bytes, soff_bytes);
-}
-// 16-byte form: every lane moves 4 consecutive dwords to lds_wave_base + 4 * lane
-__device__ inline void fbuf_load_to_lds_x4(const FBuf &b, float *lds_wave_base, int voff_bytes, int soff_bytes) {
-    for (int e = 0; e < 4; ++e)
-        lds_wave_base[4 * emu::lane_id() + e] = fbuf_load(b, voff_bytes + 4 * e, soff_bytes);
-}
-
-__device__ inline void barrier_lds_only() { __syncthreads(); }
-template <int KEEP>
-__device__ inline void barrier_dma_keep() { __syncthreads(); }
-
-#define CCA_LDS_REGISTER(arr) do { emu::lds_register((void *)(arr), sizeof(arr)); __syncthreads(); } while (0)
-#define CCA_LDS_LD(p) (emu::lds_note_read((const void *)(p), __LINE__), *(p))
-#define CCA_LDS_ST(p, v) do { emu::lds_note_write((const void *)(p), __LINE__); *(p) = (v); } while (0)
-
-#else  // ----- real gfx950 -----
-
-__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
-__device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, kWave); }
-__device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-// v_cvt_pk_bf16_f32: two fp32 -> two bf16 (round to nearest even) in one dword, first operand in the low half
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo_elem, float hi_elem) {
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo_elem, hi_elem}, bf16x2_t));
-}
-__device__ __forceinline__ f32x4 mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-
-// tell the compiler a value is wave-uniform (it is: derived from the wave id) so it lives in SGPRs
-__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// Opaque copy of a per-lane value: everything computed from the result is recomputed where it is used instead of
-// being hoisted out of the surrounding loop (loop-invariant address arithmetic of the tile-store phase would
-// otherwise occupy VGPRs across the MFMA phase, where every register is spoken for).
-__device__ __forceinline__ int recompute_here(int v) {
-    asm volatile("" : "+v"(v));
-    return v;
-}
-
-// Buffer-resource view of one image's worth of a tensor: buffer_load_dword v, voff, s[rsrc], soff offen
-// keeps ONE 32-bit VGPR offset per lane plus a scalar offset per load, instead of a 64-bit VGPR
-// address per load (which is what plain pointer arithmetic compiles to, and what spilled).
-typedef __amdgpu_buffer_rsrc_t FBuf;
-__device__ __forceinline__ FBuf make_fbuf(const float *p, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float fbuf_load(const FBuf &b, int voff_bytes, int soff_bytes) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, voff_bytes, soff_bytes, 0));
-}
-// stores whose per-lane offset is out of range (kOobOffset) are dropped by the buffer range check
-__device__ __forceinline__ void fbuf_store(const FBuf &b, float v, int voff_bytes, int soff_bytes) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), b, voff_bytes, soff_bytes, 0);
-}
-// 16-byte store (global address needs only 4-byte alignment, like the 16-byte loads)
-__device__ __forceinline__ void fbuf_store_x4(const FBuf &b, f32x4 v, int voff_bytes, int soff_bytes) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), b, voff_bytes, soff_bytes, 0);
-}
-// ds_read_b128: p must be 16-byte aligned
-__device__ __forceinline__ f32x4 lds_load_x4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
-// LDS-DMA (buffer_load_dword ... lds): no staging VGPRs, no ds_write pass; the 64 dwords of the wave land
-// contiguously at the wave-uniform LDS address (M0) + lane * 4.  Completion is tracked by vmcnt; the
-// compiler drains it before the next __syncthreads(), which is exactly the double-buffer hand-over.
-__device__ __forceinline__ void fbuf_load_to_lds(const FBuf &b, float *lds_wave_base, int voff_bytes, int soff_bytes) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void *)lds_wave_base, 4,
-                                             voff_bytes, soff_bytes, 0, 0);
-}
-
-// 16-byte form (buffer_load_dwordx4 ... lds): 1 KiB per wave instruction.  Neither the global nor the LDS
-// address needs more than 4-byte alignment (probed on MI355X: tools/probes/dma_x4_probe.hip).
-__device__ __forceinline__ void fbuf_load_to_lds_x4(const FBuf &b, float *lds_wave_base, int voff_bytes, int soff_bytes) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void *)lds_wave_base, 16,
-                                             voff_bytes, soff_bytes, 0, 0);
-}
-
-// Workgroup barrier that orders LDS traffic only: waits for this wave's LDS operations (lgkmcnt) but NOT for
-// its outstanding global stores / loads (vmcnt).  __syncthreads() drains vmcnt as well whenever an LDS-DMA
-// has been issued, which would stall every chunk on the acknowledgement of the tile stores.
-__device__ __forceinline__ void barrier_lds_only() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-// Workgroup barrier for a DMA pipeline that is more than one chunk deep: waits until at most KEEP of this
-// wave's vector-memory operations (the LDS-DMA pieces of the newest chunk) are still in flight, then
-// synchronises.  __syncthreads() would drain vmcnt to 0 and stall on the chunk that was only just requested
-// (cdna_hip_programming.md, "Pipelining across barriers": counted vmcnt + raw s_barrier).
-template <int KEEP>
-__device__ __forceinline__ void barrier_dma_keep() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KEEP) : "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-#define CCA_LDS_REGISTER(arr) do { } while (0)
-#define CCA_LDS_LD(p) (*(p))
-#define CCA_LDS_ST(p, v) do { *(p) = (v); } while (0)
-
-#endif
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

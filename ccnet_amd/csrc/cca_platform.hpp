@@ -1,0 +1,125 @@
+// cca_platform.hpp -- gfx950 implementations of the device primitives the kernels are written against:
+// wave shuffles, the MFMA wrappers, buffer-resource loads / stores, LDS-DMA, counted barriers, the launch macro.
+// (The CPU test-suite provides a header of the same name under tests/emu/ that implements the same primitives in a
+// SIMT emulator; the product never sees it.)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+namespace cca {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // 8 packed bf16 (element e in dword e/2, low half = even e)
+constexpr int kWave = 64;                 // CDNA wavefront
+
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+__device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, kWave); }
+__device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// v_cvt_pk_bf16_f32: two fp32 -> two bf16 (round to nearest even) in one dword, first operand in the low half
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo_elem, float hi_elem) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo_elem, hi_elem}, bf16x2_t));
+}
+__device__ __forceinline__ f32x4 mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// tell the compiler a value is wave-uniform (it is: derived from the wave id) so it lives in SGPRs
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Opaque copy of a per-lane value: everything computed from the result is recomputed where it is used instead of
+// being hoisted out of the surrounding loop (loop-invariant address arithmetic of the tile-store phase would
+// otherwise occupy VGPRs across the MFMA phase, where every register is spoken for).
+__device__ __forceinline__ int recompute_here(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// Buffer-resource view of one image's worth of a tensor: buffer_load_dword v, voff, s[rsrc], soff offen
+// keeps ONE 32-bit VGPR offset per lane plus a scalar offset per load, instead of a 64-bit VGPR
+// address per load (which is what plain pointer arithmetic compiles to, and what spilled).
+typedef __amdgpu_buffer_rsrc_t FBuf;
+__device__ __forceinline__ FBuf make_fbuf(const float *p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float fbuf_load(const FBuf &b, int voff_bytes, int soff_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, voff_bytes, soff_bytes, 0));
+}
+// stores whose per-lane offset is out of range (kOobOffset) are dropped by the buffer range check
+__device__ __forceinline__ void fbuf_store(const FBuf &b, float v, int voff_bytes, int soff_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), b, voff_bytes, soff_bytes, 0);
+}
+// 16-byte store (global address needs only 4-byte alignment, like the 16-byte loads)
+__device__ __forceinline__ void fbuf_store_x4(const FBuf &b, f32x4 v, int voff_bytes, int soff_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), b, voff_bytes, soff_bytes, 0);
+}
+// ds_read_b128: p must be 16-byte aligned
+__device__ __forceinline__ f32x4 lds_load_x4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+// LDS-DMA (buffer_load_dword ... lds): no staging VGPRs, no ds_write pass; the 64 dwords of the wave land
+// contiguously at the wave-uniform LDS address (M0) + lane * 4.  Completion is tracked by vmcnt; the
+// compiler drains it before the next __syncthreads(), which is exactly the double-buffer hand-over.
+__device__ __forceinline__ void fbuf_load_to_lds(const FBuf &b, float *lds_wave_base, int voff_bytes, int soff_bytes) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void *)lds_wave_base, 4,
+                                             voff_bytes, soff_bytes, 0, 0);
+}
+
+// 16-byte form (buffer_load_dwordx4 ... lds): 1 KiB per wave instruction.  Neither the global nor the LDS
+// address needs more than 4-byte alignment (probed on MI355X: tools/probes/dma_x4_probe.hip).
+__device__ __forceinline__ void fbuf_load_to_lds_x4(const FBuf &b, float *lds_wave_base, int voff_bytes, int soff_bytes) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void *)lds_wave_base, 16,
+                                             voff_bytes, soff_bytes, 0, 0);
+}
+
+// Workgroup barrier that orders LDS traffic only: waits for this wave's LDS operations (lgkmcnt) but NOT for
+// its outstanding global stores / loads (vmcnt).  __syncthreads() drains vmcnt as well whenever an LDS-DMA
+// has been issued, which would stall every chunk on the acknowledgement of the tile stores.
+__device__ __forceinline__ void barrier_lds_only() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Workgroup barrier for a DMA pipeline that is more than one chunk deep: waits until at most KEEP of this
+// wave's vector-memory operations (the LDS-DMA pieces of the newest chunk) are still in flight, then
+// synchronises.  __syncthreads() would drain vmcnt to 0 and stall on the chunk that was only just requested
+// (cdna_hip_programming.md, "Pipelining across barriers": counted vmcnt + raw s_barrier).
+template <int KEEP>
+__device__ __forceinline__ void barrier_dma_keep() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KEEP) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+#define CCA_LDS_REGISTER(arr) do { } while (0)
+#define CCA_LDS_LD(p) (*(p))
+#define CCA_LDS_ST(p, v) do { *(p) = (v); } while (0)
+
+
+}  // namespace cca
+
+// kernel launch on a caller-given stream; a stale error of an earlier, unrelated HIP call is cleared first so that
+// launch_status() reports this launch and nothing else
+#define CCA_LAUNCH(kern, grid, block, stream, ...)                                        \
+    do {                                                                                   \
+        (void)hipGetLastError();                                                           \
+        hipLaunchKernelGGL(kern, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__); \
+    } while (0)
+
+// number of compute units of the CURRENT device (the channel splits are balanced for it)
+inline int cca_current_device_cus() {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    return prop.multiProcessorCount;
+}
+inline int cca_current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess ? dev : 0;
+}

@@ -18,7 +18,11 @@
  *     (key/value at (h,j)).
  *   - outputs are fully overwritten; nothing relies on pre-zeroed buffers.
  *   - launches go to ``stream`` (a hipStream_t; NULL = the legacy default stream); no call
- *     synchronises.  All entry points are re-entrant and keep no state between calls.
+ *     synchronises.  The compute entry points hold no per-call state and may be called concurrently
+ *     from several host threads / streams; the only process-wide state are the three MODE words behind
+ *     ccnet_cca_set_impl / _set_precision / _set_branch_mask (atomics; defaults need no call).  A setter
+ *     racing with a call in flight affects that call or the next one, never part of one.  The fused
+ *     ccnet_cca_forward / backward entry points refuse to run under a profiling branch mask.
  *   - return value: 0 on success; a positive hipError_t if a launch failed; a negative
  *     CCNET_E_* code for argument errors.  ccnet_cca_last_error_string() describes the last
  *     failure on the calling thread.

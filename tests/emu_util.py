@@ -1,7 +1,7 @@
 """Build and drive the CPU SIMT-emulator build of the kernel sources (tests/emu/).
 
 The emulator library exports the same C ABI as libccnet_cca.so (it is the same cca_api.hip compiled
-for the host with -DCCNET_EMU), so the tests drive it through ccnet_amd._lib.CcaLibrary with numpy
+for the host against tests/emu/cca_platform.hpp), so the tests drive it through ccnet_amd._lib.CcaLibrary with numpy
 buffers standing in for device memory.  Test infrastructure only.
 """
 import os
@@ -19,7 +19,7 @@ HOST_CXX = "/opt/rocm/lib/llvm/bin/clang++"
 
 
 def _sources():
-    srcs = [os.path.join(EMU_DIR, f) for f in ("hip_emu.cpp", "hip_emu.hpp")]
+    srcs = [os.path.join(EMU_DIR, f) for f in ("hip_emu.cpp", "hip_emu.hpp", "cca_platform.hpp")]
     srcs += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
     srcs.append(os.path.join(ROOT, "include", "ccnet_cca.h"))
     return srcs
@@ -30,8 +30,9 @@ def build_emu(force=False):
     if not force and os.path.exists(EMU_LIB):
         if os.path.getmtime(EMU_LIB) >= max(os.path.getmtime(s) for s in _sources()):
             return EMU_LIB
-    cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DCCNET_EMU", "-Wno-pass-failed",
-           "-I" + EMU_DIR, "-I" + CSRC, os.path.join(CSRC, "cca_api.hip"),
+    cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wno-pass-failed",
+           "-I" + EMU_DIR, "-I" + CSRC,          # tests/emu FIRST: <cca_platform.hpp> resolves to the emulator's
+           os.path.join(CSRC, "cca_api.hip"),
            os.path.join(EMU_DIR, "hip_emu.cpp"), "-o", EMU_LIB]
     subprocess.run(cmd, check=True, cwd=ROOT)
     return EMU_LIB

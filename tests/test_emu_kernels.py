@@ -1,6 +1,6 @@
 """CPU execution of the HIP kernel sources in the SIMT emulator (tests/emu/) against the oracle.
 
-The container has no GPU; these tests compile ccnet_amd/csrc/cca_api.hip for the host with -DCCNET_EMU
+The container has no GPU; these tests compile ccnet_amd/csrc/cca_api.hip for the host against the emulator's cca_platform.hpp
 and run every entry point of the C ABI on numpy buffers.  They validate index maps, LDS layouts, the
 MFMA fragment maps (as documented for v_mfma_f32_16x16x4_f32), barriers and epilogues before the code
 ever reaches the MI355X.  Parity on the device itself is tests/test_gpu_parity.py (-m gpu).
@@ -428,3 +428,17 @@ def test_lds_layouts_stay_near_conflict_free():
         o.set_impl(0)
     finally:
         os.environ.pop("CCA_EMU_LDS", None)
+
+
+def test_fused_entry_points_refuse_a_profiling_branch_mask(ops):
+    """a branch mask left behind by a profiling tool must not turn the fused forward / backward into
+    silently partial results."""
+    c = rand_case(1, 16, 5, 6)
+    prev = ops.lib.ccnet_cca_set_branch_mask(1)
+    try:
+        with pytest.raises(Exception, match="branch mask"):
+            ops.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
+    finally:
+        ops.lib.ccnet_cca_set_branch_mask(prev)
+    y, A = ops.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
+    assert np.isfinite(y).all()

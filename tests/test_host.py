@@ -152,3 +152,15 @@ def test_inf_matches_reference_values():
     t = INF(2, 3, 4, device="cpu")
     assert t.shape == (2 * 4, 3, 3) and torch.isneginf(t.diagonal(dim1=1, dim2=2)).all()
     assert (t[~torch.isinf(t)] == 0).all()
+
+
+def test_product_sources_carry_no_emulator_code_and_no_env_knobs():
+    """the emulator primitives live under tests/emu/ (same header name, earlier on the include
+    path), and the product path is not steered by environment variables."""
+    csrc = os.path.join(ROOT, "ccnet_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp")):
+            text = open(os.path.join(csrc, f)).read()
+            assert "CCNET_EMU" not in text and "hip_emu" not in text, f
+            assert "getenv" not in text, f
+    assert os.path.exists(os.path.join(ROOT, "tests", "emu", "cca_platform.hpp"))
