@@ -562,8 +562,8 @@ int ccnet_ca_map_backward_f32(const float *dout, const float *A, const float *v,
 
 int ccnet_cca_forward_strided_f32(const float *q, const float *k, const float *v, const float *x, const float *gamma,
                                   float *y, float *A, int B, int C, int Cq, int H, int W,
-                                  long q_bs, long k_bs, long v_bs, ccnet_stream_t stream) {    if (int e = require_both_branches("cca_forward")) return e;
-
+                                  long q_bs, long k_bs, long v_bs, ccnet_stream_t stream) {
+    if (int e = require_both_branches("cca_forward")) return e;
     if (!q || !k || !v || !x || !gamma || !y || !A) return fail(CCNET_E_NULLPTR, "cca_forward: null tensor");
     if (int e = check_shape(B, C, H, W)) return e;
     if (int e = check_shape(B, Cq, H, W)) return e;
@@ -585,8 +585,8 @@ int ccnet_cca_backward_strided_f32(const float *dy, const float *q, const float 
                                    const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
                                    void *workspace, size_t workspace_bytes, int B, int C, int Cq, int H, int W,
                                    long q_bs, long k_bs, long v_bs, long dq_bs, long dk_bs, long dv_bs,
-                                   ccnet_stream_t stream) {    if (int e = require_both_branches("cca_backward")) return e;
-
+                                   ccnet_stream_t stream) {
+    if (int e = require_both_branches("cca_backward")) return e;
     if (!dy || !q || !k || !v || !A || !gamma || !dq || !dk || !dv || !dgamma || !scratch)
         return fail(CCNET_E_NULLPTR, "cca_backward: null tensor");
     if (int e = check_shape(B, C, H, W)) return e;
@@ -619,8 +619,8 @@ int ccnet_cca_backward_f32(const float *dy, const float *q, const float *k, cons
  * ---- accumulation, gamma.  Served by the any-shape kernels (one thread per output). ---- */
 int ccnet_cca_forward_bf16(const uint16_t *q_, const uint16_t *k_, const uint16_t *v_, const uint16_t *x_,
                            const float *gamma, uint16_t *y_, float *A, int B, int C, int Cq, int H, int W,
-                           ccnet_stream_t stream) {    if (int e = require_both_branches("cca_forward_bf16")) return e;
-
+                           ccnet_stream_t stream) {
+    if (int e = require_both_branches("cca_forward_bf16")) return e;
     if (!q_ || !k_ || !v_ || !x_ || !gamma || !y_ || !A) return fail(CCNET_E_NULLPTR, "cca_forward_bf16: null tensor");
     if (int e = check_shape(B, C, H, W)) return e;
     if (int e = check_shape(B, Cq, H, W)) return e;
@@ -641,8 +641,8 @@ int ccnet_cca_forward_bf16(const uint16_t *q_, const uint16_t *k_, const uint16_
 int ccnet_cca_backward_bf16(const uint16_t *dy_, const uint16_t *q_, const uint16_t *k_, const uint16_t *v_,
                             const float *A, const float *gamma, uint16_t *dq_, uint16_t *dk_, uint16_t *dv_,
                             float *dgamma, float *scratch, void *workspace, size_t workspace_bytes,
-                            int B, int C, int Cq, int H, int W, ccnet_stream_t stream) {    if (int e = require_both_branches("cca_backward_bf16")) return e;
-
+                            int B, int C, int Cq, int H, int W, ccnet_stream_t stream) {
+    if (int e = require_both_branches("cca_backward_bf16")) return e;
     if (!dy_ || !q_ || !k_ || !v_ || !A || !gamma || !dq_ || !dk_ || !dv_ || !dgamma || !scratch)
         return fail(CCNET_E_NULLPTR, "cca_backward_bf16: null tensor");
     if (int e = check_shape(B, C, H, W)) return e;

@@ -30,6 +30,7 @@ CASES = {
     "small_1x32x9x7": (1, 32, 9, 7, True),      # H > W, B = 1
     "small_2x64x8x8": (2, 64, 8, 8, True),
     "cfg1_2x64x32x32": (2, 64, 32, 32, False),  # BASELINE.json configs[0]; inputs regenerated from the seed
+    "fast_1x64x97x97": (1, 64, 97, 97, False),  # the headline geometry (97-long strips: the MFMA fast paths), small in C
 }
 
 
@@ -86,7 +87,10 @@ def run_case(B, C, H, W):
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: golden vectors can only be regenerated in the build container")
+    only = set(sys.argv[1:])
     for name, (B, C, H, W, full) in CASES.items():
+        if only and name not in only:
+            continue
         arrs = run_case(B, C, H, W)
         if not full:
             # keep the fixture small: inputs / params are regenerated from the seed by the tests

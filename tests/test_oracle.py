@@ -58,9 +58,11 @@ def test_module_level_matches_reference(case):
         assert torch.allclose(gr, g["grad." + n], rtol=1e-4, atol=2e-4), n
 
 
-def test_config1_matches_reference():
-    """BASELINE.json configs[0]: (2,64,32,32) fp32; inputs regenerated from the seed."""
-    g = load_golden("cfg1_2x64x32x32")
+@pytest.mark.parametrize("case", ["cfg1_2x64x32x32", "fast_1x64x97x97"])
+def test_config1_matches_reference(case):
+    """BASELINE.json configs[0]: (2,64,32,32) fp32, and the headline geometry 97x97 at C = 64; inputs regenerated from
+    the seed."""
+    g = load_golden(case)
     B, C, H, W = [int(v) for v in g["shape"]]
     x, dy, params = regenerate_module_inputs(B, C, H, W)
     if abs(float(x.double().sum()) - float(g["fingerprint.x"][0])) > 1e-6:
