@@ -6,6 +6,7 @@
 #include "../../include/ccnet_cca.h"
 
 #include "cca_common.hpp"
+#include "cca_band.hpp"
 #include "cca_direct.hpp"
 #include "cca_map.hpp"
 #include "cca_long.hpp"
@@ -552,6 +553,21 @@ int ccnet_ca_map_forward_f32(const float *A, const float *v, const float *x, con
                              int B, int C, int H, int W, ccnet_stream_t stream) {
     const long d = (long)C * H * W;
     return ca_map_forward_impl(A, v, x, gamma, out, B, C, H, W, stream, d, d, d);
+}
+
+int ccnet_ca_map_forward_pm_f32(const float *A, const float *v, const float *x, const float *gamma, float *out,
+                                int B, int C, int H, int W, long v_bs, int v_ps, ccnet_stream_t stream) {
+    if (int e = check_shape(B, C, H, W)) return e;
+    if (!A || !v || !x || !out) return fail(CCNET_E_NULLPTR, "ca_map_forward_pm: null tensor");
+    if (v_ps < C || v_bs < (long)(H * W - 1) * v_ps + C) return fail(CCNET_E_BADSHAPE, "ca_map_forward_pm: strides smaller than the tensor");
+    if ((double)H * W * v_ps >= 536870912.0) return fail(CCNET_E_BADSHAPE, "ca_map_forward_pm: per-image pixel-major view exceeds 2^29 elements");
+    if (C % 4) return fail(CCNET_E_BADSHAPE, "ca_map_forward_pm: C must be a multiple of 4");
+    const int longest = H > W ? H : W;
+    if (longest > 100) return fail(CCNET_E_BADSHAPE, "ca_map_forward_pm: strips longer than 100 are not covered by the band kernel");
+    const int nb = (H + cca::BD_R - 1) / cca::BD_R, rpb = (H + nb - 1) / nb, ncg = (C + cca::BD_CC - 1) / cca::BD_CC;
+    CCA_LAUNCH((cca::map_band_fwd_kernel<100>), dim3((unsigned)(B * ncg * nb)), dim3(cca::BD_THREADS), stream,
+               A, v, x, gamma, out, C, H, W, nb, rpb, ncg, v_bs, v_ps);
+    return launch_status("ca_map_forward_pm");
 }
 
 int ccnet_ca_map_backward_f32(const float *dout, const float *A, const float *v, const float *gamma,

@@ -211,6 +211,7 @@ __global__ __launch_bounds__(kWave * NS * WPS) void map_long_kernel(const float 
 #pragma unroll
                         for (int t = 0; t < NT; ++t) acc[t] = mfma_16x16x4(a, bf[ks][t], acc[t]);
                     }
+                mfma_f32_result_fence();
                 // D[m = channel 4 (l >> 4) + r][n = window position 16 t + (l & 15)] -> result image
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {

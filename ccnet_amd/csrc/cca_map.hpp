@@ -307,6 +307,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
 #pragma unroll
             for (int q = 0; q < QT; ++q) dma_piece(q, ch, chn, buf);   // strips outside the image still own channels
         }
+        mfma_f32_result_fence();             // the last exact-f32 MFMA may sit at the end of a conditional block
         // D[m = channel 4*(l>>4)+r][n = position t*16 + (l&15)] -> LDS -> tile stores
         if (fast && !ROW) {
             // Column launch, full tile: the results go to LDS in the band-permuted layout of the partial sums

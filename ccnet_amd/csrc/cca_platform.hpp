@@ -31,6 +31,17 @@ __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+// Wait states after an exact-f32 MFMA whose result is read straight away.  hipcc (ROCm 7.2) pads only 8 states between a
+// v_mfma_f32_16x16x4_f32 at the end of one basic block and a v_accvgpr_read of its last result register at the top of
+// the next one, three short of what the 8-pass instruction needs: the read returned the accumulator WITHOUT that MFMA's
+// contribution (found on MI355X with the row-band kernel: band rows 3, 7, 11, 15 lost their k-tail).  Call this
+// between such an MFMA and the first reader when they may end up in different basic blocks.
+__device__ __forceinline__ void mfma_f32_result_fence() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // tell the compiler a value is wave-uniform (it is: derived from the wave id) so it lives in SGPRs
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -62,6 +73,8 @@ __device__ __forceinline__ void fbuf_store_x4(const FBuf &b, f32x4 v, int voff_b
 }
 // ds_read_b128: p must be 16-byte aligned
 __device__ __forceinline__ f32x4 lds_load_x4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+// ds_write_b128: p must be 16-byte aligned
+__device__ __forceinline__ void lds_store_x4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 // LDS-DMA (buffer_load_dword ... lds): no staging VGPRs, no ds_write pass; the 64 dwords of the wave land
 // contiguously at the wave-uniform LDS address (M0) + lane * 4.  Completion is tracked by vmcnt; the
 // compiler drains it before the next __syncthreads(), which is exactly the double-buffer hand-over.

@@ -175,6 +175,7 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
     }
 
     if (!active) return;
+    mfma_f32_result_fence();
     float *Tg = T + (size_t)b * HW * S + (size_t)g * br.as_g + br.a_off;
     const int iq4 = 4 * lk;
 #pragma unroll

@@ -115,6 +115,14 @@ int ccnet_ca_softmax_backward_f32(const float *A, const float *dA, const float *
 int ccnet_ca_map_forward_f32(const float *A, const float *v, const float *x, const float *gamma,
                              float *out, int B, int C, int H, int W, ccnet_stream_t stream);
 
+/* ca_map_forward with the value tensor in PIXEL-MAJOR layout and both branches in ONE launch (row-band kernel,
+ * csrc/cca_band.hpp): replaces functions.py:42-49 like ccnet_ca_map_forward_f32, but ``v`` is (B, H*W, v_ps) --
+ * channel c of pixel p = h*W + w of image b at v[b*v_bs + p*v_ps + c] -- which is what the projection GEMM
+ * (functions.py:35) emits when it is run as x^T W^T (+ bias), e.g. the value slice of one stacked (B, H*W, 2Cq+C)
+ * projection.  x (residual, required) and out stay dense NCHW.  max(H, W) <= 100, C % 4 == 0. */
+int ccnet_ca_map_forward_pm_f32(const float *A, const float *v, const float *x, const float *gamma, float *out,
+                                int B, int C, int H, int W, long v_bs, int v_ps, ccnet_stream_t stream);
+
 /* Adjoint of the aggregation (autograd of functions.py:42-47):
  *   dA (B,H,W,H+W) = un-scaled map adjoint  (sum_c dout * v at the slot's source pixel); may be NULL
  *   dv (B,C,H,W)   = g * (A^T-weighted sums of dout), g = *gamma (1 if NULL); may be NULL */

@@ -56,6 +56,7 @@ __device__ inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     return d;
 }
 
+__device__ inline void mfma_f32_result_fence() {}
 __device__ inline int uniform(int v) { return v; }
 __device__ inline int recompute_here(int v) { return v; }
 
@@ -129,6 +130,7 @@ __device__ inline f32x4 lds_load_x4(const float *p) {
     memcpy(&v, p, 16);
     return v;
 }
+__device__ inline void lds_store_x4(float *p, f32x4 v) { memcpy(p, &v, 16); }
 // LDS-DMA: every lane fetches one dword and the wave deposits the 64 dwords CONTIGUOUSLY at
 // lds_wave_base + lane (buffer_load_dword ... lds).  The emulator completes it synchronously.
 __device__ inline void fbuf_load_to_lds(const FBuf &b, float *lds_wave_base, int voff_bytes, int soff_bytes) {

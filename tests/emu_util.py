@@ -87,6 +87,14 @@ class EmuOps:
         self.lib.check(self.lib.ccnet_ca_map_forward_f32(_p(A), _p(v), _p(x), _p(gamma), _p(out), B, C, H, W, None))
         return out
 
+    def ca_map_forward_pm(self, A, v_pm, x, gamma=None, C=None):
+        """v_pm: (B, H*W, ps) pixel-major array whose first C columns are the value channels; x, out NCHW."""
+        B, C_, H, W = x.shape
+        out = np.full_like(x, np.nan)
+        self.lib.check(self.lib.ccnet_ca_map_forward_pm_f32(_p(A), _p(v_pm), _p(x), _p(gamma), _p(out), B, C_, H, W,
+                                                            v_pm.shape[1] * v_pm.shape[2], v_pm.shape[2], None))
+        return out
+
     def ca_map_backward(self, dout, A, v, gamma=None):
         B, C, H, W = v.shape
         dA = np.full_like(A, np.nan)

@@ -442,3 +442,29 @@ def test_fused_entry_points_refuse_a_profiling_branch_mask(ops):
         ops.lib.ccnet_cca_set_branch_mask(prev)
     y, A = ops.cca_forward(c["q"], c["k"], c["v"], c["x"], c["gamma"])
     assert np.isfinite(y).all()
+
+
+BAND_SHAPES = [(2, 16, 5, 6), (1, 32, 9, 7), (1, 24, 17, 20), (1, 8, 1, 1), (1, 16, 1, 9), (1, 16, 9, 1), (2, 40, 33, 18),
+               (1, 36, 20, 37)]
+
+
+def to_pm(t, ps=None, fill=7.0):
+    """(B, C, H, W) -> pixel-major (B, H*W, ps) with ps >= C (extra columns hold junk that must never be read as v)."""
+    B, C, H, W = t.shape
+    ps = ps or C
+    out = np.full((B, H * W, ps), fill, np.float32)
+    out[:, :, :C] = t.transpose(0, 2, 3, 1).reshape(B, H * W, C)
+    return out
+
+
+@pytest.mark.parametrize("shape", BAND_SHAPES)
+def test_row_band_forward_matches_oracle(ops, shape):
+    """csrc/cca_band.hpp: both branches of ca_map_forward + gamma / residual epilogue in one launch, v pixel-major."""
+    c = rand_case(*shape, seed=3)
+    B, C, H, W = shape
+    A = O.ca_softmax(O.ca_forward(T(c["q"]), T(c["k"]))).numpy()
+    want = (c["gamma"][0] * O.ca_map_forward(T(A), T(c["v"])).numpy() + c["x"])
+    got = ops.ca_map_forward_pm(A, to_pm(c["v"]), c["x"], c["gamma"])
+    assert maxerr(got, want) < 2e-4          # split-bf16 x3 arithmetic
+    got2 = ops.ca_map_forward_pm(A, to_pm(c["v"], ps=C + 12), c["x"], c["gamma"])      # v as a slice of a wider projection
+    assert np.array_equal(got, got2)
