@@ -591,6 +591,15 @@ int ccnet_cca_forward_strided_f32(const float *q, const float *k, const float *v
     return ca_map_forward_impl(A, v, x, gamma, y, B, C, H, W, stream, v_bs, d, d);
 }
 
+int ccnet_cca_attention_strided_f32(const float *q, const float *k, float *A, int B, int Cq, int H, int W,
+                                    long q_bs, long k_bs, ccnet_stream_t stream) {
+    if (int e = require_both_branches("cca_attention")) return e;
+    if (int e = check_shape(B, Cq, H, W)) return e;
+    if (int e = check_stride(q_bs, Cq, H, W, "cca_attention(q)")) return e;
+    if (int e = check_stride(k_bs, Cq, H, W, "cca_attention(k)")) return e;
+    return ca_forward_impl(q, k, A, B, Cq, H, W, CCNET_CA_SOFTMAX, stream, q_bs, k_bs);
+}
+
 int ccnet_cca_forward_f32(const float *q, const float *k, const float *v, const float *x, const float *gamma,
                           float *y, float *A, int B, int C, int Cq, int H, int W, ccnet_stream_t stream) {
     return ccnet_cca_forward_strided_f32(q, k, v, x, gamma, y, A, B, C, Cq, H, W,

@@ -200,7 +200,7 @@ class CrissCrossFunction(torch.autograd.Function):
     families forward (affinity+softmax, aggregation+epilogue) and three backward."""
 
     @staticmethod
-    def forward(ctx, q, k, v, x, gamma):
+    def forward(ctx, q, k, v, x, gamma, recompute=False):
         q, k = _dev_f32("query", q), _dev_f32("key", k)
         v, x = _dev_f32("value", v), _dev_f32("x", x)
         gamma = _dev_f32("gamma", gamma)
@@ -218,13 +218,21 @@ class CrissCrossFunction(torch.autograd.Function):
             lib.check(lib.ccnet_cca_forward_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), x.data_ptr(),
                                                 gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
                                                 B, C, q.shape[1], H, W, _stream()), "cca_forward")
-        ctx.save_for_backward(q, k, v, A, gamma)
+        ctx.recompute = bool(recompute)
+        if ctx.recompute:
+            ctx.save_for_backward(q, k, v, gamma)              # A is rebuilt from q, k in backward
+        else:
+            ctx.save_for_backward(q, k, v, A, gamma)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        q, k, v, A, gamma = ctx.saved_tensors
+        if ctx.recompute:
+            q, k, v, gamma = ctx.saved_tensors
+            A = _recompute_attention(q, k, q.shape[1] * q.shape[2] * q.shape[3], q.shape[1] * q.shape[2] * q.shape[3])
+        else:
+            q, k, v, A, gamma = ctx.saved_tensors
         dy = _dev_f32("grad_output", dy)
         B, C, H, W = v.shape
         lib = _lib.get_lib()
@@ -239,7 +247,19 @@ class CrissCrossFunction(torch.autograd.Function):
                                                  dv.data_ptr(), dgamma.data_ptr(), scratch.data_ptr(),
                                                  ws.data_ptr(), nbytes, B, C, q.shape[1], H, W, _stream()),
                       "cca_backward")
-        return dq, dk, dv, dy, dgamma.view_as(gamma)
+        return dq, dk, dv, dy, dgamma.view_as(gamma), None
+
+
+def _recompute_attention(q, k, q_bs, k_bs):
+    """A = softmax(affinity(q, k)) again, for backward passes that did not keep it (q, k: (B,Cq,H,W) views whose
+    batch strides are q_bs / k_bs elements)."""
+    B, Cq, H, W = q.shape
+    lib = _lib.get_lib()
+    A = torch.empty((B, H, W, H + W), device=q.device, dtype=torch.float32)
+    with torch.cuda.device(q.device):
+        lib.check(lib.ccnet_cca_attention_strided_f32(q.data_ptr(), k.data_ptr(), A.data_ptr(), B, Cq, H, W,
+                                                      q_bs, k_bs, _stream()), "cca_attention")
+    return A
 
 
 class CrissCrossPackedFunction(torch.autograd.Function):
@@ -250,7 +270,7 @@ class CrissCrossPackedFunction(torch.autograd.Function):
     dv straight into the slices of one ``dqkv`` tensor, which is what the fused convolution's backward consumes."""
 
     @staticmethod
-    def forward(ctx, qkv, x, gamma, cq):
+    def forward(ctx, qkv, x, gamma, cq, recompute=False):
         qkv, x = _dev_f32("qkv", qkv), _dev_f32("x", x)
         gamma = _dev_f32("gamma", gamma)
         _same_device(qkv, x, gamma)
@@ -269,15 +289,20 @@ class CrissCrossPackedFunction(torch.autograd.Function):
             lib.check(lib.ccnet_cca_forward_strided_f32(base, base + cq * hw, base + 2 * cq * hw, x.data_ptr(),
                                                         gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
                                                         B, C, cq, H, W, bs, bs, bs, _stream()), "cca_forward")
-        ctx.save_for_backward(qkv, A, gamma)
+        ctx.recompute = bool(recompute)
+        ctx.save_for_backward(*((qkv, gamma) if ctx.recompute else (qkv, A, gamma)))
         ctx.cq = cq
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        qkv, A, gamma = ctx.saved_tensors
         cq = ctx.cq
+        if ctx.recompute:
+            qkv, gamma = ctx.saved_tensors
+            A = _recompute_attention(qkv[:, :cq], qkv[:, cq:2 * cq], qkv.stride(0), qkv.stride(0))
+        else:
+            qkv, A, gamma = ctx.saved_tensors
         dy = _dev_f32("grad_output", dy)
         B, C, H, W = dy.shape
         lib = _lib.get_lib()
@@ -295,7 +320,7 @@ class CrissCrossPackedFunction(torch.autograd.Function):
                                                          dgamma.data_ptr(), scratch.data_ptr(), ws.data_ptr(), nbytes,
                                                          B, C, cq, H, W, bs, bs, bs, bs, bs, bs, _stream()),
                       "cca_backward")
-        return dqkv, dy, dgamma.view_as(gamma), None
+        return dqkv, dy, dgamma.view_as(gamma), None, None
 
 
 def _dev_bf16(name: str, t: torch.Tensor) -> torch.Tensor:
@@ -358,7 +383,7 @@ class CrissCrossModuleFunction(torch.autograd.Function):
     The GEMMs are torch ops (hipBLASLt); only their composition is ours."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma):
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma, recompute=False):
         x, gamma = _dev_f32("x", x), _dev_f32("gamma", gamma)
         B, C, H, W = x.shape
         cq, hw = wq.shape[0], H * W
@@ -375,15 +400,22 @@ class CrissCrossModuleFunction(torch.autograd.Function):
             lib.check(lib.ccnet_cca_forward_strided_f32(base, base + cq * esz, base + 2 * cq * esz, x.data_ptr(),
                                                         gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
                                                         B, C, cq, H, W, bs, bs, bs, _stream()), "cca_forward")
-        ctx.save_for_backward(x, w, qkv, A, gamma)
+        ctx.recompute = bool(recompute)
+        ctx.save_for_backward(*((x, w, qkv, gamma) if ctx.recompute else (x, w, qkv, A, gamma)))
         ctx.cq = cq
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, w, qkv, A, gamma = ctx.saved_tensors
         cq = ctx.cq
+        if ctx.recompute:
+            x, w, qkv, gamma = ctx.saved_tensors
+            B_, _, H_, W_ = x.shape
+            q4 = qkv.view(B_, -1, H_, W_)
+            A = _recompute_attention(q4[:, :cq], q4[:, cq:2 * cq], qkv.stride(0), qkv.stride(0))
+        else:
+            x, w, qkv, A, gamma = ctx.saved_tensors
         dy = _dev_f32("grad_output", dy)
         B, C, H, W = x.shape
         hw = H * W
@@ -408,12 +440,12 @@ class CrissCrossModuleFunction(torch.autograd.Function):
         db = dqkv.sum(dim=(0, 2))
         dwq, dwk, dwv = dw[:cq], dw[cq:2 * cq], dw[2 * cq:]
         return (dx.view(B, C, H, W), dwq.reshape(cq, C, 1, 1), db[:cq], dwk.reshape(cq, C, 1, 1), db[cq:2 * cq],
-                dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma))
+                dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma), None)
 
 
-def criss_cross_attention(q, k, v, x, gamma):
-    """Functional form of the fused core."""
-    return CrissCrossFunction.apply(q, k, v, x, gamma)
+def criss_cross_attention(q, k, v, x, gamma, recompute_attention=False):
+    """Functional form of the fused core (``recompute_attention``: rebuild A in backward instead of keeping it)."""
+    return CrissCrossFunction.apply(q, k, v, x, gamma, recompute_attention)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -440,6 +472,12 @@ class CrissCrossAttention(nn.Module):
     #: the input gradient ``dy + W^T dqkv`` is a single GEMM with beta = 1); False keeps torch's conv2d autograd.
     fuse_module_backward = True
 
+    #: activation memory (networks/ccnet.py:118-119 applies the module R times): when True the
+    #: (B,H,W,H+W) attention tensor is NOT kept for backward -- it is recomputed from q, k (one affinity + softmax
+    #: launch pair, ~8 % of a fwd+bwd) -- so an application holds q, k, v only.  Under torch.no_grad() / eval nothing is
+    #: kept either way.
+    recompute_attention = False
+
     #: bf16 inputs at geometries outside the fp32 strip kernels (strips longer than 320) use the bf16-I/O entry
     #: points; everything else is computed through fp32 copies on the MFMA kernels.
     native_bf16 = True
@@ -459,7 +497,8 @@ class CrissCrossAttention(nn.Module):
                 and not torch.is_autocast_enabled()):
             return CrissCrossModuleFunction.apply(x, self.query_conv.weight, self.query_conv.bias,
                                                   self.key_conv.weight, self.key_conv.bias,
-                                                  self.value_conv.weight, self.value_conv.bias, self.gamma)
+                                                  self.value_conv.weight, self.value_conv.bias, self.gamma,
+                                                  self.recompute_attention)
         if self.fuse_projections and self._fusable():
             # one GEMM for functions.py:29,32,35: the three 1x1 convolutions share their input, so their
             # weights are stacked row-wise (parameters and state_dict keys stay the reference's three convs)
@@ -468,12 +507,13 @@ class CrissCrossAttention(nn.Module):
             qkv = torch.nn.functional.conv2d(x, w, b)
             cq = self.query_conv.out_channels
             # half inputs, or fp32 inputs whose projections autocast turned into bf16: the kernels compute in fp32
-            return CrissCrossPackedFunction.apply(qkv.float(), x.float(), self.gamma.float(), cq).to(x.dtype)
+            return CrissCrossPackedFunction.apply(qkv.float(), x.float(), self.gamma.float(), cq,
+                                                  self.recompute_attention).to(x.dtype)
         proj_query = self.query_conv(x)
         proj_key = self.key_conv(x)
         proj_value = self.value_conv(x)
         out = CrissCrossFunction.apply(proj_query.float(), proj_key.float(), proj_value.float(),
-                                       x.float(), self.gamma.float())
+                                       x.float(), self.gamma.float(), self.recompute_attention)
         return out.to(x.dtype)
 
     @staticmethod

@@ -129,6 +129,13 @@ int ccnet_ca_map_forward_pm_f32(const float *A, const float *v, const float *x, 
 int ccnet_ca_map_backward_f32(const float *dout, const float *A, const float *v, const float *gamma,
                               float *dA, float *dv, int B, int C, int H, int W, ccnet_stream_t stream);
 
+/* The attention tensor alone: A = softmax(ca_forward(q, k)) with q, k addressed through batch strides (channel
+ * slices of a stacked projection).  This is what ccnet_cca_forward_strided_f32 leaves in ``A``; the host calls it in
+ * the backward pass when it chose NOT to keep A between forward and backward (recompute instead of save:
+ * SURVEY.md 8(f) rank 4, networks/ccnet.py:118-119 -- R applications of the module hold R attention tensors). */
+int ccnet_cca_attention_strided_f32(const float *q, const float *k, float *A, int B, int Cq, int H, int W,
+                                    long q_bs, long k_bs, ccnet_stream_t stream);
+
 /* Fused core, forward: (q,k,v,x,gamma) -> y and the saved attention A  (functions.py:38-49). */
 int ccnet_cca_forward_f32(const float *q, const float *k, const float *v, const float *x,
                           const float *gamma, float *y, float *A,

@@ -111,6 +111,14 @@ class EmuOps:
                                                       B, C, q.shape[1], H, W, None))
         return y, A
 
+    def cca_attention_packed(self, qkv, cq, H, W):
+        B = qkv.shape[0]
+        A = np.full((B, H, W, H + W), np.nan, np.float32)
+        hw, bs = H * W * 4, qkv.shape[1] * H * W
+        base = qkv.ctypes.data
+        self.lib.check(self.lib.ccnet_cca_attention_strided_f32(base, base + cq * hw, _p(A), B, cq, H, W, bs, bs, None))
+        return A
+
     def cca_backward(self, dy, q, k, v, A, gamma):
         B, C, H, W = v.shape
         dq, dk, dv = np.full_like(q, np.nan), np.full_like(k, np.nan), np.full_like(v, np.nan)

@@ -468,3 +468,14 @@ def test_row_band_forward_matches_oracle(ops, shape):
     assert maxerr(got, want) < 2e-4          # split-bf16 x3 arithmetic
     got2 = ops.ca_map_forward_pm(A, to_pm(c["v"], ps=C + 12), c["x"], c["gamma"])      # v as a slice of a wider projection
     assert np.array_equal(got, got2)
+
+
+def test_attention_recompute_entry_point_equals_the_forward_attention(ops):
+    """ccnet_cca_attention_strided_f32 (recompute-instead-of-save) rebuilds bit for bit the A that the
+    fused forward wrote, from q / k slices of a packed projection."""
+    c = rand_case(2, 40, 33, 18, seed=9)
+    cq = c["q"].shape[1]
+    qkv = np.ascontiguousarray(np.concatenate([c["q"], c["k"], c["v"]], 1))
+    y, A = ops.cca_forward_packed(qkv, c["x"], c["gamma"], cq)
+    A2 = ops.cca_attention_packed(qkv, cq, 33, 18)
+    assert np.array_equal(A, A2)

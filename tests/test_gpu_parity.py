@@ -541,3 +541,42 @@ def test_split_bf16_precision_option(lib, dev):
     print("split-bf16 x3 max-abs errors vs oracle:", report)
     assert all(e < TOL for e in report.values()), report
     assert report["y"] > 0      # it really is a different arithmetic than the exact path
+
+
+@pytest.mark.gpu
+def test_recompute_attention_matches_saved_attention_and_keeps_less(lib, dev):
+    """SURVEY 8(f) rank 4 / networks/ccnet.py:118-119: with ``recompute_attention`` the module keeps q, k, v only and
+    rebuilds A in backward -- same kernels, so every gradient is bit-identical; the autograd graph holds no
+    (B,H,W,H+W) tensor; under no_grad nothing is kept at all."""
+    from ccnet_amd import CrissCrossAttention
+    lib.ccnet_cca_set_impl(0)
+    torch.manual_seed(4)
+    B, C, H, W = 2, 64, 33, 40
+    x = torch.randn(B, C, H, W, device=dev)
+    dy = torch.randn(B, C, H, W, device=dev)
+    res = {}
+    for fused in (True, False):
+        for rec in (False, True):
+            torch.manual_seed(7)
+            m = CrissCrossAttention(C).to(dev)
+            m.fuse_module_backward = fused
+            m.recompute_attention = rec
+            with torch.no_grad():
+                m.gamma.fill_(0.5)
+            xd = x.clone().requires_grad_(True)
+            kept = []
+            with torch.autograd.graph.saved_tensors_hooks(lambda t: (kept.append(tuple(t.shape)), t)[1], lambda t: t):
+                y = m(m(xd))                      # R = 2, shared weights
+            y.backward(dy)
+            res[(fused, rec)] = [y.detach(), xd.grad] + [p.grad for p in m.parameters()]
+            has_attention = (B, H, W, H + W) in kept
+            assert has_attention == (not rec), (fused, rec, kept)
+    for fused in (True, False):
+        a, b = res[(fused, False)], res[(fused, True)]
+        assert torch.equal(a[0], b[0])                       # y: the same forward
+        for u, v in zip(a[1:], b[1:]):                       # gradients pass through hipBLASLt reductions (not run-to-run
+            assert torch.allclose(u, v, rtol=1e-4, atol=1e-5)   # bit-stable); the attention they use is identical
+    m.eval()
+    with torch.no_grad():
+        y = m(x)
+    assert y.grad_fn is None and torch.isfinite(y).all()
