@@ -166,8 +166,10 @@ class CoreWorkload:
         self.scratch = torch.empty_like(self.A)
         self.dq, self.dk, self.dv = torch.empty_like(self.q), torch.empty_like(self.k), torch.empty_like(self.v)
         self.dgamma = torch.empty(1, device=device)
-        self.ws_bytes = lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
+        self.ws_bytes = lib.ccnet_cca_backward_workspace_bytes(B, C, Cq, H, W)      # incl. small-batch K-split slabs
         self.ws = torch.empty(self.ws_bytes // 4 + 1, device=device)
+        self.fws_bytes = lib.ccnet_cca_forward_workspace_bytes(B, C, Cq, H, W)
+        self.fws = torch.empty(self.fws_bytes // 4 + 1, device=device)
 
     def stream(self):
         return torch.cuda.current_stream().cuda_stream
@@ -175,9 +177,12 @@ class CoreWorkload:
     def forward(self):
         B, C, H, W = self.shape
         L = self.lib
-        L.check(L.ccnet_cca_forward_f32(self.q.data_ptr(), self.k.data_ptr(), self.v.data_ptr(), self.x.data_ptr(),
-                                        self.gamma.data_ptr(), self.y.data_ptr(), self.A.data_ptr(),
-                                        B, C, C // 8, H, W, self.stream()), "cca_forward")
+        Cq, hw = C // 8, H * W
+        L.check(L.ccnet_cca_forward_ws_f32(self.q.data_ptr(), self.k.data_ptr(), self.v.data_ptr(), self.x.data_ptr(),
+                                           self.gamma.data_ptr(), self.y.data_ptr(), self.A.data_ptr(),
+                                           B, C, Cq, H, W, Cq * hw, Cq * hw, C * hw,
+                                           self.fws.data_ptr() if self.fws_bytes else None, self.fws_bytes,
+                                           self.stream()), "cca_forward")
 
     def backward(self):
         B, C, H, W = self.shape

@@ -48,6 +48,10 @@ _PROTOTYPES = {
     "ccnet_cca_forward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ccnet_cca_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t,
                                        c_int, c_int, c_int, c_int, c_int, _P]),
+    "ccnet_cca_forward_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "ccnet_cca_backward_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "ccnet_cca_forward_ws_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
+                                         c_long, c_long, c_long, _P, c_size_t, _P]),
     "ccnet_cca_attention_strided_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_long, c_long, _P]),
     "ccnet_cca_forward_strided_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
                                               c_long, c_long, c_long, _P]),

@@ -202,32 +202,72 @@ int launch_map_pair(const float *T, const float *F, const float *resid, const fl
     return launch_map_pair_ns<8, TRANS, false, false>(T, F, resid, gamma, out, B, C, H, W, stream, what, fbs, rbs, obs);
 }
 
+// K split of the weight-type contractions for SMALL BATCHES (reference recipe: 1-2 images per GPU, README.md:97,
+// engine.py:88).  One image has 26 strip tiles, so at B = 1 the weight kernels would run on 26 of 256 CUs, each
+// walking all channels: instead the channels are cut into n ranges, every (tile, range) is a workgroup, range s
+// writes partial slab s (slab 0 = the output tensor, slabs 1.. in the caller's workspace) and the softmax kernel that
+// consumes the tensor adds the slabs in a fixed order -- deterministic, no atomics.
+struct KSplit {
+    int n = 1;              // number of channel ranges (1 = no split)
+    int cps = 0;            // 8-channel chunks per range
+    float *extra = nullptr; // slabs 1 .. n-1
+    long stride = 0;        // elements between slabs
+};
+// how many ranges a K-channel contraction is cut into at this shape (strip-stationary kernels only)
+int ksplit_count(int B, int K, int H, int W) {
+    const int longest = H > W ? H : W;
+    if (g_impl.load() == CCNET_IMPL_DIRECT || longest > cca::kMaxStrip) return 1;
+    const int per_image = (W + 7) / 8 + (H + 7) / 8, nchunks = (K + cca::W_KC - 1) / cca::W_KC;
+    int n = num_cus() / (B * per_image);
+    if (n > nchunks / 2) n = nchunks / 2;               // at least two chunks per range
+    return n < 1 ? 1 : n;
+}
+size_t ksplit_bytes(int B, int K, int H, int W) {
+    return (size_t)(ksplit_count(B, K, H, W) - 1) * B * H * W * (H + W) * sizeof(float);
+}
+// plan for a contraction whose extra slabs may live at ws[0 .. bytes): falls back to fewer ranges when they do not fit
+KSplit ksplit_plan(int B, int K, int H, int W, void *ws, size_t bytes) {
+    KSplit ks;
+    const size_t slab = (size_t)B * H * W * (H + W) * sizeof(float);
+    int n = ksplit_count(B, K, H, W);
+    if (!ws) n = 1;
+    while (n > 1 && (size_t)(n - 1) * slab > bytes) --n;
+    const int nchunks = (K + cca::W_KC - 1) / cca::W_KC;
+    ks.cps = (nchunks + n - 1) / n;
+    ks.n = (nchunks + ks.cps - 1) / ks.cps;
+    ks.extra = static_cast<float *>(ws);
+    ks.stride = (long)(slab / sizeof(float));
+    return ks;
+}
+
 // both branches in ONE launch (column workgroups first, then row workgroups)
 template <int NS, bool MASK, bool BF>
 int launch_weight_ns(const float *X, const float *Y, float *T, int B, int Cx, int H, int W,
-                     ccnet_stream_t stream, const char *what, long xbs, long ybs) {
+                     ccnet_stream_t stream, const char *what, long xbs, long ybs, const KSplit &ks) {
     const int mask = g_branch_mask.load();
     const int tc = (mask & CCNET_BRANCH_COL) ? (W + NS - 1) / NS : 0;
     const int tr = (mask & CCNET_BRANCH_ROW) ? (H + NS - 1) / NS : 0;
-    CCA_LAUNCH((cca::weight_strip_kernel<NS, MASK, BF>), dim3((tc + tr) * B), dim3(cca::kWave * NS), stream,
-               X, Y, T, Cx, H, W, tc, tr, xbs, ybs);
+    const int nchunks = (Cx + cca::W_KC - 1) / cca::W_KC;
+    CCA_LAUNCH((cca::weight_strip_kernel<NS, MASK, BF>), dim3((tc + tr) * B * ks.n), dim3(cca::kWave * NS), stream,
+               X, Y, T, Cx, H, W, tc, tr, xbs, ybs, ks.n, ks.n > 1 ? ks.cps : nchunks, ks.extra, ks.stride);
     return launch_status(what);
 }
 
 template <bool MASK>
 int launch_weight_pair(const float *X, const float *Y, float *T, int B, int Cx, int H, int W,
-                       ccnet_stream_t stream, const char *what, long xbs, long ybs) {
+                       ccnet_stream_t stream, const char *what, long xbs, long ybs, const KSplit &ks = KSplit()) {
     if (!MASK && g_weight_bf16.load() == 1)
-        return launch_weight_ns<8, false, true>(X, Y, T, B, Cx, H, W, stream, what, xbs, ybs);
-    return launch_weight_ns<8, MASK, false>(X, Y, T, B, Cx, H, W, stream, what, xbs, ybs);
+        return launch_weight_ns<8, false, true>(X, Y, T, B, Cx, H, W, stream, what, xbs, ybs, ks);
+    return launch_weight_ns<8, MASK, false>(X, Y, T, B, Cx, H, W, stream, what, xbs, ybs, ks);
 }
 
-int softmax_forward(const float *E, float *A, int B, int H, int W, ccnet_stream_t stream) {
+int softmax_forward(const float *E, float *A, int B, int H, int W, ccnet_stream_t stream, const KSplit &ks = KSplit()) {
     const int npix = B * H * W, S = H + W;
     const dim3 grid((npix + cca::SM_WAVES - 1) / cca::SM_WAVES), block(cca::SM_BLOCK);
-    if (S <= 256)      CCA_LAUNCH((cca::softmax_fwd_kernel<4>), grid, block, stream, E, A, npix, S);
-    else if (S <= 512) CCA_LAUNCH((cca::softmax_fwd_kernel<8>), grid, block, stream, E, A, npix, S);
-    else               CCA_LAUNCH(cca::softmax_fwd_generic_kernel, grid, block, stream, E, A, npix, S);
+    const float *extra = ks.extra;
+    if (S <= 256)      CCA_LAUNCH((cca::softmax_fwd_kernel<4>), grid, block, stream, E, A, npix, S, ks.n, extra, ks.stride);
+    else if (S <= 512) CCA_LAUNCH((cca::softmax_fwd_kernel<8>), grid, block, stream, E, A, npix, S, ks.n, extra, ks.stride);
+    else               CCA_LAUNCH(cca::softmax_fwd_generic_kernel, grid, block, stream, E, A, npix, S, ks.n, extra, ks.stride);
     return launch_status("softmax_fwd");
 }
 
@@ -357,14 +397,15 @@ int launch_long_weight_pair(const float *X, const float *Y, float *T, int B, int
 // ---- strided internals: every feature tensor is (B, C, H, W) with a dense (C, H, W) image per batch and a
 // ---- caller-given batch stride in elements (dense = C*H*W), so q/k/v may be channel slices of one projection.
 int ca_forward_impl(const float *q, const float *k, float *out, int B, int Cq, int H, int W, int flags,
-                    ccnet_stream_t stream, long qbs, long kbs) {
+                    ccnet_stream_t stream, long qbs, long kbs, KSplit ks = KSplit()) {
     if (int e = check_shape(B, Cq, H, W)) return e;
     if (!q || !k || !out) return fail(CCNET_E_NULLPTR, "ca_forward: null tensor");
     if (flags != CCNET_CA_ENERGY && flags != CCNET_CA_SOFTMAX) return fail(CCNET_E_BADFLAGS, "ca_forward: bad flags");
     const int impl = pick_impl(H, W);
     if (impl < 0) return impl;
+    if (impl != 1 || flags != CCNET_CA_SOFTMAX) ks = KSplit();      // slabs are summed by the softmax kernel only
     if (impl == 1) {
-        if (int e = launch_weight_pair<true>(q, k, out, B, Cq, H, W, stream, "ca_forward", qbs, kbs)) return e;
+        if (int e = launch_weight_pair<true>(q, k, out, B, Cq, H, W, stream, "ca_forward", qbs, kbs, ks)) return e;
     } else if (impl == 2) {
         if (int e = launch_long_weight_pair<true>(q, k, out, B, Cq, H, W, stream, "ca_forward(long)", qbs, kbs)) return e;
     } else {
@@ -373,7 +414,7 @@ int ca_forward_impl(const float *q, const float *k, float *out, int B, int Cq, i
                    q, k, out, Cq, H, W, total, qbs, kbs);
         if (int e = launch_status("ca_forward(direct)")) return e;
     }
-    if (flags == CCNET_CA_SOFTMAX) return softmax_forward(out, out, B, H, W, stream);
+    if (flags == CCNET_CA_SOFTMAX) return softmax_forward(out, out, B, H, W, stream, ks);
     return 0;
 }
 
@@ -419,9 +460,10 @@ int ca_map_forward_impl(const float *A, const float *v, const float *x, const fl
     return launch_status("ca_map_forward(direct)");
 }
 
+// ks: K split of the dA contraction; the caller must hand the SAME plan to the softmax backward that consumes dA
 int ca_map_backward_impl(const float *dout, const float *A, const float *v, const float *gamma,
                          float *dA, float *dv, int B, int C, int H, int W, ccnet_stream_t stream,
-                         long dobs, long vbs, long dvbs) {
+                         long dobs, long vbs, long dvbs, const KSplit &ks = KSplit()) {
     if (int e = check_shape(B, C, H, W)) return e;
     if (!dout || !A || !v) return fail(CCNET_E_NULLPTR, "ca_map_backward: null tensor");
     const int impl = pick_impl(H, W);
@@ -434,7 +476,7 @@ int ca_map_backward_impl(const float *dout, const float *A, const float *v, cons
     }
     if (dA) {
         if (impl == 1) {
-            if (int e = launch_weight_pair<false>(dout, v, dA, B, C, H, W, stream, "ca_map_backward(dA)", dobs, vbs)) return e;
+            if (int e = launch_weight_pair<false>(dout, v, dA, B, C, H, W, stream, "ca_map_backward(dA)", dobs, vbs, ks)) return e;
         } else if (impl == 2) {
             if (int e = launch_long_weight_pair<false>(dout, v, dA, B, C, H, W, stream, "ca_map_backward(dA,long)", dobs, vbs)) return e;
         } else {
@@ -523,9 +565,10 @@ size_t ccnet_ca_softmax_backward_workspace_bytes(int B, int H, int W) {
     return ((npix + cca::SM_WAVES - 1) / cca::SM_WAVES) * sizeof(float);
 }
 
-int ccnet_ca_softmax_backward_f32(const float *A, const float *dA, const float *gamma, float *dE, float *dgamma,
-                                  void *workspace, size_t workspace_bytes, int B, int H, int W,
-                                  ccnet_stream_t stream) {
+namespace {
+int softmax_backward_impl(const float *A, const float *dA, const float *gamma, float *dE, float *dgamma,
+                          void *workspace, size_t workspace_bytes, int B, int H, int W, ccnet_stream_t stream,
+                          const KSplit &ks) {
     if (int e = check_shape(B, 1, H, W)) return e;
     if (!A || !dA || !dE) return fail(CCNET_E_NULLPTR, "softmax_backward: null tensor");
     const int npix = B * H * W, S = H + W;
@@ -538,15 +581,36 @@ int ccnet_ca_softmax_backward_f32(const float *A, const float *dA, const float *
         partials = static_cast<float *>(workspace);
     }
     const dim3 grid(nblocks), block(cca::SM_BLOCK);
-    if (S <= 256)      CCA_LAUNCH((cca::softmax_bwd_kernel<4>), grid, block, stream, A, dA, gamma, dE, partials, npix, S);
-    else if (S <= 512) CCA_LAUNCH((cca::softmax_bwd_kernel<8>), grid, block, stream, A, dA, gamma, dE, partials, npix, S);
-    else               CCA_LAUNCH(cca::softmax_bwd_generic_kernel, grid, block, stream, A, dA, gamma, dE, partials, npix, S);
+    const float *extra = ks.extra;
+    if (S <= 256)      CCA_LAUNCH((cca::softmax_bwd_kernel<4>), grid, block, stream, A, dA, gamma, dE, partials, npix, S, ks.n, extra, ks.stride);
+    else if (S <= 512) CCA_LAUNCH((cca::softmax_bwd_kernel<8>), grid, block, stream, A, dA, gamma, dE, partials, npix, S, ks.n, extra, ks.stride);
+    else               CCA_LAUNCH(cca::softmax_bwd_generic_kernel, grid, block, stream, A, dA, gamma, dE, partials, npix, S, ks.n, extra, ks.stride);
     if (int e = launch_status("softmax_bwd")) return e;
     if (dgamma) {
         CCA_LAUNCH(cca::reduce_partials_kernel, dim3(1), block, stream, (const float *)partials, nblocks, dgamma);
         return launch_status("reduce_partials");
     }
     return 0;
+}
+size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+}  // namespace
+
+int ccnet_ca_softmax_backward_f32(const float *A, const float *dA, const float *gamma, float *dE, float *dgamma,
+                                  void *workspace, size_t workspace_bytes, int B, int H, int W,
+                                  ccnet_stream_t stream) {
+    return softmax_backward_impl(A, dA, gamma, dE, dgamma, workspace, workspace_bytes, B, H, W, stream, KSplit());
+}
+
+size_t ccnet_cca_forward_workspace_bytes(int B, int C, int Cq, int H, int W) {
+    (void)C;
+    if (B <= 0 || Cq <= 0 || H <= 0 || W <= 0) return 0;
+    return ksplit_bytes(B, Cq, H, W);
+}
+
+size_t ccnet_cca_backward_workspace_bytes(int B, int C, int Cq, int H, int W) {
+    (void)Cq;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    return align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W)) + ksplit_bytes(B, C, H, W);
 }
 
 int ccnet_ca_map_forward_f32(const float *A, const float *v, const float *x, const float *gamma, float *out,
@@ -576,9 +640,10 @@ int ccnet_ca_map_backward_f32(const float *dout, const float *A, const float *v,
     return ca_map_backward_impl(dout, A, v, gamma, dA, dv, B, C, H, W, stream, d, d, d);
 }
 
-int ccnet_cca_forward_strided_f32(const float *q, const float *k, const float *v, const float *x, const float *gamma,
-                                  float *y, float *A, int B, int C, int Cq, int H, int W,
-                                  long q_bs, long k_bs, long v_bs, ccnet_stream_t stream) {
+int ccnet_cca_forward_ws_f32(const float *q, const float *k, const float *v, const float *x, const float *gamma,
+                             float *y, float *A, int B, int C, int Cq, int H, int W,
+                             long q_bs, long k_bs, long v_bs, void *workspace, size_t workspace_bytes,
+                             ccnet_stream_t stream) {
     if (int e = require_both_branches("cca_forward")) return e;
     if (!q || !k || !v || !x || !gamma || !y || !A) return fail(CCNET_E_NULLPTR, "cca_forward: null tensor");
     if (int e = check_shape(B, C, H, W)) return e;
@@ -586,9 +651,16 @@ int ccnet_cca_forward_strided_f32(const float *q, const float *k, const float *v
     if (int e = check_stride(q_bs, Cq, H, W, "cca_forward(q)")) return e;
     if (int e = check_stride(k_bs, Cq, H, W, "cca_forward(k)")) return e;
     if (int e = check_stride(v_bs, C, H, W, "cca_forward(v)")) return e;
-    if (int e = ca_forward_impl(q, k, A, B, Cq, H, W, CCNET_CA_SOFTMAX, stream, q_bs, k_bs)) return e;
+    if (int e = ca_forward_impl(q, k, A, B, Cq, H, W, CCNET_CA_SOFTMAX, stream, q_bs, k_bs,
+                                ksplit_plan(B, Cq, H, W, workspace, workspace_bytes))) return e;
     const long d = (long)C * H * W;
     return ca_map_forward_impl(A, v, x, gamma, y, B, C, H, W, stream, v_bs, d, d);
+}
+
+int ccnet_cca_forward_strided_f32(const float *q, const float *k, const float *v, const float *x, const float *gamma,
+                                  float *y, float *A, int B, int C, int Cq, int H, int W,
+                                  long q_bs, long k_bs, long v_bs, ccnet_stream_t stream) {
+    return ccnet_cca_forward_ws_f32(q, k, v, x, gamma, y, A, B, C, Cq, H, W, q_bs, k_bs, v_bs, nullptr, 0, stream);
 }
 
 int ccnet_cca_attention_strided_f32(const float *q, const float *k, float *A, int B, int Cq, int H, int W,
@@ -622,12 +694,17 @@ int ccnet_cca_backward_strided_f32(const float *dy, const float *q, const float 
     if (int e = check_stride(dq_bs, Cq, H, W, "cca_backward(dq)")) return e;
     if (int e = check_stride(dk_bs, Cq, H, W, "cca_backward(dk)")) return e;
     if (int e = check_stride(dv_bs, C, H, W, "cca_backward(dv)")) return e;
-    // t = un-scaled dA into scratch, dv = gamma * (A^T-weighted sums of dy)
-    if (int e = ca_map_backward_impl(dy, A, v, gamma, scratch, dv, B, C, H, W, stream, (long)C * H * W, v_bs, dv_bs))
+    // workspace = [softmax-backward partial sums | pad to 256 B | K-split slabs of dA (small batches, optional)]
+    const size_t part = align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W));
+    KSplit ks;
+    if (workspace && workspace_bytes > part)
+        ks = ksplit_plan(B, C, H, W, static_cast<char *>(workspace) + part, workspace_bytes - part);
+    // t = un-scaled dA into scratch (+ slabs), dv = gamma * (A^T-weighted sums of dy)
+    if (int e = ca_map_backward_impl(dy, A, v, gamma, scratch, dv, B, C, H, W, stream, (long)C * H * W, v_bs, dv_bs, ks))
         return e;
-    // dgamma = sum A*t ; dE = gamma * A * (t - sum_s A t), in place
-    if (int e = ccnet_ca_softmax_backward_f32(A, scratch, gamma, scratch, dgamma, workspace, workspace_bytes,
-                                              B, H, W, stream)) return e;
+    // dgamma = sum A*t ; dE = gamma * A * (t - sum_s A t), in place (t = the sum of the slabs)
+    if (int e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, workspace_bytes,
+                                      B, H, W, stream, ks)) return e;
     return ca_backward_impl(scratch, q, k, dq, dk, B, Cq, H, W, stream, q_bs, k_bs, dq_bs, dk_bs);
 }
 

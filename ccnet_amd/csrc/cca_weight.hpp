@@ -38,7 +38,8 @@ __host__ __device__ constexpr int w_lds_floats(int ns) { return 6 * w_op(ns); } 
 template <int NS, bool ROW, bool MASK, bool FULL, bool BF>
 __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, const float *__restrict__ X,
                                                   const float *__restrict__ Y, float *__restrict__ T,
-                                                  int Cx, int H, int W, long xbs, long ybs) {
+                                                  int Ctot, int c_begin, int Cx, int H, int W, long xbs, long ybs) {
+    // channels [c_begin, Cx) of the Ctot-channel operands (a K split: the caller sums the partial results)
     constexpr int CP = w_cp(NS, ROW), OP = w_op(NS);
     const Branch br = make_branch(ROW, H, W);
     const int L = br.L, HW = H * W, S = H + W;
@@ -54,8 +55,8 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
     StripLanes4<NS, ROW> sl;
     sl.init(lane, L, W, g0, gvalid);
 
-    const FBuf Xb = make_fbuf(X + (size_t)b * xbs, (size_t)Cx * HW * sizeof(float));   // xbs: batch stride (elements)
-    const FBuf Yb = make_fbuf(Y + (size_t)b * ybs, (size_t)Cx * HW * sizeof(float));
+    const FBuf Xb = make_fbuf(X + (size_t)b * xbs, (size_t)Ctot * HW * sizeof(float));   // xbs: batch stride (elements)
+    const FBuf Yb = make_fbuf(Y + (size_t)b * ybs, (size_t)Ctot * HW * sizeof(float));
 
     // DMA of chunk c0 into buffer `buf`: (operand, channel) pairs are dealt round-robin to the NS waves
     auto issue = [&](int c0, int buf) {
@@ -94,10 +95,10 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
                                 c * HW * 4 + sl.piece_soff(m, W));
     };
 
-    const int nchunks = (Cx + W_KC - 1) / W_KC;
-    const int lastc = (nchunks - 1) * W_KC;
-    issue(0, 0);
-    issue(nchunks > 1 ? W_KC : 0, 1);
+    const int nchunks = (Cx - c_begin + W_KC - 1) / W_KC;
+    const int lastc = c_begin + (nchunks - 1) * W_KC;
+    issue(c_begin, 0);
+    issue(nchunks > 1 ? c_begin + W_KC : c_begin, 1);
     for (int n = 0; n < nchunks; ++n) {
         // chunk n landed; chunk n+1 (the newest QT pieces of every wave) may still be in flight
 #ifndef CCA_ABL_W_NOBARRIER
@@ -106,7 +107,7 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
         else                      __syncthreads();
 #endif
         // chunk n+2 -> buffer (n+2) % 3, last read in iteration n-1 (past the end: re-fetch the last chunk, harmless)
-        const int c1 = ((n + 2) * W_KC < lastc) ? (n + 2) * W_KC : lastc;
+        const int c1 = (c_begin + (n + 2) * W_KC < lastc) ? c_begin + (n + 2) * W_KC : lastc;
         const int bnext = (n + 2) % 3, bcur = n % 3;
         if (active) {
             const float *xs = lds + (bcur * 2 + 0) * OP + fr;
@@ -114,7 +115,7 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
             if constexpr (BF) {
                 // lane (position l & 15, k group l >> 4) carries channels 2 (l >> 4) and 2 (l >> 4) + 1 of the chunk
                 const int cpair = (2 * lk - lk) * CP;                    // fr already holds lk * CP
-                const bool kin0 = n * W_KC + 2 * lk < Cx, kin1 = n * W_KC + 2 * lk + 1 < Cx;
+                const bool kin0 = c_begin + n * W_KC + 2 * lk < Cx, kin1 = c_begin + n * W_KC + 2 * lk + 1 < Cx;
                 u32x4 af[kMaxTiles];
 #pragma unroll
                 for (int t = 0; t < kMaxTiles; ++t)
@@ -137,7 +138,7 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
             } else {
 #pragma unroll
             for (int ks = 0; ks < W_KC / 4; ++ks) {
-                const bool kin = n * W_KC + ks * 4 + lk < Cx;        // channels beyond Cx hold clamped data: zero A
+                const bool kin = c_begin + n * W_KC + ks * 4 + lk < Cx;   // channels beyond Cx hold clamped data: zero A
                 float a[kMaxTiles];
 #pragma unroll
                 for (int t = 0; t < kMaxTiles; ++t)
@@ -197,28 +198,37 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
 #undef CCA_TILE_ON
 }
 
-// One launch covers BOTH branches and all images: 1-D grid of B * (tiles_col + tiles_row) workgroups in
-// XCD-aware order, image-major, then column tiles, then row tiles.
+// One launch covers BOTH branches and all images: 1-D grid of B * ksplit * (tiles_col + tiles_row) workgroups in
+// XCD-aware order, image-major, then K split, then column tiles, then row tiles.  K split (small batches: 26 strip
+// tiles per image cannot fill 256 CUs): split s contracts channels [s * cps * 8, (s + 1) * cps * 8) and writes the
+// partial result to slab s -- slab 0 is T, slab s >= 1 is extra + (s - 1) * slab_stride -- and the consumer (the
+// softmax kernels) adds the slabs in a fixed order.
 template <int NS, bool MASK, bool BF>
 __global__ __launch_bounds__(kWave * NS, 2) void weight_strip_kernel(const float *__restrict__ X,
                                                                       const float *__restrict__ Y,
                                                                       float *__restrict__ T, int Cx, int H, int W,
-                                                                      int tiles_col, int tiles_row, long xbs, long ybs) {
+                                                                      int tiles_col, int tiles_row, long xbs, long ybs,
+                                                                      int ksplit, int cps, float *__restrict__ extra,
+                                                                      long slab_stride) {
     __shared__ float lds[w_lds_floats(NS)];
     CCA_LDS_REGISTER(lds);
     const int per_image = tiles_col + tiles_row;
     const int id = xcd_logical_id(blockIdx.x, gridDim.x);
-    const int b = id / per_image, t = id - b * per_image;
+    const int bs = id / per_image, t = id - bs * per_image;
+    const int b = bs / ksplit, split = bs - b * ksplit;
+    const int c_begin = split * cps * W_KC;
+    const int c_end = (c_begin + cps * W_KC < Cx) ? c_begin + cps * W_KC : Cx;
+    float *Tout = split == 0 ? T : extra + (size_t)(split - 1) * slab_stride;
     const bool row = t >= tiles_col;
     const int tile = row ? t - tiles_col : t;
     const int L = row ? W : H;
     const bool full = L > (kMaxTiles - 1) * kTile;
     if (row) {
-        if (full) weight_strip_body<NS, true, MASK, true, BF>(lds, b, tile, X, Y, T, Cx, H, W, xbs, ybs);
-        else      weight_strip_body<NS, true, MASK, false, BF>(lds, b, tile, X, Y, T, Cx, H, W, xbs, ybs);
+        if (full) weight_strip_body<NS, true, MASK, true, BF>(lds, b, tile, X, Y, Tout, Cx, c_begin, c_end, H, W, xbs, ybs);
+        else      weight_strip_body<NS, true, MASK, false, BF>(lds, b, tile, X, Y, Tout, Cx, c_begin, c_end, H, W, xbs, ybs);
     } else {
-        if (full) weight_strip_body<NS, false, MASK, true, BF>(lds, b, tile, X, Y, T, Cx, H, W, xbs, ybs);
-        else      weight_strip_body<NS, false, MASK, false, BF>(lds, b, tile, X, Y, T, Cx, H, W, xbs, ybs);
+        if (full) weight_strip_body<NS, false, MASK, true, BF>(lds, b, tile, X, Y, Tout, Cx, c_begin, c_end, H, W, xbs, ybs);
+        else      weight_strip_body<NS, false, MASK, false, BF>(lds, b, tile, X, Y, Tout, Cx, c_begin, c_end, H, W, xbs, ybs);
     }
 }
 

@@ -71,6 +71,14 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _workspace(nbytes, device):
+    """(tensor or None, pointer or None, nbytes): scratch for the library's K-split slabs / reduction partials."""
+    if nbytes <= 0:
+        return None, None, 0
+    t = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+    return t, t.data_ptr(), nbytes
+
+
 def _check_qk(q, k):
     if q.dim() != 4 or q.shape != k.shape:
         raise RuntimeError(f"query/key must both be (B, C/8, H, W); got {tuple(q.shape)} and {tuple(k.shape)}")
@@ -214,10 +222,13 @@ class CrissCrossFunction(torch.autograd.Function):
         lib = _lib.get_lib()
         y = torch.empty_like(x)
         A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
+        cq = q.shape[1]
         with torch.cuda.device(x.device):
-            lib.check(lib.ccnet_cca_forward_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), x.data_ptr(),
-                                                gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
-                                                B, C, q.shape[1], H, W, _stream()), "cca_forward")
+            _ws, wsp, wsn = _workspace(lib.ccnet_cca_forward_workspace_bytes(B, C, cq, H, W), x.device)
+            lib.check(lib.ccnet_cca_forward_ws_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), x.data_ptr(),
+                                                   gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
+                                                   B, C, cq, H, W, cq * H * W, cq * H * W, C * H * W, wsp, wsn,
+                                                   _stream()), "cca_forward")
         ctx.recompute = bool(recompute)
         if ctx.recompute:
             ctx.save_for_backward(q, k, v, gamma)              # A is rebuilt from q, k in backward
@@ -239,13 +250,12 @@ class CrissCrossFunction(torch.autograd.Function):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         dgamma = torch.empty_like(gamma)
         scratch = torch.empty_like(A)
-        nbytes = lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
-        ws = torch.empty((nbytes + 3) // 4, device=v.device, dtype=torch.float32)
         with torch.cuda.device(v.device):
+            ws, wsp, nbytes = _workspace(lib.ccnet_cca_backward_workspace_bytes(B, C, q.shape[1], H, W), v.device)
             lib.check(lib.ccnet_cca_backward_f32(dy.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
                                                  A.data_ptr(), gamma.data_ptr(), dq.data_ptr(), dk.data_ptr(),
                                                  dv.data_ptr(), dgamma.data_ptr(), scratch.data_ptr(),
-                                                 ws.data_ptr(), nbytes, B, C, q.shape[1], H, W, _stream()),
+                                                 wsp, nbytes, B, C, q.shape[1], H, W, _stream()),
                       "cca_backward")
         return dq, dk, dv, dy, dgamma.view_as(gamma), None
 
@@ -286,9 +296,10 @@ class CrissCrossPackedFunction(torch.autograd.Function):
         hw, bs = H * W * 4, (2 * cq + C) * H * W
         base = qkv.data_ptr()
         with torch.cuda.device(x.device):
-            lib.check(lib.ccnet_cca_forward_strided_f32(base, base + cq * hw, base + 2 * cq * hw, x.data_ptr(),
-                                                        gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
-                                                        B, C, cq, H, W, bs, bs, bs, _stream()), "cca_forward")
+            _ws, wsp, wsn = _workspace(lib.ccnet_cca_forward_workspace_bytes(B, C, cq, H, W), x.device)
+            lib.check(lib.ccnet_cca_forward_ws_f32(base, base + cq * hw, base + 2 * cq * hw, x.data_ptr(),
+                                                   gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
+                                                   B, C, cq, H, W, bs, bs, bs, wsp, wsn, _stream()), "cca_forward")
         ctx.recompute = bool(recompute)
         ctx.save_for_backward(*((qkv, gamma) if ctx.recompute else (qkv, A, gamma)))
         ctx.cq = cq
@@ -309,7 +320,8 @@ class CrissCrossPackedFunction(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dgamma = torch.empty_like(gamma)
         scratch = torch.empty_like(A)
-        nbytes = lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
+        with torch.cuda.device(dy.device):
+            nbytes = lib.ccnet_cca_backward_workspace_bytes(B, C, cq, H, W)
         ws = torch.empty((nbytes + 3) // 4, device=dy.device, dtype=torch.float32)
         hw, bs = H * W * 4, (2 * cq + C) * H * W
         p, g = qkv.data_ptr(), dqkv.data_ptr()
@@ -397,9 +409,10 @@ class CrissCrossModuleFunction(torch.autograd.Function):
         esz, bs = hw * 4, (2 * cq + C) * hw
         base = qkv.data_ptr()
         with torch.cuda.device(x.device):
-            lib.check(lib.ccnet_cca_forward_strided_f32(base, base + cq * esz, base + 2 * cq * esz, x.data_ptr(),
-                                                        gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
-                                                        B, C, cq, H, W, bs, bs, bs, _stream()), "cca_forward")
+            _ws, wsp, wsn = _workspace(lib.ccnet_cca_forward_workspace_bytes(B, C, cq, H, W), x.device)
+            lib.check(lib.ccnet_cca_forward_ws_f32(base, base + cq * esz, base + 2 * cq * esz, x.data_ptr(),
+                                                   gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
+                                                   B, C, cq, H, W, bs, bs, bs, wsp, wsn, _stream()), "cca_forward")
         ctx.recompute = bool(recompute)
         ctx.save_for_backward(*((x, w, qkv, gamma) if ctx.recompute else (x, w, qkv, A, gamma)))
         ctx.cq = cq
@@ -423,7 +436,8 @@ class CrissCrossModuleFunction(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dgamma = torch.empty_like(gamma)
         scratch = torch.empty_like(A)
-        nbytes = lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
+        with torch.cuda.device(dy.device):
+            nbytes = lib.ccnet_cca_backward_workspace_bytes(B, C, cq, H, W)
         ws = torch.empty((nbytes + 3) // 4, device=dy.device, dtype=torch.float32)
         esz, bs = hw * 4, (2 * cq + C) * hw
         p, g = qkv.data_ptr(), dqkv.data_ptr()

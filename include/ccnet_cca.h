@@ -129,6 +129,22 @@ int ccnet_ca_map_forward_pm_f32(const float *A, const float *v, const float *x, 
 int ccnet_ca_map_backward_f32(const float *dout, const float *A, const float *v, const float *gamma,
                               float *dA, float *dv, int B, int C, int H, int W, ccnet_stream_t stream);
 
+/* Workspace sizes of the fused entry points.  The workspace is optional scratch that lets SMALL BATCHES (the
+ * reference trains at 1-2 images per GPU: README.md:97, engine.py:88) use the whole chip: the channel contractions
+ * behind the affinity (forward) and behind dA (backward) are split into channel ranges whose partial attention-shaped
+ * results live in the workspace and are added, in a fixed order, by the softmax kernels.  With a NULL / smaller
+ * workspace the same results are computed unsplit (backward: at least
+ * ccnet_ca_softmax_backward_workspace_bytes() is always required; the backward size includes it).  At batch sizes
+ * that fill the chip the forward size is 0 and the backward size is just the softmax part. */
+size_t ccnet_cca_forward_workspace_bytes(int B, int C, int Cq, int H, int W);
+size_t ccnet_cca_backward_workspace_bytes(int B, int C, int Cq, int H, int W);
+
+/* ccnet_cca_forward_strided_f32 with the optional workspace described above. */
+int ccnet_cca_forward_ws_f32(const float *q, const float *k, const float *v, const float *x, const float *gamma,
+                             float *y, float *A, int B, int C, int Cq, int H, int W,
+                             long q_bs, long k_bs, long v_bs, void *workspace, size_t workspace_bytes,
+                             ccnet_stream_t stream);
+
 /* The attention tensor alone: A = softmax(ca_forward(q, k)) with q, k addressed through batch strides (channel
  * slices of a stacked projection).  This is what ccnet_cca_forward_strided_f32 leaves in ``A``; the host calls it in
  * the backward pass when it chose NOT to keep A between forward and backward (recompute instead of save:

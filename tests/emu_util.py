@@ -111,6 +111,30 @@ class EmuOps:
                                                       B, C, q.shape[1], H, W, None))
         return y, A
 
+    def cca_forward_ws(self, q, k, v, x, gamma):
+        """fused forward with the optional small-batch workspace (K-split slabs); returns (y, A, workspace bytes)"""
+        B, C, H, W = v.shape
+        cq = q.shape[1]
+        y = np.full_like(v, np.nan)
+        A = np.full((B, H, W, H + W), np.nan, np.float32)
+        n = self.lib.ccnet_cca_forward_workspace_bytes(B, C, cq, H, W)
+        ws = np.full(n // 4 + 1, np.nan, np.float32)
+        self.lib.check(self.lib.ccnet_cca_forward_ws_f32(_p(q), _p(k), _p(v), _p(x), _p(gamma), _p(y), _p(A), B, C, cq, H, W,
+                                                         cq * H * W, cq * H * W, C * H * W, _p(ws), n, None))
+        return y, A, n
+
+    def cca_backward_ws(self, dy, q, k, v, A, gamma):
+        B, C, H, W = v.shape
+        dq, dk, dv = np.full_like(q, np.nan), np.full_like(k, np.nan), np.full_like(v, np.nan)
+        dgamma = np.full(1, np.nan, np.float32)
+        scratch = np.full_like(A, np.nan)
+        nbytes = self.lib.ccnet_cca_backward_workspace_bytes(B, C, q.shape[1], H, W)
+        ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
+        self.lib.check(self.lib.ccnet_cca_backward_f32(_p(dy), _p(q), _p(k), _p(v), _p(A), _p(gamma), _p(dq), _p(dk),
+                                                       _p(dv), _p(dgamma), _p(scratch), _p(ws), nbytes,
+                                                       B, C, q.shape[1], H, W, None))
+        return dq, dk, dv, dgamma, nbytes
+
     def cca_attention_packed(self, qkv, cq, H, W):
         B = qkv.shape[0]
         A = np.full((B, H, W, H + W), np.nan, np.float32)

@@ -479,3 +479,31 @@ def test_attention_recompute_entry_point_equals_the_forward_attention(ops):
     y, A = ops.cca_forward_packed(qkv, c["x"], c["gamma"], cq)
     A2 = ops.cca_attention_packed(qkv, cq, 33, 18)
     assert np.array_equal(A, A2)
+
+
+def test_small_batch_k_split_matches_unsplit_and_oracle(ops):
+    """at 1-2 images per GPU the weight-type contractions are split over channel ranges (partial slabs
+    in the caller's workspace, summed in a fixed order by the softmax kernels).  Same results as unsplit, twice."""
+    ops.set_impl(MFMA)
+    B, C, H, W = 1, 256, 20, 12                    # Cq = 32: 4 chunks -> 2 ranges forward; C = 256: 32 chunks -> up to 16 backward
+    rng = np.random.default_rng(11)
+    f = lambda *s: rng.standard_normal(s, dtype=np.float32)  # noqa: E731
+    q, k, v, x, dy = f(B, C // 8, H, W) * 0.3, f(B, C // 8, H, W) * 0.3, f(B, C, H, W), f(B, C, H, W), f(B, C, H, W)
+    gamma = np.array([0.5], np.float32)
+    y0, A0 = ops.cca_forward(q, k, v, x, gamma)
+    y1, A1, nf = ops.cca_forward_ws(q, k, v, x, gamma)
+    assert nf > 0                                  # a split really happened
+    assert maxerr(A1, A0) < 1e-6 and maxerr(y1, y0) < 1e-5
+    y2, A2, _ = ops.cca_forward_ws(q, k, v, x, gamma)
+    assert np.array_equal(A1, A2) and np.array_equal(y1, y2)          # deterministic
+    Ao = O.ca_softmax(O.ca_forward(T(q), T(k))).numpy()
+    assert maxerr(A1, Ao) < TOL
+    assert np.all(A1[:, np.arange(H), :, np.arange(H)] == 0)          # the masked slot survives the slab sum
+    g0 = ops.cca_backward(dy, q, k, v, A0, gamma)
+    g1 = ops.cca_backward_ws(dy, q, k, v, A0, gamma)
+    assert g1[4] > ops.lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W) + 256
+    for a, b, name in zip(g0, g1[:4], ("dq", "dk", "dv", "dgamma")):
+        assert maxerr(a, b) < 2e-4 * max(1.0, float(np.abs(a).max())), name
+    g2 = ops.cca_backward_ws(dy, q, k, v, A0, gamma)
+    for a, b in zip(g1[:4], g2[:4]):
+        assert np.array_equal(a, b)
