@@ -97,7 +97,7 @@ unsigned direct_grid(size_t total) {
 bool map_bf16(int H, int W, bool row) {
     const int lo = H < W ? H : W, hi = H < W ? W : H;
     const int mode = g_map_bf16.load();
-    return (mode == 2 || (mode == 1 && row)) && lo > 96 && hi <= cca::kMaxStrip;
+    return (mode == 2 || (mode == 1 && row)) && lo >= 96 && hi <= cca::kMaxStrip;
 }
 
 // number of CUs of the CURRENT device (the channel splits are balanced for it; MI355X: 256), cached per device
@@ -248,8 +248,12 @@ int launch_weight_ns(const float *X, const float *Y, float *T, int B, int Cx, in
     const int tc = (mask & CCNET_BRANCH_COL) ? (W + NS - 1) / NS : 0;
     const int tr = (mask & CCNET_BRANCH_ROW) ? (H + NS - 1) / NS : 0;
     const int nchunks = (Cx + cca::W_KC - 1) / cca::W_KC;
-    CCA_LAUNCH((cca::weight_strip_kernel<NS, MASK, BF>), dim3((tc + tr) * B * ks.n), dim3(cca::kWave * NS), stream,
-               X, Y, T, Cx, H, W, tc, tr, xbs, ybs, ks.n, ks.n > 1 ? ks.cps : nchunks, ks.extra, ks.stride);
+    if (ks.n > 1)
+        CCA_LAUNCH((cca::weight_strip_kernel<NS, MASK, BF, true>), dim3((tc + tr) * B * ks.n), dim3(cca::kWave * NS), stream,
+                   X, Y, T, Cx, H, W, tc, tr, xbs, ybs, ks.n, ks.cps, ks.extra, ks.stride);
+    else
+        CCA_LAUNCH((cca::weight_strip_kernel<NS, MASK, BF, false>), dim3((tc + tr) * B), dim3(cca::kWave * NS), stream,
+                   X, Y, T, Cx, H, W, tc, tr, xbs, ybs, 1, nchunks, (float *)nullptr, 0L);
     return launch_status(what);
 }
 

@@ -27,6 +27,12 @@ constexpr int kMaxStripsPerBlock = 8;
 constexpr int kTile = 16;                 // v_mfma_f32_16x16x4_f32 output tile
 constexpr int kMaxTiles = 7;              // strips up to 112 long in the W-kernel
 constexpr int kMaxStrip = 100;            // strip-stationary kernels hold 25 k-steps x 7 n-tiles of attention
+// Strips at least this long run the compile-time-shaped ("FULL") bodies: all 7 tiles / 25 k-steps are computed whatever
+// the length (positions beyond the strip are zero operands), every DMA piece and tile store is ISSUED whatever the
+// length (lanes beyond the strip carry an out-of-range buffer offset: such a load deposits zeros in LDS, such a store
+// is dropped -- tools/probes/dma_oob_probe.hip), so the counted-vmcnt pipeline and the 16-byte store paths hold for
+// 96, 80, 65 ... as they do for 97..100.  Shorter strips take the run-time-shaped bodies.
+constexpr int kFullMinStrip = 49;
 
 // Branch geometry: how a (strip g, position i) pair maps to feature / attention addresses.
 struct Branch {
@@ -165,6 +171,7 @@ struct StripLanes4 {
     bool okg;
     int li;
     int lim;
+    bool inimg_last;                 // this lane's slot of the LAST piece lies inside the channel image
 
     __device__ __forceinline__ void init(int lane, int L, int W, int g0, int gvalid) {
         if (ROW) {
@@ -181,6 +188,7 @@ struct StripLanes4 {
             vb = 4 * (li * W + g0 + gg0);
             lim = L;
         }
+        inimg_last = (strip_pieces4_c(NS) - 1) * 256 + 4 * lane < strip_pieces_c(NS) * 64;
     }
     __device__ __forceinline__ int piece_soff(int m, int W) const {
         return ROW ? m * 1024 : m * (256 / NS) * W * 4;
@@ -188,6 +196,13 @@ struct StripLanes4 {
     __device__ __forceinline__ bool valid(int m) const {
         return ROW ? (m * 256 + li < lim) : (okg && m * (256 / NS) + li < lim);
     }
+    // compile-time-shaped bodies issue EVERY piece: a lane whose 16 bytes lie inside the channel image but outside the
+    // strip tile fetches from an out-of-range offset (zeros land in LDS); lanes past the image (the last piece overhangs
+    // it: the next channel's image starts there) stay masked -- never a whole piece, so the instruction count is fixed
+    // (only the last piece overhangs: strip_pieces_c * 64 > (strip_pieces4_c - 1) * 256; m is a compile-time constant
+    // at every call site, so the earlier pieces carry no mask at all)
+    __device__ __forceinline__ bool in_image(int m, int) const { return m < strip_pieces4_c(NS) - 1 || inimg_last; }
+    __device__ __forceinline__ int full_offset(int m) const { return valid(m) ? vb : kOobOffset; }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -209,14 +224,18 @@ __device__ __forceinline__ int blocked_offset(int h, int w, int H, int W) {
     return k * NS * W + g * 4 * nr + hh * nw + (w & 3);
 }
 
-// LDS-DMA of one channel plane slice into its image (FULL: npieces4 is the compile-time maximum)
-template <int NS, bool ROW, bool FULL>
+// LDS-DMA of one channel plane slice into its image (FULL: npieces4 is the compile-time maximum; EXACT: strips
+// 97..100 long, where every piece of a full tile holds lanes of the tile and plain lane masks keep the instruction count)
+template <int NS, bool ROW, bool FULL, bool EXACT = false>
 __device__ __forceinline__ void strip_dma_channel(const FBuf &src, float *dst, int soff, int npieces4, int W,
                                                   const StripLanes4<NS, ROW> &sl) {
 #pragma unroll
     for (int m = 0; m < strip_pieces4_c(NS); ++m)
-        if (FULL || m < npieces4)
+        if (FULL && !EXACT) {
+            if (sl.in_image(m, lane_id())) fbuf_load_to_lds_x4(src, dst + m * 256, sl.full_offset(m), soff + sl.piece_soff(m, W));
+        } else if (FULL || m < npieces4) {
             if (sl.valid(m)) fbuf_load_to_lds_x4(src, dst + m * 256, sl.vb, soff + sl.piece_soff(m, W));
+        }
 }
 
 }  // namespace cca

@@ -31,6 +31,24 @@
 
 namespace cca {
 
+// counted barrier with a run-time (wave-uniform) count
+__device__ __forceinline__ void barrier_dma_keep_n(int n) {
+    switch (n) {
+        case 0: barrier_dma_keep<0>(); break;
+        case 1: barrier_dma_keep<1>(); break;
+        case 2: barrier_dma_keep<2>(); break;
+        case 3: barrier_dma_keep<3>(); break;
+        case 4: barrier_dma_keep<4>(); break;
+        case 5: barrier_dma_keep<5>(); break;
+        case 6: barrier_dma_keep<6>(); break;
+        case 7: barrier_dma_keep<7>(); break;
+        case 8: barrier_dma_keep<8>(); break;
+        case 9: barrier_dma_keep<9>(); break;
+        case 10: barrier_dma_keep<10>(); break;
+        default: barrier_dma_keep<0>(); break;
+    }
+}
+
 constexpr int M_MC = 16;                          // channels per chunk = one MFMA M tile
 constexpr int M_KS = kMaxStrip / 4;               // 25 k-steps
 constexpr int M_BKS = 3;                          // bf16 path: 3 k-steps of 32 cover k < 96
@@ -46,10 +64,14 @@ __host__ __device__ constexpr int m_lds_floats(int ns) {
     return 3 * M_MC * m_cp(ns) > M_SPP * M_SIMG ? 3 * M_MC * m_cp(ns) : M_SPP * M_SIMG;
 }
 
-// FULL: the strip needs all 25 k-steps and 7 n-tiles (97..100 long) -> no guards in the hot loop
+// FULL: compile-time shape -- all 25 k-steps and 7 n-tiles, every DMA piece and tile store issued (strips at least
+//       kFullMinStrip long, see cca_common.hpp) -> counted-vmcnt pipeline, no shape guards in the hot loop
 // BF: split-bf16 x3 on v_mfma_f32_16x16x32_bf16 for k < 96 (+ one exact f32 k-step for k = 96..99);
-//     only instantiated together with FULL (strips 97..100 long)
-template <int NS, bool ROW, bool TRANS, int EPI, bool FULL, bool BF>
+//     only instantiated together with FULL and only used for strips 96..100 long
+// EXACT (with FULL): strips 97..100 long -- every DMA piece and store piece of a full tile holds lanes of the tile, every
+//       k-step but the last lies inside the strip: plain lane masks, compile-time store count, unguarded k-steps (the
+//       headline geometry pays nothing for the generality of the FULL bodies)
+template <int NS, bool ROW, bool TRANS, int EPI, bool FULL, bool BF, bool EXACT = false>
 __device__ __forceinline__ void map_strip_body(float *lds, const float *__restrict__ T,
                                                const float *__restrict__ F, const float *__restrict__ resid,
                                                const float *__restrict__ gamma, float *out,
@@ -93,7 +115,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
         for (int pr = 0; pr < M_MC / NS; ++pr) {
             const int cc = wv + pr * NS, c = ch * M_MC + cc;
             float *dst = lds + buf * BUF + cc * CP;
-            strip_dma_channel<NS, ROW, FULL>(Fb, dst, (c < C ? c : C - 1) * HW * 4, npieces4, W, sl4);
+            strip_dma_channel<NS, ROW, FULL, EXACT>(Fb, dst, (c < C ? c : C - 1) * HW * 4, npieces4, W, sl4);
         }
     };
 
@@ -209,6 +231,11 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
     // The addend pieces come FIRST: the barrier in front of the tile stores then only has to wait for them
     // (counted vmcnt) and the feature pieces of the next chunk keep flying through the store phase.
     constexpr int QA = (EPI != EPI_COL) ? CPW * PIECES4 : 0, QF = CPW * PIECES4, QT = QA + QF;
+#ifndef CCA_DMA_SPAN
+#define CCA_DMA_SPAN 100         // per cent of the MFMA phase over which a chunk's DMA pieces are issued
+#endif
+    // piece schedule: slot s of n issues pieces [qlo(s, n), qlo(s + 1, n))
+    auto qlo = [](int s, int n) { const int v = s * QT * 100 / (n * CCA_DMA_SPAN); return v < QT ? v : QT; };
     // Branch-free in the FULL path: channels beyond C are clamped (they are output rows that are never
     // stored), and when there is no next chunk the current one is simply fetched again into the idle buffer.
     auto dma_piece = [&](int q, int ch, int chn, int buf) {
@@ -225,14 +252,22 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
         const int cc = wv + pr * NS;
         const int c = (feat ? chn : ch) * M_MC + cc;
         float *dst = lds + (feat ? (buf ^ 1) : 2) * BUF + cc * CP + m * 256;
-        if (sl4.valid(m))
+        if constexpr (FULL && !EXACT) {
+            // every piece is issued (the counted waits rely on it): lanes inside the image but beyond the tile fetch from an
+            // out-of-range offset (zeros land), so no piece ever loses all its lanes
+            if (sl4.in_image(m, lane_))
+                fbuf_load_to_lds_x4(feat ? Fb : Ab, dst, sl4.full_offset(m), (c < C ? c : C - 1) * HW * 4 + sl4.piece_soff(m, W));
+        } else if (sl4.valid(m))
             fbuf_load_to_lds_x4(feat ? Fb : Ab, dst, sl4.vb, (c < C ? c : C - 1) * HW * 4 + sl4.piece_soff(m, W));
     };
-    // counted waits need every wave to issue exactly QA + QF pieces and at least NSTORE_MIN stores per chunk
-    const bool fast = FULL && gvalid == NS;       // full tile of 97..100-long strips: 16-byte granule stores
+    // counted waits need every wave to issue exactly QA + QF pieces per chunk (FULL bodies do, whatever the strip length)
+    const bool fast = FULL && gvalid == NS;       // full tile of strips >= kFullMinStrip long: 16-byte granule stores
+    const bool kfull = EXACT || L >= 4 * (M_KS - 1);       // every k-step but the last lies inside the strip
     const bool counted = fast && (C % M_MC == 0);
-    // guaranteed number of 16-byte tile stores per wave and chunk on the fast path (counted vmcnt): the column
-    // launch stores PIECES4 granule pieces per channel, the row launch one piece per 64 granules of NS * 24
+    // 16-byte tile stores a wave issues per chunk on the fast path: per channel, the column launch stores one piece per
+    // four bands of NS rows, the row launch one piece per 64 granules of its NS rows (+ one instruction for a ragged tail)
+    const int nstore = CPW * (ROW ? ((L >> 2) * NS + 63) / 64 + ((L & 3) ? 1 : 0) : ((L + NS - 1) / NS + 3) / 4);
+    // EXACT: at least this many, known at compile time (97..100: 24 full granules per row; 13 bands of rows)
     constexpr int NSTORE_MIN = ROW ? CPW * ((NS * 24 + 63) / 64) : CPW * PIECES4;
 
     for (int it = 0; it < nmine; ++it) {
@@ -261,7 +296,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                     for (int t = 0; t < kMaxTiles; ++t) {
                         const int sidx = ks * kMaxTiles + t;
 #pragma unroll
-                        for (int q = sidx * QT / SLOTS; q < (sidx + 1) * QT / SLOTS; ++q) dma_piece(q, ch, chn, buf);
+                        for (int q = qlo(sidx, SLOTS); q < qlo(sidx + 1, SLOTS); ++q) dma_piece(q, ch, chn, buf);
                         acc[t] = mfma_bf16_16x16x32(sp.hi, bh[ks][t], acc[t]);
                         acc[t] = mfma_bf16_16x16x32(sp.hi, bl[ks][t], acc[t]);
                         acc[t] = mfma_bf16_16x16x32(sp.lo, bh[ks][t], acc[t]);
@@ -277,7 +312,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                     for (int t = 0; t < kMaxTiles; ++t) {
                         const int sidx = M_BKS * kMaxTiles + t;
 #pragma unroll
-                        for (int q = sidx * QT / SLOTS; q < (sidx + 1) * QT / SLOTS; ++q) dma_piece(q, ch, chn, buf);
+                        for (int q = qlo(sidx, SLOTS); q < qlo(sidx + 1, SLOTS); ++q) dma_piece(q, ch, chn, buf);
                         acc[t] = mfma_16x16x4(a, btail[t], acc[t]);
                     }
                 }
@@ -286,7 +321,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
             for (int ks = 0; ks < M_KS; ++ks) {
                 // this k-step's share of the DMA pieces: next feature chunk + this chunk's addend tile
 #pragma unroll
-                for (int q = ks * QT / M_KS; q < (ks + 1) * QT / M_KS; ++q) dma_piece(q, ch, chn, buf);
+                for (int q = qlo(ks, M_KS); q < qlo(ks + 1, M_KS); ++q) dma_piece(q, ch, chn, buf);
 #ifdef CCA_ABL_NOMFMA
                 if (ks < 2) {
 #else
@@ -296,7 +331,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                     const float araw = CCA_LDS_LD(ab + koff);
                     // K padding: zero the A operand as well as the B fragment (see the bf16 path); only the last
                     // k-step of a full strip can hold padding
-                    const float a = (FULL && ks < M_KS - 1) ? araw : ((ks * 4 + lk < L) ? araw : 0.f);
+                    const float a = (FULL && kfull && ks < M_KS - 1) ? araw : ((ks * 4 + lk < L) ? araw : 0.f);
 #pragma unroll
                     for (int t = 0; t < kMaxTiles; ++t)
                         if (FULL || t < nt) acc[t] = mfma_16x16x4(a, bf[ks][t], acc[t]);
@@ -449,9 +484,16 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
             }
         }
         }
-        // images free for the next iteration and chunk ch+1 landed; the tile stores stay in flight
-        if (counted) barrier_dma_keep<NSTORE_MIN>();
-        else         barrier_lds_only();
+        // images free for the next iteration and chunk ch+1 landed; the tile stores -- exactly nstore per wave, the
+        // youngest operations -- stay in flight (vector-memory operations retire in issue order: stress-tested under
+        // concurrent HBM load, tools/stress_stage.py; an out-of-range, i.e. dropped, store does NOT: never issue one here)
+        if constexpr (EXACT) {
+            if (counted) barrier_dma_keep<NSTORE_MIN>();
+            else         barrier_lds_only();
+        } else {
+            if (counted) barrier_dma_keep_n(nstore);
+            else         barrier_lds_only();
+        }
     }
 }
 
@@ -467,10 +509,14 @@ __global__ __launch_bounds__(kWave * NS, 2) void map_strip_kernel(const float *_
     CCA_LDS_REGISTER(lds);
     const int L = ROW ? W : H;
     const int wg_linear = blockIdx.x, wg_count = gridDim.x;
-    if constexpr (BF) {           // the host only selects BF for strips 97..100 long
-        map_strip_body<NS, ROW, TRANS, EPI, true, true>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs, rbs, obs);
+    const bool exact = L > 4 * (M_KS - 1);
+    if constexpr (BF) {           // the host only selects BF for strips 96..100 long
+        if (exact) map_strip_body<NS, ROW, TRANS, EPI, true, true, true>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs, rbs, obs);
+        else       map_strip_body<NS, ROW, TRANS, EPI, true, true, false>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs, rbs, obs);
     } else {
-        if (L > (M_KS - 1) * 4)
+        if (exact)
+            map_strip_body<NS, ROW, TRANS, EPI, true, false, true>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs, rbs, obs);
+        else if (L >= kFullMinStrip)
             map_strip_body<NS, ROW, TRANS, EPI, true, false>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs, rbs, obs);
         else
             map_strip_body<NS, ROW, TRANS, EPI, false, false>(lds, T, F, resid, gamma, out, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs, rbs, obs);
@@ -498,8 +544,11 @@ __global__ __launch_bounds__(kWave * NS, 2) void map_strip_dual_kernel(const flo
         if (!second) map_strip_body<NS, ROW, false, EPI, true, true>(lds, T, F0, nullptr, gamma, out0, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs0, 0, obs0);
         else         map_strip_body<NS, ROW, true, EPI, true, true>(lds, T, F1, nullptr, gamma, out1, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs1, 0, obs1);
     } else {
-        const bool full = L > (M_KS - 1) * 4;
-        if (!second) {
+        const bool full = L >= kFullMinStrip, exact = L > 4 * (M_KS - 1);
+        if (exact) {
+            if (!second) map_strip_body<NS, ROW, false, EPI, true, false, true>(lds, T, F0, nullptr, gamma, out0, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs0, 0, obs0);
+            else         map_strip_body<NS, ROW, true, EPI, true, false, true>(lds, T, F1, nullptr, gamma, out1, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs1, 0, obs1);
+        } else if (!second) {
             if (full) map_strip_body<NS, ROW, false, EPI, true, false>(lds, T, F0, nullptr, gamma, out0, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs0, 0, obs0);
             else      map_strip_body<NS, ROW, false, EPI, false, false>(lds, T, F0, nullptr, gamma, out0, C, H, W, chunks_per_block, tiles, nsplit, wg_linear, wg_count, fbs0, 0, obs0);
         } else {

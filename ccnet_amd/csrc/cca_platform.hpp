@@ -110,6 +110,9 @@ __device__ __forceinline__ void barrier_dma_keep() {
     asm volatile("" ::: "memory");
 }
 
+// this wave's outstanding vector-memory operations (LDS-DMA pieces, loads, stores) have all completed
+__device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 #define CCA_LDS_REGISTER(arr) do { } while (0)
 #define CCA_LDS_LD(p) (*(p))
 #define CCA_LDS_ST(p, v) do { *(p) = (v); } while (0)

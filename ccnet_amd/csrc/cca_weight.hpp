@@ -32,7 +32,8 @@ __host__ __device__ constexpr int w_cpmax(int ns) { return w_pieces(ns) * 64 + 1
 __host__ __device__ constexpr int w_op(int ns) { return W_KC * w_cpmax(ns); }   // floats per operand per buffer
 __host__ __device__ constexpr int w_lds_floats(int ns) { return 6 * w_op(ns); }  // 2 operands x 3 buffers (162,816 B at NS = 8)
 
-// FULL: the strip needs all 7x7 tiles (97..100 long) -> no per-tile guards in the hot loop
+// FULL: compile-time shape -- all 7x7 tiles, every DMA piece issued (strips at least kFullMinStrip long, see
+//       cca_common.hpp) -> counted-vmcnt pipeline, no per-tile guards in the hot loop
 // BF: packed split-bf16 (one v_mfma_f32_16x16x32_bf16 per tile and 8-channel chunk, see bf16_pack_a/b) instead
 //     of two exact f32 k-steps
 template <int NS, bool ROW, bool MASK, bool FULL, bool BF>
@@ -90,7 +91,11 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
         const int pair = wv + pr * NS;
         const int op = pair / W_KC, cc = pair % W_KC;
         const int c = (c0 + cc < Cx) ? c0 + cc : Cx - 1;
-        if (sl.valid(m))
+        if (FULL) {            // always issued (counted vmcnt); lanes beyond the tile deposit zeros
+            if (sl.in_image(m, lane))
+                fbuf_load_to_lds_x4(op ? Yb : Xb, lds + (buf * 2 + op) * OP + cc * CP + m * 256,
+                                    sl.full_offset(m), c * HW * 4 + sl.piece_soff(m, W));
+        } else if (sl.valid(m))
             fbuf_load_to_lds_x4(op ? Yb : Xb, lds + (buf * 2 + op) * OP + cc * CP + m * 256, sl.vb,
                                 c * HW * 4 + sl.piece_soff(m, W));
     };
@@ -203,7 +208,8 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
 // tiles per image cannot fill 256 CUs): split s contracts channels [s * cps * 8, (s + 1) * cps * 8) and writes the
 // partial result to slab s -- slab 0 is T, slab s >= 1 is extra + (s - 1) * slab_stride -- and the consumer (the
 // softmax kernels) adds the slabs in a fixed order.
-template <int NS, bool MASK, bool BF>
+// KS: the K split is in use (otherwise ksplit == 1 and the channel range is the compile-time [0, Cx))
+template <int NS, bool MASK, bool BF, bool KS = false>
 __global__ __launch_bounds__(kWave * NS, 2) void weight_strip_kernel(const float *__restrict__ X,
                                                                       const float *__restrict__ Y,
                                                                       float *__restrict__ T, int Cx, int H, int W,
@@ -215,14 +221,14 @@ __global__ __launch_bounds__(kWave * NS, 2) void weight_strip_kernel(const float
     const int per_image = tiles_col + tiles_row;
     const int id = xcd_logical_id(blockIdx.x, gridDim.x);
     const int bs = id / per_image, t = id - bs * per_image;
-    const int b = bs / ksplit, split = bs - b * ksplit;
-    const int c_begin = split * cps * W_KC;
-    const int c_end = (c_begin + cps * W_KC < Cx) ? c_begin + cps * W_KC : Cx;
-    float *Tout = split == 0 ? T : extra + (size_t)(split - 1) * slab_stride;
+    const int b = KS ? bs / ksplit : bs, split = KS ? bs - b * ksplit : 0;
+    const int c_begin = KS ? split * cps * W_KC : 0;
+    const int c_end = KS ? ((c_begin + cps * W_KC < Cx) ? c_begin + cps * W_KC : Cx) : Cx;
+    float *Tout = (!KS || split == 0) ? T : extra + (size_t)(split - 1) * slab_stride;
     const bool row = t >= tiles_col;
     const int tile = row ? t - tiles_col : t;
     const int L = row ? W : H;
-    const bool full = L > (kMaxTiles - 1) * kTile;
+    const bool full = L >= kFullMinStrip;
     if (row) {
         if (full) weight_strip_body<NS, true, MASK, true, BF>(lds, b, tile, X, Y, Tout, Cx, c_begin, c_end, H, W, xbs, ybs);
         else      weight_strip_body<NS, true, MASK, false, BF>(lds, b, tile, X, Y, Tout, Cx, c_begin, c_end, H, W, xbs, ybs);

@@ -57,6 +57,7 @@ __device__ inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
 }
 
 __device__ inline void mfma_f32_result_fence() {}
+__device__ inline void wait_vmem_all() {}
 __device__ inline int uniform(int v) { return v; }
 __device__ inline int recompute_here(int v) { return v; }
 
