@@ -44,6 +44,8 @@ _PROTOTYPES = {
     "ccnet_ca_softmax_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, _P]),
     "ccnet_ca_map_forward_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ccnet_ca_map_forward_pm_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_long, c_int, _P]),
+    "ccnet_ca_strip_map_pm_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_long, c_int, c_long, c_int,
+                                          c_int, c_int, _P]),
     "ccnet_ca_map_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ccnet_cca_forward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ccnet_cca_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t,

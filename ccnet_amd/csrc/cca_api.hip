@@ -8,6 +8,7 @@
 #include "cca_common.hpp"
 #include "cca_band.hpp"
 #include "cca_direct.hpp"
+#include "cca_gmap.hpp"
 #include "cca_map.hpp"
 #include "cca_long.hpp"
 #include "cca_softmax.hpp"
@@ -636,6 +637,26 @@ int ccnet_ca_map_forward_pm_f32(const float *A, const float *v, const float *x, 
     CCA_LAUNCH((cca::map_band_fwd_kernel<100>), dim3((unsigned)(B * ncg * nb)), dim3(cca::BD_THREADS), stream,
                A, v, x, gamma, out, C, H, W, nb, rpb, ncg, v_bs, v_ps);
     return launch_status("ca_map_forward_pm");
+}
+
+int ccnet_ca_strip_map_pm_f32(const float *T, const float *F, const float *addend, const float *gamma, float *out,
+                              int B, int C, int H, int W, long f_bs, int f_ps, long o_bs, int o_ps,
+                              int row, int trans, ccnet_stream_t stream) {
+    if (int e = check_shape(B, C, H, W)) return e;
+    if (!T || !F || !out) return fail(CCNET_E_NULLPTR, "ca_strip_map_pm: null tensor");
+    if ((H > W ? H : W) > 100 || C % 4) return fail(CCNET_E_BADSHAPE, "ca_strip_map_pm: strips <= 100, C % 4 == 0");
+    const dim3 grid((unsigned)(B * (row ? H : W))), block(cca::GM_THREADS);
+#define CCA_GMAP(ROW_, TRANS_)                                                                                          \
+    do {                                                                                                                \
+        if (addend) CCA_LAUNCH((cca::gmap_kernel<100, ROW_, TRANS_, cca::GM_EPI_PM_ADD>), grid, block, stream, T, F,     \
+                               addend, gamma, out, C, H, W, f_bs, f_ps, o_bs, o_ps);                                    \
+        else        CCA_LAUNCH((cca::gmap_kernel<100, ROW_, TRANS_, cca::GM_EPI_PM>), grid, block, stream, T, F, addend, \
+                               gamma, out, C, H, W, f_bs, f_ps, o_bs, o_ps);                                            \
+    } while (0)
+    if (row) { if (trans) CCA_GMAP(true, true); else CCA_GMAP(true, false); }
+    else     { if (trans) CCA_GMAP(false, true); else CCA_GMAP(false, false); }
+#undef CCA_GMAP
+    return launch_status("ca_strip_map_pm");
 }
 
 int ccnet_ca_map_backward_f32(const float *dout, const float *A, const float *v, const float *gamma,

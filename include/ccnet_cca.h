@@ -123,6 +123,14 @@ int ccnet_ca_map_forward_f32(const float *A, const float *v, const float *x, con
 int ccnet_ca_map_forward_pm_f32(const float *A, const float *v, const float *x, const float *gamma, float *out,
                                 int B, int C, int H, int W, long v_bs, int v_ps, ccnet_stream_t stream);
 
+/* One branch of a map-type contraction on PIXEL-MAJOR features (csrc/cca_gmap.hpp): per strip g of the branch
+ * (row != 0: rows, else columns)  out[pixel, c] = alpha * sum P_g * F [+ addend[pixel, c]]  with the strip's attention
+ * block P_g taken from T (B,H,W,H+W) as is (trans == 0: ca_map_forward / dq) or transposed (trans != 0: dv / dk).
+ * F, addend and out are (B, H*W, pixel stride) fp32; addend (may be NULL) and out share strides and may alias. */
+int ccnet_ca_strip_map_pm_f32(const float *T, const float *F, const float *addend, const float *gamma, float *out,
+                              int B, int C, int H, int W, long f_bs, int f_ps, long o_bs, int o_ps,
+                              int row, int trans, ccnet_stream_t stream);
+
 /* Adjoint of the aggregation (autograd of functions.py:42-47):
  *   dA (B,H,W,H+W) = un-scaled map adjoint  (sum_c dout * v at the slot's source pixel); may be NULL
  *   dv (B,C,H,W)   = g * (A^T-weighted sums of dout), g = *gamma (1 if NULL); may be NULL */
