@@ -56,9 +56,10 @@ constexpr int EPI_COL = 0, EPI_ROW = 1, EPI_COL_RESID = 2;    // column launch w
 // channel pitch of the LDS image: pieces * 64 + 20 (a multiple of 4 so that 16-byte LDS reads of the tile-store
 // phase stay aligned; >= NS*L + 3 for the K-padding reads)
 __host__ __device__ constexpr int m_cp(int ns) { return strip_pieces_c(ns) * 64 + 20; }
-// prologue images of the attention blocks: 4 strips x 100 rows x pitch 102 (>= 100, == 2 mod 4: the
-// stride-pitch fragment reads of the non-transposed orientation are bank-conflict-free)
-constexpr int M_PP = kMaxStrip + 2, M_SIMG = kMaxStrip * M_PP, M_SPP = 4;
+// prologue images of the attention blocks: 4 strips x 100 rows x pitch 100 = 25 16-byte DMA lanes per row, rows back
+// to back, so one LDS-DMA instruction moves 2.56 rows (pitch 102 made the fragment reads conflict-free but needed
+// 4-byte DMA lanes: 5x the instructions, ~4.5 us of every launch)
+constexpr int M_PP = kMaxStrip, M_SIMG = kMaxStrip * M_PP, M_SPP = 4;
 // LDS: max(2 feature buffers + addend image, prologue images) = 40,896 floats = 163,584 B of 163,840 B
 __host__ __device__ constexpr int m_lds_floats(int ns) {
     return 3 * M_MC * m_cp(ns) > M_SPP * M_SIMG ? 3 * M_MC * m_cp(ns) : M_SPP * M_SIMG;
@@ -138,13 +139,12 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                 const int gs = g0 + ph * SPP + s;
                 if (gs >= br.G) continue;
                 float *img = lds + s * SIMG;
-                for (int iq = wv; iq < L; iq += NS) {
-                    const int soff = 4 * (iq * br.as_q + gs * br.as_g + br.a_off);
-#pragma unroll
-                    for (int pc = 0; pc < 2; ++pc) {
-                        const int j = pc * 64 + lane;
-                        if (j < L) fbuf_load_to_lds(Tb, img + iq * PP + pc * 64, 4 * j, soff);
-                    }
+                // lane idx of the image = (row idx / 25, 16-byte chunk idx % 25); the last chunk of a row reads up to 3
+                // slots past the strip's L (the pixel's other branch / the next pixel): never used as operands
+                const int soff = 4 * (gs * br.as_g + br.a_off), nit = (L * (PP / 4) + 63) / 64;
+                for (int it = wv; it < nit; it += NS) {
+                    const int idx = 64 * it + lane, iq = idx / (PP / 4), chk = idx - iq * (PP / 4);
+                    if (iq < L && 4 * chk < L) fbuf_load_to_lds_x4(Tb, img + 256 * it, 4 * iq * br.as_q + 16 * chk, soff);
                 }
             }
             __syncthreads();                              // images landed (vmcnt drained by the barrier)
@@ -204,7 +204,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
 
     // masked DMA lanes leave their LDS slots untouched, and slots just past a strip are read as K padding (and then
     // discarded): start from an all-zero LDS so that what is read there is at least defined
-    for (int idx = tid; idx < 3 * BUF; idx += kBlock) CCA_LDS_ST(&lds[idx], 0.f);
+    for (int idx = 4 * tid; idx < 3 * BUF; idx += 4 * kBlock) lds_store_x4(&lds[idx], f32x4{0.f, 0.f, 0.f, 0.f});
     __syncthreads();
     // Chunk order.  The column launch of a pair walks its channel chunks upwards, the row launch (which runs right
     // after it) DOWNWARDS: the column launch's last chunks -- features, and the partial sums it has just written --

@@ -429,8 +429,10 @@ def test_precision_modes_leave_short_strips_exact(ops):
 
 def test_lds_layouts_stay_near_conflict_free():
     """The swizzle / pitch constants of the DMA images: the weight kernel's fragment reads are conflict-free,
-    the map kernel's are at most 2-way and its result write-back at most 4-way; on average an LDS access must
-    stay below 1.75x the conflict-free cost (2 cycles per wave64 ds_read_b32 / ds_write_b32)."""
+    the map kernel's are at most 2-way and its result write-back at most 4-way.  With C = 16 there is ONE chunk per
+    workgroup, so the once-per-workgroup prologue dominates this count: its attention images have pitch 100 (16-byte
+    DMA lanes, 5x fewer DMA instructions) and their fragment reads are 2-way conflicted -- measured on MI355X the
+    trade is a net win (profiles/r02f).  Budget: 2.25x the conflict-free cost (2 cycles per wave64 ds_read_b32)."""
     os.environ["CCA_EMU_LDS"] = "1"
     try:
         o = EmuOps()
@@ -441,7 +443,7 @@ def test_lds_layouts_stay_near_conflict_free():
         o.cca_backward(c["dy"], c["q"], c["k"], c["v"], A, c["gamma"])
         rd_i, rd_c, wr_i, wr_c, mfma, launches = emu_stats(o, reset=True)
         assert rd_i > 0 and wr_i > 0 and mfma > 0
-        assert rd_c <= 3.5 * rd_i
+        assert rd_c <= 4.5 * rd_i
         assert wr_c <= 4.5 * wr_i        # dominated by the 4-way conflicted result write-back (28 per chunk)
         o.set_impl(0)
     finally:
