@@ -444,7 +444,8 @@ def test_lds_layouts_stay_near_conflict_free():
         rd_i, rd_c, wr_i, wr_c, mfma, launches = emu_stats(o, reset=True)
         assert rd_i > 0 and wr_i > 0 and mfma > 0
         assert rd_c <= 4.5 * rd_i
-        assert wr_c <= 4.5 * wr_i        # dominated by the 4-way conflicted result write-back (28 per chunk)
+        assert wr_c <= 4.75 * wr_i       # the 4-way conflicted result write-back (28 per chunk) is all that is counted:
+                                         # the conflict-free zero fill went to 16-byte stores, which are not instrumented
         o.set_impl(0)
     finally:
         os.environ.pop("CCA_EMU_LDS", None)
