@@ -648,10 +648,12 @@ int ccnet_ca_strip_map_pm_f32(const float *T, const float *F, const float *adden
     const dim3 grid((unsigned)(B * (row ? H : W))), block(cca::GM_THREADS);
 #define CCA_GMAP(ROW_, TRANS_)                                                                                          \
     do {                                                                                                                \
-        if (addend) CCA_LAUNCH((cca::gmap_kernel<100, ROW_, TRANS_, cca::GM_EPI_PM_ADD>), grid, block, stream, T, F,     \
-                               addend, gamma, out, C, H, W, f_bs, f_ps, o_bs, o_ps);                                    \
-        else        CCA_LAUNCH((cca::gmap_kernel<100, ROW_, TRANS_, cca::GM_EPI_PM>), grid, block, stream, T, F, addend, \
-                               gamma, out, C, H, W, f_bs, f_ps, o_bs, o_ps);                                            \
+        if (addend) CCA_LAUNCH((cca::gmap_kernel<100, ROW_, TRANS_, true, float, float>), grid, block, stream, T, F,     \
+                               addend, (const float *)nullptr, gamma, out, C, H, W, f_bs, f_ps, o_bs, o_ps, 0L, 0,      \
+                               o_bs, o_ps);                                                                             \
+        else        CCA_LAUNCH((cca::gmap_kernel<100, ROW_, TRANS_, false, float, float>), grid, block, stream, T, F,    \
+                               addend, (const float *)nullptr, gamma, out, C, H, W, f_bs, f_ps, o_bs, o_ps, 0L, 0,      \
+                               o_bs, o_ps);                                                                             \
     } while (0)
     if (row) { if (trans) CCA_GMAP(true, true); else CCA_GMAP(true, false); }
     else     { if (trans) CCA_GMAP(false, true); else CCA_GMAP(false, false); }
@@ -797,6 +799,113 @@ int ccnet_cca_backward_bf16(const uint16_t *dy_, const uint16_t *q_, const uint1
     return launch_status("cca_backward_bf16(dk)");
 }
 
+
+/* ---- pixel-major bf16 path (cca_gmap.hpp): bf16 features as (B, H*W, pixel stride) views, fp32 attention ---- */
+extern "C++" {
+namespace {
+using cca::bf16_t;
+int check_pm_view(const char *what, long bs, int ps, int C, int H, int W) {
+    if (ps < C || ps % 8 || bs < (long)(H * W - 1) * ps + C || bs % 8) return fail(CCNET_E_BADSHAPE, what);
+    if ((double)H * W * ps >= 536870912.0) return fail(CCNET_E_BADSHAPE, what);
+    return 0;
+}
+// out = bf16(alpha * contraction + resid): column strips into the fp32 partial, row strips add it and round once
+template <int P, bool TRANS>
+int launch_gmap_bf16(const float *T, const bf16_t *F, const bf16_t *resid, const float *gamma, bf16_t *out,
+                     float *partial, int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs,
+                     int ops, ccnet_stream_t stream) {
+    const long pbs = (long)H * W * C;
+    CCA_LAUNCH((cca::gmap_kernel<P, false, TRANS, false, bf16_t, float>), dim3((unsigned)(B * W)), dim3(cca::GM_THREADS),
+               stream, T, F, (const float *)nullptr, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0,
+               0L, 0, pbs, C);
+    if (int e = launch_status("gmap_bf16(column)")) return e;
+    CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, bf16_t, bf16_t>), dim3((unsigned)(B * H)), dim3(cca::GM_THREADS),
+               stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C, rbs, rps, obs, ops);
+    return launch_status("gmap_bf16(row)");
+}
+template <bool TRANS>
+int gmap_bf16(const float *T, const bf16_t *F, const bf16_t *resid, const float *gamma, bf16_t *out, float *partial,
+              int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops,
+              ccnet_stream_t stream) {
+    if ((H > W ? H : W) <= 100)
+        return launch_gmap_bf16<100, TRANS>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+    return launch_gmap_bf16<132, TRANS>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+}
+template <bool MASK>
+int gweight_bf16(const bf16_t *X, const bf16_t *Y, float *T, int B, int Cx, int H, int W, long xbs, int xps, long ybs,
+                 int yps, ccnet_stream_t stream) {
+    const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
+    if ((H > W ? H : W) <= 100) CCA_LAUNCH((cca::gweight_kernel<100, MASK>), grid, block, stream, X, Y, T, Cx, H, W, xbs, xps, ybs, yps);
+    else                        CCA_LAUNCH((cca::gweight_kernel<132, MASK>), grid, block, stream, X, Y, T, Cx, H, W, xbs, xps, ybs, yps);
+    return launch_status("gweight_bf16");
+}
+int check_pm_problem(const char *what, int B, int C, int Cq, int H, int W) {
+    if (int e = check_shape(B, C, H, W)) return e;
+    if (int e = check_shape(B, Cq, H, W)) return e;
+    if ((H > W ? H : W) > 132 || C % 8 || Cq % 8) return fail(CCNET_E_BADSHAPE, what);
+    return 0;
+}
+}  // namespace
+}  // extern "C++"
+
+size_t ccnet_cca_pm_bf16_workspace_bytes(int B, int C, int Cq, int H, int W, int backward) {
+    if (B <= 0 || C <= 0 || Cq <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t partial = (size_t)B * H * W * (C > Cq ? C : Cq) * sizeof(float);
+    return (backward ? align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W)) : 0) + partial;
+}
+
+int ccnet_cca_forward_pm_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v, const uint16_t *x,
+                              const float *gamma, uint16_t *y, float *A, int B, int C, int Cq, int H, int W,
+                              long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long x_bs, int x_ps,
+                              long y_bs, int y_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
+    if (int e = require_both_branches("cca_forward_pm_bf16")) return e;
+    if (!q || !k || !v || !x || !gamma || !y || !A) return fail(CCNET_E_NULLPTR, "cca_forward_pm_bf16: null tensor");
+    if (int e = check_pm_problem("cca_forward_pm_bf16: strips <= 132, C % 8 == 0, Cq % 8 == 0", B, C, Cq, H, W)) return e;
+    if (int e = check_pm_view("cca_forward_pm_bf16: q view", q_bs, q_ps, Cq, H, W)) return e;
+    if (int e = check_pm_view("cca_forward_pm_bf16: k view", k_bs, k_ps, Cq, H, W)) return e;
+    if (int e = check_pm_view("cca_forward_pm_bf16: v view", v_bs, v_ps, C, H, W)) return e;
+    if (int e = check_pm_view("cca_forward_pm_bf16: x view", x_bs, x_ps, C, H, W)) return e;
+    if (int e = check_pm_view("cca_forward_pm_bf16: y view", y_bs, y_ps, C, H, W)) return e;
+    if (!workspace || workspace_bytes < ccnet_cca_pm_bf16_workspace_bytes(B, C, Cq, H, W, 0))
+        return fail(CCNET_E_WORKSPACE, "cca_forward_pm_bf16: workspace missing or too small");
+    if (int e = gweight_bf16<true>((const bf16_t *)q, (const bf16_t *)k, A, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
+    if (int e = softmax_forward(A, A, B, H, W, stream)) return e;
+    return gmap_bf16<false>(A, (const bf16_t *)v, (const bf16_t *)x, gamma, (bf16_t *)y, (float *)workspace, B, C, H, W,
+                            v_bs, v_ps, x_bs, x_ps, y_bs, y_ps, stream);
+}
+
+int ccnet_cca_backward_pm_bf16(const uint16_t *dy, const uint16_t *q, const uint16_t *k, const uint16_t *v,
+                               const float *A, const float *gamma, uint16_t *dq, uint16_t *dk, uint16_t *dv,
+                               float *dgamma, float *scratch, int B, int C, int Cq, int H, int W,
+                               long dy_bs, int dy_ps, long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
+                               long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
+                               void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
+    if (int e = require_both_branches("cca_backward_pm_bf16")) return e;
+    if (!dy || !q || !k || !v || !A || !gamma || !dq || !dk || !dv || !dgamma || !scratch)
+        return fail(CCNET_E_NULLPTR, "cca_backward_pm_bf16: null tensor");
+    if (int e = check_pm_problem("cca_backward_pm_bf16: strips <= 132, C % 8 == 0, Cq % 8 == 0", B, C, Cq, H, W)) return e;
+    if (int e = check_pm_view("cca_backward_pm_bf16: dy view", dy_bs, dy_ps, C, H, W)) return e;
+    if (int e = check_pm_view("cca_backward_pm_bf16: q view", q_bs, q_ps, Cq, H, W)) return e;
+    if (int e = check_pm_view("cca_backward_pm_bf16: k view", k_bs, k_ps, Cq, H, W)) return e;
+    if (int e = check_pm_view("cca_backward_pm_bf16: v view", v_bs, v_ps, C, H, W)) return e;
+    if (int e = check_pm_view("cca_backward_pm_bf16: dq view", dq_bs, dq_ps, Cq, H, W)) return e;
+    if (int e = check_pm_view("cca_backward_pm_bf16: dk view", dk_bs, dk_ps, Cq, H, W)) return e;
+    if (int e = check_pm_view("cca_backward_pm_bf16: dv view", dv_bs, dv_ps, C, H, W)) return e;
+    if (!workspace || workspace_bytes < ccnet_cca_pm_bf16_workspace_bytes(B, C, Cq, H, W, 1))
+        return fail(CCNET_E_WORKSPACE, "cca_backward_pm_bf16: workspace missing or too small");
+    const size_t sm = align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W));
+    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + sm);
+    // t = un-scaled dA (functions.py:110-112 through the aggregation's adjoint), dv = gamma * A^T-weighted dy
+    if (int e = gweight_bf16<false>((const bf16_t *)dy, (const bf16_t *)v, scratch, B, C, H, W, dy_bs, dy_ps, v_bs, v_ps, stream)) return e;
+    if (int e = gmap_bf16<true>(A, (const bf16_t *)dy, nullptr, gamma, (bf16_t *)dv, partial, B, C, H, W, dy_bs, dy_ps,
+                                0L, 0, dv_bs, dv_ps, stream)) return e;
+    // dgamma = sum A t;  dE = gamma * A * (t - sum_s A t), in place
+    if (int e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, sm, B, H, W, stream, KSplit())) return e;
+    if (int e = gmap_bf16<false>(scratch, (const bf16_t *)k, nullptr, nullptr, (bf16_t *)dq, partial, B, Cq, H, W, k_bs, k_ps,
+                                 0L, 0, dq_bs, dq_ps, stream)) return e;
+    return gmap_bf16<true>(scratch, (const bf16_t *)q, nullptr, nullptr, (bf16_t *)dk, partial, B, Cq, H, W, q_bs, q_ps,
+                           0L, 0, dk_bs, dk_ps, stream);
+}
 
 int ccnet_cca_mfma_selftest(float *scratch, ccnet_stream_t stream) {
     if (!scratch) return fail(CCNET_E_NULLPTR, "mfma_selftest: null scratch");

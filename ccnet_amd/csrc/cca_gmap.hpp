@@ -1,59 +1,137 @@
-// cca_gmap.hpp -- strip aggregation on PIXEL-MAJOR features: one strip per workgroup, the strip's attention block
-// stationary in LDS as pre-split bf16, channel groups of 64 streaming through.
+// cca_gmap.hpp -- the strip contractions on PIXEL-MAJOR features: one strip per workgroup, channel groups of 64
+// streaming through LDS.  Feature element type fp32 or bf16 (BASELINE configs[4]: bf16 I/O, fp32 attention / softmax /
+// accumulation).
 //
-//   TRANS = false   out[pixel(i, g), c] (+)= alpha * sum_j P_g[i][j] * F[pixel(j, g), c]
-//   TRANS = true    out[pixel(j, g), c] (+)= alpha * sum_i P_g[i][j] * F[pixel(i, g), c]
-//   with P_g[i][j] = T[b, pixel(i, g), a_off + j]  (cca_map.hpp has the same contractions on NCHW features)
+//   gmap_kernel     TRANS = false   out[pixel(i, g), c] (+)= alpha * sum_j P_g[i][j] * F[pixel(j, g), c]
+//                   TRANS = true    out[pixel(j, g), c] (+)= alpha * sum_i P_g[i][j] * F[pixel(i, g), c]
+//                   with P_g[i][j] = T[b, pixel(i, g), a_off + j]  (cca_map.hpp has the same contractions on NCHW)
+//   gweight_kernel  T[b, pixel(i, g), a_off + j] = sum_c X[pixel(i, g), c] * Y[pixel(j, g), c]      (bf16 features)
 //
 // Why another kernel family: in NCHW the column branch of a strip tile is a stream of 32-byte segments (8 strips x
-// 4 B), which the L1 / TA path serves at a third of the row rate -- the column launches of cca_map.hpp are the
-// slowest kernels of a step.  With the features PIXEL-MAJOR (B, H*W, pixel stride) -- the layout the value projection
-// has when it is computed as x^T W^T -- a pixel's 64 channels are one 256-byte segment, for column strips and row
-// strips alike.
+// 4 B), which the L1 / TA path serves at a third of the row rate.  With the features PIXEL-MAJOR (B, H*W, pixel
+// stride) -- the layout of a channels_last tensor, and of a projection computed as x^T W^T -- a pixel's 64 channels
+// are one 256-byte (fp32) / 128-byte (bf16) segment for column strips and row strips alike, the channel axis is the
+// contiguous one (so the K = channel contraction of gweight reads MFMA fragments straight out of LDS), and nothing
+// depends on the strip length being 97..100.
 //
-// Work decomposition (MI355X): workgroup = one strip g of one image, 4 wavefronts = the four 16-channel N tiles of a
-// 64-channel group.  Prologue: the L rows of P_g (contiguous in T) arrive by LDS-DMA and are rewritten ONCE as two
-// bf16 images (hi, lo = the split of cca_common.hpp; transposed for TRANS; zero beyond the strip), row pitch 272 B so
-// that a 16 x 32 MFMA A fragment is one ds_read_b128 per image and no VALU.  Then, per channel group: the L x 64
-// feature tile arrives by LDS-DMA (double-buffered, 4 pixels per instruction), each wavefront gathers its B fragments
-// (8 ds_read_b32 + split per k-step, reused by all 7 M tiles: 21 MFMAs per gather), accumulates 7 tiles of
-// v_mfma_f32_16x16x32_bf16 (+ one exact f32 step for a k remainder <= 4), adds the addend tile that the DMA dropped
-// into the output image, and the image leaves as 256-byte pixel rows.
+// gmap (MI355X): workgroup = one strip g of one image, 4 wavefronts = the four 16-channel N tiles of a 64-channel
+// group.  Prologue: the L rows of P_g (contiguous in T) arrive by LDS-DMA and are rewritten ONCE as two bf16 images
+// (hi, lo = the split of cca_common.hpp; transposed for TRANS; zero beyond the strip), row pitch 272 B, so that a
+// 16 x 32 MFMA A fragment is one ds_read_b128 per image and no VALU.  Per channel group: the L x 64 feature tile
+// arrives by LDS-DMA (double-buffered), each wavefront gathers its B fragments (fp32: 8 ds_read_b32 + hi/lo split,
+// 3 MFMAs per tile; bf16: 8 ds_read_u16 + pack, exact, 2 MFMAs per tile), accumulates up to 9 tiles of
+// v_mfma_f32_16x16x32_bf16 (+ one exact f32 step for a k remainder <= 4), adds the fp32 addend tile the DMA dropped
+// into the output image, and the image leaves as whole pixel rows (fp32 or rounded to bf16).
 #pragma once
 #include "cca_band.hpp"
 #include "cca_common.hpp"
+
+#include <type_traits>
 
 namespace cca {
 
 constexpr int GM_CG = 64;                       // channels per group = four MFMA N tiles
 constexpr int GM_THREADS = 256;
-constexpr int GM_PP = 4 * GM_CG + 8;            // floats per 4-pixel DMA piece of a feature tile (+8: bank spread)
+constexpr int GM_PP = 4 * GM_CG + 8;            // dwords per 4-pixel piece of an fp32 tile (+8: bank spread)
+constexpr int GM_PB = 8 * GM_CG / 2 + 8;        // dwords per 8-pixel piece of a bf16 tile (+8)
 constexpr int GM_BP = 68;                       // dwords per row of a bf16 attention image (136 bf16: 128 + pad)
-constexpr int GM_EPI_PM = 0, GM_EPI_PM_ADD = 1; // output pixel-major, without / with a pixel-major addend
 
-template <int P>
-struct GmapCfg {
-    static constexpr int NT = (P + 15) / 16;                // M tiles
-    static constexpr int NPF = (P + 3) / 4;                 // 4-pixel pieces per feature tile
-    static constexpr int FSZ = NPF * GM_PP;                 // floats per feature / output tile
-    static constexpr int ASZ = P * GM_BP;                   // dwords per bf16 image
-    static constexpr int TSZ = P * 4;                       // exact f32 k tail
-    static constexpr int OFF_PH = 0, OFF_PL = ASZ, OFF_PT = 2 * ASZ, OFF_F = 2 * ASZ + TSZ, OFF_O = OFF_F + 2 * FSZ;
-    static constexpr int LDS = OFF_O + 2 * FSZ;             // floats (P = 100: 40,400 = 161,600 B)
-    static constexpr int NPA = (P * (P / 4) + 63) / 64;     // DMA instructions of the raw attention block
-    static_assert(P % 4 == 0 && P <= 128, "GmapCfg: padded strip length");
-    static_assert(P * P <= 4 * FSZ, "the raw attention block is staged in the feature / output buffers");
+// ---- bf16 tiles: 8 pixels x 64 channels per 1 KiB DMA piece; the 16-byte chunk q of pixel p sits at chunk
+// ---- position q ^ (p & 7) (the DMA lane fetches the permuted source chunk), so that fragment reads of 16
+// ---- consecutive pixels at one chunk spread over the banks
+template <typename FT>
+struct GTile {
+    static constexpr bool BF = std::is_same<FT, bf16_t>::value;
+    static constexpr int PIX = BF ? 8 : 4;                          // pixels per DMA piece
+    static constexpr int PITCH = BF ? GM_PB : GM_PP;                // dwords per piece
+    __host__ __device__ static constexpr int pieces(int P) { return (P + PIX - 1) / PIX; }
+    __host__ __device__ static constexpr int size(int P) { return pieces(P) * PITCH; }       // dwords
 };
 
-template <int P, bool ROW, bool TRANS, int EPI>
-__global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__restrict__ T, const float *__restrict__ F,
+// one DMA piece of a pixel-major tile: pixels pix0 + i * pstep (i < n), channels c0 .. c0 + 63 of a tensor with
+// pixel stride ps (elements of FT); lane -> (pixel, 16-byte chunk)
+template <typename FT>
+__device__ __forceinline__ void gtile_dma_piece(const FBuf &src, float *img, int piece, int lane, int pix0, int pstep, int n,
+                                                int ps, int c0, int C) {
+    if constexpr (GTile<FT>::BF) {
+        const int p = lane >> 3, i = 8 * piece + p, q = (lane & 7) ^ (p & 7), c = c0 + 8 * q;
+        if (i < n && c < C) fbuf_load_to_lds_x4(src, img + piece * GM_PB, ((pix0 + i * pstep) * ps + c) * 2, 0);
+    } else {
+        const int i = 4 * piece + (lane >> 4), c = c0 + 4 * (lane & 15);
+        if (i < n && c < C) fbuf_load_to_lds_x4(src, img + piece * GM_PP, ((pix0 + i * pstep) * ps + c) * 4, 0);
+    }
+}
+// byte offset of channel c (0..63) of line position j inside a bf16 tile
+__device__ __forceinline__ int gtile_bf_byte(int j, int c) {
+    return ((j >> 3) * GM_PB + (j & 7) * 32) * 4 + ((((c >> 3) ^ (j & 7)) << 4) | ((c & 7) << 1));
+}
+__device__ __forceinline__ uint32_t lds_load_u16(const float *base, int byte_off) {
+    return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
+template <int P, typename FT, int NOB_>
+struct GmapCfg {
+    static constexpr int NT = (P + 15) / 16;                // M tiles
+    static constexpr int FSZ = GTile<FT>::size(P);          // dwords per feature tile
+    static constexpr int OSZ = GTile<float>::size(P);       // dwords per (fp32) output / addend tile
+    static constexpr int ASZ = P * GM_BP;                   // dwords per bf16 attention image
+    static constexpr int TSZ = P * 4;                       // exact f32 k tail
+    static constexpr int NOB = NOB_;                        // output images (2: the next group's addend lands early)
+    static constexpr int OFF_PH = 0, OFF_PL = ASZ, OFF_PT = 2 * ASZ, OFF_F = 2 * ASZ + TSZ, OFF_O = OFF_F + 2 * FSZ;
+    static constexpr int LDS = OFF_O + NOB * OSZ;           // dwords
+    static constexpr int NPA = (P * (P / 4) + 63) / 64;     // DMA instructions of the raw attention block
+    static_assert(P % 4 == 0 && P <= 136, "GmapCfg: padded strip length");
+    static_assert(P * P <= 2 * FSZ + NOB * OSZ, "the raw attention block is staged in the tile buffers");
+    static_assert(LDS * 4 <= 163840, "GmapCfg: LDS");
+};
+__host__ __device__ constexpr int gmap_nob(int P, bool bf) {
+    return (2 * P * GM_BP + P * 4 + 2 * (bf ? GTile<bf16_t>::size(P) : GTile<float>::size(P)) + 2 * GTile<float>::size(P)) * 4 <= 163840 ? 2 : 1;
+}
+
+// raw rows of the strip's attention block -> bf16 hi / lo images [m][k] (+ exact f32 k tail); `stage` = P * P floats
+template <int P, bool TRANS>
+__device__ __forceinline__ void gmap_attention_images(const FBuf &Tb, float *stage, uint32_t *PH, uint32_t *PL, float *PT,
+                                                      int L, int row_off0, int row_step, const BandK &kp, int tid, int lane,
+                                                      int wave) {
+    constexpr int P4 = P / 4, NPA = (P * P4 + 63) / 64;
+    for (int it = wave; it < NPA; it += 4) {
+        const int idx = 64 * it + lane, i = idx / P4, chk = idx - i * P4;
+        if (i < L && 4 * chk < L) fbuf_load_to_lds_x4(Tb, stage + 256 * it, (row_off0 + i * row_step + 4 * chk) * 4, 0);
+    }
+    __syncthreads();                                     // (drains the DMA)
+    for (int e = tid; e < P * (P / 2); e += GM_THREADS) {
+        const int m = e / (P / 2), k = 2 * (e - m * (P / 2));
+        float v0 = 0.f, v1 = 0.f;
+        if (m < L) {
+            if (k < L)     v0 = CCA_LDS_LD(stage + (TRANS ? k * P + m : m * P + k));
+            if (k + 1 < L) v1 = CCA_LDS_LD(stage + (TRANS ? (k + 1) * P + m : m * P + k + 1));
+        }
+        const uint32_t h = cvt_pk_bf16(v0, v1);
+        const float h0 = __builtin_bit_cast(float, h << 16), h1 = __builtin_bit_cast(float, h & 0xffff0000u);
+        PH[m * GM_BP + (k >> 1)] = h;
+        PL[m * GM_BP + (k >> 1)] = cvt_pk_bf16(v0 - h0, v1 - h1);
+    }
+    for (int e = tid; e < P * 4; e += GM_THREADS) {
+        const int m = e >> 2, k = 32 * kp.nbf + (e & 3);
+        PT[e] = (kp.tail && m < L && k < L) ? CCA_LDS_LD(stage + (TRANS ? k * P + m : m * P + k)) : 0.f;
+    }
+    __syncthreads();
+}
+
+// FT: feature element, OT: output element; the addend (ADD) is always fp32 pixel-major with its own strides
+template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT>
+__global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__restrict__ T, const FT *__restrict__ F,
                                                               const float *__restrict__ addend,
-                                                              const float *__restrict__ gamma, float *out,
-                                                              int C, int H, int W, long fbs, int fps, long obs, int ops) {
-    using Cfg = GmapCfg<P>;
+                                                              const OT *__restrict__ resid,
+                                                              const float *__restrict__ gamma, OT *out,
+                                                              int C, int H, int W, long fbs, int fps, long abs_, int aps,
+                                                              long rbs, int rps, long obs, int ops) {
+    using Cfg = GmapCfg<P, FT, gmap_nob(P, GTile<FT>::BF)>;
+    constexpr bool BF = GTile<FT>::BF, OBF = std::is_same<OT, bf16_t>::value;
+    constexpr int NT = Cfg::NT, FSZ = Cfg::FSZ, OSZ = Cfg::OSZ, NOB = Cfg::NOB;
+    constexpr int NPF = GTile<FT>::pieces(P), NPO = GTile<float>::pieces(P);
     __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS];
     CCA_LDS_REGISTER(lds);
-    constexpr int NT = Cfg::NT, NPF = Cfg::NPF, FSZ = Cfg::FSZ, P4 = P / 4;
     const int HW = H * W, S = H + W;
     const int L = ROW ? W : H, G = ROW ? H : W;
     const int id = xcd_logical_id(blockIdx.x, gridDim.x);
@@ -64,9 +142,11 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__rest
     const int a_off = ROW ? H : 0;
 
     const FBuf Tb = make_fbuf(T + (size_t)b * HW * S, (size_t)HW * S * sizeof(float));
-    const FBuf Fb = make_fbuf(F + (size_t)b * fbs, ((size_t)(HW - 1) * fps + C) * sizeof(float));
-    const FBuf Ob = make_fbuf(out + (size_t)b * obs, ((size_t)(HW - 1) * ops + C) * sizeof(float));
-    const FBuf Db = make_fbuf((EPI == GM_EPI_PM_ADD ? addend : out) + (size_t)b * obs, ((size_t)(HW - 1) * ops + C) * sizeof(float));
+    const FBuf Fb = make_fbuf(reinterpret_cast<const float *>(F + (size_t)b * fbs), ((size_t)(HW - 1) * fps + C) * sizeof(FT));
+    const FBuf Ob = make_fbuf(reinterpret_cast<const float *>(out + (size_t)b * obs), ((size_t)(HW - 1) * ops + C) * sizeof(OT));
+    const FBuf Rb = make_fbuf(reinterpret_cast<const float *>(resid ? resid + (size_t)b * rbs : out),
+                              resid ? ((size_t)(HW - 1) * rps + C) * sizeof(OT) : 4);
+    const FBuf Db = make_fbuf(ADD ? addend + (size_t)b * abs_ : T, ADD ? ((size_t)(HW - 1) * aps + C) * sizeof(float) : 4);
     const float alpha = gamma ? gamma[0] : 1.f;
     const int ncg = (C + GM_CG - 1) / GM_CG;
     const BandK kp = band_ksteps(L);
@@ -74,86 +154,71 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__rest
     uint32_t *const PH = reinterpret_cast<uint32_t *>(lds + Cfg::OFF_PH), *const PL = reinterpret_cast<uint32_t *>(lds + Cfg::OFF_PL);
     float *const PT = lds + Cfg::OFF_PT, *const FB = lds + Cfg::OFF_F, *const OB = lds + Cfg::OFF_O;
 
-    // ---- prologue: raw rows of P_g -> staging (the tile buffers) -> bf16 hi / lo images (+ exact k tail) ----------
-    {
-        float *stage = FB;                                   // [i][P], P * P floats
-        for (int it = nt; it < Cfg::NPA; it += 4) {
-            const int idx = 64 * it + lane, i = idx / P4, chk = idx - i * P4;
-            if (i < L && 4 * chk < L)
-                fbuf_load_to_lds_x4(Tb, stage + 256 * it, ((pix0 + i * pstep) * S + a_off + 4 * chk) * 4, 0);
-        }
-        __syncthreads();                                     // (drains the DMA)
-        // destination element [m][k]: m = output position, k = contraction position
-        for (int e = tid; e < P * (P / 2); e += GM_THREADS) {
-            const int m = e / (P / 2), k = 2 * (e - m * (P / 2));
-            float v0 = 0.f, v1 = 0.f;
-            if (m < L) {
-                if (k < L)     v0 = CCA_LDS_LD(stage + (TRANS ? k * P + m : m * P + k));
-                if (k + 1 < L) v1 = CCA_LDS_LD(stage + (TRANS ? (k + 1) * P + m : m * P + k + 1));
-            }
-            const uint32_t h = cvt_pk_bf16(v0, v1);
-            const float h0 = __builtin_bit_cast(float, h << 16), h1 = __builtin_bit_cast(float, h & 0xffff0000u);
-            PH[m * GM_BP + (k >> 1)] = h;
-            PL[m * GM_BP + (k >> 1)] = cvt_pk_bf16(v0 - h0, v1 - h1);
-        }
-        for (int e = tid; e < P * 4; e += GM_THREADS) {
-            const int m = e >> 2, k = 32 * kp.nbf + (e & 3);
-            PT[e] = (kp.tail && m < L && k < L) ? CCA_LDS_LD(stage + (TRANS ? k * P + m : m * P + k)) : 0.f;
-        }
-        __syncthreads();
-        // the staging area becomes tile buffers: masked DMA lanes leave their slots alone and the k padding of a
-        // feature tile meets zero attention operands -- it has to be finite
-        for (int i = tid * 4; i < 4 * FSZ; i += GM_THREADS * 4) lds_store_x4(&FB[i], f32x4{0.f, 0.f, 0.f, 0.f});
-        __syncthreads();
-    }
+    gmap_attention_images<P, TRANS>(Tb, FB, PH, PL, PT, L, pix0 * S + a_off, pstep * S, kp, tid, lane, nt);
+    // the staging area becomes tile buffers: masked DMA lanes leave their slots alone and the k padding of a feature
+    // tile meets zero attention operands -- it has to be finite
+    for (int i = tid * 4; i < 2 * FSZ + NOB * OSZ; i += GM_THREADS * 4) lds_store_x4(&FB[i], f32x4{0.f, 0.f, 0.f, 0.f});
+    __syncthreads();
 
-    // one 4-pixel piece of a pixel-major tile (pixels pix0 + i * pstep, channels cg*64 ..) -> img
-    auto dma_piece = [&](const FBuf &src, float *img, int piece, int cg, int ps) {
-        const int i = 4 * piece + (lane >> 4), c = cg * GM_CG + 4 * (lane & 15);
-        if (i < L && c < C) fbuf_load_to_lds_x4(src, img + piece * GM_PP, ((pix0 + i * pstep) * ps + c) * 4, 0);
+    auto issue_feat = [&](int cg) {
+        for (int it = nt; it < NPF; it += 4) gtile_dma_piece<FT>(Fb, FB + (cg & 1) * FSZ, it, lane, pix0, pstep, L, fps, cg * GM_CG, C);
     };
-    auto issue = [&](int cg) {
-        for (int it = nt; it < NPF; it += 4) dma_piece(Fb, FB + (cg & 1) * FSZ, it, cg, fps);
-        if (EPI == GM_EPI_PM_ADD)
-            for (int it = nt; it < NPF; it += 4) dma_piece(Db, OB + (cg & 1) * FSZ, it, cg, ops);
+    auto issue_add = [&](int cg) {
+        for (int it = nt; it < NPO; it += 4)
+            gtile_dma_piece<float>(Db, OB + (NOB == 2 ? cg & 1 : 0) * OSZ, it, lane, pix0, pstep, L, aps, cg * GM_CG, C);
     };
 
-    issue(0);
+    issue_feat(0);
+    if (ADD) issue_add(0);
     for (int cg = 0; cg < ncg; ++cg) {
         const float *img = FB + (cg & 1) * FSZ;
-        float *oimg = OB + (cg & 1) * FSZ;
+        float *oimg = OB + (NOB == 2 ? cg & 1 : 0) * OSZ;
         barrier_dma_keep<0>();                   // tile cg (and its addend) landed; every wave is done with group cg - 1
-        if (cg + 1 < ncg) issue(cg + 1);
+        if (cg + 1 < ncg) {
+            issue_feat(cg + 1);
+            if (ADD && NOB == 2) issue_add(cg + 1);
+        }
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int ks = 0; ks < kp.nbf; ++ks) {
             // B fragment: positions 32 ks + 8 lg + e of channel 16 nt + ln
-            const float *p = img + (8 * ks + 2 * lg) * GM_PP + 16 * nt + ln;
-            float x[8];
+            BfSplit fb;
+            if constexpr (BF) {
+                uint32_t x[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = CCA_LDS_LD(p + (e >> 2) * GM_PP + (e & 3) * GM_CG);
-            const BfSplit fb = bf16_split8(x);
+                for (int e = 0; e < 8; ++e) x[e] = lds_load_u16(img, gtile_bf_byte(32 * ks + 8 * lg + e, 16 * nt + ln));
+                fb.hi = u32x4{x[0] | (x[1] << 16), x[2] | (x[3] << 16), x[4] | (x[5] << 16), x[6] | (x[7] << 16)};
+                fb.lo = fb.hi;
+            } else {
+                const float *p = img + (8 * ks + 2 * lg) * GM_PP + 16 * nt + ln;
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = CCA_LDS_LD(p + (e >> 2) * GM_PP + (e & 3) * GM_CG);
+                fb = bf16_split8(x);
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (t * 16 < L) {
                     const int ao = (16 * t + ln) * GM_BP + 16 * ks + 4 * lg;
                     const u32x4 ah = *reinterpret_cast<const u32x4 *>(PH + ao), al = *reinterpret_cast<const u32x4 *>(PL + ao);
                     acc[t] = mfma_bf16_16x16x32(ah, fb.hi, acc[t]);
-                    acc[t] = mfma_bf16_16x16x32(ah, fb.lo, acc[t]);
+                    if (!BF) acc[t] = mfma_bf16_16x16x32(ah, fb.lo, acc[t]);
                     acc[t] = mfma_bf16_16x16x32(al, fb.hi, acc[t]);
                 }
             }
         }
         if (kp.tail) {
             const int pos = 32 * kp.nbf + lg;
-            const float fbv = CCA_LDS_LD(img + (pos >> 2) * GM_PP + (pos & 3) * GM_CG + 16 * nt + ln);
+            float fbv;
+            if constexpr (BF) fbv = __builtin_bit_cast(float, lds_load_u16(img, gtile_bf_byte(pos, 16 * nt + ln)) << 16);
+            else              fbv = CCA_LDS_LD(img + (pos >> 2) * GM_PP + (pos & 3) * GM_CG + 16 * nt + ln);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 if (t * 16 < L) acc[t] = mfma_16x16x4(CCA_LDS_LD(PT + (16 * t + ln) * 4 + lg), fbv, acc[t]);
             mfma_f32_result_fence();
         }
-        // D[m = position 16 t + 4 lg + q][n = channel 16 nt + ln] -> output image (pixel-major pieces), + addend
+        // D[m = position 16 t + 4 lg + q][n = channel 16 nt + ln] -> output image (fp32 pixel-major pieces), + addend
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -162,17 +227,128 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__rest
                 if (i < L) {
                     float *d = oimg + (i >> 2) * GM_PP + (i & 3) * GM_CG + 16 * nt + ln;
                     float val = alpha * acc[t][q];
-                    if (EPI == GM_EPI_PM_ADD) val += CCA_LDS_LD(d);
+                    if (ADD) val += CCA_LDS_LD(d);
                     CCA_LDS_ST(d, val);
                 }
             }
         barrier_lds_only();
-        for (int it = nt; it < NPF; it += 4) {
-            const int i = 4 * it + (lane >> 4), c = cg * GM_CG + 4 * (lane & 15);
-            if (i < L && c < C)
-                fbuf_store_x4(Ob, lds_load_x4(oimg + it * GM_PP + 4 * lane), ((pix0 + i * pstep) * ops + c) * 4, 0);
+        if constexpr (OBF) {
+            // 8 pixels x 64 channels per instruction: a lane rounds 8 consecutive channels to bf16 (16 bytes)
+            for (int it = nt; it < (L + 7) / 8; it += 4) {
+                const int i = 8 * it + (lane >> 3), c8 = 8 * (lane & 7), c = cg * GM_CG + c8;
+                if (i < L && c < C) {
+                    const float *s = oimg + (i >> 2) * GM_PP + (i & 3) * GM_CG + c8;
+                    f32x4 u = lds_load_x4(s), v = lds_load_x4(s + 4);
+                    if (resid) {                 // + the bf16 residual (x of functions.py:104), the same 16 bytes
+                        const u32x4 r = __builtin_bit_cast(u32x4, fbuf_load_x4(Rb, ((pix0 + i * pstep) * rps + c) * 2, 0));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float lo = __builtin_bit_cast(float, r[e] << 16), hi = __builtin_bit_cast(float, r[e] & 0xffff0000u);
+                            if (e < 2) { u[2 * e] += lo; u[2 * e + 1] += hi; } else { v[2 * e - 4] += lo; v[2 * e - 3] += hi; }
+                        }
+                    }
+                    const f32x4 packed = __builtin_bit_cast(f32x4, u32x4{cvt_pk_bf16(u[0], u[1]), cvt_pk_bf16(u[2], u[3]),
+                                                                         cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])});
+                    fbuf_store_x4(Ob, packed, ((pix0 + i * pstep) * ops + c) * 2, 0);
+                }
+            }
+        } else {
+            for (int it = nt; it < NPO; it += 4) {
+                const int i = 4 * it + (lane >> 4), c = cg * GM_CG + 4 * (lane & 15);
+                if (i < L && c < C)
+                    fbuf_store_x4(Ob, lds_load_x4(oimg + it * GM_PP + 4 * lane), ((pix0 + i * pstep) * ops + c) * 4, 0);
+            }
+        }
+        if (ADD && NOB == 1 && cg + 1 < ncg) {
+            barrier_lds_only();                  // the single output image has been read out: the next addend may land
+            issue_add(cg + 1);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gweight: T[b, pixel(i, g), a_off + j] = sum_c X[pixel(i, g), c] * Y[pixel(j, g), c], bf16 pixel-major X / Y
+//   ca_forward (X = q, Y = k, K = C/8, MASK: the column self slot is -inf) and the dA half of ca_map_backward
+//   (X = dy, Y = v, K = C).  Workgroup = one strip; the channel axis is contiguous, so both MFMA operands are single
+//   ds_read_b128 fragments of the swizzled bf16 tiles and the products are exact: no split, one
+//   v_mfma_f32_16x16x32_bf16 per tile and 32 channels.  Wavefront w owns the tile rows ti = w, w + 4, ...
+// ---------------------------------------------------------------------------------------------------------------
+template <int P, bool MASK>
+__global__ __launch_bounds__(GM_THREADS, 1) void gweight_kernel(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Y,
+                                                                 float *__restrict__ T, int Cx, int H, int W,
+                                                                 long xbs, int xps, long ybs, int yps) {
+    constexpr int NT = (P + 15) / 16, NTR = (NT + 3) / 4, TSZ = GTile<bf16_t>::size(P), NPF = GTile<bf16_t>::pieces(P);
+    __shared__ __attribute__((aligned(16))) float lds[4 * TSZ];
+    CCA_LDS_REGISTER(lds);
+    const int HW = H * W, S = H + W;
+    const int id = xcd_logical_id(blockIdx.x, gridDim.x);
+    const int per_image = W + H;                              // W column strips, then H row strips
+    const int b = id / per_image, r = id - b * per_image;
+    const bool row = r >= W;
+    const int g = row ? r - W : r;
+    const int L = row ? W : H;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
+    const int ln = lane & 15, lg = lane >> 4;
+    const int pix0 = row ? g * W : g, pstep = row ? 1 : W, a_off = row ? H : 0;
+    const FBuf Xb = make_fbuf(reinterpret_cast<const float *>(X + (size_t)b * xbs), ((size_t)(HW - 1) * xps + Cx) * 2);
+    const FBuf Yb = make_fbuf(reinterpret_cast<const float *>(Y + (size_t)b * ybs), ((size_t)(HW - 1) * yps + Cx) * 2);
+    const int nch = (Cx + GM_CG - 1) / GM_CG;
+
+    for (int i = tid * 4; i < 4 * TSZ; i += GM_THREADS * 4) lds_store_x4(&lds[i], f32x4{0.f, 0.f, 0.f, 0.f});
+    __syncthreads();
+    auto issue = [&](int ch) {
+        float *xb = lds + (ch & 1) * 2 * TSZ, *yb = xb + TSZ;
+        for (int it = wv; it < 2 * NPF; it += 4) {
+            if (it < NPF) gtile_dma_piece<bf16_t>(Xb, xb, it, lane, pix0, pstep, L, xps, ch * GM_CG, Cx);
+            else          gtile_dma_piece<bf16_t>(Yb, yb, it - NPF, lane, pix0, pstep, L, yps, ch * GM_CG, Cx);
+        }
+    };
+    f32x4 acc[NTR][NT];
+#pragma unroll
+    for (int a = 0; a < NTR; ++a)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragment = 8 consecutive channels (one 16-byte chunk) of one pixel: chunk q of pixel p at chunk position q ^ (p & 7)
+    auto frag = [&](const float *tile, int pixel, int chunk) {
+        const int off = (pixel >> 3) * GM_PB + (pixel & 7) * 32 + ((chunk ^ (pixel & 7)) << 2);
+        return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint32_t *>(tile) + off);
+    };
+    issue(0);
+    for (int ch = 0; ch < nch; ++ch) {
+        const float *xb = lds + (ch & 1) * 2 * TSZ, *yb = xb + TSZ;
+        barrier_dma_keep<0>();
+        if (ch + 1 < nch) issue(ch + 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {                       // two k-steps of 32 channels
+            u32x4 af[NTR];
+#pragma unroll
+            for (int a = 0; a < NTR; ++a) af[a] = frag(xb, 16 * (wv + 4 * a) + ln, 4 * kk + lg);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (t * 16 < L) {
+                    const u32x4 bf = frag(yb, 16 * t + ln, 4 * kk + lg);
+#pragma unroll
+                    for (int a = 0; a < NTR; ++a)
+                        if ((wv + 4 * a) * 16 < L) acc[a][t] = mfma_bf16_16x16x32(af[a], bf, acc[a][t]);
+                }
+            }
+        }
+    }
+    // D[m = query position 16 ti + 4 lg + q][n = key position 16 t + ln] -> T rows (64-byte runs per query)
+    float *Tg = T + (size_t)b * HW * S;
+#pragma unroll
+    for (int a = 0; a < NTR; ++a)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 16 * (wv + 4 * a) + 4 * lg + q, j = 16 * t + ln;
+                if (i < L && j < L) {
+                    float val = acc[a][t][q];
+                    if (MASK && !row && i == j) val = -INFINITY;            // functions.py:11-12 (column self slot)
+                    Tg[(size_t)(pix0 + i * pstep) * S + a_off + j] = val;
+                }
+            }
 }
 
 }  // namespace cca

@@ -63,6 +63,9 @@ __device__ __forceinline__ FBuf make_fbuf(const float *p, size_t bytes) {
 __device__ __forceinline__ float fbuf_load(const FBuf &b, int voff_bytes, int soff_bytes) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, voff_bytes, soff_bytes, 0));
 }
+__device__ __forceinline__ f32x4 fbuf_load_x4(const FBuf &b, int voff_bytes, int soff_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, voff_bytes, soff_bytes, 0));
+}
 // stores whose per-lane offset is out of range (kOobOffset) are dropped by the buffer range check
 __device__ __forceinline__ void fbuf_store(const FBuf &b, float v, int voff_bytes, int soff_bytes) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), b, voff_bytes, soff_bytes, 0);

@@ -387,6 +387,84 @@ class CrissCrossBF16Function(torch.autograd.Function):
         return dq, dk, dv, dy, dgamma.view_as(gamma)
 
 
+def _pm_view(name, t, C=None):
+    """(B, H, W, C) bf16 view whose channel axis is contiguous and whose rows follow each other at the pixel stride:
+    returns (tensor, batch stride, pixel stride) in elements; copies only when the view does not qualify."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a bfloat16 tensor on an AMD GPU (there is no CPU fallback)")
+    if t.dtype != torch.bfloat16 or t.dim() != 4:
+        raise RuntimeError(f"{name}: expected a 4-D (B, H, W, C) bfloat16 tensor, got {t.dtype} {tuple(t.shape)}")
+    B, H, W, c = t.shape
+    ok = (t.stride(3) == 1 and t.stride(1) == W * t.stride(2) and t.stride(2) % 8 == 0 and t.stride(0) % 8 == 0
+          and t.stride(2) >= c and t.stride(0) >= H * W * t.stride(2) - (t.stride(2) - c) and t.data_ptr() % 16 == 0)
+    if not ok:
+        t = t.contiguous()
+    return t, t.stride(0), t.stride(2)
+
+
+def pm_bf16_covers(B, C, Cq, H, W):
+    """geometry of the pixel-major bf16 kernels (csrc/cca_gmap.hpp)"""
+    return max(H, W) <= 132 and C % 8 == 0 and Cq % 8 == 0 and H * W * (C + 2 * Cq) < 2 ** 29
+
+
+class CrissCrossPMBF16Function(torch.autograd.Function):
+    """Fused core on PIXEL-MAJOR bf16 features (BASELINE configs[4], csrc/cca_gmap.hpp): ``qkv`` is the packed
+    (B, H, W, 2*Cq + C) projection (query | key | value channel slices, functions.py:29-35 computed as one
+    ``x^T W^T`` GEMM), ``x`` the (B, H, W, C) residual input; returns y (B, H, W, C) bf16.  Attention, softmax,
+    accumulation and gamma are fp32.  Backward returns the packed dqkv, so the projection's backward is again one GEMM."""
+
+    @staticmethod
+    def forward(ctx, qkv, x, gamma, cq):
+        qkv, q_bs, q_ps = _pm_view("qkv", qkv)
+        x, x_bs, x_ps = _pm_view("x", x)
+        gamma = _dev_f32("gamma", gamma)
+        _same_device(qkv, x, gamma)
+        B, H, W, ct = qkv.shape
+        C = ct - 2 * cq
+        if tuple(x.shape) != (B, H, W, C):
+            raise RuntimeError(f"shape mismatch: qkv {tuple(qkv.shape)} (Cq = {cq}), x {tuple(x.shape)}")
+        if not pm_bf16_covers(B, C, cq, H, W):
+            raise RuntimeError(f"pixel-major bf16 kernels cover strips <= 132 and channel counts divisible by 8; got "
+                               f"C = {C}, Cq = {cq}, H = {H}, W = {W}")
+        lib = _lib.get_lib()
+        y = torch.empty((B, H, W, C), device=x.device, dtype=torch.bfloat16)
+        A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
+        _ws, ws_ptr, nbytes = _workspace(lib.ccnet_cca_pm_bf16_workspace_bytes(B, C, cq, H, W, 0), x.device)
+        p = qkv.data_ptr()
+        with torch.cuda.device(x.device):
+            lib.check(lib.ccnet_cca_forward_pm_bf16(p, p + 2 * cq, p + 4 * cq, x.data_ptr(), gamma.data_ptr(),
+                                                    y.data_ptr(), A.data_ptr(), B, C, cq, H, W,
+                                                    q_bs, q_ps, q_bs, q_ps, q_bs, q_ps, x_bs, x_ps, H * W * C, C,
+                                                    ws_ptr, nbytes, _stream()), "cca_forward_pm_bf16")
+        ctx.save_for_backward(qkv, A, gamma)
+        ctx.cq = cq
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        qkv, A, gamma = ctx.saved_tensors
+        cq = ctx.cq
+        dy, dy_bs, dy_ps = _pm_view("grad_output", dy)
+        B, H, W, ct = qkv.shape
+        C = ct - 2 * cq
+        lib = _lib.get_lib()
+        dqkv = torch.empty((B, H, W, ct), device=qkv.device, dtype=torch.bfloat16)
+        dgamma = torch.empty_like(gamma)
+        scratch = torch.empty_like(A)
+        _ws, ws_ptr, nbytes = _workspace(lib.ccnet_cca_pm_bf16_workspace_bytes(B, C, cq, H, W, 1), qkv.device)
+        p, g = qkv.data_ptr(), dqkv.data_ptr()
+        bs, ps = qkv.stride(0), qkv.stride(2)
+        with torch.cuda.device(qkv.device):
+            lib.check(lib.ccnet_cca_backward_pm_bf16(dy.data_ptr(), p, p + 2 * cq, p + 4 * cq, A.data_ptr(),
+                                                     gamma.data_ptr(), g, g + 2 * cq, g + 4 * cq, dgamma.data_ptr(),
+                                                     scratch.data_ptr(), B, C, cq, H, W, dy_bs, dy_ps,
+                                                     bs, ps, bs, ps, bs, ps, H * W * ct, ct, H * W * ct, ct,
+                                                     H * W * ct, ct, ws_ptr, nbytes, _stream()),
+                      "cca_backward_pm_bf16")
+        return dqkv, dy, dgamma.view_as(gamma), None
+
+
 class CrissCrossModuleFunction(torch.autograd.Function):
     """The whole module of functions.py:27-49 as ONE autograd node (fp32, no autocast): stacked projection GEMM ->
     fused criss-cross core -> hand-written backward in which the input gradient of the projection is a GEMM with
@@ -492,8 +570,9 @@ class CrissCrossAttention(nn.Module):
     #: kept either way.
     recompute_attention = False
 
-    #: bf16 inputs at geometries outside the fp32 strip kernels (strips longer than 320) use the bf16-I/O entry
-    #: points; everything else is computed through fp32 copies on the MFMA kernels.
+    #: bf16 inputs: strips <= 132 (C, C/8 divisible by 8) run on the pixel-major bf16 MFMA kernels; geometries outside
+    #: every strip kernel (strips longer than 320) use the any-shape bf16-I/O entry points; the rest is computed
+    #: through fp32 copies on the fp32 MFMA kernels.
     native_bf16 = True
 
     def forward(self, x):
@@ -501,6 +580,17 @@ class CrissCrossAttention(nn.Module):
             raise RuntimeError(
                 "CrissCrossAttention (ccnet_amd): input is on the CPU. This module runs its attention core as HIP "
                 "kernels on an AMD GPU and has no CPU fallback; move the module and its input to the device.")
+        if (x.dtype == torch.bfloat16 and self.native_bf16 and self._fusable(x)
+                and pm_bf16_covers(x.shape[0], x.shape[1], self.query_conv.out_channels, x.shape[2], x.shape[3])):
+            # bf16 activations (BASELINE configs[4]): pixel-major bf16 kernels.  x as (B, H, W, C) is a free view of a
+            # channels_last tensor (one transposing copy otherwise); query | key | value are ONE GEMM x^T W^T whose
+            # output the kernels read through channel-slice strides; y comes back as a channels_last NCHW view.
+            cq = self.query_conv.out_channels
+            xp = x.permute(0, 2, 3, 1)
+            w = torch.cat([self.query_conv.weight, self.key_conv.weight, self.value_conv.weight], 0).flatten(1)
+            b = torch.cat([self.query_conv.bias, self.key_conv.bias, self.value_conv.bias], 0)
+            qkv = torch.nn.functional.linear(xp, w, b)
+            return CrissCrossPMBF16Function.apply(qkv, xp, self.gamma.float(), cq).permute(0, 3, 1, 2)
         if x.dtype == torch.bfloat16 and self.native_bf16 and not self._strip_kernels_cover(x):
             # bf16 activations at a geometry the fp32 MFMA strip kernels do not cover: run the bf16-I/O entry points
             # (fp32 attention / softmax / accumulation inside) instead of materialising fp32 copies of every tensor

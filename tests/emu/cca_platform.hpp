@@ -118,6 +118,11 @@ __device__ inline float fbuf_load(const FBuf &b, int voff_bytes, int soff_bytes)
     memcpy(&r, b.base + o, 4);
     return r;
 }
+__device__ inline f32x4 fbuf_load_x4(const FBuf &b, int voff_bytes, int soff_bytes) {
+    f32x4 v;
+    for (int e = 0; e < 4; ++e) v[e] = fbuf_load(b, voff_bytes + 4 * e, soff_bytes);
+    return v;
+}
 __device__ inline void fbuf_store(const FBuf &b, float v, int voff_bytes, int soff_bytes) {
     const uint32_t o = (uint32_t)voff_bytes + (uint32_t)soff_bytes;
     if ((uint32_t)voff_bytes >= b.bytes || (size_t)o + 4 > b.bytes) return;      // out-of-range stores are dropped

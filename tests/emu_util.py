@@ -213,6 +213,37 @@ class EmuOps:
                                                         B, C, q.shape[1], H, W, None))
         return dq, dk, dv, dgamma
 
+    def cca_forward_pm_bf16(self, qkv, x, gamma, cq):
+        """qkv: uint16 (B, H, W, 2*cq + C) packed pixel-major projection (q | k | v channel slices, bf16 bit patterns),
+        x: uint16 (B, H, W, ps >= C); returns (y bits (B, H, W, C), A fp32)."""
+        B, H, W, ct = qkv.shape
+        C = ct - 2 * cq
+        y = np.zeros((B, H, W, C), np.uint16)
+        A = np.full((B, H, W, H + W), np.nan, np.float32)
+        nbytes = self.lib.ccnet_cca_pm_bf16_workspace_bytes(B, C, cq, H, W, 0)
+        ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
+        base, bs = qkv.ctypes.data, H * W * ct
+        self.lib.check(self.lib.ccnet_cca_forward_pm_bf16(base, base + 2 * cq, base + 4 * cq, _p(x), _p(gamma), _p(y), _p(A),
+                                                          B, C, cq, H, W, bs, ct, bs, ct, bs, ct,
+                                                          H * W * x.shape[3], x.shape[3], H * W * C, C, _p(ws), nbytes, None))
+        return y, A
+
+    def cca_backward_pm_bf16(self, dy, qkv, A, gamma, cq):
+        """dy: uint16 (B, H, W, C); returns (dqkv bits packed like qkv, dgamma)."""
+        B, H, W, ct = qkv.shape
+        C = ct - 2 * cq
+        dqkv = np.zeros_like(qkv)
+        dgamma = np.full(1, np.nan, np.float32)
+        scratch = np.full_like(A, np.nan)
+        nbytes = self.lib.ccnet_cca_pm_bf16_workspace_bytes(B, C, cq, H, W, 1)
+        ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
+        base, g, bs = qkv.ctypes.data, dqkv.ctypes.data, H * W * ct
+        self.lib.check(self.lib.ccnet_cca_backward_pm_bf16(_p(dy), base, base + 2 * cq, base + 4 * cq, _p(A), _p(gamma),
+                                                           g, g + 2 * cq, g + 4 * cq, _p(dgamma), _p(scratch),
+                                                           B, C, cq, H, W, H * W * C, C, bs, ct, bs, ct, bs, ct,
+                                                           bs, ct, bs, ct, bs, ct, _p(ws), nbytes, None))
+        return dqkv, dgamma
+
     def mfma_selftest(self):
         scratch = np.zeros(16, np.float32)
         return self.lib.ccnet_cca_mfma_selftest(_p(scratch), None)

@@ -546,3 +546,39 @@ def test_pixel_major_strip_map_matches_oracle(ops, shape):
     bothT = ops.strip_map_pm(A, to_pm(dy), shape, row=True, trans=True, addend=colT, gamma=gamma)
     _, dvo = O.ca_map_backward(T(dy), T(A), T(v))
     assert maxerr(from_pm(bothT), 0.5 * dvo.numpy()) < 2e-4
+
+
+def _pm(a):
+    """(B, C, H, W) -> (B, H, W, C) contiguous"""
+    return np.ascontiguousarray(np.transpose(a, (0, 2, 3, 1)))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 128, 17, 20), (1, 64, 9, 1), (1, 192, 33, 18), (1, 64, 3, 129), (1, 64, 101, 2)])
+def test_pixel_major_bf16_path_matches_oracle(ops, shape):
+    """csrc/cca_gmap.hpp through ccnet_cca_forward_pm_bf16 / ccnet_cca_backward_pm_bf16 (BASELINE configs[4]): q | k | v as
+    channel slices of one packed pixel-major bf16 projection, bf16 x / y / dy / gradients, fp32 attention.  Oracle = the fp32
+    restatement on the same bf16-rounded inputs; allowed on top of the fp32 tolerance: one rounding of each output."""
+    B, C, H, W = shape
+    cq = C // 8
+    c = rand_case(*shape, seed=43)
+    bits, vals = {}, {}
+    for n in ("q", "k", "v", "x", "dy"):
+        b, vals[n] = _bf16_bits(c[n])
+        bits[n] = _pm(b)
+    qkv = np.ascontiguousarray(np.concatenate([bits["q"], bits["k"], bits["v"]], axis=3))
+    g = T(c["gamma"])
+    y, A = ops.cca_forward_pm_bf16(qkv, bits["x"], c["gamma"], cq)
+    yo, Ao = O.cca_core_forward(vals["q"], vals["k"], vals["v"], vals["x"], g)
+    assert maxerr(A, Ao.numpy()) < TOL
+    assert np.all(A[:, np.arange(H), :, np.arange(H)] == 0)
+    rnd = lambda ref: 2.0 ** -8 * ref.abs() + 2e-4                            # noqa: E731
+    nchw = lambda b_: _from_bits(np.ascontiguousarray(np.transpose(b_, (0, 3, 1, 2))))   # noqa: E731
+    assert bool(((nchw(y) - yo).abs() <= rnd(yo)).all())
+    dqkv, dg = ops.cca_backward_pm_bf16(bits["dy"], qkv, A, c["gamma"], cq)
+    go = O.cca_core_backward(vals["dy"], vals["q"], vals["k"], vals["v"], Ao, g)
+    for name, got in (("dq", dqkv[..., :cq]), ("dk", dqkv[..., cq:2 * cq]), ("dv", dqkv[..., 2 * cq:])):
+        assert bool(((nchw(got) - go[name]).abs() <= rnd(go[name])).all()), name
+    assert abs(float(dg[0]) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
+    # gamma = 0: y is x exactly (as values: 0 * out + (-0) is +0 in the reference too)
+    y0, _ = ops.cca_forward_pm_bf16(qkv, bits["x"], np.zeros(1, np.float32), cq)
+    assert torch.equal(_from_bits(y0), _from_bits(bits["x"]))

@@ -406,6 +406,85 @@ def test_bf16_config5_full_size_against_the_fp32_path(lib, dev):
     assert ym.dtype == torch.bfloat16 and m.gamma.grad is not None and xm.grad is not None
 
 
+def _pm_inputs(B, C, H, W, dev, seed, qk_scale=1.0):
+    q, k, v, x, dy = _bf16_core_inputs(B, C, H, W, dev, seed=seed)
+    q, k = q * qk_scale, k * qk_scale
+    pm = lambda t: t.permute(0, 2, 3, 1).contiguous()                       # noqa: E731
+    qkv = torch.cat([pm(q), pm(k), pm(v)], dim=3).contiguous()
+    return q, k, v, x, dy, qkv, pm(x), pm(dy)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 128, 17, 20), (2, 64, 40, 33), (1, 64, 97, 97), (1, 64, 129, 70),
+                                   (1, 128, 100, 132), (1, 64, 1, 9)])
+def test_pixel_major_bf16_kernels_match_oracle(lib, dev, shape):
+    """BASELINE configs[4] on the pixel-major bf16 MFMA kernels (csrc/cca_gmap.hpp) at oracle-sized shapes, both
+    padded strip lengths (100, 132): packed bf16 projection in, bf16 y / packed dqkv out, fp32 attention.  Oracle: the fp32
+    restatement on the same bf16-rounded inputs; tolerance = the fp32 bar + one rounding of each output to bf16."""
+    from ccnet_amd.functions import CrissCrossPMBF16Function
+    B, C, H, W = shape
+    cq = C // 8
+    q, k, v, x, dy, qkv, xp, dyp = _pm_inputs(B, C, H, W, dev, seed=53)
+    gamma = torch.tensor([0.5], device=dev, requires_grad=True)
+    qkv.requires_grad_(True)
+    xp.requires_grad_(True)
+    y = CrissCrossPMBF16Function.apply(qkv, xp, gamma, cq)
+    assert y.dtype == torch.bfloat16 and tuple(y.shape) == (B, H, W, C)
+    y.backward(dyp)
+    f = lambda t: t.detach().float().cpu()                                  # noqa: E731
+    nchw = lambda t: f(t).permute(0, 3, 1, 2)                               # noqa: E731
+    yo, Ao = O.cca_core_forward(f(q), f(k), f(v), f(x), f(gamma))
+    go = O.cca_core_backward(f(dy), f(q), f(k), f(v), Ao, f(gamma))
+    tol = lambda ref: 2.0 ** -8 * ref.abs() + TOL                           # noqa: E731
+    assert bool(((nchw(y) - yo).abs() <= tol(yo)).all())
+    g = qkv.grad
+    for got, name in ((g[..., :cq], "dq"), (g[..., cq:2 * cq], "dk"), (g[..., 2 * cq:], "dv")):
+        assert bool(((nchw(got) - go[name]).abs() <= tol(go[name])).all()), name
+    assert torch.equal(xp.grad, dyp)
+    assert abs(float(gamma.grad) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
+
+
+def test_pixel_major_bf16_module_route_and_full_size(lib, dev):
+    """The module takes bf16 activations through the pixel-major kernels (channels_last in, channels_last out), and at
+    BASELINE configs[4]'s full size (16,512,129,129) the path agrees with the fp32 strip kernels on the same bf16-rounded
+    inputs to one rounding of each output (the size is beyond the CPU oracle; the fp32 path is checked against it)."""
+    from ccnet_amd import CrissCrossAttention, criss_cross_attention
+    from ccnet_amd.functions import CrissCrossPMBF16Function
+    lib.ccnet_cca_set_impl(0)
+    B, C, H, W = 16, 512, 129, 129
+    cq = C // 8
+    q, k, v, x, dy, qkv, xp, dyp = _pm_inputs(B, C, H, W, dev, seed=63, qk_scale=0.35)
+    gamma = torch.tensor([0.5], device=dev)
+    ga = gamma.clone().requires_grad_(True)
+    qkv.requires_grad_(True)
+    ya = CrissCrossPMBF16Function.apply(qkv, xp, ga, cq)
+    ya.backward(dyp)
+    b = [t.float().requires_grad_(True) for t in (q, k, v, x)] + [gamma.clone().requires_grad_(True)]
+    del q, k, v, x
+    yb = criss_cross_attention(*b)
+    yb.backward(dy.float())
+    tol = lambda ref: 2.0 ** -8 * ref.abs() + 2e-4                          # noqa: E731
+    nchw = lambda t: t.permute(0, 3, 1, 2).float()                          # noqa: E731
+    assert bool(((nchw(ya) - yb).abs() <= tol(yb)).all())
+    g = qkv.grad
+    for got, ref, name in ((g[..., :cq], b[0].grad, "dq"), (g[..., cq:2 * cq], b[1].grad, "dk"), (g[..., 2 * cq:], b[2].grad, "dv")):
+        assert bool(((nchw(got) - ref).abs() <= tol(ref)).all()), name
+    assert abs(float(ga.grad) - float(b[4].grad)) < 2e-3 * max(1.0, abs(float(b[4].grad)))
+    del b, ya, yb, g, qkv, xp, dyp, dy
+    torch.cuda.empty_cache()
+    # module route: bf16 channels_last activations
+    m = CrissCrossAttention(64).to(dev).to(torch.bfloat16)
+    with torch.no_grad():
+        m.gamma.fill_(0.5)
+    xm = torch.randn(2, 64, 33, 18, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ym = m(xm)
+    assert ym.dtype == torch.bfloat16 and tuple(ym.shape) == (2, 64, 33, 18) and ym.is_contiguous(memory_format=torch.channels_last)
+    ym.float().square().sum().backward()
+    qo, ko, vo = (c(xm.detach()).float().cpu() for c in (m.query_conv, m.key_conv, m.value_conv))
+    yo, _ = O.cca_core_forward(qo, ko, vo, xm.detach().float().cpu(), torch.tensor([0.5]))
+    assert err(ym.float(), yo) < 0.05                                       # bf16 projections (torch GEMM) + one output rounding
+    assert xm.grad is not None and m.gamma.grad is not None and m.value_conv.weight.grad is not None
+
+
 @pytest.mark.parametrize("shape", [(1, 32, 129, 129), (2, 24, 101, 160), (1, 64, 129, 257), (1, 16, 320, 33)])
 def test_long_strip_kernels_match_oracle(lib, dev, shape):
     """Strips 101..320 long on the windowed MFMA kernels (cca_long.hpp): 129 x 129 (BASELINE configs[4] geometry),
