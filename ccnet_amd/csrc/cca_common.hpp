@@ -238,4 +238,22 @@ __device__ __forceinline__ void strip_dma_channel(const FBuf &src, float *dst, i
         }
 }
 
+// counted barrier with a run-time (wave-uniform) count
+__device__ __forceinline__ void barrier_dma_keep_n(int n) {
+    switch (n) {
+        case 0: barrier_dma_keep<0>(); break;
+        case 1: barrier_dma_keep<1>(); break;
+        case 2: barrier_dma_keep<2>(); break;
+        case 3: barrier_dma_keep<3>(); break;
+        case 4: barrier_dma_keep<4>(); break;
+        case 5: barrier_dma_keep<5>(); break;
+        case 6: barrier_dma_keep<6>(); break;
+        case 7: barrier_dma_keep<7>(); break;
+        case 8: barrier_dma_keep<8>(); break;
+        case 9: barrier_dma_keep<9>(); break;
+        case 10: barrier_dma_keep<10>(); break;
+        default: barrier_dma_keep<0>(); break;
+    }
+}
+
 }  // namespace cca

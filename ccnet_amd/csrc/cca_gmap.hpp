@@ -14,14 +14,16 @@
 // contiguous one (so the K = channel contraction of gweight reads MFMA fragments straight out of LDS), and nothing
 // depends on the strip length being 97..100.
 //
-// gmap (MI355X): workgroup = one strip g of one image, 4 wavefronts = the four 16-channel N tiles of a 64-channel
-// group.  Prologue: the L rows of P_g (contiguous in T) arrive by LDS-DMA and are rewritten ONCE as two bf16 images
-// (hi, lo = the split of cca_common.hpp; transposed for TRANS; zero beyond the strip), row pitch 272 B, so that a
-// 16 x 32 MFMA A fragment is one ds_read_b128 per image and no VALU.  Per channel group: the L x 64 feature tile
-// arrives by LDS-DMA (double-buffered), each wavefront gathers its B fragments (fp32: 8 ds_read_b32 + hi/lo split,
-// 3 MFMAs per tile; bf16: 8 ds_read_u16 + pack, exact, 2 MFMAs per tile), accumulates up to 9 tiles of
-// v_mfma_f32_16x16x32_bf16 (+ one exact f32 step for a k remainder <= 4), adds the fp32 addend tile the DMA dropped
-// into the output image, and the image leaves as whole pixel rows (fp32 or rounded to bf16).
+// gmap (MI355X): workgroup = one strip g of one image, 8 wavefronts = (the four 16-channel N tiles of a 64-channel
+// group) x (two interleaved halves of the M tiles).  Prologue: the L rows of P_g (contiguous in T) arrive by LDS-DMA and
+// are rewritten ONCE as two bf16 images (hi, lo = the split of cca_common.hpp; transposed for TRANS; zero beyond the
+// strip), row pitch 272 B, so that a 16 x 32 MFMA A fragment is one ds_read_b128 per image and no VALU.  Per channel
+// group: the L x 64 feature tile arrives by LDS-DMA (double-buffered); each wavefront gathers its B fragments (fp32:
+// 8 ds_read_b32 + hi/lo split, 3 MFMAs per tile; bf16: 8 ds_read_u16 + pack, exact, 2 MFMAs per tile), accumulates its
+// tiles of v_mfma_f32_16x16x32_bf16 (+ one exact f32 step for a k remainder <= 4) and drops them into the fp32 output
+// image; the image then leaves as whole pixel rows, each lane adding the fp32 addend (and bf16 residual) slice it
+// loaded into registers before the MFMA phase -- fp32, or rounded to bf16 once.  The stores of a group stay in flight
+// across the next group's barrier (counted vmcnt).
 #pragma once
 #include "cca_band.hpp"
 #include "cca_common.hpp"
@@ -31,7 +33,8 @@
 namespace cca {
 
 constexpr int GM_CG = 64;                       // channels per group = four MFMA N tiles
-constexpr int GM_THREADS = 256;
+constexpr int GM_WAVES = 8;
+constexpr int GM_THREADS = GM_WAVES * 64;
 constexpr int GM_PP = 4 * GM_CG + 8;            // dwords per 4-pixel piece of an fp32 tile (+8: bank spread)
 constexpr int GM_PB = 8 * GM_CG / 2 + 8;        // dwords per 8-pixel piece of a bf16 tile (+8)
 constexpr int GM_BP = 68;                       // dwords per row of a bf16 attention image (136 bf16: 128 + pad)
@@ -69,24 +72,19 @@ __device__ __forceinline__ uint32_t lds_load_u16(const float *base, int byte_off
     return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-template <int P, typename FT, int NOB_>
+template <int P, typename FT>
 struct GmapCfg {
     static constexpr int NT = (P + 15) / 16;                // M tiles
     static constexpr int FSZ = GTile<FT>::size(P);          // dwords per feature tile
-    static constexpr int OSZ = GTile<float>::size(P);       // dwords per (fp32) output / addend tile
+    static constexpr int OSZ = GTile<float>::size(P);       // dwords per (fp32) output tile
     static constexpr int ASZ = P * GM_BP;                   // dwords per bf16 attention image
     static constexpr int TSZ = P * 4;                       // exact f32 k tail
-    static constexpr int NOB = NOB_;                        // output images (2: the next group's addend lands early)
     static constexpr int OFF_PH = 0, OFF_PL = ASZ, OFF_PT = 2 * ASZ, OFF_F = 2 * ASZ + TSZ, OFF_O = OFF_F + 2 * FSZ;
-    static constexpr int LDS = OFF_O + NOB * OSZ;           // dwords
-    static constexpr int NPA = (P * (P / 4) + 63) / 64;     // DMA instructions of the raw attention block
+    static constexpr int LDS = OFF_O + OSZ;                 // dwords
     static_assert(P % 4 == 0 && P <= 136, "GmapCfg: padded strip length");
-    static_assert(P * P <= 2 * FSZ + NOB * OSZ, "the raw attention block is staged in the tile buffers");
+    static_assert(P * P <= 2 * FSZ + OSZ, "the raw attention block is staged in the tile buffers");
     static_assert(LDS * 4 <= 163840, "GmapCfg: LDS");
 };
-__host__ __device__ constexpr int gmap_nob(int P, bool bf) {
-    return (2 * P * GM_BP + P * 4 + 2 * (bf ? GTile<bf16_t>::size(P) : GTile<float>::size(P)) + 2 * GTile<float>::size(P)) * 4 <= 163840 ? 2 : 1;
-}
 
 // raw rows of the strip's attention block -> bf16 hi / lo images [m][k] (+ exact f32 k tail); `stage` = P * P floats
 template <int P, bool TRANS>
@@ -94,7 +92,7 @@ __device__ __forceinline__ void gmap_attention_images(const FBuf &Tb, float *sta
                                                       int L, int row_off0, int row_step, const BandK &kp, int tid, int lane,
                                                       int wave) {
     constexpr int P4 = P / 4, NPA = (P * P4 + 63) / 64;
-    for (int it = wave; it < NPA; it += 4) {
+    for (int it = wave; it < NPA; it += GM_WAVES) {
         const int idx = 64 * it + lane, i = idx / P4, chk = idx - i * P4;
         if (i < L && 4 * chk < L) fbuf_load_to_lds_x4(Tb, stage + 256 * it, (row_off0 + i * row_step + 4 * chk) * 4, 0);
     }
@@ -118,7 +116,9 @@ __device__ __forceinline__ void gmap_attention_images(const FBuf &Tb, float *sta
     __syncthreads();
 }
 
-// FT: feature element, OT: output element; the addend (ADD) is always fp32 pixel-major with its own strides
+// FT: feature element, OT: output element; the addend (ADD) is fp32 pixel-major with its own strides; resid (bf16 output
+// only, may be null) has the output's type.  8 wavefronts: wave = (N tile nt = w & 3, M half mh = w >> 2); a wave
+// accumulates the M tiles t = mh, mh + 2, ... of its 16 channels.
 template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT>
 __global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__restrict__ T, const FT *__restrict__ F,
                                                               const float *__restrict__ addend,
@@ -126,17 +126,20 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__rest
                                                               const float *__restrict__ gamma, OT *out,
                                                               int C, int H, int W, long fbs, int fps, long abs_, int aps,
                                                               long rbs, int rps, long obs, int ops) {
-    using Cfg = GmapCfg<P, FT, gmap_nob(P, GTile<FT>::BF)>;
+    using Cfg = GmapCfg<P, FT>;
     constexpr bool BF = GTile<FT>::BF, OBF = std::is_same<OT, bf16_t>::value;
-    constexpr int NT = Cfg::NT, FSZ = Cfg::FSZ, OSZ = Cfg::OSZ, NOB = Cfg::NOB;
-    constexpr int NPF = GTile<FT>::pieces(P), NPO = GTile<float>::pieces(P);
+    constexpr int NT = Cfg::NT, NTW = (NT + 1) / 2, FSZ = Cfg::FSZ, OSZ = Cfg::OSZ;
+    constexpr int NPF = GTile<FT>::pieces(P);
+    constexpr int SPX = OBF ? 8 : 4;                                  // pixels per store instruction
+    constexpr int NSI = ((P + SPX - 1) / SPX + GM_WAVES - 1) / GM_WAVES;     // store instructions per wave and group (max)
     __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS];
     CCA_LDS_REGISTER(lds);
     const int HW = H * W, S = H + W;
     const int L = ROW ? W : H, G = ROW ? H : W;
     const int id = xcd_logical_id(blockIdx.x, gridDim.x);
     const int b = id / G, g = id - b * G;
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), nt = uniform(tid >> 6);     // wave = N tile
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
+    const int nt = wv & 3, mh = wv >> 2;
     const int ln = lane & 15, lg = lane >> 4;
     const int pix0 = ROW ? g * W : g, pstep = ROW ? 1 : W;                             // pixel(i) = pix0 + i * pstep
     const int a_off = ROW ? H : 0;
@@ -152,35 +155,48 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__rest
     const BandK kp = band_ksteps(L);
 
     uint32_t *const PH = reinterpret_cast<uint32_t *>(lds + Cfg::OFF_PH), *const PL = reinterpret_cast<uint32_t *>(lds + Cfg::OFF_PL);
-    float *const PT = lds + Cfg::OFF_PT, *const FB = lds + Cfg::OFF_F, *const OB = lds + Cfg::OFF_O;
+    float *const PT = lds + Cfg::OFF_PT, *const FB = lds + Cfg::OFF_F, *const oimg = lds + Cfg::OFF_O;
 
-    gmap_attention_images<P, TRANS>(Tb, FB, PH, PL, PT, L, pix0 * S + a_off, pstep * S, kp, tid, lane, nt);
+    gmap_attention_images<P, TRANS>(Tb, FB, PH, PL, PT, L, pix0 * S + a_off, pstep * S, kp, tid, lane, wv);
     // the staging area becomes tile buffers: masked DMA lanes leave their slots alone and the k padding of a feature
     // tile meets zero attention operands -- it has to be finite
-    for (int i = tid * 4; i < 2 * FSZ + NOB * OSZ; i += GM_THREADS * 4) lds_store_x4(&FB[i], f32x4{0.f, 0.f, 0.f, 0.f});
+    for (int i = tid * 4; i < 2 * FSZ + OSZ; i += GM_THREADS * 4) lds_store_x4(&FB[i], f32x4{0.f, 0.f, 0.f, 0.f});
     __syncthreads();
 
     auto issue_feat = [&](int cg) {
-        for (int it = nt; it < NPF; it += 4) gtile_dma_piece<FT>(Fb, FB + (cg & 1) * FSZ, it, lane, pix0, pstep, L, fps, cg * GM_CG, C);
+        for (int it = wv; it < NPF; it += GM_WAVES) gtile_dma_piece<FT>(Fb, FB + (cg & 1) * FSZ, it, lane, pix0, pstep, L, fps, cg * GM_CG, C);
     };
-    auto issue_add = [&](int cg) {
-        for (int it = nt; it < NPO; it += 4)
-            gtile_dma_piece<float>(Db, OB + (NOB == 2 ? cg & 1 : 0) * OSZ, it, lane, pix0, pstep, L, aps, cg * GM_CG, C);
-    };
+    // this lane's slice of store instruction k of its wave: pixel position and first channel (within the group)
+    const int nsi_total = (L + SPX - 1) / SPX;
+    const int nstore = (nsi_total - wv + GM_WAVES - 1) / GM_WAVES;          // store instructions this wave issues per group
+    auto st_pos = [&](int k) { return SPX * (wv + GM_WAVES * k) + (OBF ? lane >> 3 : lane >> 4); };
+    const int st_c = OBF ? 8 * (lane & 7) : 4 * (lane & 15);
 
     issue_feat(0);
-    if (ADD) issue_add(0);
     for (int cg = 0; cg < ncg; ++cg) {
         const float *img = FB + (cg & 1) * FSZ;
-        float *oimg = OB + (NOB == 2 ? cg & 1 : 0) * OSZ;
-        barrier_dma_keep<0>();                   // tile cg (and its addend) landed; every wave is done with group cg - 1
-        if (cg + 1 < ncg) {
-            issue_feat(cg + 1);
-            if (ADD && NOB == 2) issue_add(cg + 1);
-        }
-        f32x4 acc[NT];
+        // tile cg landed, every wave is done with group cg - 1; the stores of group cg - 1 (the most recent vector
+        // memory operations of this wave) may stay in flight
+        if (cg == 0) barrier_dma_keep<0>();
+        else         barrier_dma_keep_n(nstore);
+        if (cg + 1 < ncg) issue_feat(cg + 1);
+        // the fp32 addend / bf16 residual slices this lane will store over: in registers by the time the tiles are done
+        f32x4 add0[NSI], add1[NSI];
+        u32x4 res[NSI];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < NSI; ++k) {
+            const int i = st_pos(k), c = cg * GM_CG + st_c;
+            const bool ok = i < L && c < C;
+            const int pix = pix0 + i * pstep;
+            if (ADD) {
+                add0[k] = fbuf_load_x4(Db, ok ? (pix * aps + c) * 4 : kOobOffset, 0);
+                if (OBF) add1[k] = fbuf_load_x4(Db, ok ? (pix * aps + c + 4) * 4 : kOobOffset, 0);
+            }
+            if (OBF) res[k] = __builtin_bit_cast(u32x4, fbuf_load_x4(Rb, (ok && resid) ? (pix * rps + c) * 2 : kOobOffset, 0));
+        }
+        f32x4 acc[NTW];
+#pragma unroll
+        for (int a = 0; a < NTW; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int ks = 0; ks < kp.nbf; ++ks) {
             // B fragment: positions 32 ks + 8 lg + e of channel 16 nt + ln
             BfSplit fb;
@@ -198,13 +214,14 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__rest
                 fb = bf16_split8(x);
             }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+            for (int a = 0; a < NTW; ++a) {
+                const int t = 2 * a + mh;
                 if (t * 16 < L) {
                     const int ao = (16 * t + ln) * GM_BP + 16 * ks + 4 * lg;
                     const u32x4 ah = *reinterpret_cast<const u32x4 *>(PH + ao), al = *reinterpret_cast<const u32x4 *>(PL + ao);
-                    acc[t] = mfma_bf16_16x16x32(ah, fb.hi, acc[t]);
-                    if (!BF) acc[t] = mfma_bf16_16x16x32(ah, fb.lo, acc[t]);
-                    acc[t] = mfma_bf16_16x16x32(al, fb.hi, acc[t]);
+                    acc[a] = mfma_bf16_16x16x32(ah, fb.hi, acc[a]);
+                    if (!BF) acc[a] = mfma_bf16_16x16x32(ah, fb.lo, acc[a]);
+                    acc[a] = mfma_bf16_16x16x32(al, fb.hi, acc[a]);
                 }
             }
         }
@@ -214,54 +231,46 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__rest
             if constexpr (BF) fbv = __builtin_bit_cast(float, lds_load_u16(img, gtile_bf_byte(pos, 16 * nt + ln)) << 16);
             else              fbv = CCA_LDS_LD(img + (pos >> 2) * GM_PP + (pos & 3) * GM_CG + 16 * nt + ln);
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (t * 16 < L) acc[t] = mfma_16x16x4(CCA_LDS_LD(PT + (16 * t + ln) * 4 + lg), fbv, acc[t]);
+            for (int a = 0; a < NTW; ++a) {
+                const int t = 2 * a + mh;
+                if (t * 16 < L) acc[a] = mfma_16x16x4(CCA_LDS_LD(PT + (16 * t + ln) * 4 + lg), fbv, acc[a]);
+            }
             mfma_f32_result_fence();
         }
-        // D[m = position 16 t + 4 lg + q][n = channel 16 nt + ln] -> output image (fp32 pixel-major pieces), + addend
+        // D[m = position 16 t + 4 lg + q][n = channel 16 nt + ln] -> output image (fp32 pixel-major pieces)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int a = 0; a < NTW; ++a)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int i = 16 * t + 4 * lg + q;
-                if (i < L) {
-                    float *d = oimg + (i >> 2) * GM_PP + (i & 3) * GM_CG + 16 * nt + ln;
-                    float val = alpha * acc[t][q];
-                    if (ADD) val += CCA_LDS_LD(d);
-                    CCA_LDS_ST(d, val);
-                }
+                const int i = 16 * (2 * a + mh) + 4 * lg + q;
+                if (i < L) CCA_LDS_ST(oimg + (i >> 2) * GM_PP + (i & 3) * GM_CG + 16 * nt + ln, alpha * acc[a][q]);
             }
         barrier_lds_only();
-        if constexpr (OBF) {
-            // 8 pixels x 64 channels per instruction: a lane rounds 8 consecutive channels to bf16 (16 bytes)
-            for (int it = nt; it < (L + 7) / 8; it += 4) {
-                const int i = 8 * it + (lane >> 3), c8 = 8 * (lane & 7), c = cg * GM_CG + c8;
-                if (i < L && c < C) {
-                    const float *s = oimg + (i >> 2) * GM_PP + (i & 3) * GM_CG + c8;
-                    f32x4 u = lds_load_x4(s), v = lds_load_x4(s + 4);
-                    if (resid) {                 // + the bf16 residual (x of functions.py:104), the same 16 bytes
-                        const u32x4 r = __builtin_bit_cast(u32x4, fbuf_load_x4(Rb, ((pix0 + i * pstep) * rps + c) * 2, 0));
+        // whole pixel rows leave: 256 (fp32) / 128 (bf16) bytes per pixel, + addend (+ residual), rounded once
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float lo = __builtin_bit_cast(float, r[e] << 16), hi = __builtin_bit_cast(float, r[e] & 0xffff0000u);
+        for (int k = 0; k < NSI; ++k) {
+            if (wv + GM_WAVES * k < nsi_total) {                         // wave-uniform: exactly `nstore` instructions
+                const int i = st_pos(k), c = cg * GM_CG + st_c;
+                const float *s = oimg + (i >> 2) * GM_PP + (i & 3) * GM_CG + st_c;
+                if (i < L && c < C) {
+                    f32x4 u = lds_load_x4(s);
+                    if (ADD) u += add0[k];
+                    if constexpr (OBF) {
+                        f32x4 v = lds_load_x4(s + 4);
+                        if (ADD) v += add1[k];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {              // + the bf16 residual (x of functions.py:104)
+                            const float lo = __builtin_bit_cast(float, res[k][e] << 16), hi = __builtin_bit_cast(float, res[k][e] & 0xffff0000u);
                             if (e < 2) { u[2 * e] += lo; u[2 * e + 1] += hi; } else { v[2 * e - 4] += lo; v[2 * e - 3] += hi; }
                         }
+                        const f32x4 packed = __builtin_bit_cast(f32x4, u32x4{cvt_pk_bf16(u[0], u[1]), cvt_pk_bf16(u[2], u[3]),
+                                                                             cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])});
+                        fbuf_store_x4(Ob, packed, ((pix0 + i * pstep) * ops + c) * 2, 0);
+                    } else {
+                        fbuf_store_x4(Ob, u, ((pix0 + i * pstep) * ops + c) * 4, 0);
                     }
-                    const f32x4 packed = __builtin_bit_cast(f32x4, u32x4{cvt_pk_bf16(u[0], u[1]), cvt_pk_bf16(u[2], u[3]),
-                                                                         cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])});
-                    fbuf_store_x4(Ob, packed, ((pix0 + i * pstep) * ops + c) * 2, 0);
                 }
             }
-        } else {
-            for (int it = nt; it < NPO; it += 4) {
-                const int i = 4 * it + (lane >> 4), c = cg * GM_CG + 4 * (lane & 15);
-                if (i < L && c < C)
-                    fbuf_store_x4(Ob, lds_load_x4(oimg + it * GM_PP + 4 * lane), ((pix0 + i * pstep) * ops + c) * 4, 0);
-            }
-        }
-        if (ADD && NOB == 1 && cg + 1 < ncg) {
-            barrier_lds_only();                  // the single output image has been read out: the next addend may land
-            issue_add(cg + 1);
         }
     }
 }
@@ -271,13 +280,13 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__rest
 //   ca_forward (X = q, Y = k, K = C/8, MASK: the column self slot is -inf) and the dA half of ca_map_backward
 //   (X = dy, Y = v, K = C).  Workgroup = one strip; the channel axis is contiguous, so both MFMA operands are single
 //   ds_read_b128 fragments of the swizzled bf16 tiles and the products are exact: no split, one
-//   v_mfma_f32_16x16x32_bf16 per tile and 32 channels.  Wavefront w owns the tile rows ti = w, w + 4, ...
+//   v_mfma_f32_16x16x32_bf16 per tile and 32 channels.  Wavefront w owns the tile rows ti = w, w + 8, ...
 // ---------------------------------------------------------------------------------------------------------------
 template <int P, bool MASK>
 __global__ __launch_bounds__(GM_THREADS, 1) void gweight_kernel(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Y,
                                                                  float *__restrict__ T, int Cx, int H, int W,
                                                                  long xbs, int xps, long ybs, int yps) {
-    constexpr int NT = (P + 15) / 16, NTR = (NT + 3) / 4, TSZ = GTile<bf16_t>::size(P), NPF = GTile<bf16_t>::pieces(P);
+    constexpr int NT = (P + 15) / 16, NTR = (NT + GM_WAVES - 1) / GM_WAVES, TSZ = GTile<bf16_t>::size(P), NPF = GTile<bf16_t>::pieces(P);
     __shared__ __attribute__((aligned(16))) float lds[4 * TSZ];
     CCA_LDS_REGISTER(lds);
     const int HW = H * W, S = H + W;
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gweight_kernel(const bf16_t *__
     __syncthreads();
     auto issue = [&](int ch) {
         float *xb = lds + (ch & 1) * 2 * TSZ, *yb = xb + TSZ;
-        for (int it = wv; it < 2 * NPF; it += 4) {
+        for (int it = wv; it < 2 * NPF; it += GM_WAVES) {
             if (it < NPF) gtile_dma_piece<bf16_t>(Xb, xb, it, lane, pix0, pstep, L, xps, ch * GM_CG, Cx);
             else          gtile_dma_piece<bf16_t>(Yb, yb, it - NPF, lane, pix0, pstep, L, yps, ch * GM_CG, Cx);
         }
@@ -322,14 +331,14 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gweight_kernel(const bf16_t *__
         for (int kk = 0; kk < 2; ++kk) {                       // two k-steps of 32 channels
             u32x4 af[NTR];
 #pragma unroll
-            for (int a = 0; a < NTR; ++a) af[a] = frag(xb, 16 * (wv + 4 * a) + ln, 4 * kk + lg);
+            for (int a = 0; a < NTR; ++a) af[a] = frag(xb, 16 * (wv + GM_WAVES * a) + ln, 4 * kk + lg);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (t * 16 < L) {
                     const u32x4 bf = frag(yb, 16 * t + ln, 4 * kk + lg);
 #pragma unroll
                     for (int a = 0; a < NTR; ++a)
-                        if ((wv + 4 * a) * 16 < L) acc[a][t] = mfma_bf16_16x16x32(af[a], bf, acc[a][t]);
+                        if ((wv + GM_WAVES * a) * 16 < L) acc[a][t] = mfma_bf16_16x16x32(af[a], bf, acc[a][t]);
                 }
             }
         }
@@ -342,7 +351,7 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gweight_kernel(const bf16_t *__
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int i = 16 * (wv + 4 * a) + 4 * lg + q, j = 16 * t + ln;
+                const int i = 16 * (wv + GM_WAVES * a) + 4 * lg + q, j = 16 * t + ln;
                 if (i < L && j < L) {
                     float val = acc[a][t][q];
                     if (MASK && !row && i == j) val = -INFINITY;            // functions.py:11-12 (column self slot)

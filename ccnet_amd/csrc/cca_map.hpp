@@ -31,24 +31,6 @@
 
 namespace cca {
 
-// counted barrier with a run-time (wave-uniform) count
-__device__ __forceinline__ void barrier_dma_keep_n(int n) {
-    switch (n) {
-        case 0: barrier_dma_keep<0>(); break;
-        case 1: barrier_dma_keep<1>(); break;
-        case 2: barrier_dma_keep<2>(); break;
-        case 3: barrier_dma_keep<3>(); break;
-        case 4: barrier_dma_keep<4>(); break;
-        case 5: barrier_dma_keep<5>(); break;
-        case 6: barrier_dma_keep<6>(); break;
-        case 7: barrier_dma_keep<7>(); break;
-        case 8: barrier_dma_keep<8>(); break;
-        case 9: barrier_dma_keep<9>(); break;
-        case 10: barrier_dma_keep<10>(); break;
-        default: barrier_dma_keep<0>(); break;
-    }
-}
-
 constexpr int M_MC = 16;                          // channels per chunk = one MFMA M tile
 constexpr int M_KS = kMaxStrip / 4;               // 25 k-steps
 constexpr int M_BKS = 3;                          // bf16 path: 3 k-steps of 32 cover k < 96

@@ -1,7 +1,8 @@
 """Time the pixel-major bf16 core (csrc/cca_gmap.hpp) fwd+bwd through the C ABI: python tools/pm_bf16_time.py [B C H W]"""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ccnet_amd import _lib
 
 B, C, H, W = (int(a) for a in sys.argv[1:5]) if len(sys.argv) >= 5 else (16, 512, 129, 129)
