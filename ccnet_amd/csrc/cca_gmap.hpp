@@ -52,16 +52,17 @@ struct GTile {
 };
 
 // one DMA piece of a pixel-major tile: pixels pix0 + i * pstep (i < n), channels c0 .. c0 + 63 of a tensor with
-// pixel stride ps (elements of FT); lane -> (pixel, 16-byte chunk)
+// pixel stride ps (elements of FT); lane -> (pixel, 16-byte chunk).  Lanes beyond the strip / the channel count are
+// issued out of range: the DMA deposits zeros for them, so a tile is complete (and finite) after every fill
 template <typename FT>
 __device__ __forceinline__ void gtile_dma_piece(const FBuf &src, float *img, int piece, int lane, int pix0, int pstep, int n,
                                                 int ps, int c0, int C) {
     if constexpr (GTile<FT>::BF) {
         const int p = lane >> 3, i = 8 * piece + p, q = (lane & 7) ^ (p & 7), c = c0 + 8 * q;
-        if (i < n && c < C) fbuf_load_to_lds_x4(src, img + piece * GM_PB, ((pix0 + i * pstep) * ps + c) * 2, 0);
+        fbuf_load_to_lds_x4(src, img + piece * GM_PB, (i < n && c < C) ? ((pix0 + i * pstep) * ps + c) * 2 : kOobOffset, 0);
     } else {
         const int i = 4 * piece + (lane >> 4), c = c0 + 4 * (lane & 15);
-        if (i < n && c < C) fbuf_load_to_lds_x4(src, img + piece * GM_PP, ((pix0 + i * pstep) * ps + c) * 4, 0);
+        fbuf_load_to_lds_x4(src, img + piece * GM_PP, (i < n && c < C) ? ((pix0 + i * pstep) * ps + c) * 4 : kOobOffset, 0);
     }
 }
 // byte offset of channel c (0..63) of line position j inside a bf16 tile
@@ -98,7 +99,9 @@ __device__ __forceinline__ void gmap_attention_images(const FBuf &Tb, float *sta
     }
     __syncthreads();                                     // (drains the DMA)
     for (int e = tid; e < P * (P / 2); e += GM_THREADS) {
-        const int m = e / (P / 2), k = 2 * (e - m * (P / 2));
+        // consecutive lanes: consecutive k pairs of one row (stage rows are read along k), or -- transposed -- consecutive m
+        // of one k pair (stage rows are read along m): the stage reads are conflict-free either way
+        const int m = TRANS ? e % P : e / (P / 2), k = 2 * (TRANS ? e / P : e - m * (P / 2));
         float v0 = 0.f, v1 = 0.f;
         if (m < L) {
             if (k < L)     v0 = CCA_LDS_LD(stage + (TRANS ? k * P + m : m * P + k));
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__rest
                                                               const OT *__restrict__ resid,
                                                               const float *__restrict__ gamma, OT *out,
                                                               int C, int H, int W, long fbs, int fps, long abs_, int aps,
-                                                              long rbs, int rps, long obs, int ops) {
+                                                              long rbs, int rps, long obs, int ops, int n_whole, int split) {
     using Cfg = GmapCfg<P, FT>;
     constexpr bool BF = GTile<FT>::BF, OBF = std::is_same<OT, bf16_t>::value;
     constexpr int NT = Cfg::NT, NTW = (NT + 1) / 2, FSZ = Cfg::FSZ, OSZ = Cfg::OSZ;
@@ -136,7 +139,16 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__rest
     CCA_LDS_REGISTER(lds);
     const int HW = H * W, S = H + W;
     const int L = ROW ? W : H, G = ROW ? H : W;
-    const int id = xcd_logical_id(blockIdx.x, gridDim.x);
+    // workgroups are dispatched in index order, one per CU: the first n_whole take a whole strip each, the remaining
+    // strips (fewer than there are CUs) are cut into `split` channel ranges so that the last round is a short one
+    const int ncg = (C + GM_CG - 1) / GM_CG;
+    int id = blockIdx.x, cg0 = 0, cg1 = ncg;
+    if (id >= n_whole) {
+        const int r = id - n_whole, part = r % split;
+        id = n_whole + r / split;
+        cg0 = part * ncg / split;
+        cg1 = (part + 1) * ncg / split;
+    }
     const int b = id / G, g = id - b * G;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
     const int nt = wv & 3, mh = wv >> 2;
@@ -151,20 +163,15 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__rest
                               resid ? ((size_t)(HW - 1) * rps + C) * sizeof(OT) : 4);
     const FBuf Db = make_fbuf(ADD ? addend + (size_t)b * abs_ : T, ADD ? ((size_t)(HW - 1) * aps + C) * sizeof(float) : 4);
     const float alpha = gamma ? gamma[0] : 1.f;
-    const int ncg = (C + GM_CG - 1) / GM_CG;
     const BandK kp = band_ksteps(L);
 
     uint32_t *const PH = reinterpret_cast<uint32_t *>(lds + Cfg::OFF_PH), *const PL = reinterpret_cast<uint32_t *>(lds + Cfg::OFF_PL);
     float *const PT = lds + Cfg::OFF_PT, *const FB = lds + Cfg::OFF_F, *const oimg = lds + Cfg::OFF_O;
 
     gmap_attention_images<P, TRANS>(Tb, FB, PH, PL, PT, L, pix0 * S + a_off, pstep * S, kp, tid, lane, wv);
-    // the staging area becomes tile buffers: masked DMA lanes leave their slots alone and the k padding of a feature
-    // tile meets zero attention operands -- it has to be finite
-    for (int i = tid * 4; i < 2 * FSZ + OSZ; i += GM_THREADS * 4) lds_store_x4(&FB[i], f32x4{0.f, 0.f, 0.f, 0.f});
-    __syncthreads();
-
     auto issue_feat = [&](int cg) {
-        for (int it = wv; it < NPF; it += GM_WAVES) gtile_dma_piece<FT>(Fb, FB + (cg & 1) * FSZ, it, lane, pix0, pstep, L, fps, cg * GM_CG, C);
+        for (int it = wv; it < NPF; it += GM_WAVES)
+            gtile_dma_piece<FT>(Fb, FB + ((cg - cg0) & 1) * FSZ, it, lane, pix0, pstep, L, fps, cg * GM_CG, C);
     };
     // this lane's slice of store instruction k of its wave: pixel position and first channel (within the group)
     const int nsi_total = (L + SPX - 1) / SPX;
@@ -172,14 +179,14 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__rest
     auto st_pos = [&](int k) { return SPX * (wv + GM_WAVES * k) + (OBF ? lane >> 3 : lane >> 4); };
     const int st_c = OBF ? 8 * (lane & 7) : 4 * (lane & 15);
 
-    issue_feat(0);
-    for (int cg = 0; cg < ncg; ++cg) {
-        const float *img = FB + (cg & 1) * FSZ;
+    issue_feat(cg0);
+    for (int cg = cg0; cg < cg1; ++cg) {
+        const float *img = FB + ((cg - cg0) & 1) * FSZ;
         // tile cg landed, every wave is done with group cg - 1; the stores of group cg - 1 (the most recent vector
         // memory operations of this wave) may stay in flight
-        if (cg == 0) barrier_dma_keep<0>();
-        else         barrier_dma_keep_n(nstore);
-        if (cg + 1 < ncg) issue_feat(cg + 1);
+        if (cg == cg0) barrier_dma_keep<0>();
+        else           barrier_dma_keep_n(nstore);
+        if (cg + 1 < cg1) issue_feat(cg + 1);
         // the fp32 addend / bf16 residual slices this lane will store over: in registers by the time the tiles are done
         f32x4 add0[NSI], add1[NSI];
         u32x4 res[NSI];
