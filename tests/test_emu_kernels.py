@@ -554,7 +554,8 @@ def _pm(a):
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 128, 17, 20), (1, 64, 9, 1), (1, 192, 33, 18), (1, 64, 3, 129), (1, 64, 101, 2),
-                                   (2, 128, 3, 130)])      # (last: 260 column strips = one whole round of 256 + 4 cut in two)
+                                   (2, 128, 3, 130),       # 260 column strips = one whole round of 256 + 4 cut in two
+                                   (1, 64, 2, 99)])        # the last chunks of a 100-padded strip
 def test_pixel_major_bf16_path_matches_oracle(ops, shape):
     """csrc/cca_gmap.hpp through ccnet_cca_forward_pm_bf16 / ccnet_cca_backward_pm_bf16 (BASELINE configs[4]): q | k | v as
     channel slices of one packed pixel-major bf16 projection, bf16 x / y / dy / gradients, fp32 attention.  Oracle = the fp32
