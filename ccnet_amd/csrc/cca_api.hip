@@ -641,13 +641,13 @@ int ccnet_ca_map_forward_pm_f32(const float *A, const float *v, const float *x, 
 
 extern "C++" {
 namespace {
-// one strip per workgroup and one workgroup per CU: whole rounds of strips first, then the remainder cut into channel
+// one strip per workgroup and two workgroups per CU: whole rounds of strips first, then the remainder cut into channel
 // ranges (a short last round instead of a full-length one that keeps a few CUs busy)
 struct GmapPlan {
     int grid, n_whole, split;
 };
 GmapPlan gmap_plan(int strips, int C) {
-    const int cus = num_cus(), ncg = (C + cca::GM_CG - 1) / cca::GM_CG;
+    const int cus = 2 * num_cus(), ncg = (C + cca::GM_CG - 1) / cca::GM_CG;
     GmapPlan p;
     p.n_whole = strips / cus * cus;
     const int rem = strips - p.n_whole;
@@ -666,7 +666,7 @@ int ccnet_ca_strip_map_pm_f32(const float *T, const float *F, const float *adden
     if (!T || !F || !out) return fail(CCNET_E_NULLPTR, "ca_strip_map_pm: null tensor");
     if ((H > W ? H : W) > 100 || C % 4) return fail(CCNET_E_BADSHAPE, "ca_strip_map_pm: strips <= 100, C % 4 == 0");
     const GmapPlan gp = gmap_plan(B * (row ? H : W), C);
-    const dim3 grid((unsigned)gp.grid), block(cca::GM_THREADS);
+    const dim3 grid((unsigned)gp.grid), block(cca::GS_THREADS);
 #define CCA_GMAP(ROW_, TRANS_)                                                                                          \
     do {                                                                                                                \
         if (addend) CCA_LAUNCH((cca::gmap_kernel<100, ROW_, TRANS_, true, float, float>), grid, block, stream, T, F,     \
@@ -837,11 +837,11 @@ int launch_gmap_bf16(const float *T, const bf16_t *F, const bf16_t *resid, const
                      int ops, ccnet_stream_t stream) {
     const long pbs = (long)H * W * C;
     const GmapPlan gc = gmap_plan(B * W, C), gr = gmap_plan(B * H, C);
-    CCA_LAUNCH((cca::gmap_kernel<P, false, TRANS, false, bf16_t, float>), dim3((unsigned)gc.grid), dim3(cca::GM_THREADS),
+    CCA_LAUNCH((cca::gmap_kernel<P, false, TRANS, false, bf16_t, float>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS),
                stream, T, F, (const float *)nullptr, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0,
                0L, 0, pbs, C, gc.n_whole, gc.split);
     if (int e = launch_status("gmap_bf16(column)")) return e;
-    CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, bf16_t, bf16_t>), dim3((unsigned)gr.grid), dim3(cca::GM_THREADS),
+    CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, bf16_t, bf16_t>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS),
                stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C, rbs, rps, obs, ops,
                gr.n_whole, gr.split);
     return launch_status("gmap_bf16(row)");

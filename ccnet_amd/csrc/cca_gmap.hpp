@@ -33,8 +33,10 @@
 namespace cca {
 
 constexpr int GM_CG = 64;                       // channels per group = four MFMA N tiles
-constexpr int GM_WAVES = 8;
+constexpr int GM_WAVES = 8;                     // gweight / gmap_qk: one workgroup per CU
 constexpr int GM_THREADS = GM_WAVES * 64;
+constexpr int GS_WAVES = 4;                     // gmap: two workgroups per CU
+constexpr int GS_THREADS = GS_WAVES * 64;
 constexpr int GM_PP = 4 * GM_CG + 8;            // dwords per 4-pixel piece of an fp32 tile (+8: bank spread)
 constexpr int GM_PB = 8 * GM_CG / 2 + 8;        // dwords per 8-pixel piece of a bf16 tile (+8)
 constexpr int GM_BP = 68;                       // dwords per row of a bf16 attention image (136 bf16: 128 + pad)
@@ -73,74 +75,30 @@ __device__ __forceinline__ uint32_t lds_load_u16(const float *base, int byte_off
     return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-template <int P, typename FT>
-struct GmapCfg {
-    static constexpr int NT = (P + 15) / 16;                // M tiles
-    static constexpr int FSZ = GTile<FT>::size(P);          // dwords per feature tile
-    static constexpr int OSZ = GTile<float>::size(P);       // dwords per (fp32) output tile
-    static constexpr int ASZ = P * GM_BP;                   // dwords per bf16 attention image
-    static constexpr int TSZ = P * 4;                       // exact f32 k tail
-    static constexpr int OFF_PH = 0, OFF_PL = ASZ, OFF_PT = 2 * ASZ, OFF_F = 2 * ASZ + TSZ, OFF_O = OFF_F + 2 * FSZ;
-    static constexpr int LDS = OFF_O + OSZ;                 // dwords
-    static_assert(P % 4 == 0 && P <= 136, "GmapCfg: padded strip length");
-    static_assert(P * P <= 2 * FSZ + OSZ, "the raw attention block is staged in the tile buffers");
-    static_assert(LDS * 4 <= 163840, "GmapCfg: LDS");
-};
-
-// raw rows of the strip's attention block -> bf16 hi / lo images [m][k] (+ exact f32 k tail); `stage` = P * P floats
-template <int P, bool TRANS>
-__device__ __forceinline__ void gmap_attention_images(const FBuf &Tb, float *stage, uint32_t *PH, uint32_t *PL, float *PT,
-                                                      int L, int row_off0, int row_step, const BandK &kp, int tid, int lane,
-                                                      int wave) {
-    constexpr int P4 = P / 4, NPA = (P * P4 + 63) / 64;
-    for (int it = wave; it < NPA; it += GM_WAVES) {
-        const int idx = 64 * it + lane, i = idx / P4, chk = idx - i * P4;
-        if (i < L && 4 * chk < L) fbuf_load_to_lds_x4(Tb, stage + 256 * it, (row_off0 + i * row_step + 4 * chk) * 4, 0);
-    }
-    __syncthreads();                                     // (drains the DMA)
-    for (int e = tid; e < P * (P / 2); e += GM_THREADS) {
-        // consecutive lanes: consecutive k pairs of one row (stage rows are read along k), or -- transposed -- consecutive m
-        // of one k pair (stage rows are read along m): the stage reads are conflict-free either way
-        const int m = TRANS ? e % P : e / (P / 2), k = 2 * (TRANS ? e / P : e - m * (P / 2));
-        float v0 = 0.f, v1 = 0.f;
-        if (m < L) {
-            if (k < L)     v0 = CCA_LDS_LD(stage + (TRANS ? k * P + m : m * P + k));
-            if (k + 1 < L) v1 = CCA_LDS_LD(stage + (TRANS ? (k + 1) * P + m : m * P + k + 1));
-        }
-        const uint32_t h = cvt_pk_bf16(v0, v1);
-        const float h0 = __builtin_bit_cast(float, h << 16), h1 = __builtin_bit_cast(float, h & 0xffff0000u);
-        PH[m * GM_BP + (k >> 1)] = h;
-        PL[m * GM_BP + (k >> 1)] = cvt_pk_bf16(v0 - h0, v1 - h1);
-    }
-    for (int e = tid; e < P * 4; e += GM_THREADS) {
-        const int m = e >> 2, k = 32 * kp.nbf + (e & 3);
-        PT[e] = (kp.tail && m < L && k < L) ? CCA_LDS_LD(stage + (TRANS ? k * P + m : m * P + k)) : 0.f;
-    }
-    __syncthreads();
-}
-
 // FT: feature element, OT: output element; the addend (ADD) is fp32 pixel-major with its own strides; resid (bf16 output
-// only, may be null) has the output's type.  8 wavefronts: wave = (N tile nt = w & 3, M half mh = w >> 2); a wave
-// accumulates the M tiles t = mh, mh + 2, ... of its 16 channels.
+// only, may be null) has the output's type.  4 wavefronts, two workgroups per CU: wavefront w owns the M tiles (16
+// strip positions each) t = w, w + 4, w + 8 of all four 16-channel N tiles, and keeps their attention fragments -- hi and
+// lo bf16 halves, every k-step -- in registers for the whole strip (A-stationary: 96 VGPRs at 132 positions).
 template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT>
-__global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__restrict__ T, const FT *__restrict__ F,
+__global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__restrict__ T, const FT *__restrict__ F,
                                                               const float *__restrict__ addend,
                                                               const OT *__restrict__ resid,
                                                               const float *__restrict__ gamma, OT *out,
                                                               int C, int H, int W, long fbs, int fps, long abs_, int aps,
                                                               long rbs, int rps, long obs, int ops, int n_whole, int split) {
-    using Cfg = GmapCfg<P, FT>;
     constexpr bool BF = GTile<FT>::BF, OBF = std::is_same<OT, bf16_t>::value;
-    constexpr int NT = Cfg::NT, NTW = (NT + 1) / 2, FSZ = Cfg::FSZ, OSZ = Cfg::OSZ;
-    constexpr int NPF = GTile<FT>::pieces(P);
+    constexpr int NT = (P + 15) / 16, TPW = (NT + GS_WAVES - 1) / GS_WAVES, NKS = P / 32;
+    constexpr int FSZ = GTile<FT>::size(P), OSZ = GTile<float>::size(P), NPF = GTile<FT>::pieces(P);
     constexpr int SPX = OBF ? 8 : 4;                                  // pixels per store instruction
-    constexpr int NSI = ((P + SPX - 1) / SPX + GM_WAVES - 1) / GM_WAVES;     // store instructions per wave and group (max)
-    __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS];
+    constexpr int NSI = ((P + SPX - 1) / SPX + GS_WAVES - 1) / GS_WAVES;     // store instructions per wave and group (max)
+    static_assert(P % 4 == 0 && (2 * FSZ + OSZ) * 4 * 2 <= 163840, "gmap: two workgroups per CU");
+    __shared__ __attribute__((aligned(16))) float lds[2 * FSZ + OSZ];
     CCA_LDS_REGISTER(lds);
+    float *const FB = lds, *const oimg = lds + 2 * FSZ;
     const int HW = H * W, S = H + W;
     const int L = ROW ? W : H, G = ROW ? H : W;
-    // workgroups are dispatched in index order, one per CU: the first n_whole take a whole strip each, the remaining
-    // strips (fewer than there are CUs) are cut into `split` channel ranges so that the last round is a short one
+    // workgroups are dispatched in index order, two per CU: the first n_whole take a whole strip each, the remaining
+    // strips (fewer than one round) are cut into `split` channel ranges so that the last round is a short one
     const int ncg = (C + GM_CG - 1) / GM_CG;
     int id = blockIdx.x, cg0 = 0, cg1 = ncg;
     if (id >= n_whole) {
@@ -151,7 +109,6 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__rest
     }
     const int b = id / G, g = id - b * G;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
-    const int nt = wv & 3, mh = wv >> 2;
     const int ln = lane & 15, lg = lane >> 4;
     const int pix0 = ROW ? g * W : g, pstep = ROW ? 1 : W;                             // pixel(i) = pix0 + i * pstep
     const int a_off = ROW ? H : 0;
@@ -165,21 +122,54 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__rest
     const float alpha = gamma ? gamma[0] : 1.f;
     const BandK kp = band_ksteps(L);
 
-    uint32_t *const PH = reinterpret_cast<uint32_t *>(lds + Cfg::OFF_PH), *const PL = reinterpret_cast<uint32_t *>(lds + Cfg::OFF_PL);
-    float *const PT = lds + Cfg::OFF_PT, *const FB = lds + Cfg::OFF_F, *const oimg = lds + Cfg::OFF_O;
-
-    gmap_attention_images<P, TRANS>(Tb, FB, PH, PL, PT, L, pix0 * S + a_off, pstep * S, kp, tid, lane, wv);
     auto issue_feat = [&](int cg) {
-        for (int it = wv; it < NPF; it += GM_WAVES)
+        for (int it = wv; it < NPF; it += GS_WAVES)
             gtile_dma_piece<FT>(Fb, FB + ((cg - cg0) & 1) * FSZ, it, lane, pix0, pstep, L, fps, cg * GM_CG, C);
     };
+    issue_feat(cg0);
+
+    // ---- the strip's attention block -> MFMA fragments in registers.  Fragment (tile t, k-step ks) of lane (ln, lg):
+    // ---- P_g[m][32 ks + 8 lg + e] (TRANS: P_g[32 ks + 8 lg + e][m]), m = 16 t + ln, e < 8; zero beyond the strip
+    u32x4 ah[TPW][NKS], al[TPW][NKS];
+    float at[TPW];
+#pragma unroll
+    for (int a = 0; a < TPW; ++a) {
+        const int t = wv + GS_WAVES * a, m = 16 * t + ln;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            float x[8];
+            if (ks < kp.nbf && 16 * t < L) {                          // wave-uniform
+                const int k0 = 32 * ks + 8 * lg;
+                if (!TRANS) {
+                    const int base = ((pix0 + m * pstep) * S + a_off + k0) * 4;
+                    const f32x4 u = fbuf_load_x4(Tb, (m < L && k0 < L) ? base : kOobOffset, 0);
+                    const f32x4 v = fbuf_load_x4(Tb, (m < L && k0 + 4 < L) ? base + 16 : kOobOffset, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { x[e] = k0 + e < L ? u[e] : 0.f; x[4 + e] = k0 + 4 + e < L ? v[e] : 0.f; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        x[e] = fbuf_load(Tb, (m < L && k0 + e < L) ? ((pix0 + (k0 + e) * pstep) * S + a_off + m) * 4 : kOobOffset, 0);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = 0.f;
+            }
+            const BfSplit sp = bf16_split8(x);
+            ah[a][ks] = sp.hi;
+            al[a][ks] = sp.lo;
+        }
+        const int kt = 32 * kp.nbf + lg;
+        at[a] = fbuf_load(Tb, (kp.tail && m < L && kt < L) ? (TRANS ? ((pix0 + kt * pstep) * S + a_off + m) * 4
+                                                                     : ((pix0 + m * pstep) * S + a_off + kt) * 4) : kOobOffset, 0);
+    }
+
     // this lane's slice of store instruction k of its wave: pixel position and first channel (within the group)
     const int nsi_total = (L + SPX - 1) / SPX;
-    const int nstore = (nsi_total - wv + GM_WAVES - 1) / GM_WAVES;          // store instructions this wave issues per group
-    auto st_pos = [&](int k) { return SPX * (wv + GM_WAVES * k) + (OBF ? lane >> 3 : lane >> 4); };
+    const int nstore = (nsi_total - wv + GS_WAVES - 1) / GS_WAVES;          // store instructions this wave issues per group
+    auto st_pos = [&](int k) { return SPX * (wv + GS_WAVES * k) + (OBF ? lane >> 3 : lane >> 4); };
     const int st_c = OBF ? 8 * (lane & 7) : 4 * (lane & 15);
 
-    issue_feat(cg0);
     for (int cg = cg0; cg < cg1; ++cg) {
         const float *img = FB + ((cg - cg0) & 1) * FSZ;
         // tile cg landed, every wave is done with group cg - 1; the stores of group cg - 1 (the most recent vector
@@ -201,62 +191,71 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gmap_kernel(const float *__rest
             }
             if (OBF) res[k] = __builtin_bit_cast(u32x4, fbuf_load_x4(Rb, (ok && resid) ? (pix * rps + c) * 2 : kOobOffset, 0));
         }
-        f32x4 acc[NTW];
+        // D^T[m = channel][n = strip position] = features^T x attention^T: a lane ends up with 4 consecutive channels of
+        // one position (one ds_write_b128 into the pixel-major output image)
+        f32x4 acc[TPW][4];
 #pragma unroll
-        for (int a = 0; a < NTW; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < kp.nbf; ++ks) {
-            // B fragment: positions 32 ks + 8 lg + e of channel 16 nt + ln
-            BfSplit fb;
-            if constexpr (BF) {
-                uint32_t x[8];
+        for (int a = 0; a < TPW; ++a)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = lds_load_u16(img, gtile_bf_byte(32 * ks + 8 * lg + e, 16 * nt + ln));
-                fb.hi = u32x4{x[0] | (x[1] << 16), x[2] | (x[3] << 16), x[4] | (x[5] << 16), x[6] | (x[7] << 16)};
-                fb.lo = fb.hi;
-            } else {
-                const float *p = img + (8 * ks + 2 * lg) * GM_PP + 16 * nt + ln;
-                float x[8];
+            for (int nt = 0; nt < 4; ++nt) acc[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = CCA_LDS_LD(p + (e >> 2) * GM_PP + (e & 3) * GM_CG);
-                fb = bf16_split8(x);
-            }
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks < kp.nbf) {
 #pragma unroll
-            for (int a = 0; a < NTW; ++a) {
-                const int t = 2 * a + mh;
-                if (t * 16 < L) {
-                    const int ao = (16 * t + ln) * GM_BP + 16 * ks + 4 * lg;
-                    const u32x4 ah = *reinterpret_cast<const u32x4 *>(PH + ao), al = *reinterpret_cast<const u32x4 *>(PL + ao);
-                    acc[a] = mfma_bf16_16x16x32(ah, fb.hi, acc[a]);
-                    if (!BF) acc[a] = mfma_bf16_16x16x32(ah, fb.lo, acc[a]);
-                    acc[a] = mfma_bf16_16x16x32(al, fb.hi, acc[a]);
+                for (int nt = 0; nt < 4; ++nt) {
+                    // feature fragment: positions 32 ks + 8 lg + e of channel 16 nt + ln
+                    BfSplit fb;
+                    if constexpr (BF) {
+                        uint32_t x[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = lds_load_u16(img, gtile_bf_byte(32 * ks + 8 * lg + e, 16 * nt + ln));
+                        fb.hi = u32x4{x[0] | (x[1] << 16), x[2] | (x[3] << 16), x[4] | (x[5] << 16), x[6] | (x[7] << 16)};
+                        fb.lo = fb.hi;
+                    } else {
+                        const float *p = img + (8 * ks + 2 * lg) * GM_PP + 16 * nt + ln;
+                        float x[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = CCA_LDS_LD(p + (e >> 2) * GM_PP + (e & 3) * GM_CG);
+                        fb = bf16_split8(x);
+                    }
+#pragma unroll
+                    for (int a = 0; a < TPW; ++a) {
+                        if ((wv + GS_WAVES * a) * 16 < L) {
+                            acc[a][nt] = mfma_bf16_16x16x32(fb.hi, ah[a][ks], acc[a][nt]);
+                            if (!BF) acc[a][nt] = mfma_bf16_16x16x32(fb.lo, ah[a][ks], acc[a][nt]);
+                            acc[a][nt] = mfma_bf16_16x16x32(fb.hi, al[a][ks], acc[a][nt]);
+                        }
+                    }
                 }
             }
         }
         if (kp.tail) {
             const int pos = 32 * kp.nbf + lg;
-            float fbv;
-            if constexpr (BF) fbv = __builtin_bit_cast(float, lds_load_u16(img, gtile_bf_byte(pos, 16 * nt + ln)) << 16);
-            else              fbv = CCA_LDS_LD(img + (pos >> 2) * GM_PP + (pos & 3) * GM_CG + 16 * nt + ln);
 #pragma unroll
-            for (int a = 0; a < NTW; ++a) {
-                const int t = 2 * a + mh;
-                if (t * 16 < L) acc[a] = mfma_16x16x4(CCA_LDS_LD(PT + (16 * t + ln) * 4 + lg), fbv, acc[a]);
+            for (int nt = 0; nt < 4; ++nt) {
+                float fbv;
+                if constexpr (BF) fbv = __builtin_bit_cast(float, lds_load_u16(img, gtile_bf_byte(pos, 16 * nt + ln)) << 16);
+                else              fbv = CCA_LDS_LD(img + (pos >> 2) * GM_PP + (pos & 3) * GM_CG + 16 * nt + ln);
+#pragma unroll
+                for (int a = 0; a < TPW; ++a)
+                    if ((wv + GS_WAVES * a) * 16 < L) acc[a][nt] = mfma_16x16x4(fbv, at[a], acc[a][nt]);
             }
             mfma_f32_result_fence();
         }
-        // D[m = position 16 t + 4 lg + q][n = channel 16 nt + ln] -> output image (fp32 pixel-major pieces)
 #pragma unroll
-        for (int a = 0; a < NTW; ++a)
+        for (int a = 0; a < TPW; ++a) {
+            const int i = 16 * (wv + GS_WAVES * a) + ln;
+            if (i < L) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = 16 * (2 * a + mh) + 4 * lg + q;
-                if (i < L) CCA_LDS_ST(oimg + (i >> 2) * GM_PP + (i & 3) * GM_CG + 16 * nt + ln, alpha * acc[a][q]);
+                for (int nt = 0; nt < 4; ++nt)
+                    lds_store_x4(oimg + (i >> 2) * GM_PP + (i & 3) * GM_CG + 16 * nt + 4 * lg, alpha * acc[a][nt]);
             }
+        }
         barrier_lds_only();
         // whole pixel rows leave: 256 (fp32) / 128 (bf16) bytes per pixel, + addend (+ residual), rounded once
 #pragma unroll
         for (int k = 0; k < NSI; ++k) {
-            if (wv + GM_WAVES * k < nsi_total) {                         // wave-uniform: exactly `nstore` instructions
+            if (wv + GS_WAVES * k < nsi_total) {                         // wave-uniform: exactly `nstore` instructions
                 const int i = st_pos(k), c = cg * GM_CG + st_c;
                 const float *s = oimg + (i >> 2) * GM_PP + (i & 3) * GM_CG + st_c;
                 if (i < L && c < C) {
