@@ -233,6 +233,73 @@ class CoreWorkload:
         }
 
 
+class PixelMajorBF16Workload:
+    """BASELINE.json configs[4]: bf16 features as pixel-major views (q | k | v = channel slices of one packed projection),
+    fp32 attention / softmax / accumulation -- ccnet_cca_forward_pm_bf16 + ccnet_cca_backward_pm_bf16 (csrc/cca_gmap.hpp)."""
+
+    def __init__(self, lib, B, C, H, W, device, seed):
+        self.lib, self.shape, self.device = lib, (B, C, H, W), device
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        Cq = C // 8
+        self.ct = ct = C + 2 * Cq
+
+        def rnd(*s, scale=1.0):
+            return (torch.randn(*s, generator=g) * scale).to(device).to(torch.bfloat16)
+
+        self.qkv = rnd(B, H, W, ct, scale=0.5)
+        self.x, self.dy = rnd(B, H, W, C), rnd(B, H, W, C)
+        self.gamma = torch.full((1,), 0.5, device=device)
+        self.y, self.dqkv = torch.empty_like(self.x), torch.empty_like(self.qkv)
+        self.A = torch.empty(B, H, W, H + W, device=device)
+        self.scratch = torch.empty_like(self.A)
+        self.dgamma = torch.empty(1, device=device)
+        self.fws_bytes = lib.ccnet_cca_pm_bf16_workspace_bytes(B, C, Cq, H, W, 0)
+        self.ws_bytes = lib.ccnet_cca_pm_bf16_workspace_bytes(B, C, Cq, H, W, 1)
+        self.ws = torch.empty(max(self.fws_bytes, self.ws_bytes) // 4 + 64, device=device)
+
+    def stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def forward(self):
+        B, C, H, W = self.shape
+        L, cq, ct, p = self.lib, C // 8, self.ct, self.qkv.data_ptr()
+        bs = H * W * ct
+        L.check(L.ccnet_cca_forward_pm_bf16(p, p + 2 * cq, p + 4 * cq, self.x.data_ptr(), self.gamma.data_ptr(),
+                                            self.y.data_ptr(), self.A.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct, bs, ct,
+                                            H * W * C, C, H * W * C, C, self.ws.data_ptr(), self.fws_bytes, self.stream()),
+                "cca_forward_pm_bf16")
+
+    def backward(self):
+        B, C, H, W = self.shape
+        L, cq, ct, p, g = self.lib, C // 8, self.ct, self.qkv.data_ptr(), self.dqkv.data_ptr()
+        bs = H * W * ct
+        L.check(L.ccnet_cca_backward_pm_bf16(self.dy.data_ptr(), p, p + 2 * cq, p + 4 * cq, self.A.data_ptr(),
+                                             self.gamma.data_ptr(), g, g + 2 * cq, g + 4 * cq, self.dgamma.data_ptr(),
+                                             self.scratch.data_ptr(), B, C, cq, H, W, H * W * C, C, bs, ct, bs, ct, bs, ct,
+                                             bs, ct, bs, ct, bs, ct, self.ws.data_ptr(), self.ws_bytes, self.stream()),
+                "cca_backward_pm_bf16")
+
+    def step(self):
+        self.forward()
+        self.backward()
+
+
+def bf16_config5(lib, device, shape=(16, 512, 129, 129), iters=20):
+    """BASELINE.json configs[4] as an extra of the fp32 line: fwd+bwd of the pixel-major bf16 core, per-step statistics."""
+    wl = PixelMajorBF16Workload(lib, *shape, device, 4321)
+    st = per_step_stats(wl.step, iters)
+    nbytes = core_bytes(*shape, elt=2)
+    traffic = measured_traffic(lib, "traffic_bf16_latest.json")
+    out = {"shape": list(shape), "dtype": "bf16 features (pixel-major), fp32 attention/softmax/accumulate",
+           "ms_per_step": st, "fwd_ms": round(time_region(wl.forward, 10), 4), "bwd_ms": round(time_region(wl.backward, 10), 4),
+           "algorithmic_bytes_per_step": nbytes, "GB_per_s": round(nbytes / (st["median"] * 1e-3) / 1e9, 1),
+           "frac_of_hbm_roofline": round(nbytes / (st["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "traffic_bytes_per_step": traffic.get("_step_total_bytes") if traffic else None}
+    del wl
+    torch.cuda.empty_cache()
+    return out
+
+
 def time_region(fn, iters):
     """HIP events on torch's current stream (the stream the C ABI launches on)."""
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -272,10 +339,10 @@ def lib_sha16(lib):
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
-def measured_traffic(lib):
+def measured_traffic(lib, name="traffic_latest.json"):
     """Per-launch HBM bytes from the PMC passes (tools/pmc.sh -> tools/traffic_from_pmc.py), accepted only when
     they were taken on the library that is being benched (sha recorded next to them); otherwise None."""
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    tpath = os.path.join(ROOT, "profiles", name)
     try:
         with open(tpath) as f:
             t = json.load(f)
@@ -490,10 +557,12 @@ def main(argv=None, workload_factory=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 8 (f32) / 16 (bf16)")
     ap.add_argument("--channels", type=int, default=512)
-    ap.add_argument("--height", type=int, default=97)
-    ap.add_argument("--width", type=int, default=97)
+    ap.add_argument("--height", type=int, default=None, help="default 97 (f32) / 129 (bf16)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"),
+                    help="bf16 = BASELINE.json configs[4]: pixel-major bf16 core, default shape (16,512,129,129)")
     ap.add_argument("--allreduce-grads", action="store_true",
                     help="all-reduce the module's 7 parameter gradients after every step (engine.py:75)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -533,7 +602,11 @@ def main(argv=None, workload_factory=None):
         else:
             dist.init_process_group("gloo")
 
-    B, C, H, W = args.batch, args.channels, args.height, args.width
+    bf16 = args.dtype == "bf16"
+    B = args.batch or (16 if bf16 else 8)
+    H = args.height or (129 if bf16 else 97)
+    W = args.width or H
+    C = args.channels
     lib = None
     if workload_factory is None and args.workload_factory:
         mod, attr = args.workload_factory.split(":")
@@ -545,7 +618,7 @@ def main(argv=None, workload_factory=None):
             sys.exit("bench.py: --backend gloo needs --workload-factory (tests); the product path is HIP-only")
         from ccnet_amd import _lib
         lib = _lib.get_lib()
-        wl = CoreWorkload(lib, B, C, H, W, device, shard_seed(1234, rank))
+        wl = (PixelMajorBF16Workload if bf16 else CoreWorkload)(lib, B, C, H, W, device, shard_seed(1234, rank))
 
     grads = torch.zeros(CCA_PARAM_FLOATS(C), device=device) if args.allreduce_grads else None
 
@@ -576,17 +649,21 @@ def main(argv=None, workload_factory=None):
     local_s = time.perf_counter() - t0
     secs = max_over_ranks(local_s, device, world)
 
-    nbytes = core_bytes(B, C, H, W)
+    nbytes = core_bytes(B, C, H, W, elt=2 if bf16 else 4)
     value = aggregate_value(nbytes, args.steps, world, secs)
     ms = secs / args.steps * 1e3
-    impl = "injected" if lib is None else ("mfma-strip" if lib.ccnet_cca_shape_uses_mfma(B, C, H, W) else "direct")
+    impl = "injected" if lib is None else ("pixel-major bf16 mfma" if bf16 else
+                                           "mfma-strip" if lib.ccnet_cca_shape_uses_mfma(B, C, H, W) else "direct")
     out = {
         "metric": metric_label(C, H, W),
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[1]: single-op CrissCrossAttention core fwd+bwd, "
-                               f"({B},{C},{H},{W}) fp32 per GPU, R=1",
+        "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+        "config": {"workload": (f"BASELINE.json configs[4]: bf16 mixed-precision CrissCrossAttention core fwd+bwd (bf16 "
+                                f"pixel-major features, fp32 attention / softmax / accumulate), ({B},{C},{H},{W}) per GPU"
+                                if bf16 else
+                                f"BASELINE.json configs[1]: single-op CrissCrossAttention core fwd+bwd, "
+                                f"({B},{C},{H},{W}) fp32 per GPU, R=1"),
                    "per_gpu_batch": B, "global_batch": B * world, "shape": [B, C, H, W],
                    "parallelism": f"batch-sharded x{world} (no data-path collective"
                                   + (", + all-reduce of the 7 parameter gradients per step)" if grads is not None else ")"),
@@ -598,6 +675,17 @@ def main(argv=None, workload_factory=None):
     }
 
     extras = on_gpu and lib is not None and not args.no_extras
+    if extras and bf16 and rank == 0:
+        out["step_ms_stats"] = {"warm": per_step_stats(wl.step, 50)}
+        out["fwd_ms"], out["bwd_ms"] = round(time_region(wl.forward, 10), 4), round(time_region(wl.backward, 10), 4)
+        traffic = measured_traffic(lib, "traffic_bf16_latest.json")
+        out["roofline"] = {"bound": "hbm", "achieved": round(value / world, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(value / world / HBM_PEAK_GBS, 4),
+                           "traffic": traffic.get("_step_total_bytes") if traffic else None,
+                           "note": "op level: algorithmic bytes of the fwd+bwd step / step time; traffic = PMC bytes of "
+                                   "the whole step (tools/pmc.sh --script tools/pm_bf16_time.py), null unless taken on "
+                                   "this build"}
+    extras = extras and not bf16
     if extras and rank == 0:
         out["step_ms_stats"] = {"warm": per_step_stats(wl.step, 100)}
         flush = torch.zeros(128 * 1024 * 1024, device=device)                 # 512 MiB > the 256 MiB Infinity Cache
@@ -611,7 +699,8 @@ def main(argv=None, workload_factory=None):
         out["roofline"] = roof
         out["kernels_ms"] = {r["kernel"]: round(r["ms"], 4) for r in rows}
         out["stages_ms"] = {k: round(v, 4) for k, v in roofline_object.stages.items()}
-        for key, fn in (("small_batch_core_ms", lambda: small_batch_ms(lib, C, H, W, device)),
+        for key, fn in (("bf16_config5", lambda: bf16_config5(lib, device)),
+                        ("small_batch_core_ms", lambda: small_batch_ms(lib, C, H, W, device)),
                         ("rcca_head_R2_2048x97x97", lambda: rcca_head_ms(device)),
                         ("stock_pytorch_core", lambda: stock_pytorch_core(B, C, H, W, device))):
             try:

@@ -854,26 +854,6 @@ int gmap_bf16(const float *T, const bf16_t *F, const bf16_t *resid, const float 
         return launch_gmap_bf16<100, TRANS>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
     return launch_gmap_bf16<132, TRANS>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
 }
-template <int P>
-int launch_gmap_qk_bf16(const float *dE, const bf16_t *k, const bf16_t *q, bf16_t *dq, bf16_t *dk, float *partial, int B, int Cq,
-                        int H, int W, long kbs, int kps, long qbs, int qps, long dqbs, int dqps, long dkbs, int dkps,
-                        ccnet_stream_t stream) {
-    const long pbs = (long)H * W * Cq;
-    float *pq = partial, *pk = partial + (size_t)B * pbs;
-    CCA_LAUNCH((cca::gmap_qk_kernel<P, false, float>), dim3((unsigned)(B * W)), dim3(cca::GM_THREADS), stream, dE, k, q,
-               (const float *)nullptr, (const float *)nullptr, pq, pk, Cq, H, W, kbs, kps, qbs, qps, 0L, 0, pbs, Cq, pbs, Cq);
-    if (int e = launch_status("gmap_qk_bf16(column)")) return e;
-    CCA_LAUNCH((cca::gmap_qk_kernel<P, true, bf16_t>), dim3((unsigned)(B * H)), dim3(cca::GM_THREADS), stream, dE, k, q,
-               (const float *)pq, (const float *)pk, dq, dk, Cq, H, W, kbs, kps, qbs, qps, pbs, Cq, dqbs, dqps, dkbs, dkps);
-    return launch_status("gmap_qk_bf16(row)");
-}
-int gmap_qk_bf16(const float *dE, const bf16_t *k, const bf16_t *q, bf16_t *dq, bf16_t *dk, float *partial, int B, int Cq,
-                 int H, int W, long kbs, int kps, long qbs, int qps, long dqbs, int dqps, long dkbs, int dkps,
-                 ccnet_stream_t stream) {
-    if ((H > W ? H : W) <= 100)
-        return launch_gmap_qk_bf16<100>(dE, k, q, dq, dk, partial, B, Cq, H, W, kbs, kps, qbs, qps, dqbs, dqps, dkbs, dkps, stream);
-    return launch_gmap_qk_bf16<132>(dE, k, q, dq, dk, partial, B, Cq, H, W, kbs, kps, qbs, qps, dqbs, dqps, dkbs, dkps, stream);
-}
 template <bool MASK>
 int gweight_bf16(const bf16_t *X, const bf16_t *Y, float *T, int B, int Cx, int H, int W, long xbs, int xps, long ybs,
                  int yps, ccnet_stream_t stream) {
@@ -944,9 +924,6 @@ int ccnet_cca_backward_pm_bf16(const uint16_t *dy, const uint16_t *q, const uint
                                 0L, 0, dv_bs, dv_ps, stream)) return e;
     // dgamma = sum A t;  dE = gamma * A * (t - sum_s A t), in place
     if (int e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, sm, B, H, W, stream, KSplit())) return e;
-    if (Cq <= cca::GM_CG)        // one channel group: dq and dk of a strip from one staged block of dE
-        return gmap_qk_bf16(scratch, (const bf16_t *)k, (const bf16_t *)q, (bf16_t *)dq, (bf16_t *)dk, partial, B, Cq, H, W,
-                            k_bs, k_ps, q_bs, q_ps, dq_bs, dq_ps, dk_bs, dk_ps, stream);
     if (int e = gmap_bf16<false>(scratch, (const bf16_t *)k, nullptr, nullptr, (bf16_t *)dq, partial, B, Cq, H, W, k_bs, k_ps,
                                  0L, 0, dq_bs, dq_ps, stream)) return e;
     return gmap_bf16<true>(scratch, (const bf16_t *)q, nullptr, nullptr, (bf16_t *)dk, partial, B, Cq, H, W, q_bs, q_ps,

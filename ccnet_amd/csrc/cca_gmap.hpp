@@ -14,16 +14,19 @@
 // contiguous one (so the K = channel contraction of gweight reads MFMA fragments straight out of LDS), and nothing
 // depends on the strip length being 97..100.
 //
-// gmap (MI355X): workgroup = one strip g of one image, 8 wavefronts = (the four 16-channel N tiles of a 64-channel
-// group) x (two interleaved halves of the M tiles).  Prologue: the L rows of P_g (contiguous in T) arrive by LDS-DMA and
-// are rewritten ONCE as two bf16 images (hi, lo = the split of cca_common.hpp; transposed for TRANS; zero beyond the
-// strip), row pitch 272 B, so that a 16 x 32 MFMA A fragment is one ds_read_b128 per image and no VALU.  Per channel
-// group: the L x 64 feature tile arrives by LDS-DMA (double-buffered); each wavefront gathers its B fragments (fp32:
-// 8 ds_read_b32 + hi/lo split, 3 MFMAs per tile; bf16: 8 ds_read_u16 + pack, exact, 2 MFMAs per tile), accumulates its
-// tiles of v_mfma_f32_16x16x32_bf16 (+ one exact f32 step for a k remainder <= 4) and drops them into the fp32 output
-// image; the image then leaves as whole pixel rows, each lane adding the fp32 addend (and bf16 residual) slice it
-// loaded into registers before the MFMA phase -- fp32, or rounded to bf16 once.  The stores of a group stay in flight
-// across the next group's barrier (counted vmcnt).
+// gmap (MI355X): workgroup = one strip g of one image, 4 wavefronts, two workgroups per CU.  ATTENTION-STATIONARY:
+// wavefront w owns the 16-position M tiles w, w + 4, w + 8 of the strip and loads their slice of P_g straight from
+// global memory into MFMA fragments -- split once into bf16 hi + lo (cca_common.hpp), every k-step, 96 VGPRs at 132
+// positions -- where they stay for the strip's whole life; no attention image in LDS, so a workgroup needs only the
+// streaming tiles (71 KB) and two fit a CU, one's prologue and stores hiding behind the other's MFMA phase.  Per
+// 64-channel group: the L x 64 feature tile arrives by LDS-DMA (double-buffered, out-of-range lanes zero-fill the
+// padding); a wavefront gathers the feature fragment of each 16-channel N tile (bf16: 8 ds_read_u16 + pack, exact;
+// fp32: 8 ds_read_b32 + hi/lo split) and issues v_mfma_f32_16x16x32_bf16 with the operands SWAPPED (D^T = F^T P^T: 2 per
+// tile for bf16 features, 3 for fp32; + one exact f32 step for a k remainder <= 4), so that a lane ends up with 4
+// consecutive channels of one position: one ds_write_b128 into the fp32 pixel-major output image.  The image leaves as
+// whole pixel rows (256 / 128 bytes), each lane adding the fp32 addend (and bf16 residual) slice it loaded into registers
+// before the MFMA phase; rounded to bf16 once.  A group's stores stay in flight across the next group's barrier (counted
+// vmcnt).  Measured (profiles/r02f_*): the 512-channel launches move their bytes at 4.2 - 4.6 TB/s.
 #pragma once
 #include "cca_band.hpp"
 #include "cca_common.hpp"
@@ -33,7 +36,7 @@
 namespace cca {
 
 constexpr int GM_CG = 64;                       // channels per group = four MFMA N tiles
-constexpr int GM_WAVES = 8;                     // gweight / gmap_qk: one workgroup per CU
+constexpr int GM_WAVES = 8;                     // gweight
 constexpr int GM_THREADS = GM_WAVES * 64;
 constexpr int GS_WAVES = 4;                     // gmap: two workgroups per CU
 constexpr int GS_THREADS = GS_WAVES * 64;
@@ -279,153 +282,6 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
             }
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// gmap_qk: both halves of ca_backward for one strip from ONE staged block of dE (bf16 features, C/8 <= 64 channels):
-//     dq[pixel(i, g), c] (+)= sum_j dE_g[i][j] * k[pixel(j, g), c]        dk[pixel(j, g), c] (+)= sum_i dE_g[i][j] * q[pixel(i, g), c]
-// With a single channel group the bf16 images of gmap_kernel would be built to be read once, and a strip's life is one
-// latency chain (block in, images, tile in, MFMA, rows out), so: the raw fp32 block stays in LDS (16-byte chunks
-// permuted by bit 3 of the row, so that the transposed fragments of dk spread over the banks), fragments are split into
-// hi / lo in registers, the k and q tiles arrive together with the block, and the two results leave one after the other.
-// ---------------------------------------------------------------------------------------------------------------
-template <int P>
-__device__ __forceinline__ int qk_pos(int i, int j) {
-    int ch = j >> 2;
-    if (ch < P / 32 * 8) ch ^= ((i >> 3) & 1) << 2;          // (whole groups of 8 chunks only)
-    return i * P + 4 * ch + (j & 3);
-}
-
-template <int P, bool ROW, typename OT>
-__global__ __launch_bounds__(GM_THREADS, 1) void gmap_qk_kernel(const float *__restrict__ T, const bf16_t *__restrict__ Kf,
-                                                                 const bf16_t *__restrict__ Qf,
-                                                                 const float *__restrict__ add_q, const float *__restrict__ add_k,
-                                                                 OT *out_q, OT *out_k, int Cq, int H, int W,
-                                                                 long kbs, int kps, long qbs, int qps, long abs_, int aps,
-                                                                 long oqbs, int oqps, long okbs, int okps) {
-    constexpr bool OBF = std::is_same<OT, bf16_t>::value, ADD = ROW;
-    constexpr int NT = (P + 15) / 16, NTW = (NT + 1) / 2, FSZ = GTile<bf16_t>::size(P), OSZ = GTile<float>::size(P);
-    constexpr int NPF = GTile<bf16_t>::pieces(P), P4 = P / 4, NPA = (P * P4 + 63) / 64;
-    constexpr int SPX = OBF ? 8 : 4, NSI = ((P + SPX - 1) / SPX + GM_WAVES - 1) / GM_WAVES;
-    static_assert((P * P + 2 * FSZ + OSZ) * 4 <= 163840, "gmap_qk: LDS");
-    __shared__ __attribute__((aligned(16))) float lds[P * P + 2 * FSZ + OSZ];
-    CCA_LDS_REGISTER(lds);
-    float *const stage = lds, *const FK = lds + P * P, *const FQ = FK + FSZ, *const oimg = FQ + FSZ;
-    const int HW = H * W, S = H + W;
-    const int L = ROW ? W : H, G = ROW ? H : W;
-    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
-    const int nt = wv & 3, mh = wv >> 2, ln = lane & 15, lg = lane >> 4;
-    const int pix0 = ROW ? g * W : g, pstep = ROW ? 1 : W, a_off = ROW ? H : 0;
-    const FBuf Tb = make_fbuf(T + (size_t)b * HW * S, (size_t)HW * S * sizeof(float));
-    const FBuf Kb = make_fbuf(reinterpret_cast<const float *>(Kf + (size_t)b * kbs), ((size_t)(HW - 1) * kps + Cq) * 2);
-    const FBuf Qb = make_fbuf(reinterpret_cast<const float *>(Qf + (size_t)b * qbs), ((size_t)(HW - 1) * qps + Cq) * 2);
-    const FBuf Aq = make_fbuf(ADD ? add_q + (size_t)b * abs_ : T, ADD ? ((size_t)(HW - 1) * aps + Cq) * sizeof(float) : 4);
-    const FBuf Ak = make_fbuf(ADD ? add_k + (size_t)b * abs_ : T, ADD ? ((size_t)(HW - 1) * aps + Cq) * sizeof(float) : 4);
-    const FBuf Oq = make_fbuf(reinterpret_cast<const float *>(out_q + (size_t)b * oqbs), ((size_t)(HW - 1) * oqps + Cq) * sizeof(OT));
-    const FBuf Ok = make_fbuf(reinterpret_cast<const float *>(out_k + (size_t)b * okbs), ((size_t)(HW - 1) * okps + Cq) * sizeof(OT));
-    const BandK kp = band_ksteps(L);
-
-    // the block: row i of the strip's L x L slice of T at stage row i, chunk slot s holding chunk s ^ ((i >> 3 & 1) << 2);
-    // rows / chunks beyond the strip are issued out of range (zeros): they are the k padding of the fragments
-    for (int it = wv; it < NPA; it += GM_WAVES) {
-        const int idx = 64 * it + lane, i = idx / P4, sl = idx - i * P4;
-        const int ch = sl < P / 32 * 8 ? sl ^ (((i >> 3) & 1) << 2) : sl;
-        if (idx < P * P4)
-            fbuf_load_to_lds_x4(Tb, stage + 256 * it, (i < L && 4 * ch < L) ? ((pix0 + i * pstep) * S + a_off + 4 * ch) * 4 : kOobOffset, 0);
-    }
-    for (int it = wv; it < 2 * NPF; it += GM_WAVES) {
-        if (it < NPF) gtile_dma_piece<bf16_t>(Kb, FK, it, lane, pix0, pstep, L, kps, 0, Cq);
-        else          gtile_dma_piece<bf16_t>(Qb, FQ, it - NPF, lane, pix0, pstep, L, qps, 0, Cq);
-    }
-    const int nsi_total = (L + SPX - 1) / SPX;
-    auto st_pos = [&](int k) { return SPX * (wv + GM_WAVES * k) + (OBF ? lane >> 3 : lane >> 4); };
-    const int st_c = OBF ? 8 * (lane & 7) : 4 * (lane & 15);
-    f32x4 aq0[NSI], aq1[NSI], ak0[NSI], ak1[NSI];
-    if (ADD) {
-#pragma unroll
-        for (int k = 0; k < NSI; ++k) {
-            const int i = st_pos(k);
-            const int off = (i < L && st_c < Cq) ? ((pix0 + i * pstep) * aps + st_c) * 4 : kOobOffset;
-            const int off1 = (i < L && st_c < Cq) ? off + 16 : kOobOffset;
-            aq0[k] = fbuf_load_x4(Aq, off, 0);
-            ak0[k] = fbuf_load_x4(Ak, off, 0);
-            if (OBF) { aq1[k] = fbuf_load_x4(Aq, off1, 0); ak1[k] = fbuf_load_x4(Ak, off1, 0); }
-        }
-    }
-    barrier_dma_keep<0>();
-
-    auto half = [&](auto trans_tag, const float *tile, const FBuf &Ob, int ops, const f32x4 (&a0)[NSI], const f32x4 (&a1)[NSI]) {
-        constexpr bool TRANS = decltype(trans_tag)::value;
-        f32x4 acc[NTW];
-#pragma unroll
-        for (int a = 0; a < NTW; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < kp.nbf; ++ks) {
-            uint32_t y[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = lds_load_u16(tile, gtile_bf_byte(32 * ks + 8 * lg + e, 16 * nt + ln));
-            const u32x4 fb = u32x4{y[0] | (y[1] << 16), y[2] | (y[3] << 16), y[4] | (y[5] << 16), y[6] | (y[7] << 16)};
-#pragma unroll
-            for (int a = 0; a < NTW; ++a) {
-                const int t = 2 * a + mh, m = 16 * t + ln;
-                if (t * 16 < L) {
-                    float x[8];
-                    if (!TRANS) {
-                        const f32x4 u = lds_load_x4(stage + qk_pos<P>(m, 32 * ks + 8 * lg)), v = lds_load_x4(stage + qk_pos<P>(m, 32 * ks + 8 * lg + 4));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { x[e] = u[e]; x[4 + e] = v[e]; }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) x[e] = CCA_LDS_LD(stage + qk_pos<P>(32 * ks + 8 * lg + e, m));
-                    }
-                    const BfSplit sp = bf16_split8(x);
-                    acc[a] = mfma_bf16_16x16x32(sp.hi, fb, acc[a]);
-                    acc[a] = mfma_bf16_16x16x32(sp.lo, fb, acc[a]);
-                }
-            }
-        }
-        if (kp.tail) {
-            const int pos = 32 * kp.nbf + lg;
-            const float fbv = __builtin_bit_cast(float, lds_load_u16(tile, gtile_bf_byte(pos, 16 * nt + ln)) << 16);
-#pragma unroll
-            for (int a = 0; a < NTW; ++a) {
-                const int t = 2 * a + mh, m = 16 * t + ln;
-                if (t * 16 < L) acc[a] = mfma_16x16x4(CCA_LDS_LD(stage + (TRANS ? qk_pos<P>(pos, m) : qk_pos<P>(m, pos))), fbv, acc[a]);
-            }
-            mfma_f32_result_fence();
-        }
-#pragma unroll
-        for (int a = 0; a < NTW; ++a)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = 16 * (2 * a + mh) + 4 * lg + q;
-                if (i < L) CCA_LDS_ST(oimg + (i >> 2) * GM_PP + (i & 3) * GM_CG + 16 * nt + ln, acc[a][q]);
-            }
-        barrier_lds_only();
-#pragma unroll
-        for (int k = 0; k < NSI; ++k) {
-            if (wv + GM_WAVES * k < nsi_total) {
-                const int i = st_pos(k);
-                const float *s = oimg + (i >> 2) * GM_PP + (i & 3) * GM_CG + st_c;
-                if (i < L && st_c < Cq) {
-                    f32x4 u = lds_load_x4(s);
-                    if (ADD) u += a0[k];
-                    if constexpr (OBF) {
-                        f32x4 v = lds_load_x4(s + 4);
-                        if (ADD) v += a1[k];
-                        const f32x4 packed = __builtin_bit_cast(f32x4, u32x4{cvt_pk_bf16(u[0], u[1]), cvt_pk_bf16(u[2], u[3]),
-                                                                             cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])});
-                        fbuf_store_x4(Ob, packed, ((pix0 + i * pstep) * ops + st_c) * 2, 0);
-                    } else {
-                        fbuf_store_x4(Ob, u, ((pix0 + i * pstep) * ops + st_c) * 4, 0);
-                    }
-                }
-            }
-        }
-    };
-    half(std::false_type{}, FK, Oq, oqps, aq0, aq1);
-    barrier_lds_only();                          // the output image has been read out
-    half(std::true_type{}, FQ, Ok, okps, ak0, ak1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

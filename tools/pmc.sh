@@ -1,15 +1,17 @@
 #!/bin/bash
 # PMC passes (separate runs per counter group: TCC slot limits) for a run_stage.py invocation.
-# usage: bash tools/pmc.sh <outdir-tag> <run_stage args...>
+# usage: bash tools/pmc.sh <outdir-tag> [--script tools/other.py] <script args...>
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+SCRIPT=tools/run_stage.py
+if [ "${1:-}" = "--script" ]; then SCRIPT=$2; shift 2; fi
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/p$i" -- python "$R/tools/run_stage.py" "$@" > "$OUT/p$i.log" 2>&1
+  timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/p$i" -- python "$R/$SCRIPT" "$@" > "$OUT/p$i.log" 2>&1
   echo "pass $i ($grp) rc=$?"
 done
 cd "$R"

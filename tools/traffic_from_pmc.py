@@ -8,11 +8,19 @@ matched the known write volume of the same kernel (57.0 MiB vs 58.4 MB) and is u
 
 The file also records the sha256 prefix of the library the counters were taken on (``_lib_sha16``: bench.py only
 quotes the traffic when it benches that same build) and the per-step total (every kernel is launched once per step).
-usage: traffic_from_pmc.py <summary.json> [<libccnet_cca.so>]"""
-import hashlib, json, os, re, sys
+With ``--steps N`` the profiled command ran N steps in which a kernel may be launched several times (the pixel-major bf16
+step, tools/pm_bf16_time.py: 3 warm-up + 10 timed forward/backward pairs = 13): the per-step total is then
+sum(kernel average * dispatches) / N, and ``--out`` names the file (profiles/traffic_bf16_latest.json).
+usage: traffic_from_pmc.py <summary.json> [--steps N] [--out NAME.json] [--lib libccnet_cca.so]"""
+import argparse, hashlib, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1]
-lib = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "ccnet_amd", "csrc", "libccnet_cca.so")
+ap = argparse.ArgumentParser()
+ap.add_argument("src")
+ap.add_argument("--steps", type=int, default=0)
+ap.add_argument("--out", default="traffic_latest.json")
+ap.add_argument("--lib", default=os.path.join(ROOT, "ccnet_amd", "csrc", "libccnet_cca.so"))
+a = ap.parse_args()
+src, lib = a.src, a.lib
 
 
 def label(k):
@@ -33,8 +41,8 @@ for k, v in d.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         nbytes = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
         out[label(k) or k] = nbytes
-        total += nbytes
-out["_step_total_bytes"] = total
+        total += nbytes * v.get("dispatches", 1) / a.steps if a.steps else nbytes
+out["_step_total_bytes"] = int(total)
 out["_lib_sha16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
-json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", a.out), "w"), indent=1)
 print(json.dumps(out, indent=1))
