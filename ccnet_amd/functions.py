@@ -580,17 +580,20 @@ class CrissCrossAttention(nn.Module):
             raise RuntimeError(
                 "CrissCrossAttention (ccnet_amd): input is on the CPU. This module runs its attention core as HIP "
                 "kernels on an AMD GPU and has no CPU fallback; move the module and its input to the device.")
-        if (x.dtype == torch.bfloat16 and self.native_bf16 and self._fusable(x)
+        if (x.dtype == torch.bfloat16 and self.native_bf16
+                and (self._fusable(x) or (torch.is_autocast_enabled() and self._fusable()))   # (autocast casts W for linear)
                 and pm_bf16_covers(x.shape[0], x.shape[1], self.query_conv.out_channels, x.shape[2], x.shape[3])):
             # bf16 activations (BASELINE configs[4]): pixel-major bf16 kernels.  x as (B, H, W, C) is a free view of a
             # channels_last tensor (one transposing copy otherwise); query | key | value are ONE GEMM x^T W^T whose
-            # output the kernels read through channel-slice strides; y comes back as a channels_last NCHW view.
+            # output the kernels read through channel-slice strides; y comes back in x's memory format.
             cq = self.query_conv.out_channels
             xp = x.permute(0, 2, 3, 1)
             w = torch.cat([self.query_conv.weight, self.key_conv.weight, self.value_conv.weight], 0).flatten(1)
             b = torch.cat([self.query_conv.bias, self.key_conv.bias, self.value_conv.bias], 0)
-            qkv = torch.nn.functional.linear(xp, w, b)
-            return CrissCrossPMBF16Function.apply(qkv, xp, self.gamma.float(), cq).permute(0, 3, 1, 2)
+            qkv = torch.nn.functional.linear(xp, w, b).to(torch.bfloat16)
+            y = CrissCrossPMBF16Function.apply(qkv, xp, self.gamma.float(), cq).permute(0, 3, 1, 2)
+            # memory format follows the input: NCHW-contiguous in -> NCHW-contiguous out (one transposing copy each way)
+            return y if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() else y.contiguous()
         if x.dtype == torch.bfloat16 and self.native_bf16 and not self._strip_kernels_cover(x):
             # bf16 activations at a geometry the fp32 MFMA strip kernels do not cover: run the bf16-I/O entry points
             # (fp32 attention / softmax / accumulation inside) instead of materialising fp32 copies of every tensor

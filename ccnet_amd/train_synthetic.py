@@ -129,7 +129,7 @@ def build_parser():
     ap.add_argument("--lr", type=float, default=1e-2)
     ap.add_argument("--weight-decay", type=float, default=1e-4)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--bf16", action="store_true", help="autocast convolutions to bf16 (the attention core stays fp32)")
+    ap.add_argument("--bf16", action="store_true", help="autocast to bf16: convolutions in bf16, the attention core on the pixel-major bf16 kernels (fp32 attention / softmax / accumulate)")
     ap.add_argument("--cpu", action="store_true", help="tests only: gloo on CPU with an injected model")
     ap.add_argument("--no-destroy-group", dest="destroy_group", action="store_false")
     return ap

@@ -415,7 +415,8 @@ def _pm_inputs(B, C, H, W, dev, seed, qk_scale=1.0):
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 128, 17, 20), (2, 64, 40, 33), (1, 64, 97, 97), (1, 64, 129, 70),
-                                   (1, 128, 100, 132), (1, 64, 1, 9)])
+                                   (1, 128, 100, 132), (1, 64, 1, 9),
+                                   (1, 512, 129, 129)])     # one image of BASELINE configs[4] at its full geometry
 def test_pixel_major_bf16_kernels_match_oracle(lib, dev, shape):
     """BASELINE configs[4] on the pixel-major bf16 MFMA kernels (csrc/cca_gmap.hpp) at oracle-sized shapes, both
     padded strip lengths (100, 132): packed bf16 projection in, bf16 y / packed dqkv out, fp32 attention.  Oracle: the fp32
@@ -423,7 +424,7 @@ def test_pixel_major_bf16_kernels_match_oracle(lib, dev, shape):
     from ccnet_amd.functions import CrissCrossPMBF16Function
     B, C, H, W = shape
     cq = C // 8
-    q, k, v, x, dy, qkv, xp, dyp = _pm_inputs(B, C, H, W, dev, seed=53)
+    q, k, v, x, dy, qkv, xp, dyp = _pm_inputs(B, C, H, W, dev, seed=53, qk_scale=0.35 if C >= 512 else 1.0)
     gamma = torch.tensor([0.5], device=dev, requires_grad=True)
     qkv.requires_grad_(True)
     xp.requires_grad_(True)
@@ -690,3 +691,15 @@ def test_small_batch_k_split_at_the_headline_geometry(lib, dev, B):
     print(f"B={B} K-split max-abs errors vs oracle:", report)
     assert all(e < TOL for e in report.values()), report
     assert float(runs[0][4]) == pytest.approx(float(go["dgamma"]), rel=1e-3)
+
+
+def test_bench_bf16_line_has_the_contract_keys(lib, dev):
+    """bench.py --dtype bf16 (BASELINE configs[4]) on a small shape: one JSON-able dict with the contract's keys."""
+    import bench
+    out = bench.main(["--dtype", "bf16", "--batch", "2", "--channels", "64", "--height", "33", "--width", "18", "--steps", "3",
+                      "--warmup", "1", "--prewarm-s", "0.05", "--no-train", "--no-cpu-baseline"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["dtype"] == "bf16" and out["value"] > 0 and out["roofline"]["bound"] == "hbm"
+    assert "pixel-major" in out["config"]["impl"]
