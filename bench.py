@@ -297,6 +297,28 @@ def bf16_config5(lib, device, shape=(16, 512, 129, 129), iters=20):
            "traffic_bytes_per_step": traffic.get("_step_total_bytes") if traffic else None}
     del wl
     torch.cuda.empty_cache()
+    try:
+        from ccnet_amd import CrissCrossAttention
+        B, C, H, W = shape
+        m = CrissCrossAttention(C).to(device).to(torch.bfloat16)
+        with torch.no_grad():
+            m.gamma.fill_(0.5)
+        x = torch.randn(B, C, H, W, device=device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        x.requires_grad_(True)
+        dy = torch.randn(B, C, H, W, device=device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+        def one():
+            x.grad = None
+            m.zero_grad(set_to_none=True)
+            m(x).backward(dy)
+
+        one()
+        out["module_ms_per_step"] = round(time_region(one, 5), 4)
+        out["module_what"] = "CrissCrossAttention(512) bf16, channels_last in / out: one x^T W^T projection + the core + autograd"
+        del m, x, dy
+    except Exception as e:          # the metric does not depend on it
+        out["module_ms_per_step"] = f"failed: {e}"
+    torch.cuda.empty_cache()
     return out
 
 
