@@ -821,80 +821,145 @@ int ccnet_cca_backward_bf16(const uint16_t *dy_, const uint16_t *q_, const uint1
 }
 
 
-/* ---- pixel-major bf16 path (cca_gmap.hpp): bf16 features as (B, H*W, pixel stride) views, fp32 attention ---- */
+/* ---- pixel-major paths (cca_gmap.hpp): features as (B, H*W, pixel stride) views, fp32 attention ---- */
 extern "C++" {
 namespace {
 using cca::bf16_t;
+template <typename FT> struct PmTraits;
+template <> struct PmTraits<bf16_t> { static constexpr int kAlign = 8, kMaxStrip = 132; };
+template <> struct PmTraits<float>  { static constexpr int kAlign = 4, kMaxStrip = 100; };
+
+template <typename FT>
 int check_pm_view(const char *what, long bs, int ps, int C, int H, int W) {
-    if (ps < C || ps % 8 || bs < (long)(H * W - 1) * ps + C || bs % 8) return fail(CCNET_E_BADSHAPE, what);
+    constexpr int al = PmTraits<FT>::kAlign;
+    if (ps < C || ps % al || bs < (long)(H * W - 1) * ps + C || bs % al) return fail(CCNET_E_BADSHAPE, what);
     if ((double)H * W * ps >= 536870912.0) return fail(CCNET_E_BADSHAPE, what);
     return 0;
 }
-// out = bf16(alpha * contraction + resid): column strips into the fp32 partial, row strips add it and round once
-template <int P, bool TRANS>
-int launch_gmap_bf16(const float *T, const bf16_t *F, const bf16_t *resid, const float *gamma, bf16_t *out,
-                     float *partial, int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs,
-                     int ops, ccnet_stream_t stream) {
+// out = FT(alpha * contraction + resid): column strips into the fp32 partial, row strips add it and round once
+template <int P, bool TRANS, typename FT>
+int launch_gmap_pm(const float *T, const FT *F, const FT *resid, const float *gamma, FT *out, float *partial, int B, int C,
+                   int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
     const long pbs = (long)H * W * C;
     const GmapPlan gc = gmap_plan(B * W, C), gr = gmap_plan(B * H, C);
-    CCA_LAUNCH((cca::gmap_kernel<P, false, TRANS, false, bf16_t, float>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS),
+    CCA_LAUNCH((cca::gmap_kernel<P, false, TRANS, false, FT, float>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS),
                stream, T, F, (const float *)nullptr, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0,
                0L, 0, pbs, C, gc.n_whole, gc.split);
-    if (int e = launch_status("gmap_bf16(column)")) return e;
-    CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, bf16_t, bf16_t>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS),
+    if (int e = launch_status("gmap_pm(column)")) return e;
+    CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, FT, FT>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS),
                stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C, rbs, rps, obs, ops,
                gr.n_whole, gr.split);
-    return launch_status("gmap_bf16(row)");
+    return launch_status("gmap_pm(row)");
 }
-template <bool TRANS>
-int gmap_bf16(const float *T, const bf16_t *F, const bf16_t *resid, const float *gamma, bf16_t *out, float *partial,
-              int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops,
-              ccnet_stream_t stream) {
+template <bool TRANS, typename FT>
+int gmap_pm(const float *T, const FT *F, const FT *resid, const float *gamma, FT *out, float *partial,
+            int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
     if ((H > W ? H : W) <= 100)
-        return launch_gmap_bf16<100, TRANS>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
-    return launch_gmap_bf16<132, TRANS>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+        return launch_gmap_pm<100, TRANS, FT>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+    if constexpr (PmTraits<FT>::kMaxStrip >= 132)
+        return launch_gmap_pm<132, TRANS, FT>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+    return fail(CCNET_E_BADSHAPE, "gmap_pm: strip too long for this element type");
 }
-template <bool MASK>
-int gweight_bf16(const bf16_t *X, const bf16_t *Y, float *T, int B, int Cx, int H, int W, long xbs, int xps, long ybs,
-                 int yps, ccnet_stream_t stream) {
+template <bool MASK, typename FT>
+int gweight_pm(const FT *X, const FT *Y, float *T, int B, int Cx, int H, int W, long xbs, int xps, long ybs, int yps,
+               ccnet_stream_t stream) {
     const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
-    if ((H > W ? H : W) <= 100) CCA_LAUNCH((cca::gweight_kernel<100, MASK>), grid, block, stream, X, Y, T, Cx, H, W, xbs, xps, ybs, yps);
-    else                        CCA_LAUNCH((cca::gweight_kernel<132, MASK>), grid, block, stream, X, Y, T, Cx, H, W, xbs, xps, ybs, yps);
-    return launch_status("gweight_bf16");
+    if ((H > W ? H : W) <= 100) {
+        CCA_LAUNCH((cca::gweight_kernel<100, MASK, FT>), grid, block, stream, X, Y, T, Cx, H, W, xbs, xps, ybs, yps);
+    } else {
+        if constexpr (PmTraits<FT>::kMaxStrip >= 132)
+            CCA_LAUNCH((cca::gweight_kernel<132, MASK, FT>), grid, block, stream, X, Y, T, Cx, H, W, xbs, xps, ybs, yps);
+        else
+            return fail(CCNET_E_BADSHAPE, "gweight_pm: strip too long for this element type");
+    }
+    return launch_status("gweight_pm");
 }
+template <typename FT>
 int check_pm_problem(const char *what, int B, int C, int Cq, int H, int W) {
     if (int e = check_shape(B, C, H, W)) return e;
     if (int e = check_shape(B, Cq, H, W)) return e;
-    if ((H > W ? H : W) > 132 || C % 8 || Cq % 8) return fail(CCNET_E_BADSHAPE, what);
+    constexpr int al = PmTraits<FT>::kAlign;
+    if ((H > W ? H : W) > PmTraits<FT>::kMaxStrip || C % al || Cq % al) return fail(CCNET_E_BADSHAPE, what);
     return 0;
+}
+size_t pm_workspace_bytes(int B, int C, int Cq, int H, int W, int backward) {
+    if (B <= 0 || C <= 0 || Cq <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t partial = (size_t)B * H * W * (C > Cq ? C : Cq) * sizeof(float);
+    return (backward ? align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W)) : 0) + partial;
+}
+
+template <typename FT>
+int cca_forward_pm(const char *name, const FT *q, const FT *k, const FT *v, const FT *x, const float *gamma, FT *y, float *A,
+                   int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
+                   long x_bs, int x_ps, long y_bs, int y_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
+    if (int e = require_both_branches(name)) return e;
+    if (!q || !k || !v || !x || !gamma || !y || !A) return fail(CCNET_E_NULLPTR, "cca_forward_pm: null tensor");
+    if (int e = check_pm_problem<FT>("cca_forward_pm: strip length / channel divisibility (see ccnet_cca.h)", B, C, Cq, H, W)) return e;
+    if (int e = check_pm_view<FT>("cca_forward_pm: q view", q_bs, q_ps, Cq, H, W)) return e;
+    if (int e = check_pm_view<FT>("cca_forward_pm: k view", k_bs, k_ps, Cq, H, W)) return e;
+    if (int e = check_pm_view<FT>("cca_forward_pm: v view", v_bs, v_ps, C, H, W)) return e;
+    if (int e = check_pm_view<FT>("cca_forward_pm: x view", x_bs, x_ps, C, H, W)) return e;
+    if (int e = check_pm_view<FT>("cca_forward_pm: y view", y_bs, y_ps, C, H, W)) return e;
+    if (!workspace || workspace_bytes < pm_workspace_bytes(B, C, Cq, H, W, 0))
+        return fail(CCNET_E_WORKSPACE, "cca_forward_pm: workspace missing or too small");
+    if (int e = gweight_pm<true, FT>(q, k, A, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
+    if (int e = softmax_forward(A, A, B, H, W, stream)) return e;
+    return gmap_pm<false, FT>(A, v, x, gamma, y, (float *)workspace, B, C, H, W, v_bs, v_ps, x_bs, x_ps, y_bs, y_ps, stream);
+}
+
+template <typename FT>
+int cca_backward_pm(const char *name, const FT *dy, const FT *q, const FT *k, const FT *v, const float *A, const float *gamma,
+                    FT *dq, FT *dk, FT *dv, float *dgamma, float *scratch, int B, int C, int Cq, int H, int W,
+                    long dy_bs, int dy_ps, long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
+                    long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
+                    void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
+    if (int e = require_both_branches(name)) return e;
+    if (!dy || !q || !k || !v || !A || !gamma || !dq || !dk || !dv || !dgamma || !scratch)
+        return fail(CCNET_E_NULLPTR, "cca_backward_pm: null tensor");
+    if (int e = check_pm_problem<FT>("cca_backward_pm: strip length / channel divisibility (see ccnet_cca.h)", B, C, Cq, H, W)) return e;
+    if (int e = check_pm_view<FT>("cca_backward_pm: dy view", dy_bs, dy_ps, C, H, W)) return e;
+    if (int e = check_pm_view<FT>("cca_backward_pm: q view", q_bs, q_ps, Cq, H, W)) return e;
+    if (int e = check_pm_view<FT>("cca_backward_pm: k view", k_bs, k_ps, Cq, H, W)) return e;
+    if (int e = check_pm_view<FT>("cca_backward_pm: v view", v_bs, v_ps, C, H, W)) return e;
+    if (int e = check_pm_view<FT>("cca_backward_pm: dq view", dq_bs, dq_ps, Cq, H, W)) return e;
+    if (int e = check_pm_view<FT>("cca_backward_pm: dk view", dk_bs, dk_ps, Cq, H, W)) return e;
+    if (int e = check_pm_view<FT>("cca_backward_pm: dv view", dv_bs, dv_ps, C, H, W)) return e;
+    if (!workspace || workspace_bytes < pm_workspace_bytes(B, C, Cq, H, W, 1))
+        return fail(CCNET_E_WORKSPACE, "cca_backward_pm: workspace missing or too small");
+    const size_t sm = align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W));
+    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + sm);
+    // t = un-scaled dA (functions.py:110-112 through the aggregation's adjoint), dv = gamma * A^T-weighted dy
+    if (int e = gweight_pm<false, FT>(dy, v, scratch, B, C, H, W, dy_bs, dy_ps, v_bs, v_ps, stream)) return e;
+    if (int e = gmap_pm<true, FT>(A, dy, nullptr, gamma, dv, partial, B, C, H, W, dy_bs, dy_ps, 0L, 0, dv_bs, dv_ps, stream)) return e;
+    // dgamma = sum A t;  dE = gamma * A * (t - sum_s A t), in place
+    if (int e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, sm, B, H, W, stream, KSplit())) return e;
+    if (int e = gmap_pm<false, FT>(scratch, k, nullptr, nullptr, dq, partial, B, Cq, H, W, k_bs, k_ps, 0L, 0, dq_bs, dq_ps, stream)) return e;
+    return gmap_pm<true, FT>(scratch, q, nullptr, nullptr, dk, partial, B, Cq, H, W, q_bs, q_ps, 0L, 0, dk_bs, dk_ps, stream);
 }
 }  // namespace
 }  // extern "C++"
 
 size_t ccnet_cca_pm_bf16_workspace_bytes(int B, int C, int Cq, int H, int W, int backward) {
-    if (B <= 0 || C <= 0 || Cq <= 0 || H <= 0 || W <= 0) return 0;
-    const size_t partial = (size_t)B * H * W * (C > Cq ? C : Cq) * sizeof(float);
-    return (backward ? align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W)) : 0) + partial;
+    return pm_workspace_bytes(B, C, Cq, H, W, backward);
+}
+size_t ccnet_cca_pm_f32_workspace_bytes(int B, int C, int Cq, int H, int W, int backward) {
+    return pm_workspace_bytes(B, C, Cq, H, W, backward);
 }
 
 int ccnet_cca_forward_pm_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v, const uint16_t *x,
                               const float *gamma, uint16_t *y, float *A, int B, int C, int Cq, int H, int W,
                               long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long x_bs, int x_ps,
                               long y_bs, int y_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
-    if (int e = require_both_branches("cca_forward_pm_bf16")) return e;
-    if (!q || !k || !v || !x || !gamma || !y || !A) return fail(CCNET_E_NULLPTR, "cca_forward_pm_bf16: null tensor");
-    if (int e = check_pm_problem("cca_forward_pm_bf16: strips <= 132, C % 8 == 0, Cq % 8 == 0", B, C, Cq, H, W)) return e;
-    if (int e = check_pm_view("cca_forward_pm_bf16: q view", q_bs, q_ps, Cq, H, W)) return e;
-    if (int e = check_pm_view("cca_forward_pm_bf16: k view", k_bs, k_ps, Cq, H, W)) return e;
-    if (int e = check_pm_view("cca_forward_pm_bf16: v view", v_bs, v_ps, C, H, W)) return e;
-    if (int e = check_pm_view("cca_forward_pm_bf16: x view", x_bs, x_ps, C, H, W)) return e;
-    if (int e = check_pm_view("cca_forward_pm_bf16: y view", y_bs, y_ps, C, H, W)) return e;
-    if (!workspace || workspace_bytes < ccnet_cca_pm_bf16_workspace_bytes(B, C, Cq, H, W, 0))
-        return fail(CCNET_E_WORKSPACE, "cca_forward_pm_bf16: workspace missing or too small");
-    if (int e = gweight_bf16<true>((const bf16_t *)q, (const bf16_t *)k, A, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
-    if (int e = softmax_forward(A, A, B, H, W, stream)) return e;
-    return gmap_bf16<false>(A, (const bf16_t *)v, (const bf16_t *)x, gamma, (bf16_t *)y, (float *)workspace, B, C, H, W,
-                            v_bs, v_ps, x_bs, x_ps, y_bs, y_ps, stream);
+    return cca_forward_pm<bf16_t>("cca_forward_pm_bf16", (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)x,
+                                  gamma, (bf16_t *)y, A, B, C, Cq, H, W, q_bs, q_ps, k_bs, k_ps, v_bs, v_ps, x_bs, x_ps, y_bs, y_ps,
+                                  workspace, workspace_bytes, stream);
+}
+int ccnet_cca_forward_pm_f32(const float *q, const float *k, const float *v, const float *x,
+                             const float *gamma, float *y, float *A, int B, int C, int Cq, int H, int W,
+                             long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long x_bs, int x_ps,
+                             long y_bs, int y_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
+    return cca_forward_pm<float>("cca_forward_pm_f32", q, k, v, x, gamma, y, A, B, C, Cq, H, W, q_bs, q_ps, k_bs, k_ps, v_bs, v_ps,
+                                 x_bs, x_ps, y_bs, y_ps, workspace, workspace_bytes, stream);
 }
 
 int ccnet_cca_backward_pm_bf16(const uint16_t *dy, const uint16_t *q, const uint16_t *k, const uint16_t *v,
@@ -903,31 +968,20 @@ int ccnet_cca_backward_pm_bf16(const uint16_t *dy, const uint16_t *q, const uint
                                long dy_bs, int dy_ps, long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
                                long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
                                void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
-    if (int e = require_both_branches("cca_backward_pm_bf16")) return e;
-    if (!dy || !q || !k || !v || !A || !gamma || !dq || !dk || !dv || !dgamma || !scratch)
-        return fail(CCNET_E_NULLPTR, "cca_backward_pm_bf16: null tensor");
-    if (int e = check_pm_problem("cca_backward_pm_bf16: strips <= 132, C % 8 == 0, Cq % 8 == 0", B, C, Cq, H, W)) return e;
-    if (int e = check_pm_view("cca_backward_pm_bf16: dy view", dy_bs, dy_ps, C, H, W)) return e;
-    if (int e = check_pm_view("cca_backward_pm_bf16: q view", q_bs, q_ps, Cq, H, W)) return e;
-    if (int e = check_pm_view("cca_backward_pm_bf16: k view", k_bs, k_ps, Cq, H, W)) return e;
-    if (int e = check_pm_view("cca_backward_pm_bf16: v view", v_bs, v_ps, C, H, W)) return e;
-    if (int e = check_pm_view("cca_backward_pm_bf16: dq view", dq_bs, dq_ps, Cq, H, W)) return e;
-    if (int e = check_pm_view("cca_backward_pm_bf16: dk view", dk_bs, dk_ps, Cq, H, W)) return e;
-    if (int e = check_pm_view("cca_backward_pm_bf16: dv view", dv_bs, dv_ps, C, H, W)) return e;
-    if (!workspace || workspace_bytes < ccnet_cca_pm_bf16_workspace_bytes(B, C, Cq, H, W, 1))
-        return fail(CCNET_E_WORKSPACE, "cca_backward_pm_bf16: workspace missing or too small");
-    const size_t sm = align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W));
-    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + sm);
-    // t = un-scaled dA (functions.py:110-112 through the aggregation's adjoint), dv = gamma * A^T-weighted dy
-    if (int e = gweight_bf16<false>((const bf16_t *)dy, (const bf16_t *)v, scratch, B, C, H, W, dy_bs, dy_ps, v_bs, v_ps, stream)) return e;
-    if (int e = gmap_bf16<true>(A, (const bf16_t *)dy, nullptr, gamma, (bf16_t *)dv, partial, B, C, H, W, dy_bs, dy_ps,
-                                0L, 0, dv_bs, dv_ps, stream)) return e;
-    // dgamma = sum A t;  dE = gamma * A * (t - sum_s A t), in place
-    if (int e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, sm, B, H, W, stream, KSplit())) return e;
-    if (int e = gmap_bf16<false>(scratch, (const bf16_t *)k, nullptr, nullptr, (bf16_t *)dq, partial, B, Cq, H, W, k_bs, k_ps,
-                                 0L, 0, dq_bs, dq_ps, stream)) return e;
-    return gmap_bf16<true>(scratch, (const bf16_t *)q, nullptr, nullptr, (bf16_t *)dk, partial, B, Cq, H, W, q_bs, q_ps,
-                           0L, 0, dk_bs, dk_ps, stream);
+    return cca_backward_pm<bf16_t>("cca_backward_pm_bf16", (const bf16_t *)dy, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
+                                   A, gamma, (bf16_t *)dq, (bf16_t *)dk, (bf16_t *)dv, dgamma, scratch, B, C, Cq, H, W,
+                                   dy_bs, dy_ps, q_bs, q_ps, k_bs, k_ps, v_bs, v_ps, dq_bs, dq_ps, dk_bs, dk_ps, dv_bs, dv_ps,
+                                   workspace, workspace_bytes, stream);
+}
+int ccnet_cca_backward_pm_f32(const float *dy, const float *q, const float *k, const float *v,
+                              const float *A, const float *gamma, float *dq, float *dk, float *dv,
+                              float *dgamma, float *scratch, int B, int C, int Cq, int H, int W,
+                              long dy_bs, int dy_ps, long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
+                              long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
+                              void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
+    return cca_backward_pm<float>("cca_backward_pm_f32", dy, q, k, v, A, gamma, dq, dk, dv, dgamma, scratch, B, C, Cq, H, W,
+                                  dy_bs, dy_ps, q_bs, q_ps, k_bs, k_ps, v_bs, v_ps, dq_bs, dq_ps, dk_bs, dk_ps, dv_bs, dv_ps,
+                                  workspace, workspace_bytes, stream);
 }
 
 int ccnet_cca_mfma_selftest(float *scratch, ccnet_stream_t stream) {

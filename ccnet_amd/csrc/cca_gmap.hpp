@@ -5,7 +5,7 @@
 //   gmap_kernel     TRANS = false   out[pixel(i, g), c] (+)= alpha * sum_j P_g[i][j] * F[pixel(j, g), c]
 //                   TRANS = true    out[pixel(j, g), c] (+)= alpha * sum_i P_g[i][j] * F[pixel(i, g), c]
 //                   with P_g[i][j] = T[b, pixel(i, g), a_off + j]  (cca_map.hpp has the same contractions on NCHW)
-//   gweight_kernel  T[b, pixel(i, g), a_off + j] = sum_c X[pixel(i, g), c] * Y[pixel(j, g), c]      (bf16 features)
+//   gweight_kernel  T[b, pixel(i, g), a_off + j] = sum_c X[pixel(i, g), c] * Y[pixel(j, g), c]
 //
 // Why another kernel family: in NCHW the column branch of a strip tile is a stream of 32-byte segments (8 strips x
 // 4 B), which the L1 / TA path serves at a third of the row rate.  With the features PIXEL-MAJOR (B, H*W, pixel
@@ -66,9 +66,15 @@ __device__ __forceinline__ void gtile_dma_piece(const FBuf &src, float *img, int
         const int p = lane >> 3, i = 8 * piece + p, q = (lane & 7) ^ (p & 7), c = c0 + 8 * q;
         fbuf_load_to_lds_x4(src, img + piece * GM_PB, (i < n && c < C) ? ((pix0 + i * pstep) * ps + c) * 2 : kOobOffset, 0);
     } else {
-        const int i = 4 * piece + (lane >> 4), c = c0 + 4 * (lane & 15);
+        const int i = 4 * piece + (lane >> 4), c = c0 + 4 * ((lane & 15) ^ (i & 1));
         fbuf_load_to_lds_x4(src, img + piece * GM_PP, (i < n && c < C) ? ((pix0 + i * pstep) * ps + c) * 4 : kOobOffset, 0);
     }
+}
+// fp32 tiles: 4 pixels x 64 channels per 1 KiB DMA piece; the 16-byte chunk q of pixel p sits at chunk position
+// q ^ (p & 1): 16 consecutive pixels reading one chunk (gweight fragments) then meet every bank group twice, not 4 times.
+// dword index of channel c (0..63) of line position j inside an fp32 tile
+__device__ __forceinline__ int gtile_f32_idx(int j, int c) {
+    return (j >> 2) * GM_PP + (j & 3) * GM_CG + ((((c >> 2) ^ (j & 1)) << 2) | (c & 3));
 }
 // byte offset of channel c (0..63) of line position j inside a bf16 tile
 __device__ __forceinline__ int gtile_bf_byte(int j, int c) {
@@ -78,8 +84,8 @@ __device__ __forceinline__ uint32_t lds_load_u16(const float *base, int byte_off
     return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-// FT: feature element, OT: output element; the addend (ADD) is fp32 pixel-major with its own strides; resid (bf16 output
-// only, may be null) has the output's type.  4 wavefronts, two workgroups per CU: wavefront w owns the M tiles (16
+// FT: feature element, OT: output element; the addend (ADD) is fp32 pixel-major with its own strides; resid (may be
+// null) has the output's type.  4 wavefronts, two workgroups per CU: wavefront w owns the M tiles (16
 // strip positions each) t = w, w + 4, w + 8 of all four 16-channel N tiles, and keeps their attention fragments -- hi and
 // lo bf16 halves, every k-step -- in registers for the whole strip (A-stationary: 96 VGPRs at 132 positions).
 template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT>
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
                 add0[k] = fbuf_load_x4(Db, ok ? (pix * aps + c) * 4 : kOobOffset, 0);
                 if (OBF) add1[k] = fbuf_load_x4(Db, ok ? (pix * aps + c + 4) * 4 : kOobOffset, 0);
             }
-            if (OBF) res[k] = __builtin_bit_cast(u32x4, fbuf_load_x4(Rb, (ok && resid) ? (pix * rps + c) * 2 : kOobOffset, 0));
+            res[k] = __builtin_bit_cast(u32x4, fbuf_load_x4(Rb, (ok && resid) ? (pix * rps + c) * (int)sizeof(OT) : kOobOffset, 0));
         }
         // D^T[m = channel][n = strip position] = features^T x attention^T: a lane ends up with 4 consecutive channels of
         // one position (one ds_write_b128 into the pixel-major output image)
@@ -215,10 +221,9 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
                         fb.hi = u32x4{x[0] | (x[1] << 16), x[2] | (x[3] << 16), x[4] | (x[5] << 16), x[6] | (x[7] << 16)};
                         fb.lo = fb.hi;
                     } else {
-                        const float *p = img + (8 * ks + 2 * lg) * GM_PP + 16 * nt + ln;
                         float x[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) x[e] = CCA_LDS_LD(p + (e >> 2) * GM_PP + (e & 3) * GM_CG);
+                        for (int e = 0; e < 8; ++e) x[e] = CCA_LDS_LD(img + gtile_f32_idx(32 * ks + 8 * lg + e, 16 * nt + ln));
                         fb = bf16_split8(x);
                     }
 #pragma unroll
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
             for (int nt = 0; nt < 4; ++nt) {
                 float fbv;
                 if constexpr (BF) fbv = __builtin_bit_cast(float, lds_load_u16(img, gtile_bf_byte(pos, 16 * nt + ln)) << 16);
-                else              fbv = CCA_LDS_LD(img + (pos >> 2) * GM_PP + (pos & 3) * GM_CG + 16 * nt + ln);
+                else              fbv = CCA_LDS_LD(img + gtile_f32_idx(pos, 16 * nt + ln));
 #pragma unroll
                 for (int a = 0; a < TPW; ++a)
                     if ((wv + GS_WAVES * a) * 16 < L) acc[a][nt] = mfma_16x16x4(fbv, at[a], acc[a][nt]);
@@ -276,6 +281,7 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
                                                                              cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])});
                         fbuf_store_x4(Ob, packed, ((pix0 + i * pstep) * ops + c) * 2, 0);
                     } else {
+                        u += __builtin_bit_cast(f32x4, res[k]);          // (+ the fp32 residual; zeros when there is none)
                         fbuf_store_x4(Ob, u, ((pix0 + i * pstep) * ops + c) * 4, 0);
                     }
                 }
@@ -291,11 +297,13 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
 //   ds_read_b128 fragments of the swizzled bf16 tiles and the products are exact: no split, one
 //   v_mfma_f32_16x16x32_bf16 per tile and 32 channels.  Wavefront w owns the tile rows ti = w, w + 8, ...
 // ---------------------------------------------------------------------------------------------------------------
-template <int P, bool MASK>
-__global__ __launch_bounds__(GM_THREADS, 1) void gweight_kernel(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Y,
+template <int P, bool MASK, typename FT>
+__global__ __launch_bounds__(GM_THREADS, 1) void gweight_kernel(const FT *__restrict__ X, const FT *__restrict__ Y,
                                                                  float *__restrict__ T, int Cx, int H, int W,
                                                                  long xbs, int xps, long ybs, int yps) {
-    constexpr int NT = (P + 15) / 16, NTR = (NT + GM_WAVES - 1) / GM_WAVES, TSZ = GTile<bf16_t>::size(P), NPF = GTile<bf16_t>::pieces(P);
+    constexpr bool BF = GTile<FT>::BF;
+    constexpr int NT = (P + 15) / 16, NTR = (NT + GM_WAVES - 1) / GM_WAVES, TSZ = GTile<FT>::size(P), NPF = GTile<FT>::pieces(P);
+    static_assert(4 * TSZ * 4 <= 163840, "gweight: LDS");
     __shared__ __attribute__((aligned(16))) float lds[4 * TSZ];
     CCA_LDS_REGISTER(lds);
     const int HW = H * W, S = H + W;
@@ -308,17 +316,15 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gweight_kernel(const bf16_t *__
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
     const int ln = lane & 15, lg = lane >> 4;
     const int pix0 = row ? g * W : g, pstep = row ? 1 : W, a_off = row ? H : 0;
-    const FBuf Xb = make_fbuf(reinterpret_cast<const float *>(X + (size_t)b * xbs), ((size_t)(HW - 1) * xps + Cx) * 2);
-    const FBuf Yb = make_fbuf(reinterpret_cast<const float *>(Y + (size_t)b * ybs), ((size_t)(HW - 1) * yps + Cx) * 2);
+    const FBuf Xb = make_fbuf(reinterpret_cast<const float *>(X + (size_t)b * xbs), ((size_t)(HW - 1) * xps + Cx) * sizeof(FT));
+    const FBuf Yb = make_fbuf(reinterpret_cast<const float *>(Y + (size_t)b * ybs), ((size_t)(HW - 1) * yps + Cx) * sizeof(FT));
     const int nch = (Cx + GM_CG - 1) / GM_CG;
 
-    for (int i = tid * 4; i < 4 * TSZ; i += GM_THREADS * 4) lds_store_x4(&lds[i], f32x4{0.f, 0.f, 0.f, 0.f});
-    __syncthreads();
     auto issue = [&](int ch) {
         float *xb = lds + (ch & 1) * 2 * TSZ, *yb = xb + TSZ;
         for (int it = wv; it < 2 * NPF; it += GM_WAVES) {
-            if (it < NPF) gtile_dma_piece<bf16_t>(Xb, xb, it, lane, pix0, pstep, L, xps, ch * GM_CG, Cx);
-            else          gtile_dma_piece<bf16_t>(Yb, yb, it - NPF, lane, pix0, pstep, L, yps, ch * GM_CG, Cx);
+            if (it < NPF) gtile_dma_piece<FT>(Xb, xb, it, lane, pix0, pstep, L, xps, ch * GM_CG, Cx);
+            else          gtile_dma_piece<FT>(Yb, yb, it - NPF, lane, pix0, pstep, L, yps, ch * GM_CG, Cx);
         }
     };
     f32x4 acc[NTR][NT];
@@ -326,32 +332,76 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gweight_kernel(const bf16_t *__
     for (int a = 0; a < NTR; ++a)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // fragment = 8 consecutive channels (one 16-byte chunk) of one pixel: chunk q of pixel p at chunk position q ^ (p & 7)
-    auto frag = [&](const float *tile, int pixel, int chunk) {
-        const int off = (pixel >> 3) * GM_PB + (pixel & 7) * 32 + ((chunk ^ (pixel & 7)) << 2);
-        return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint32_t *>(tile) + off);
+    // fragment = the 8 consecutive channels 32 kk + 8 lg .. + 7 of one pixel.  bf16: one 16-byte chunk (chunk q of pixel
+    // p at chunk position q ^ (p & 7)), exact.  fp32: two chunks, split into hi + lo in registers.
+    auto frag = [&](const float *tile, int pixel_, int kk) {
+        const int pixel = pixel_ < NPF * GTile<FT>::PIX ? pixel_ : 0;      // (tile rows beyond the strip: results unused)
+        BfSplit f;
+        if constexpr (BF) {
+            const int chunk = 4 * kk + lg;
+            const int off = (pixel >> 3) * GM_PB + (pixel & 7) * 32 + ((chunk ^ (pixel & 7)) << 2);
+            f.hi = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint32_t *>(tile) + off);
+            f.lo = f.hi;
+        } else {
+            const int c0 = 32 * kk + 8 * lg;
+            const f32x4 u = lds_load_x4(tile + gtile_f32_idx(pixel, c0)), v = lds_load_x4(tile + gtile_f32_idx(pixel, c0 + 4));
+            const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+            f = bf16_split8(x);
+        }
+        return f;
     };
     issue(0);
     for (int ch = 0; ch < nch; ++ch) {
         const float *xb = lds + (ch & 1) * 2 * TSZ, *yb = xb + TSZ;
         barrier_dma_keep<0>();
         if (ch + 1 < nch) issue(ch + 1);
+        if constexpr (!BF && MASK) {
+            // the energies feed exp(): exact fp32 products (v_mfma_f32_16x16x4_f32, bit-identical to an fmaf chain), 16
+            // k-steps of 4 channels; lane (ln, lg) holds channel 4 ks + lg of pixel ln of its tile
+#pragma unroll 4
+            for (int ks = 0; ks < GM_CG / 4; ++ks) {
+                float af[NTR];
+#pragma unroll
+                for (int a = 0; a < NTR; ++a) {
+                    const int px = 16 * (wv + GM_WAVES * a) + ln;
+                    af[a] = CCA_LDS_LD(xb + gtile_f32_idx(px < NPF * 4 ? px : 0, 4 * ks + lg));
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (t * 16 < L) {
+                        const int px = 16 * t + ln;
+                        const float bv = CCA_LDS_LD(yb + gtile_f32_idx(px < NPF * 4 ? px : 0, 4 * ks + lg));
+#pragma unroll
+                        for (int a = 0; a < NTR; ++a)
+                            if ((wv + GM_WAVES * a) * 16 < L) acc[a][t] = mfma_16x16x4(af[a], bv, acc[a][t]);
+                    }
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {                       // two k-steps of 32 channels
-            u32x4 af[NTR];
+            BfSplit af[NTR];
 #pragma unroll
-            for (int a = 0; a < NTR; ++a) af[a] = frag(xb, 16 * (wv + GM_WAVES * a) + ln, 4 * kk + lg);
+            for (int a = 0; a < NTR; ++a) af[a] = frag(xb, 16 * (wv + GM_WAVES * a) + ln, kk);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (t * 16 < L) {
-                    const u32x4 bf = frag(yb, 16 * t + ln, 4 * kk + lg);
+                    const BfSplit bf = frag(yb, 16 * t + ln, kk);
 #pragma unroll
                     for (int a = 0; a < NTR; ++a)
-                        if ((wv + GM_WAVES * a) * 16 < L) acc[a][t] = mfma_bf16_16x16x32(af[a], bf, acc[a][t]);
+                        if ((wv + GM_WAVES * a) * 16 < L) {
+                            acc[a][t] = mfma_bf16_16x16x32(af[a].hi, bf.hi, acc[a][t]);
+                            if (!BF) {
+                                acc[a][t] = mfma_bf16_16x16x32(af[a].hi, bf.lo, acc[a][t]);
+                                acc[a][t] = mfma_bf16_16x16x32(af[a].lo, bf.hi, acc[a][t]);
+                            }
+                        }
                 }
             }
         }
     }
+    if constexpr (!BF && MASK) mfma_f32_result_fence();
     // D[m = query position 16 ti + 4 lg + q][n = key position 16 t + ln] -> T rows (64-byte runs per query)
     float *Tg = T + (size_t)b * HW * S;
 #pragma unroll

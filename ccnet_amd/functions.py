@@ -387,55 +387,69 @@ class CrissCrossBF16Function(torch.autograd.Function):
         return dq, dk, dv, dy, dgamma.view_as(gamma)
 
 
-def _pm_view(name, t, C=None):
-    """(B, H, W, C) bf16 view whose channel axis is contiguous and whose rows follow each other at the pixel stride:
-    returns (tensor, batch stride, pixel stride) in elements; copies only when the view does not qualify."""
+_PM_DTYPES = {torch.bfloat16: (2, 8, 132, "bf16"), torch.float32: (4, 4, 100, "f32")}   # bytes, alignment (elements), max strip
+
+
+def _pm_view(name, t, dtype=None):
+    """(B, H, W, C) bf16 / fp32 view whose channel axis is contiguous and whose rows follow each other at the pixel
+    stride: returns (tensor, batch stride, pixel stride) in elements; copies only when the view does not qualify."""
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
-        raise RuntimeError(f"{name}: expected a bfloat16 tensor on an AMD GPU (there is no CPU fallback)")
-    if t.dtype != torch.bfloat16 or t.dim() != 4:
-        raise RuntimeError(f"{name}: expected a 4-D (B, H, W, C) bfloat16 tensor, got {t.dtype} {tuple(t.shape)}")
+        raise RuntimeError(f"{name}: expected a tensor on an AMD GPU (there is no CPU fallback)")
+    if t.dtype not in _PM_DTYPES or (dtype is not None and t.dtype != dtype) or t.dim() != 4:
+        raise RuntimeError(f"{name}: expected a 4-D (B, H, W, C) {dtype or 'bfloat16 / float32'} tensor, got {t.dtype} "
+                           f"{tuple(t.shape)}")
     B, H, W, c = t.shape
-    ok = (t.stride(3) == 1 and t.stride(1) == W * t.stride(2) and t.stride(2) % 8 == 0 and t.stride(0) % 8 == 0
+    es, al = _PM_DTYPES[t.dtype][:2]
+    ok = (t.stride(3) == 1 and t.stride(1) == W * t.stride(2) and t.stride(2) % al == 0 and t.stride(0) % al == 0
           and t.stride(2) >= c and t.stride(0) >= H * W * t.stride(2) - (t.stride(2) - c) and t.data_ptr() % 16 == 0)
     if not ok:
         t = t.contiguous()
     return t, t.stride(0), t.stride(2)
 
 
+def pm_covers(dtype, B, C, Cq, H, W):
+    """geometry of the pixel-major kernels (csrc/cca_gmap.hpp) for this element type"""
+    if dtype not in _PM_DTYPES:
+        return False
+    _, al, longest, _ = _PM_DTYPES[dtype]
+    return max(H, W) <= longest and C % al == 0 and Cq % al == 0 and H * W * (C + 2 * Cq) < 2 ** 29
+
+
 def pm_bf16_covers(B, C, Cq, H, W):
-    """geometry of the pixel-major bf16 kernels (csrc/cca_gmap.hpp)"""
-    return max(H, W) <= 132 and C % 8 == 0 and Cq % 8 == 0 and H * W * (C + 2 * Cq) < 2 ** 29
+    return pm_covers(torch.bfloat16, B, C, Cq, H, W)
 
 
-class CrissCrossPMBF16Function(torch.autograd.Function):
-    """Fused core on PIXEL-MAJOR bf16 features (BASELINE configs[4], csrc/cca_gmap.hpp): ``qkv`` is the packed
-    (B, H, W, 2*Cq + C) projection (query | key | value channel slices, functions.py:29-35 computed as one
-    ``x^T W^T`` GEMM), ``x`` the (B, H, W, C) residual input; returns y (B, H, W, C) bf16.  Attention, softmax,
-    accumulation and gamma are fp32.  Backward returns the packed dqkv, so the projection's backward is again one GEMM."""
+class CrissCrossPMFunction(torch.autograd.Function):
+    """Fused core on PIXEL-MAJOR features (csrc/cca_gmap.hpp; bf16 = BASELINE configs[4], fp32 = the small-batch path):
+    ``qkv`` is the packed (B, H, W, 2*Cq + C) projection (query | key | value channel slices, functions.py:29-35
+    computed as one ``x^T W^T`` GEMM), ``x`` the (B, H, W, C) residual input of the same dtype; returns y (B, H, W, C).
+    Attention, softmax, accumulation and gamma are fp32.  Backward returns the packed dqkv, so the projection's backward
+    is again one GEMM."""
 
     @staticmethod
     def forward(ctx, qkv, x, gamma, cq):
         qkv, q_bs, q_ps = _pm_view("qkv", qkv)
-        x, x_bs, x_ps = _pm_view("x", x)
+        x, x_bs, x_ps = _pm_view("x", x, qkv.dtype)
         gamma = _dev_f32("gamma", gamma)
         _same_device(qkv, x, gamma)
         B, H, W, ct = qkv.shape
         C = ct - 2 * cq
+        es, _, longest, tag = _PM_DTYPES[qkv.dtype]
         if tuple(x.shape) != (B, H, W, C):
             raise RuntimeError(f"shape mismatch: qkv {tuple(qkv.shape)} (Cq = {cq}), x {tuple(x.shape)}")
-        if not pm_bf16_covers(B, C, cq, H, W):
-            raise RuntimeError(f"pixel-major bf16 kernels cover strips <= 132 and channel counts divisible by 8; got "
-                               f"C = {C}, Cq = {cq}, H = {H}, W = {W}")
+        if not pm_covers(qkv.dtype, B, C, cq, H, W):
+            raise RuntimeError(f"pixel-major {tag} kernels cover strips <= {longest} and channel counts divisible by "
+                               f"{_PM_DTYPES[qkv.dtype][1]}; got C = {C}, Cq = {cq}, H = {H}, W = {W}")
         lib = _lib.get_lib()
-        y = torch.empty((B, H, W, C), device=x.device, dtype=torch.bfloat16)
+        y = torch.empty((B, H, W, C), device=x.device, dtype=qkv.dtype)
         A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
         _ws, ws_ptr, nbytes = _workspace(lib.ccnet_cca_pm_bf16_workspace_bytes(B, C, cq, H, W, 0), x.device)
         p = qkv.data_ptr()
+        fwd = getattr(lib, "ccnet_cca_forward_pm_" + tag)
         with torch.cuda.device(x.device):
-            lib.check(lib.ccnet_cca_forward_pm_bf16(p, p + 2 * cq, p + 4 * cq, x.data_ptr(), gamma.data_ptr(),
-                                                    y.data_ptr(), A.data_ptr(), B, C, cq, H, W,
-                                                    q_bs, q_ps, q_bs, q_ps, q_bs, q_ps, x_bs, x_ps, H * W * C, C,
-                                                    ws_ptr, nbytes, _stream()), "cca_forward_pm_bf16")
+            lib.check(fwd(p, p + es * cq, p + 2 * es * cq, x.data_ptr(), gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
+                          B, C, cq, H, W, q_bs, q_ps, q_bs, q_ps, q_bs, q_ps, x_bs, x_ps, H * W * C, C,
+                          ws_ptr, nbytes, _stream()), "cca_forward_pm_" + tag)
         ctx.save_for_backward(qkv, A, gamma)
         ctx.cq = cq
         return y
@@ -445,24 +459,27 @@ class CrissCrossPMBF16Function(torch.autograd.Function):
     def backward(ctx, dy):
         qkv, A, gamma = ctx.saved_tensors
         cq = ctx.cq
-        dy, dy_bs, dy_ps = _pm_view("grad_output", dy)
+        dy, dy_bs, dy_ps = _pm_view("grad_output", dy, qkv.dtype)
         B, H, W, ct = qkv.shape
         C = ct - 2 * cq
+        es, _, _, tag = _PM_DTYPES[qkv.dtype]
         lib = _lib.get_lib()
-        dqkv = torch.empty((B, H, W, ct), device=qkv.device, dtype=torch.bfloat16)
+        dqkv = torch.empty((B, H, W, ct), device=qkv.device, dtype=qkv.dtype)
         dgamma = torch.empty_like(gamma)
         scratch = torch.empty_like(A)
         _ws, ws_ptr, nbytes = _workspace(lib.ccnet_cca_pm_bf16_workspace_bytes(B, C, cq, H, W, 1), qkv.device)
         p, g = qkv.data_ptr(), dqkv.data_ptr()
         bs, ps = qkv.stride(0), qkv.stride(2)
+        bwd = getattr(lib, "ccnet_cca_backward_pm_" + tag)
         with torch.cuda.device(qkv.device):
-            lib.check(lib.ccnet_cca_backward_pm_bf16(dy.data_ptr(), p, p + 2 * cq, p + 4 * cq, A.data_ptr(),
-                                                     gamma.data_ptr(), g, g + 2 * cq, g + 4 * cq, dgamma.data_ptr(),
-                                                     scratch.data_ptr(), B, C, cq, H, W, dy_bs, dy_ps,
-                                                     bs, ps, bs, ps, bs, ps, H * W * ct, ct, H * W * ct, ct,
-                                                     H * W * ct, ct, ws_ptr, nbytes, _stream()),
-                      "cca_backward_pm_bf16")
+            lib.check(bwd(dy.data_ptr(), p, p + es * cq, p + 2 * es * cq, A.data_ptr(), gamma.data_ptr(),
+                          g, g + es * cq, g + 2 * es * cq, dgamma.data_ptr(), scratch.data_ptr(), B, C, cq, H, W,
+                          dy_bs, dy_ps, bs, ps, bs, ps, bs, ps, H * W * ct, ct, H * W * ct, ct, H * W * ct, ct,
+                          ws_ptr, nbytes, _stream()), "cca_backward_pm_" + tag)
         return dqkv, dy, dgamma.view_as(gamma), None
+
+
+CrissCrossPMBF16Function = CrissCrossPMFunction          # (the name round-2 code and tests imported first)
 
 
 class CrissCrossModuleFunction(torch.autograd.Function):

@@ -224,6 +224,22 @@ int ccnet_cca_backward_pm_bf16(const uint16_t *dy, const uint16_t *q, const uint
                                long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
                                void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
 
+/* The same core on fp32 pixel-major views (strips <= 100, C % 4 == 0, Cq % 4 == 0, every bs / ps a multiple of 4): one
+ * strip per workgroup instead of 8 per workgroup -- 26x more workgroups per launch, which is what 1-2 images per GPU
+ * need.  fp32 features are split into bf16 hi + lo on the fly (the three-product form of DESIGN.md 3.7);
+ * same arguments and semantics as the bf16 pair. */
+size_t ccnet_cca_pm_f32_workspace_bytes(int B, int C, int Cq, int H, int W, int backward);
+int ccnet_cca_forward_pm_f32(const float *q, const float *k, const float *v, const float *x,
+                             const float *gamma, float *y, float *A, int B, int C, int Cq, int H, int W,
+                             long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long x_bs, int x_ps,
+                             long y_bs, int y_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
+int ccnet_cca_backward_pm_f32(const float *dy, const float *q, const float *k, const float *v,
+                              const float *A, const float *gamma, float *dq, float *dk, float *dv,
+                              float *dgamma, float *scratch, int B, int C, int Cq, int H, int W,
+                              long dy_bs, int dy_ps, long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
+                              long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
+                              void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
+
 /* Which kernel family serves this shape under the current impl setting: 1 = stationary MFMA strip kernels
  * (max(H,W) <= 100), 2 = windowed MFMA strip kernels (101 .. 320), 0 = any-shape kernels. */
 int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W);

@@ -215,15 +215,18 @@ class EmuOps:
 
     def cca_forward_pm_bf16(self, qkv, x, gamma, cq):
         """qkv: uint16 (B, H, W, 2*cq + C) packed pixel-major projection (q | k | v channel slices, bf16 bit patterns),
-        x: uint16 (B, H, W, ps >= C); returns (y bits (B, H, W, C), A fp32)."""
+        x: uint16 (B, H, W, ps >= C); returns (y bits (B, H, W, C), A fp32).  float32 arrays take the fp32 entry points."""
         B, H, W, ct = qkv.shape
         C = ct - 2 * cq
-        y = np.zeros((B, H, W, C), np.uint16)
+        y = np.zeros((B, H, W, C), qkv.dtype)
         A = np.full((B, H, W, H + W), np.nan, np.float32)
+        f32 = qkv.dtype == np.float32
+        es = 4 if f32 else 2
+        fwd = self.lib.ccnet_cca_forward_pm_f32 if f32 else self.lib.ccnet_cca_forward_pm_bf16
         nbytes = self.lib.ccnet_cca_pm_bf16_workspace_bytes(B, C, cq, H, W, 0)
         ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
         base, bs = qkv.ctypes.data, H * W * ct
-        self.lib.check(self.lib.ccnet_cca_forward_pm_bf16(base, base + 2 * cq, base + 4 * cq, _p(x), _p(gamma), _p(y), _p(A),
+        self.lib.check(fwd(base, base + es * cq, base + 2 * es * cq, _p(x), _p(gamma), _p(y), _p(A),
                                                           B, C, cq, H, W, bs, ct, bs, ct, bs, ct,
                                                           H * W * x.shape[3], x.shape[3], H * W * C, C, _p(ws), nbytes, None))
         return y, A
@@ -238,8 +241,11 @@ class EmuOps:
         nbytes = self.lib.ccnet_cca_pm_bf16_workspace_bytes(B, C, cq, H, W, 1)
         ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
         base, g, bs = qkv.ctypes.data, dqkv.ctypes.data, H * W * ct
-        self.lib.check(self.lib.ccnet_cca_backward_pm_bf16(_p(dy), base, base + 2 * cq, base + 4 * cq, _p(A), _p(gamma),
-                                                           g, g + 2 * cq, g + 4 * cq, _p(dgamma), _p(scratch),
+        f32 = qkv.dtype == np.float32
+        es = 4 if f32 else 2
+        bwd = self.lib.ccnet_cca_backward_pm_f32 if f32 else self.lib.ccnet_cca_backward_pm_bf16
+        self.lib.check(bwd(_p(dy), base, base + es * cq, base + 2 * es * cq, _p(A), _p(gamma),
+                                                           g, g + es * cq, g + 2 * es * cq, _p(dgamma), _p(scratch),
                                                            B, C, cq, H, W, H * W * C, C, bs, ct, bs, ct, bs, ct,
                                                            bs, ct, bs, ct, bs, ct, _p(ws), nbytes, None))
         return dqkv, dgamma

@@ -584,3 +584,25 @@ def test_pixel_major_bf16_path_matches_oracle(ops, shape):
     # gamma = 0: y is x exactly (as values: 0 * out + (-0) is +0 in the reference too)
     y0, _ = ops.cca_forward_pm_bf16(qkv, bits["x"], np.zeros(1, np.float32), cq)
     assert torch.equal(_from_bits(y0), _from_bits(bits["x"]))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 96, 17, 20), (1, 64, 9, 1), (1, 160, 33, 18), (1, 32, 2, 99), (1, 64, 100, 3)])
+def test_pixel_major_fp32_path_matches_oracle(ops, shape):
+    """ccnet_cca_forward_pm_f32 / ccnet_cca_backward_pm_f32: the pixel-major family on fp32 views (one strip per workgroup; fp32
+    features split into bf16 hi + lo on the fly, three products).  Oracle: the fp32 restatement; bar: the fp32 path's."""
+    B, C, H, W = shape
+    cq = C // 8
+    c = rand_case(*shape, seed=47)
+    qkv = np.ascontiguousarray(np.concatenate([_pm(c["q"]), _pm(c["k"]), _pm(c["v"])], axis=3))
+    g = T(c["gamma"])
+    y, A = ops.cca_forward_pm_bf16(qkv, _pm(c["x"]), c["gamma"], cq)
+    yo, Ao = O.cca_core_forward(T(c["q"]), T(c["k"]), T(c["v"]), T(c["x"]), g)
+    assert maxerr(A, Ao.numpy()) < TOL
+    assert np.all(A[:, np.arange(H), :, np.arange(H)] == 0)
+    nchw = lambda a: np.transpose(a, (0, 3, 1, 2))                                 # noqa: E731
+    assert maxerr(nchw(y), yo.numpy()) < 2e-4 * max(1.0, float(yo.abs().max()))
+    dqkv, dg = ops.cca_backward_pm_bf16(_pm(c["dy"]), qkv, A, c["gamma"], cq)
+    go = O.cca_core_backward(T(c["dy"]), T(c["q"]), T(c["k"]), T(c["v"]), Ao, g)
+    for name, got in (("dq", dqkv[..., :cq]), ("dk", dqkv[..., cq:2 * cq]), ("dv", dqkv[..., 2 * cq:])):
+        assert maxerr(nchw(got), go[name].numpy()) < 5e-4 * max(1.0, float(go[name].abs().max())), name
+    assert abs(float(dg[0]) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))

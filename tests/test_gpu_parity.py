@@ -444,6 +444,37 @@ def test_pixel_major_bf16_kernels_match_oracle(lib, dev, shape):
     assert abs(float(gamma.grad) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 96, 17, 20), (2, 64, 40, 33), (1, 64, 100, 70), (1, 32, 1, 9),
+                                   (1, 512, 97, 97)])
+def test_pixel_major_fp32_kernels_match_oracle(lib, dev, shape):
+    """The pixel-major family on fp32 views (ccnet_cca_{forward,backward}_pm_f32: one strip per workgroup -- the small-batch
+    path): packed fp32 projection in, y / packed dqkv out, against the oracle at the north_star bar (1e-3 max abs); the
+    attention itself (exact fp32 energies) at the tight bar, the column self slot exactly 0."""
+    from ccnet_amd.functions import CrissCrossPMFunction
+    B, C, H, W = shape
+    cq = C // 8
+    q, k, v, x, dy = make_core_inputs(B, C, H, W, seed=57)
+    if C >= 512:
+        q, k = q * 0.35, k * 0.35
+    pm = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)               # noqa: E731
+    qkv = torch.cat([pm(q), pm(k), pm(v)], dim=3).contiguous().requires_grad_(True)
+    xp = pm(x).requires_grad_(True)
+    gamma = torch.tensor([0.5], device=dev, requires_grad=True)
+    y = CrissCrossPMFunction.apply(qkv, xp, gamma, cq)
+    assert y.dtype == torch.float32 and tuple(y.shape) == (B, H, W, C)
+    y.backward(pm(dy))
+    nchw = lambda t: t.detach().cpu().permute(0, 3, 1, 2)                   # noqa: E731
+    yo, Ao = O.cca_core_forward(q, k, v, x, torch.tensor([0.5]))
+    go = O.cca_core_backward(dy, q, k, v, Ao, torch.tensor([0.5]))
+    g = qkv.grad
+    errs = {"y": err(nchw(y), yo), "dq": err(nchw(g[..., :cq]), go["dq"]), "dk": err(nchw(g[..., cq:2 * cq]), go["dk"]),
+            "dv": err(nchw(g[..., 2 * cq:]), go["dv"])}
+    print("pixel-major fp32 max-abs errors vs oracle", shape, {n: f"{e:.1e}" for n, e in errs.items()})
+    assert all(e < TOL for e in errs.values()), errs
+    assert torch.equal(xp.grad, pm(dy))
+    assert abs(float(gamma.grad) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
+
+
 def test_pixel_major_bf16_module_route_and_full_size(lib, dev):
     """The module takes bf16 activations through the pixel-major kernels (channels_last in, channels_last out), and at
     BASELINE configs[4]'s full size (16,512,129,129) the path agrees with the fp32 strip kernels on the same bf16-rounded

@@ -1,4 +1,4 @@
-"""Time the pixel-major bf16 core (csrc/cca_gmap.hpp) fwd+bwd through the C ABI: python tools/pm_bf16_time.py [B C H W]"""
+"""Time the pixel-major core (csrc/cca_gmap.hpp) fwd+bwd through the C ABI: python tools/pm_bf16_time.py [B C H W [bf16|f32]]"""
 import sys
 import torch
 import os
@@ -6,13 +6,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ccnet_amd import _lib
 
 B, C, H, W = (int(a) for a in sys.argv[1:5]) if len(sys.argv) >= 5 else (16, 512, 129, 129)
+F32 = len(sys.argv) > 5 and sys.argv[5] == "f32"
+dt, es = (torch.float32, 4) if F32 else (torch.bfloat16, 2)
 cq, dev = C // 8, torch.device("cuda:0")
 L = _lib.get_lib()
 ct = C + 2 * cq
 g = torch.Generator(device="cpu").manual_seed(1)
-qkv = (torch.randn(B, H, W, ct, generator=g) * 0.5).to(dev).to(torch.bfloat16)
-x = torch.randn(B, H, W, C, generator=g).to(dev).to(torch.bfloat16)
-dy = torch.randn(B, H, W, C, generator=g).to(dev).to(torch.bfloat16)
+qkv = (torch.randn(B, H, W, ct, generator=g) * 0.5).to(dev).to(dt)
+x = torch.randn(B, H, W, C, generator=g).to(dev).to(dt)
+dy = torch.randn(B, H, W, C, generator=g).to(dev).to(dt)
 gamma = torch.tensor([0.5], device=dev)
 y, dqkv = torch.empty_like(x), torch.empty_like(qkv)
 A = torch.empty(B, H, W, H + W, device=dev)
@@ -25,13 +27,13 @@ p, gq, bs = qkv.data_ptr(), dqkv.data_ptr(), H * W * ct
 
 
 def fwd():
-    L.check(L.ccnet_cca_forward_pm_bf16(p, p + 2 * cq, p + 4 * cq, x.data_ptr(), gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
+    L.check((L.ccnet_cca_forward_pm_f32 if F32 else L.ccnet_cca_forward_pm_bf16)(p, p + es * cq, p + 2 * es * cq, x.data_ptr(), gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
                                         B, C, cq, H, W, bs, ct, bs, ct, bs, ct, H * W * C, C, H * W * C, C, ws.data_ptr(), nf, st))
 
 
 def bwd():
-    L.check(L.ccnet_cca_backward_pm_bf16(dy.data_ptr(), p, p + 2 * cq, p + 4 * cq, A.data_ptr(), gamma.data_ptr(), gq, gq + 2 * cq,
-                                         gq + 4 * cq, dg.data_ptr(), scr.data_ptr(), B, C, cq, H, W, H * W * C, C, bs, ct, bs, ct,
+    L.check((L.ccnet_cca_backward_pm_f32 if F32 else L.ccnet_cca_backward_pm_bf16)(dy.data_ptr(), p, p + es * cq, p + 2 * es * cq, A.data_ptr(), gamma.data_ptr(), gq, gq + es * cq,
+                                         gq + 2 * es * cq, dg.data_ptr(), scr.data_ptr(), B, C, cq, H, W, H * W * C, C, bs, ct, bs, ct,
                                          bs, ct, bs, ct, bs, ct, bs, ct, ws.data_ptr(), nb, st))
 
 
@@ -50,11 +52,11 @@ def timeit(fn, n=10):
 
 tf, tb = timeit(fwd), timeit(bwd)
 # algorithmic bytes: bf16 q,k,v,x,y + dy,dq,dk,dv; fp32 A written once + read (fwd), read twice + dA/dE traffic
-feat = B * H * W * 2
+feat = B * H * W * es
 alg = feat * (2 * cq + C + C + C) + feat * (C + 2 * cq + C + 2 * cq + C) + 2 * B * H * W * (H + W) * 4
-print(f"pm bf16 ({B},{C},{H},{W}): fwd {tf:.3f} ms  bwd {tb:.3f} ms  total {tf + tb:.3f} ms ; minimal bytes {alg / 1e9:.3f} GB "
+print(f"pm {'f32' if F32 else 'bf16'} ({B},{C},{H},{W}): fwd {tf:.3f} ms  bwd {tb:.3f} ms  total {tf + tb:.3f} ms ; minimal bytes {alg / 1e9:.3f} GB "
       f"-> {alg / (tf + tb) / 1e6:.0f} GB/s")
-if len(sys.argv) < 6:
+if len(sys.argv) < 7:
     sys.exit(0)
 # compare with the fp32 strip path on the same values
 from ccnet_amd import criss_cross_attention
