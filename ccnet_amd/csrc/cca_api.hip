@@ -864,14 +864,21 @@ template <bool MASK, typename FT>
 int gweight_pm(const FT *X, const FT *Y, float *T, int B, int Cx, int H, int W, long xbs, int xps, long ybs, int yps,
                ccnet_stream_t stream) {
     const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
+    const bool single = Cx <= cca::GM_CG;           // one chunk: the single-buffered form (more workgroups per CU)
+#define CCA_GWEIGHT(P_)                                                                                                   \
+    do {                                                                                                                  \
+        if (single) CCA_LAUNCH((cca::gweight_kernel<P_, MASK, FT, true>), grid, block, stream, X, Y, T, Cx, H, W, xbs, xps, ybs, yps); \
+        else        CCA_LAUNCH((cca::gweight_kernel<P_, MASK, FT, false>), grid, block, stream, X, Y, T, Cx, H, W, xbs, xps, ybs, yps); \
+    } while (0)
     if ((H > W ? H : W) <= 100) {
-        CCA_LAUNCH((cca::gweight_kernel<100, MASK, FT>), grid, block, stream, X, Y, T, Cx, H, W, xbs, xps, ybs, yps);
+        CCA_GWEIGHT(100);
     } else {
         if constexpr (PmTraits<FT>::kMaxStrip >= 132)
-            CCA_LAUNCH((cca::gweight_kernel<132, MASK, FT>), grid, block, stream, X, Y, T, Cx, H, W, xbs, xps, ybs, yps);
+            CCA_GWEIGHT(132);
         else
             return fail(CCNET_E_BADSHAPE, "gweight_pm: strip too long for this element type");
     }
+#undef CCA_GWEIGHT
     return launch_status("gweight_pm");
 }
 template <typename FT>

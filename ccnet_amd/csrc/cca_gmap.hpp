@@ -297,14 +297,21 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
 //   ds_read_b128 fragments of the swizzled bf16 tiles and the products are exact: no split, one
 //   v_mfma_f32_16x16x32_bf16 per tile and 32 channels.  Wavefront w owns the tile rows ti = w, w + 8, ...
 // ---------------------------------------------------------------------------------------------------------------
-template <int P, bool MASK, typename FT>
-__global__ __launch_bounds__(GM_THREADS, 1) void gweight_kernel(const FT *__restrict__ X, const FT *__restrict__ Y,
-                                                                 float *__restrict__ T, int Cx, int H, int W,
-                                                                 long xbs, int xps, long ybs, int yps) {
+// SINGLE: the contraction is one 64-channel chunk (the energies, K = C/8 <= 64): no double buffering, half the LDS, and
+// two (fp32) or more workgroups per CU overlap their latency chains.
+template <int P, bool MASK, typename FT, bool SINGLE>
+__global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(const FT *__restrict__ X, const FT *__restrict__ Y,
+                                                                              float *__restrict__ T, int Cx, int H, int W,
+                                                                              long xbs, int xps, long ybs, int yps) {
     constexpr bool BF = GTile<FT>::BF;
+    constexpr bool EXACT = !BF && MASK;          // the energies feed exp(): exact fp32 products
+    constexpr bool PRESPLIT = !BF && !MASK;      // fp32 dA: tiles are split into bf16 hi / lo images once per chunk
     constexpr int NT = (P + 15) / 16, NTR = (NT + GM_WAVES - 1) / GM_WAVES, TSZ = GTile<FT>::size(P), NPF = GTile<FT>::pieces(P);
-    static_assert(4 * TSZ * 4 <= 163840, "gweight: LDS");
-    __shared__ __attribute__((aligned(16))) float lds[4 * TSZ];
+    constexpr int TSB = GTile<bf16_t>::size(P);                       // dwords per bf16 image
+    constexpr int NBUF = SINGLE ? 1 : 2;
+    constexpr int LDS = 2 * NBUF * TSZ + (PRESPLIT ? 4 * TSB : 0);
+    static_assert(LDS * 4 <= 163840, "gweight: LDS");
+    __shared__ __attribute__((aligned(16))) float lds[LDS];
     CCA_LDS_REGISTER(lds);
     const int HW = H * W, S = H + W;
     const int id = xcd_logical_id(blockIdx.x, gridDim.x);
@@ -318,10 +325,10 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gweight_kernel(const FT *__rest
     const int pix0 = row ? g * W : g, pstep = row ? 1 : W, a_off = row ? H : 0;
     const FBuf Xb = make_fbuf(reinterpret_cast<const float *>(X + (size_t)b * xbs), ((size_t)(HW - 1) * xps + Cx) * sizeof(FT));
     const FBuf Yb = make_fbuf(reinterpret_cast<const float *>(Y + (size_t)b * ybs), ((size_t)(HW - 1) * yps + Cx) * sizeof(FT));
-    const int nch = (Cx + GM_CG - 1) / GM_CG;
+    const int nch = (Cx + GM_CG - 1) / GM_CG;                 // (SINGLE: the host launches this form only when nch == 1)
 
     auto issue = [&](int ch) {
-        float *xb = lds + (ch & 1) * 2 * TSZ, *yb = xb + TSZ;
+        float *xb = lds + (ch % NBUF) * 2 * TSZ, *yb = xb + TSZ;
         for (int it = wv; it < 2 * NPF; it += GM_WAVES) {
             if (it < NPF) gtile_dma_piece<FT>(Xb, xb, it, lane, pix0, pstep, L, xps, ch * GM_CG, Cx);
             else          gtile_dma_piece<FT>(Yb, yb, it - NPF, lane, pix0, pstep, L, yps, ch * GM_CG, Cx);
@@ -332,32 +339,23 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gweight_kernel(const FT *__rest
     for (int a = 0; a < NTR; ++a)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // fragment = the 8 consecutive channels 32 kk + 8 lg .. + 7 of one pixel.  bf16: one 16-byte chunk (chunk q of pixel
-    // p at chunk position q ^ (p & 7)), exact.  fp32: two chunks, split into hi + lo in registers.
+    // bf16 fragment = the 8 consecutive channels 32 kk + 8 lg .. + 7 of one pixel = one 16-byte chunk (chunk q of pixel p
+    // at chunk position q ^ (p & 7)) of a bf16 image
     auto frag = [&](const float *tile, int pixel_, int kk) {
-        const int pixel = pixel_ < NPF * GTile<FT>::PIX ? pixel_ : 0;      // (tile rows beyond the strip: results unused)
-        BfSplit f;
-        if constexpr (BF) {
-            const int chunk = 4 * kk + lg;
-            const int off = (pixel >> 3) * GM_PB + (pixel & 7) * 32 + ((chunk ^ (pixel & 7)) << 2);
-            f.hi = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint32_t *>(tile) + off);
-            f.lo = f.hi;
-        } else {
-            const int c0 = 32 * kk + 8 * lg;
-            const f32x4 u = lds_load_x4(tile + gtile_f32_idx(pixel, c0)), v = lds_load_x4(tile + gtile_f32_idx(pixel, c0 + 4));
-            const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
-            f = bf16_split8(x);
-        }
-        return f;
+        const int pixel = pixel_ < 8 * GTile<bf16_t>::pieces(P) ? pixel_ : 0;      // (tile rows beyond the strip: results unused)
+        const int chunk = 4 * kk + lg;
+        const int off = (pixel >> 3) * GM_PB + (pixel & 7) * 32 + ((chunk ^ (pixel & 7)) << 2);
+        return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint32_t *>(tile) + off);
     };
+    float *const img = lds + 2 * NBUF * TSZ;     // PRESPLIT: X_hi | X_lo | Y_hi | Y_lo
     issue(0);
     for (int ch = 0; ch < nch; ++ch) {
-        const float *xb = lds + (ch & 1) * 2 * TSZ, *yb = xb + TSZ;
+        const float *xb = lds + (ch % NBUF) * 2 * TSZ, *yb = xb + TSZ;
         barrier_dma_keep<0>();
         if (ch + 1 < nch) issue(ch + 1);
-        if constexpr (!BF && MASK) {
-            // the energies feed exp(): exact fp32 products (v_mfma_f32_16x16x4_f32, bit-identical to an fmaf chain), 16
-            // k-steps of 4 channels; lane (ln, lg) holds channel 4 ks + lg of pixel ln of its tile
+        if constexpr (EXACT) {
+            // v_mfma_f32_16x16x4_f32 (bit-identical to an fmaf chain), 16 k-steps of 4 channels; lane (ln, lg) holds
+            // channel 4 ks + lg of pixel ln of its tile
 #pragma unroll 4
             for (int ks = 0; ks < GM_CG / 4; ++ks) {
                 float af[NTR];
@@ -379,22 +377,44 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gweight_kernel(const FT *__rest
             }
             continue;
         }
+        const float *xh = xb, *xl = xb, *yh = yb, *yl = yb;
+        if constexpr (PRESPLIT) {
+            // every element is split ONCE (not once per wavefront that needs it): thread -> (tensor, pixel, 8-channel chunk)
+            for (int e = tid; e < 2 * P * 8; e += GM_THREADS) {
+                const int ten = e >= P * 8, e2 = ten ? e - P * 8 : e, px = e2 >> 3, q = e2 & 7;
+                const float *src = ten ? yb : xb;
+                const f32x4 u = lds_load_x4(src + gtile_f32_idx(px, 8 * q)), v = lds_load_x4(src + gtile_f32_idx(px, 8 * q + 4));
+                const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+                const BfSplit sp = bf16_split8(x);
+                const int off = (px >> 3) * GM_PB + (px & 7) * 32 + ((q ^ (px & 7)) << 2);
+                uint32_t *d = reinterpret_cast<uint32_t *>(img + ten * 2 * TSB) + off;
+                *reinterpret_cast<u32x4 *>(d) = sp.hi;
+                *reinterpret_cast<u32x4 *>(d + TSB) = sp.lo;
+            }
+            barrier_lds_only();
+            xh = img; xl = img + TSB; yh = img + 2 * TSB; yl = img + 3 * TSB;
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {                       // two k-steps of 32 channels
-            BfSplit af[NTR];
+            u32x4 ah[NTR], al[NTR];
 #pragma unroll
-            for (int a = 0; a < NTR; ++a) af[a] = frag(xb, 16 * (wv + GM_WAVES * a) + ln, kk);
+            for (int a = 0; a < NTR; ++a) {
+                ah[a] = frag(xh, 16 * (wv + GM_WAVES * a) + ln, kk);
+                if (!BF) al[a] = frag(xl, 16 * (wv + GM_WAVES * a) + ln, kk);
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (t * 16 < L) {
-                    const BfSplit bf = frag(yb, 16 * t + ln, kk);
+                    const u32x4 bh = frag(yh, 16 * t + ln, kk);
+                    u32x4 bl = bh;
+                    if (!BF) bl = frag(yl, 16 * t + ln, kk);
 #pragma unroll
                     for (int a = 0; a < NTR; ++a)
                         if ((wv + GM_WAVES * a) * 16 < L) {
-                            acc[a][t] = mfma_bf16_16x16x32(af[a].hi, bf.hi, acc[a][t]);
+                            acc[a][t] = mfma_bf16_16x16x32(ah[a], bh, acc[a][t]);
                             if (!BF) {
-                                acc[a][t] = mfma_bf16_16x16x32(af[a].hi, bf.lo, acc[a][t]);
-                                acc[a][t] = mfma_bf16_16x16x32(af[a].lo, bf.hi, acc[a][t]);
+                                acc[a][t] = mfma_bf16_16x16x32(ah[a], bl, acc[a][t]);
+                                acc[a][t] = mfma_bf16_16x16x32(al[a], bh, acc[a][t]);
                             }
                         }
                 }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-kernel durations of one pixel-major bf16 fwd+bwd (tools/pm_bf16_time.py) under rocprofv3; usage: bash tools/pm_prof.sh <tag> [B C H W]
+# per-kernel durations of one pixel-major fwd+bwd (tools/pm_bf16_time.py) under rocprofv3; usage: bash tools/pm_prof.sh <tag> [B C H W [bf16|f32]]
 TAG=${1:-pm}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
