@@ -284,6 +284,54 @@ class PixelMajorBF16Workload:
         self.backward()
 
 
+class PixelMajorF32Workload:
+    """The fp32 core on the pixel-major family with the module's boundary: q | k | v = channel slices of the packed pixel-major
+    projection, x / y / dy NCHW (ccnet_cca_forward_pm_nchw_f32 + ccnet_cca_backward_pm_nchw_f32; the transposition of dy is
+    inside the timed step)."""
+
+    def __init__(self, lib, B, C, H, W, device, seed):
+        self.lib, self.shape = lib, (B, C, H, W)
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        Cq = C // 8
+        self.ct = ct = C + 2 * Cq
+        rnd = lambda *s: torch.randn(*s, generator=g).to(device)              # noqa: E731
+        self.qkv = rnd(B, H, W, ct)
+        self.x, self.dy = rnd(B, C, H, W), rnd(B, C, H, W)
+        self.gamma = torch.full((1,), 0.5, device=device)
+        self.y, self.dqkv = torch.empty_like(self.x), torch.empty_like(self.qkv)
+        self.A = torch.empty(B, H, W, H + W, device=device)
+        self.scratch = torch.empty_like(self.A)
+        self.dgamma = torch.empty(1, device=device)
+        self.fws_bytes = lib.ccnet_cca_pm_nchw_f32_workspace_bytes(B, C, Cq, H, W, 0)
+        self.ws_bytes = lib.ccnet_cca_pm_nchw_f32_workspace_bytes(B, C, Cq, H, W, 1)
+        self.ws = torch.empty(max(self.fws_bytes, self.ws_bytes) // 4 + 64, device=device)
+
+    def stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def forward(self):
+        B, C, H, W = self.shape
+        L, cq, ct, p = self.lib, C // 8, self.ct, self.qkv.data_ptr()
+        bs = H * W * ct
+        L.check(L.ccnet_cca_forward_pm_nchw_f32(p, p + 4 * cq, p + 8 * cq, self.x.data_ptr(), self.gamma.data_ptr(),
+                                                self.y.data_ptr(), self.A.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct, bs, ct,
+                                                self.ws.data_ptr(), self.fws_bytes, self.stream()), "cca_forward_pm_nchw")
+
+    def backward(self):
+        B, C, H, W = self.shape
+        L, cq, ct, p, g = self.lib, C // 8, self.ct, self.qkv.data_ptr(), self.dqkv.data_ptr()
+        bs = H * W * ct
+        L.check(L.ccnet_cca_backward_pm_nchw_f32(self.dy.data_ptr(), p, p + 4 * cq, p + 8 * cq, self.A.data_ptr(),
+                                                 self.gamma.data_ptr(), g, g + 4 * cq, g + 8 * cq, self.dgamma.data_ptr(),
+                                                 self.scratch.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct, bs, ct,
+                                                 bs, ct, bs, ct, bs, ct, self.ws.data_ptr(), self.ws_bytes, self.stream()),
+                "cca_backward_pm_nchw")
+
+    def step(self):
+        self.forward()
+        self.backward()
+
+
 def bf16_config5(lib, device, shape=(16, 512, 129, 129), iters=20):
     """BASELINE.json configs[4] as an extra of the fp32 line: fwd+bwd of the pixel-major bf16 core, per-step statistics."""
     wl = PixelMajorBF16Workload(lib, *shape, device, 4321)
@@ -553,14 +601,24 @@ def rcca_head_ms(device, batches=(1, 2), iters=5):
 
 
 def small_batch_ms(lib, C, H, W, device, batches=(1, 2), iters=30):
-    """The reference trains at 1-2 images per GPU (README.md:97, engine.py:88): core fwd+bwd at those batches."""
+    """CCNet's own recipe runs 1-2 images per GPU (engine.py:88): the core step at those batches on the NCHW strip kernels
+    and on the pixel-major family (module boundary: q | k | v pixel-major, x / y / dy NCHW)."""
     out = {}
-    for b in batches:
-        wl = CoreWorkload(lib, b, C, H, W, device, 99 + b)
-        for _ in range(5):
-            wl.step()
-        torch.cuda.synchronize()
-        out[f"B{b}_ms"] = round(time_region(wl.step, iters), 4)
+    for B in batches:
+        wl = CoreWorkload(lib, B, C, H, W, device, 77 + B)
+        wl.step()
+        out[f"B{B}_ms"] = round(time_region(wl.step, iters), 4)
+        del wl
+    pm = {}
+    for B in tuple(batches) + (8,):
+        wl = PixelMajorF32Workload(lib, B, C, H, W, device, 177 + B)
+        wl.step()
+        pm[f"B{B}_ms"] = round(time_region(wl.step, iters), 4)
+        del wl
+    out["pixel_major_family"] = pm
+    out["what"] = ("fp32 core fwd+bwd; pixel_major_family = ccnet_cca_*_pm_nchw_f32 (one workgroup per strip; q | k | v are "
+                   "slices of the packed pixel-major projection, x / y / dy NCHW, dy transposed inside the step)")
+    torch.cuda.empty_cache()
     return out
 
 

@@ -836,8 +836,9 @@ int check_pm_view(const char *what, long bs, int ps, int C, int H, int W) {
     if ((double)H * W * ps >= 536870912.0) return fail(CCNET_E_BADSHAPE, what);
     return 0;
 }
-// out = FT(alpha * contraction + resid): column strips into the fp32 partial, row strips add it and round once
-template <int P, bool TRANS, typename FT>
+// out = FT(alpha * contraction + resid): column strips into the fp32 partial, row strips add it and round once.
+// NCHW (fp32, TRANS = false): resid / out are NCHW tensors with batch strides rbs / obs (rps / ops unused).
+template <int P, bool TRANS, typename FT, bool NCHW = false>
 int launch_gmap_pm(const float *T, const FT *F, const FT *resid, const float *gamma, FT *out, float *partial, int B, int C,
                    int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
     const long pbs = (long)H * W * C;
@@ -846,7 +847,7 @@ int launch_gmap_pm(const float *T, const FT *F, const FT *resid, const float *ga
                stream, T, F, (const float *)nullptr, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0,
                0L, 0, pbs, C, gc.n_whole, gc.split);
     if (int e = launch_status("gmap_pm(column)")) return e;
-    CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, FT, FT>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS),
+    CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, FT, FT, NCHW>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS),
                stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C, rbs, rps, obs, ops,
                gr.n_whole, gr.split);
     return launch_status("gmap_pm(row)");
@@ -989,6 +990,64 @@ int ccnet_cca_backward_pm_f32(const float *dy, const float *q, const float *k, c
     return cca_backward_pm<float>("cca_backward_pm_f32", dy, q, k, v, A, gamma, dq, dk, dv, dgamma, scratch, B, C, Cq, H, W,
                                   dy_bs, dy_ps, q_bs, q_ps, k_bs, k_ps, v_bs, v_ps, dq_bs, dq_ps, dk_bs, dk_ps, dv_bs, dv_ps,
                                   workspace, workspace_bytes, stream);
+}
+
+/* ---- the same fp32 core with the module's own tensors left NCHW: x, y, dy are (B, C, H, W) fp32, q | k | v (dq | dk | dv)
+ * ---- pixel-major views (the packed projection).  y leaves the final row pass as runs of W floats per channel; dy is
+ * ---- brought pixel-major once (workspace) because it is a contraction operand of the column strips. ---- */
+size_t ccnet_cca_pm_nchw_f32_workspace_bytes(int B, int C, int Cq, int H, int W, int backward) {
+    const size_t base = pm_workspace_bytes(B, C, Cq, H, W, backward);
+    if (!base) return 0;
+    return align256(base) + (backward ? (size_t)B * H * W * C * sizeof(float) : 0);
+}
+
+int ccnet_nchw_to_pm_f32(const float *src, float *dst, int B, int C, int H, int W, long src_bs, long dst_bs, int dst_ps,
+                         ccnet_stream_t stream) {
+    if (int e = check_shape(B, C, H, W)) return e;
+    if (!src || !dst) return fail(CCNET_E_NULLPTR, "nchw_to_pm: null tensor");
+    if (dst_ps < C || dst_ps % 4 || dst_bs % 4 || src_bs < (long)C * H * W || (double)H * W * dst_ps >= 536870912.0)
+        return fail(CCNET_E_BADSHAPE, "nchw_to_pm: strides");
+    const int hw = H * W;
+    CCA_LAUNCH(cca::nchw_to_pm_kernel, dim3((unsigned)(B * ((hw + 63) / 64)), (unsigned)((C + 63) / 64)), dim3(256), stream,
+               src, dst, C, hw, src_bs, dst_bs, dst_ps);
+    return launch_status("nchw_to_pm");
+}
+
+int ccnet_cca_forward_pm_nchw_f32(const float *q, const float *k, const float *v, const float *x, const float *gamma,
+                                  float *y, float *A, int B, int C, int Cq, int H, int W,
+                                  long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
+                                  void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
+    if (int e = require_both_branches("cca_forward_pm_nchw_f32")) return e;
+    if (!q || !k || !v || !x || !gamma || !y || !A) return fail(CCNET_E_NULLPTR, "cca_forward_pm_nchw: null tensor");
+    if (int e = check_pm_problem<float>("cca_forward_pm_nchw: strips <= 100, C % 4 == 0, Cq % 4 == 0", B, C, Cq, H, W)) return e;
+    if (int e = check_pm_view<float>("cca_forward_pm_nchw: q view", q_bs, q_ps, Cq, H, W)) return e;
+    if (int e = check_pm_view<float>("cca_forward_pm_nchw: k view", k_bs, k_ps, Cq, H, W)) return e;
+    if (int e = check_pm_view<float>("cca_forward_pm_nchw: v view", v_bs, v_ps, C, H, W)) return e;
+    if ((double)C * H * W >= 536870912.0) return fail(CCNET_E_BADSHAPE, "cca_forward_pm_nchw: image exceeds 2^29 elements");
+    if (!workspace || workspace_bytes < ccnet_cca_pm_nchw_f32_workspace_bytes(B, C, Cq, H, W, 0))
+        return fail(CCNET_E_WORKSPACE, "cca_forward_pm_nchw: workspace missing or too small");
+    if (int e = gweight_pm<true, float>(q, k, A, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
+    if (int e = softmax_forward(A, A, B, H, W, stream)) return e;
+    const long img = (long)C * H * W;
+    return launch_gmap_pm<100, false, float, true>(A, v, x, gamma, y, (float *)workspace, B, C, H, W, v_bs, v_ps, img, 0, img, 0, stream);
+}
+
+int ccnet_cca_backward_pm_nchw_f32(const float *dy, const float *q, const float *k, const float *v, const float *A,
+                                   const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
+                                   int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps,
+                                   long v_bs, int v_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
+                                   void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
+    if (!dy) return fail(CCNET_E_NULLPTR, "cca_backward_pm_nchw: null tensor");
+    if (int e = check_pm_problem<float>("cca_backward_pm_nchw: strips <= 100, C % 4 == 0, Cq % 4 == 0", B, C, Cq, H, W)) return e;
+    const size_t need = ccnet_cca_pm_nchw_f32_workspace_bytes(B, C, Cq, H, W, 1);
+    if (!workspace || workspace_bytes < need) return fail(CCNET_E_WORKSPACE, "cca_backward_pm_nchw: workspace missing or too small");
+    const size_t base = align256(pm_workspace_bytes(B, C, Cq, H, W, 1));
+    float *dy_pm = reinterpret_cast<float *>(static_cast<char *>(workspace) + base);
+    const long pbs = (long)H * W * C;
+    if (int e = ccnet_nchw_to_pm_f32(dy, dy_pm, B, C, H, W, (long)C * H * W, pbs, C, stream)) return e;
+    return cca_backward_pm<float>("cca_backward_pm_nchw_f32", dy_pm, q, k, v, A, gamma, dq, dk, dv, dgamma, scratch, B, C, Cq, H, W,
+                                  pbs, C, q_bs, q_ps, k_bs, k_ps, v_bs, v_ps, dq_bs, dq_ps, dk_bs, dk_ps, dv_bs, dv_ps,
+                                  workspace, base, stream);
 }
 
 int ccnet_cca_mfma_selftest(float *scratch, ccnet_stream_t stream) {

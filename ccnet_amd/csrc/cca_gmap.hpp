@@ -88,7 +88,10 @@ __device__ __forceinline__ uint32_t lds_load_u16(const float *base, int byte_off
 // null) has the output's type.  4 wavefronts, two workgroups per CU: wavefront w owns the M tiles (16
 // strip positions each) t = w, w + 4, w + 8 of all four 16-channel N tiles, and keeps their attention fragments -- hi and
 // lo bf16 halves, every k-step -- in registers for the whole strip (A-stationary: 96 VGPRs at 132 positions).
-template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT>
+// NCHW (fp32 row strips with an addend only): ``resid`` and ``out`` are NCHW tensors (batch strides rbs / obs in elements):
+// the addend slices are loaded in the accumulator layout, the output image is kept [channel][position] and leaves as runs
+// of W floats per channel -- the module's x and y never exist pixel-major.
+template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT, bool NCHW = false>
 __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__restrict__ T, const FT *__restrict__ F,
                                                               const float *__restrict__ addend,
                                                               const OT *__restrict__ resid,
@@ -99,9 +102,12 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
     constexpr int NT = (P + 15) / 16, TPW = (NT + GS_WAVES - 1) / GS_WAVES, NKS = P / 32;
     constexpr int FSZ = GTile<FT>::size(P), OSZ = GTile<float>::size(P), NPF = GTile<FT>::pieces(P);
     constexpr int SPX = OBF ? 8 : 4;                                  // pixels per store instruction
-    constexpr int NSI = ((P + SPX - 1) / SPX + GS_WAVES - 1) / GS_WAVES;     // store instructions per wave and group (max)
-    static_assert(P % 4 == 0 && (2 * FSZ + OSZ) * 4 * 2 <= 163840, "gmap: two workgroups per CU");
-    __shared__ __attribute__((aligned(16))) float lds[2 * FSZ + OSZ];
+    constexpr int NSI = NCHW ? 1 : ((P + SPX - 1) / SPX + GS_WAVES - 1) / GS_WAVES;   // store instructions per wave and group (max)
+    constexpr int PO = P + 4, OIMG = NCHW ? GM_CG * PO : OSZ;         // NCHW: [channel][position] image, pitch PO
+    constexpr int NSX = GM_CG / 2 / GS_WAVES;                         // NCHW: store instructions per wave and group (2 channels each)
+    static_assert(!NCHW || (ROW && ADD && !OBF && !TRANS), "gmap: the NCHW epilogue belongs to the final fp32 row pass");
+    static_assert(P % 4 == 0 && (2 * FSZ + OIMG) * 4 * 2 <= 163840, "gmap: two workgroups per CU");
+    __shared__ __attribute__((aligned(16))) float lds[2 * FSZ + OIMG];
     CCA_LDS_REGISTER(lds);
     float *const FB = lds, *const oimg = lds + 2 * FSZ;
     const int HW = H * W, S = H + W;
@@ -124,9 +130,10 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
 
     const FBuf Tb = make_fbuf(T + (size_t)b * HW * S, (size_t)HW * S * sizeof(float));
     const FBuf Fb = make_fbuf(reinterpret_cast<const float *>(F + (size_t)b * fbs), ((size_t)(HW - 1) * fps + C) * sizeof(FT));
-    const FBuf Ob = make_fbuf(reinterpret_cast<const float *>(out + (size_t)b * obs), ((size_t)(HW - 1) * ops + C) * sizeof(OT));
+    const FBuf Ob = make_fbuf(reinterpret_cast<const float *>(out + (size_t)b * obs),
+                              NCHW ? (size_t)C * HW * sizeof(OT) : ((size_t)(HW - 1) * ops + C) * sizeof(OT));
     const FBuf Rb = make_fbuf(reinterpret_cast<const float *>(resid ? resid + (size_t)b * rbs : out),
-                              resid ? ((size_t)(HW - 1) * rps + C) * sizeof(OT) : 4);
+                              !resid ? 4 : NCHW ? (size_t)C * HW * sizeof(OT) : ((size_t)(HW - 1) * rps + C) * sizeof(OT));
     const FBuf Db = make_fbuf(ADD ? addend + (size_t)b * abs_ : T, ADD ? ((size_t)(HW - 1) * aps + C) * sizeof(float) : 4);
     const float alpha = gamma ? gamma[0] : 1.f;
     const BandK kp = band_ksteps(L);
@@ -183,14 +190,31 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
         const float *img = FB + ((cg - cg0) & 1) * FSZ;
         // tile cg landed, every wave is done with group cg - 1; the stores of group cg - 1 (the most recent vector
         // memory operations of this wave) may stay in flight
-        if (cg == cg0) barrier_dma_keep<0>();
-        else           barrier_dma_keep_n(nstore);
+        if (cg == cg0 || NCHW) barrier_dma_keep<0>();        // (NCHW: the store count of a group is not a constant)
+        else                   barrier_dma_keep_n(nstore);
         if (cg + 1 < cg1) issue_feat(cg + 1);
         // the fp32 addend / bf16 residual slices this lane will store over: in registers by the time the tiles are done
         f32x4 add0[NSI], add1[NSI];
         u32x4 res[NSI];
+        f32x4 addp[NCHW ? TPW : 1][4], resx[NCHW ? NSX : 1];
+        if constexpr (NCHW) {
 #pragma unroll
-        for (int k = 0; k < NSI; ++k) {
+            for (int a = 0; a < TPW; ++a) {                 // addend in the accumulator layout: 4 channels of position i
+                const int i = 16 * (wv + GS_WAVES * a) + ln;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int c = cg * GM_CG + 16 * nt + 4 * lg;
+                    addp[a][nt] = fbuf_load_x4(Db, (i < L && c < C) ? ((pix0 + i) * aps + c) * 4 : kOobOffset, 0);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NSX; ++k) {                 // residual in the store layout: 4 positions of channel c
+                const int c = cg * GM_CG + 2 * (wv + GS_WAVES * k) + (lane >> 5), w4 = lane & 31;
+                resx[k] = fbuf_load_x4(Rb, (resid && 4 * w4 < L && c < C) ? (c * HW + pix0 + 4 * w4) * 4 : kOobOffset, 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < (NCHW ? 0 : NSI); ++k) {
             const int i = st_pos(k), c = cg * GM_CG + st_c;
             const bool ok = i < L && c < C;
             const int pix = pix0 + i * pstep;
@@ -255,11 +279,37 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
             const int i = 16 * (wv + GS_WAVES * a) + ln;
             if (i < L) {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    lds_store_x4(oimg + (i >> 2) * GM_PP + (i & 3) * GM_CG + 16 * nt + 4 * lg, alpha * acc[a][nt]);
+                for (int nt = 0; nt < 4; ++nt) {
+                    if constexpr (NCHW) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            CCA_LDS_ST(oimg + (16 * nt + 4 * lg + q) * PO + i, alpha * acc[a][nt][q] + addp[a][nt][q]);
+                    } else {
+                        lds_store_x4(oimg + (i >> 2) * GM_PP + (i & 3) * GM_CG + 16 * nt + 4 * lg, alpha * acc[a][nt]);
+                    }
+                }
             }
         }
         barrier_lds_only();
+        if constexpr (NCHW) {
+            // runs of W floats per channel: 2 channels x 32 lanes (4 positions each) per instruction
+#pragma unroll
+            for (int k = 0; k < NSX; ++k) {
+                const int ch = 2 * (wv + GS_WAVES * k) + (lane >> 5), c = cg * GM_CG + ch, w4 = lane & 31;
+                if (4 * w4 < L && c < C) {
+                    const f32x4 u = lds_load_x4(oimg + ch * PO + 4 * w4) + resx[k];
+                    const int off = (c * HW + pix0 + 4 * w4) * 4;
+                    if (4 * w4 + 3 < L) {
+                        fbuf_store_x4(Ob, u, off, 0);
+                    } else {                                  // the last, partial granule must not reach into the next row
+#pragma unroll
+                        for (int e = 0; e < 3; ++e)
+                            if (4 * w4 + e < L) fbuf_store(Ob, u[e], off + 4 * e, 0);
+                    }
+                }
+            }
+            continue;
+        }
         // whole pixel rows leave: 256 (fp32) / 128 (bf16) bytes per pixel, + addend (+ residual), rounded once
 #pragma unroll
         for (int k = 0; k < NSI; ++k) {
@@ -287,6 +337,35 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
                 }
             }
         }
+    }
+}
+
+// NCHW fp32 -> pixel-major fp32 (the gradient dy of an NCHW module output, ca_map_backward's features): 64 pixels x 64
+// channels per workgroup through a padded LDS tile; reads runs of 64 pixels per channel, writes 256-byte pixel rows.
+__global__ __launch_bounds__(256) void nchw_to_pm_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int HW,
+                                                         long sbs, long dbs, int dps) {
+    __shared__ float tile[64 * 65];
+    const int ntp = (HW + 63) / 64;
+    const int b = blockIdx.x / ntp, p0 = (blockIdx.x - b * ntp) * 64, c0 = blockIdx.y * 64;
+    const FBuf Sb = make_fbuf(src + (size_t)b * sbs, (size_t)C * HW * sizeof(float));
+    const FBuf Db = make_fbuf(dst + (size_t)b * dbs, ((size_t)(HW - 1) * dps + C) * sizeof(float));
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int ch = (tid >> 4) + 16 * it, p4 = 4 * (tid & 15);
+        const bool ok = c0 + ch < C && p0 + p4 < HW;
+        const f32x4 v = fbuf_load_x4(Sb, ok ? ((c0 + ch) * HW + p0 + p4) * 4 : kOobOffset, 0);   // (dwords beyond the tensor read 0)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[ch * 65 + p4 + e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int px = (tid >> 4) + 16 * it, c4 = 4 * (tid & 15);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tile[(c4 + e) * 65 + px];
+        if (p0 + px < HW && c0 + c4 < C) fbuf_store_x4(Db, v, ((p0 + px) * dps + c0 + c4) * 4, 0);
     }
 }
 

@@ -552,6 +552,65 @@ class CrissCrossModuleFunction(torch.autograd.Function):
                 dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma), None)
 
 
+class CrissCrossPMModuleFunction(torch.autograd.Function):
+    """The whole module as ONE autograd node on the pixel-major family with the module's own tensors left NCHW (fp32, no
+    autocast): the stacked projection is the GEMM ``x^T W^T`` (x read through its (B, C, HW) view as the transposed operand:
+    no copy) whose (B, HW, 2Cq + C) output IS the packed pixel-major q | k | v; the core (``ccnet_cca_*_pm_nchw_f32``) reads x,
+    writes y and reads dy as NCHW tensors; ``dx = dy + W^T dqkv^T`` is one GEMM with beta = 1 writing NCHW.  One workgroup per
+    strip: the path for 1-2 images per GPU, and since round 2 no slower than the NCHW strips at 8."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma):
+        x, gamma = _dev_f32("x", x), _dev_f32("gamma", gamma)
+        B, C, H, W = x.shape
+        cq, hw = wq.shape[0], H * W
+        ct = 2 * cq + C
+        w = torch.cat([wq.reshape(cq, C), wk.reshape(cq, C), wv.reshape(C, C)], 0)          # (2Cq + C, C)
+        b = torch.cat([bq, bk, bv], 0)
+        xm = x.view(B, C, hw)
+        qkv = torch.baddbmm(b.view(1, 1, -1), xm.transpose(1, 2), w.t().unsqueeze(0).expand(B, -1, -1))   # (B, HW, 2Cq + C)
+        lib = _lib.get_lib()
+        y = torch.empty_like(x)
+        A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
+        p, bs = qkv.data_ptr(), hw * ct
+        with torch.cuda.device(x.device):
+            _ws, wsp, wsn = _workspace(lib.ccnet_cca_pm_nchw_f32_workspace_bytes(B, C, cq, H, W, 0), x.device)
+            lib.check(lib.ccnet_cca_forward_pm_nchw_f32(p, p + 4 * cq, p + 8 * cq, x.data_ptr(), gamma.data_ptr(),
+                                                        y.data_ptr(), A.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct, bs, ct,
+                                                        wsp, wsn, _stream()), "cca_forward_pm_nchw")
+        ctx.save_for_backward(x, w, qkv, A, gamma)
+        ctx.cq = cq
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        cq = ctx.cq
+        x, w, qkv, A, gamma = ctx.saved_tensors
+        dy = _dev_f32("grad_output", dy)
+        B, C, H, W = x.shape
+        hw, ct = H * W, 2 * cq + C
+        lib = _lib.get_lib()
+        dqkv = torch.empty_like(qkv)
+        dgamma = torch.empty_like(gamma)
+        scratch = torch.empty_like(A)
+        p, g, bs = qkv.data_ptr(), dqkv.data_ptr(), hw * ct
+        with torch.cuda.device(dy.device):
+            _ws, wsp, wsn = _workspace(lib.ccnet_cca_pm_nchw_f32_workspace_bytes(B, C, cq, H, W, 1), dy.device)
+            lib.check(lib.ccnet_cca_backward_pm_nchw_f32(dy.data_ptr(), p, p + 4 * cq, p + 8 * cq, A.data_ptr(),
+                                                         gamma.data_ptr(), g, g + 4 * cq, g + 8 * cq, dgamma.data_ptr(),
+                                                         scratch.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct, bs, ct,
+                                                         bs, ct, bs, ct, bs, ct, wsp, wsn, _stream()), "cca_backward_pm_nchw")
+        xm = x.view(B, C, hw)
+        dqt = dqkv.transpose(1, 2)                                                            # (B, 2Cq + C, HW) view
+        dx = torch.baddbmm(dy.view(B, C, hw), w.t().unsqueeze(0).expand(B, -1, -1), dqt)      # dy + W^T dqkv^T  (NCHW)
+        dw = torch.bmm(dqt, xm.transpose(1, 2)).sum(0)                                        # (2Cq + C, C)
+        db = dqkv.sum(dim=(0, 1))
+        dwq, dwk, dwv = dw[:cq], dw[cq:2 * cq], dw[2 * cq:]
+        return (dx.view(B, C, H, W), dwq.reshape(cq, C, 1, 1), db[:cq], dwk.reshape(cq, C, 1, 1), db[cq:2 * cq],
+                dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma))
+
+
 def criss_cross_attention(q, k, v, x, gamma, recompute_attention=False):
     """Functional form of the fused core (``recompute_attention``: rebuild A in backward instead of keeping it)."""
     return CrissCrossFunction.apply(q, k, v, x, gamma, recompute_attention)
@@ -588,12 +647,13 @@ class CrissCrossAttention(nn.Module):
     recompute_attention = False
 
     #: fp32 channels_last inputs run on the pixel-major family (one workgroup per strip; x as (B, H, W, C) is then a free
-    #: view and nothing is copied).  Measured on MI355X at (B,512,97,97), core fwd+bwd: B = 1 0.166 vs 0.265 ms on the NCHW
-    #: strips, B = 2 0.249 vs 0.358 ms, B = 8 0.88 vs 0.85 ms; module fwd+bwd B = 1 0.445 vs 0.533 ms, B = 2 0.683 vs 0.941 ms.
+    #: view and nothing is copied).
     pixel_major_for_channels_last = True
-    #: NCHW-contiguous fp32 inputs with at most this many images take the same route through one transposing copy each way
-    #: (0 = never: the copies cost what the kernels gain -- module fwd+bwd B = 1 0.579 vs 0.533 ms)
-    small_batch_pixel_major = 0
+    #: NCHW fp32 inputs with at most this many images run on the pixel-major family through ``CrissCrossPMModuleFunction``
+    #: (q | k | v pixel-major out of the projection GEMM, x / y / dy left NCHW).  Measured on MI355X at (B,512,97,97), core
+    #: fwd+bwd: B = 1 0.16 vs 0.265 ms on the NCHW strips, B = 2 0.24 vs 0.358 ms, B = 8 0.82 vs 0.85 ms (all-pixel-major
+    #: boundary); module fwd+bwd B = 1 0.505 vs 0.548, B = 2 0.718 vs 0.806, B = 4 1.229 vs 1.316, B = 8 2.31 vs 2.30 ms.  0 = never.
+    pixel_major_max_batch = 4
 
     #: bf16 inputs: strips <= 132 (C, C/8 divisible by 8) run on the pixel-major bf16 MFMA kernels; geometries outside
     #: every strip kernel (strips longer than 320) use the any-shape bf16-I/O entry points; the rest is computed
@@ -626,19 +686,21 @@ class CrissCrossAttention(nn.Module):
             return CrissCrossBF16Function.apply(q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16),
                                                 x, self.gamma.float())
         if (x.dtype == torch.float32 and not torch.is_autocast_enabled() and self._fusable(x)
-                and (x.shape[0] <= self.small_batch_pixel_major
-                     or (self.pixel_major_for_channels_last and x.is_contiguous(memory_format=torch.channels_last)
-                         and not x.is_contiguous()))
                 and pm_covers(torch.float32, x.shape[0], x.shape[1], self.query_conv.out_channels, x.shape[2], x.shape[3])):
-            # 1-2 images per GPU (CCNet's own recipe, engine.py:88): the NCHW strip kernels launch 26*B workgroups per
-            # branch, the pixel-major family one workgroup per strip (194*B at 97x97).  x goes pixel-major once (a free view
-            # of a channels_last tensor), the projection is one GEMM x^T W^T, y returns in x's memory format.
-            cq = self.query_conv.out_channels
-            xp = x.permute(0, 2, 3, 1)
-            w = torch.cat([self.query_conv.weight, self.key_conv.weight, self.value_conv.weight], 0).flatten(1)
-            b = torch.cat([self.query_conv.bias, self.key_conv.bias, self.value_conv.bias], 0)
-            y = CrissCrossPMFunction.apply(torch.nn.functional.linear(xp, w, b), xp, self.gamma, cq).permute(0, 3, 1, 2)
-            return y if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() else y.contiguous()
+            cl = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+            if cl and self.pixel_major_for_channels_last:
+                # channels_last in, channels_last out: x as (B, H, W, C) is a free view, the projection one GEMM x^T W^T
+                cq = self.query_conv.out_channels
+                xp = x.permute(0, 2, 3, 1)
+                w = torch.cat([self.query_conv.weight, self.key_conv.weight, self.value_conv.weight], 0).flatten(1)
+                b = torch.cat([self.query_conv.bias, self.key_conv.bias, self.value_conv.bias], 0)
+                return CrissCrossPMFunction.apply(torch.nn.functional.linear(xp, w, b), xp, self.gamma, cq).permute(0, 3, 1, 2)
+            if (not cl and self.fuse_module_backward and not self.recompute_attention
+                    and x.shape[0] <= self.pixel_major_max_batch):
+                # NCHW in, NCHW out, one autograd node, one workgroup per strip (CCNet's own recipe is 1 image per GPU)
+                return CrissCrossPMModuleFunction.apply(x, self.query_conv.weight, self.query_conv.bias,
+                                                        self.key_conv.weight, self.key_conv.bias,
+                                                        self.value_conv.weight, self.value_conv.bias, self.gamma)
         if (self.fuse_projections and self.fuse_module_backward and self._fusable(x) and x.dtype == torch.float32
                 and not torch.is_autocast_enabled()):
             return CrissCrossModuleFunction.apply(x, self.query_conv.weight, self.query_conv.bias,

@@ -240,6 +240,23 @@ int ccnet_cca_backward_pm_f32(const float *dy, const float *q, const float *k, c
                               long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
                               void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
 
+/* ... and with the module's own tensors left NCHW: x, y, dy are (B, C, H, W) fp32 contiguous, q | k | v and dq | dk | dv stay
+ * pixel-major views (the packed x^T W^T projection and its gradient).  y is written by the final row pass as runs of W
+ * floats per channel; dy -- a contraction operand of the column strips -- is brought pixel-major once, inside the
+ * workspace (ccnet_nchw_to_pm_f32 is that transposition on its own).  Nothing of the module is copied on the host side. */
+size_t ccnet_cca_pm_nchw_f32_workspace_bytes(int B, int C, int Cq, int H, int W, int backward);
+int ccnet_nchw_to_pm_f32(const float *src, float *dst, int B, int C, int H, int W, long src_bs, long dst_bs, int dst_ps,
+                         ccnet_stream_t stream);
+int ccnet_cca_forward_pm_nchw_f32(const float *q, const float *k, const float *v, const float *x, const float *gamma,
+                                  float *y, float *A, int B, int C, int Cq, int H, int W,
+                                  long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
+                                  void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
+int ccnet_cca_backward_pm_nchw_f32(const float *dy, const float *q, const float *k, const float *v, const float *A,
+                                   const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
+                                   int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps,
+                                   long v_bs, int v_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
+                                   void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
+
 /* Which kernel family serves this shape under the current impl setting: 1 = stationary MFMA strip kernels
  * (max(H,W) <= 100), 2 = windowed MFMA strip kernels (101 .. 320), 0 = any-shape kernels. */
 int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W);

@@ -250,6 +250,34 @@ class EmuOps:
                                                            bs, ct, bs, ct, bs, ct, _p(ws), nbytes, None))
         return dqkv, dgamma
 
+    def cca_forward_pm_nchw(self, qkv, x, gamma, cq):
+        """qkv: float32 (B, H, W, 2*cq + C) packed pixel-major projection; x: float32 NCHW; returns (y NCHW, A)."""
+        B, H, W, ct = qkv.shape
+        C = ct - 2 * cq
+        y = np.full((B, C, H, W), np.nan, np.float32)
+        A = np.full((B, H, W, H + W), np.nan, np.float32)
+        nbytes = self.lib.ccnet_cca_pm_nchw_f32_workspace_bytes(B, C, cq, H, W, 0)
+        ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
+        base, bs = qkv.ctypes.data, H * W * ct
+        self.lib.check(self.lib.ccnet_cca_forward_pm_nchw_f32(base, base + 4 * cq, base + 8 * cq, _p(x), _p(gamma), _p(y), _p(A),
+                                                              B, C, cq, H, W, bs, ct, bs, ct, bs, ct, _p(ws), nbytes, None))
+        return y, A
+
+    def cca_backward_pm_nchw(self, dy, qkv, A, gamma, cq):
+        B, H, W, ct = qkv.shape
+        C = ct - 2 * cq
+        dqkv = np.full_like(qkv, np.nan)
+        dgamma = np.full(1, np.nan, np.float32)
+        scratch = np.full_like(A, np.nan)
+        nbytes = self.lib.ccnet_cca_pm_nchw_f32_workspace_bytes(B, C, cq, H, W, 1)
+        ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
+        base, g, bs = qkv.ctypes.data, dqkv.ctypes.data, H * W * ct
+        self.lib.check(self.lib.ccnet_cca_backward_pm_nchw_f32(_p(dy), base, base + 4 * cq, base + 8 * cq, _p(A), _p(gamma),
+                                                               g, g + 4 * cq, g + 8 * cq, _p(dgamma), _p(scratch),
+                                                               B, C, cq, H, W, bs, ct, bs, ct, bs, ct, bs, ct, bs, ct, bs, ct,
+                                                               _p(ws), nbytes, None))
+        return dqkv, dgamma
+
     def mfma_selftest(self):
         scratch = np.zeros(16, np.float32)
         return self.lib.ccnet_cca_mfma_selftest(_p(scratch), None)

@@ -606,3 +606,25 @@ def test_pixel_major_fp32_path_matches_oracle(ops, shape):
     for name, got in (("dq", dqkv[..., :cq]), ("dk", dqkv[..., cq:2 * cq]), ("dv", dqkv[..., 2 * cq:])):
         assert maxerr(nchw(got), go[name].numpy()) < 5e-4 * max(1.0, float(go[name].abs().max())), name
     assert abs(float(dg[0]) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 96, 17, 20), (1, 64, 9, 1), (1, 160, 33, 18), (1, 32, 2, 99), (1, 64, 100, 3),
+                                   (1, 64, 3, 97)])
+def test_pixel_major_fp32_core_with_nchw_module_tensors(ops, shape):
+    """ccnet_cca_forward_pm_nchw_f32 / ccnet_cca_backward_pm_nchw_f32: q | k | v pixel-major, the module's x, y, dy NCHW (the final
+    row pass stores runs of W floats per channel -- also when W is not a multiple of 4 --, dy is transposed into the workspace).
+    Must equal the all-pixel-major entry points bit for bit, and the oracle at the fp32 bar."""
+    B, C, H, W = shape
+    cq = C // 8
+    c = rand_case(*shape, seed=49)
+    qkv = np.ascontiguousarray(np.concatenate([_pm(c["q"]), _pm(c["k"]), _pm(c["v"])], axis=3))
+    y, A = ops.cca_forward_pm_nchw(qkv, c["x"], c["gamma"], cq)
+    y2, A2 = ops.cca_forward_pm_bf16(qkv, _pm(c["x"]), c["gamma"], cq)
+    assert np.array_equal(A, A2)
+    nchw = lambda a: np.transpose(a, (0, 3, 1, 2))                                 # noqa: E731
+    assert maxerr(y, nchw(y2)) < 1e-6                 # (the addend is added in a different association)
+    yo, Ao = O.cca_core_forward(T(c["q"]), T(c["k"]), T(c["v"]), T(c["x"]), T(c["gamma"]))
+    assert maxerr(y, yo.numpy()) < 2e-4 * max(1.0, float(yo.abs().max()))
+    dqkv, dg = ops.cca_backward_pm_nchw(c["dy"], qkv, A, c["gamma"], cq)
+    dqkv2, dg2 = ops.cca_backward_pm_bf16(_pm(c["dy"]), qkv, A, c["gamma"], cq)
+    assert np.array_equal(dqkv, dqkv2) and np.array_equal(dg, dg2)

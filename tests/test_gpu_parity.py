@@ -274,6 +274,7 @@ def test_fused_projection_matches_three_separate_convolutions(lib, dev, shape):
     B, C, H, W = shape
     torch.manual_seed(5)
     m = CrissCrossAttention(C).to(dev)
+    m.pixel_major_max_batch = 0              # this test is about the NCHW strip family (the pixel-major node has its own)
     with torch.no_grad():
         m.gamma.fill_(0.7)
     assert m.fuse_projections and m._fusable()
@@ -475,6 +476,42 @@ def test_pixel_major_fp32_kernels_match_oracle(lib, dev, shape):
     assert abs(float(gamma.grad) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 20, 24), (2, 96, 33, 18), (1, 512, 97, 97)])
+def test_pixel_major_fp32_module_node_matches_the_strip_node_and_the_oracle(lib, dev, shape):
+    """CrissCrossPMModuleFunction (projection GEMM emitting the packed pixel-major q | k | v, core with NCHW x / y / dy, one
+    autograd node) is what the module runs for small fp32 batches: same y, dx and parameter gradients as the NCHW-strip node
+    (tolerance: the two families' own arithmetic), and y against the oracle at the north_star bar."""
+    from ccnet_amd import CrissCrossAttention
+    B, C, H, W = shape
+    torch.manual_seed(5)
+    ms = CrissCrossAttention(C).to(dev)
+    with torch.no_grad():
+        ms.gamma.fill_(0.5)
+        for c in (ms.query_conv, ms.key_conv):
+            c.weight.mul_(0.5)
+    mp = CrissCrossAttention(C).to(dev)
+    mp.load_state_dict(ms.state_dict())
+    ms.pixel_major_max_batch, mp.pixel_major_max_batch = 0, 1 << 30
+    x = torch.randn(B, C, H, W, device=dev)
+    dy = torch.randn(B, C, H, W, device=dev)
+    outs = []
+    for m in (ms, mp):
+        xi = x.clone().requires_grad_(True)
+        y = m(xi)
+        y.backward(dy)
+        outs.append((y.detach(), xi.grad, {n: p.grad for n, p in m.named_parameters()}))
+    assert outs[1][0].is_contiguous() and err(outs[0][0], outs[1][0]) < 2e-4
+    assert err(outs[0][1], outs[1][1]) < 5e-4 * max(1.0, float(outs[0][1].abs().max()))
+    for n, g in outs[0][2].items():
+        ref = float(g.abs().max())
+        assert err(g, outs[1][2][n]) < 2e-3 * max(1.0, ref), n
+    with torch.no_grad():
+        f = lambda t: t.detach().float().cpu()                              # noqa: E731
+        qo, ko, vo = (f(c(x)) for c in (ms.query_conv, ms.key_conv, ms.value_conv))
+    yo, _ = O.cca_core_forward(qo, ko, vo, f(x), torch.tensor([0.5]))
+    assert err(outs[1][0], yo) < TOL
+
+
 def test_pixel_major_bf16_module_route_and_full_size(lib, dev):
     """The module takes bf16 activations through the pixel-major kernels (channels_last in, channels_last out), and at
     BASELINE configs[4]'s full size (16,512,129,129) the path agrees with the fp32 strip kernels on the same bf16-rounded
@@ -672,6 +709,7 @@ def test_recompute_attention_matches_saved_attention_and_keeps_less(lib, dev):
             m = CrissCrossAttention(C).to(dev)
             m.fuse_module_backward = fused
             m.recompute_attention = rec
+            m.pixel_major_max_batch = 0           # (recompute is a feature of the NCHW strip nodes; keep both runs on them)
             with torch.no_grad():
                 m.gamma.fill_(0.5)
             xd = x.clone().requires_grad_(True)

@@ -1,4 +1,5 @@
-"""module fwd+bwd (projections + core + autograd) at small batches: NCHW strip route vs pixel-major route, NCHW and channels_last inputs"""
+"""module fwd+bwd (projections + core + autograd) at several batch sizes: NCHW strip family vs pixel-major family (one autograd
+node each, NCHW fp32 tensors), and the pixel-major family on channels_last tensors"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,11 +7,12 @@ import bench
 from ccnet_amd import CrissCrossAttention
 dev = torch.device("cuda:0")
 C, H, W = 512, 97, 97
-for B in (1, 2, 3, 4, 8):
-    row = []
-    for pm, cl in ((0, False), (B, False), (B, True)):
+for B in (1, 2, 4, 8):
+    row, ys = [], []
+    for maxb, cl in ((0, False), (1 << 30, False), (1 << 30, True)):
+        torch.manual_seed(0)
         m = CrissCrossAttention(C).to(dev)
-        m.small_batch_pixel_major = pm
+        m.pixel_major_max_batch = maxb
         with torch.no_grad():
             m.gamma.fill_(0.5)
         x = torch.randn(B, C, H, W, device=dev)
@@ -20,8 +22,11 @@ for B in (1, 2, 3, 4, 8):
         x.requires_grad_(True)
         def one():
             m.zero_grad(set_to_none=True); x.grad = None
-            m(x).backward(dy)
-        for _ in range(3): one()
+            y = m(x); y.backward(dy); return y
+        for _ in range(3): y = one()
         torch.cuda.synchronize()
+        ys.append((y.detach().clone(), x.grad.clone(), m.value_conv.weight.grad.clone()))
         row.append(bench.time_region(one, 20))
-    print(f"B={B}: module fwd+bwd  NCHW-strip route {row[0]:.3f} ms | pixel-major route, NCHW x {row[1]:.3f} ms | pixel-major route, channels_last x {row[2]:.3f} ms", flush=True)
+    d = [float((a - b).abs().max()) for a, b in zip(ys[0], ys[1])]
+    print(f"B={B}: module fwd+bwd  NCHW-strip family {row[0]:.3f} ms | pixel-major family, NCHW tensors {row[1]:.3f} ms | pixel-major "
+          f"family, channels_last tensors {row[2]:.3f} ms   (max |diff| strip vs pixel-major: y {d[0]:.1e} dx {d[1]:.1e} dWv {d[2]:.1e})", flush=True)
