@@ -241,17 +241,12 @@ __device__ __forceinline__ void strip_dma_channel(const FBuf &src, float *dst, i
 // counted barrier with a run-time (wave-uniform) count
 __device__ __forceinline__ void barrier_dma_keep_n(int n) {
     switch (n) {
-        case 0: barrier_dma_keep<0>(); break;
-        case 1: barrier_dma_keep<1>(); break;
-        case 2: barrier_dma_keep<2>(); break;
-        case 3: barrier_dma_keep<3>(); break;
-        case 4: barrier_dma_keep<4>(); break;
-        case 5: barrier_dma_keep<5>(); break;
-        case 6: barrier_dma_keep<6>(); break;
-        case 7: barrier_dma_keep<7>(); break;
-        case 8: barrier_dma_keep<8>(); break;
-        case 9: barrier_dma_keep<9>(); break;
-        case 10: barrier_dma_keep<10>(); break;
+#define CCA_KEEP(N_) case N_: barrier_dma_keep<N_>(); break;
+        CCA_KEEP(0) CCA_KEEP(1) CCA_KEEP(2) CCA_KEEP(3) CCA_KEEP(4) CCA_KEEP(5) CCA_KEEP(6) CCA_KEEP(7) CCA_KEEP(8) CCA_KEEP(9)
+        CCA_KEEP(10) CCA_KEEP(11) CCA_KEEP(12) CCA_KEEP(13) CCA_KEEP(14) CCA_KEEP(15) CCA_KEEP(16) CCA_KEEP(17) CCA_KEEP(18)
+        CCA_KEEP(19) CCA_KEEP(20) CCA_KEEP(21) CCA_KEEP(22) CCA_KEEP(23) CCA_KEEP(24) CCA_KEEP(25) CCA_KEEP(26) CCA_KEEP(27)
+        CCA_KEEP(28) CCA_KEEP(29) CCA_KEEP(30) CCA_KEEP(31) CCA_KEEP(32)
+#undef CCA_KEEP
         default: barrier_dma_keep<0>(); break;
     }
 }

@@ -88,6 +88,16 @@ __device__ __forceinline__ uint32_t lds_load_u16(const float *base, int byte_off
 // null) has the output's type.  4 wavefronts, two workgroups per CU: wavefront w owns the M tiles (16
 // strip positions each) t = w, w + 4, w + 8 of all four 16-channel N tiles, and keeps their attention fragments -- hi and
 // lo bf16 halves, every k-step -- in registers for the whole strip (A-stationary: 96 VGPRs at 132 positions).
+// [channel][position] output image of the NCHW epilogue: pitch P + 4; the 4-position granule g of channel ch sits at granule
+// g ^ (((ch >> 2) & 1) << 2) (whole groups of 8 granules only): the 4 lane groups of an accumulator write (channels 4 apart)
+// then meet two bank halves instead of one
+template <int P>
+__device__ __forceinline__ int oimg_nchw_idx(int ch, int i) {
+    int g = i >> 2;
+    if (g < (P + 4) / 32 * 8) g ^= ((ch >> 2) & 1) << 2;
+    return ch * (P + 4) + 4 * g + (i & 3);
+}
+
 // NCHW (fp32 row strips with an addend only): ``resid`` and ``out`` are NCHW tensors (batch strides rbs / obs in elements):
 // the addend slices are loaded in the accumulator layout, the output image is kept [channel][position] and leaves as runs
 // of W floats per channel -- the module's x and y never exist pixel-major.
@@ -185,13 +195,14 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
     const int nstore = (nsi_total - wv + GS_WAVES - 1) / GS_WAVES;          // store instructions this wave issues per group
     auto st_pos = [&](int k) { return SPX * (wv + GS_WAVES * k) + (OBF ? lane >> 3 : lane >> 4); };
     const int st_c = OBF ? 8 * (lane & 7) : 4 * (lane & 15);
+    int nstore_nchw = 0;
 
     for (int cg = cg0; cg < cg1; ++cg) {
         const float *img = FB + ((cg - cg0) & 1) * FSZ;
         // tile cg landed, every wave is done with group cg - 1; the stores of group cg - 1 (the most recent vector
         // memory operations of this wave) may stay in flight
-        if (cg == cg0 || NCHW) barrier_dma_keep<0>();        // (NCHW: the store count of a group is not a constant)
-        else                   barrier_dma_keep_n(nstore);
+        if (cg == cg0) barrier_dma_keep<0>();
+        else           barrier_dma_keep_n(NCHW ? nstore_nchw : nstore);
         if (cg + 1 < cg1) issue_feat(cg + 1);
         // the fp32 addend / bf16 residual slices this lane will store over: in registers by the time the tiles are done
         f32x4 add0[NSI], add1[NSI];
@@ -210,7 +221,8 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
 #pragma unroll
             for (int k = 0; k < NSX; ++k) {                 // residual in the store layout: 4 positions of channel c
                 const int c = cg * GM_CG + 2 * (wv + GS_WAVES * k) + (lane >> 5), w4 = lane & 31;
-                resx[k] = fbuf_load_x4(Rb, (resid && 4 * w4 < L && c < C) ? (c * HW + pix0 + 4 * w4) * 4 : kOobOffset, 0);
+                const int w0 = (4 * w4 + 3 < L || L < 4) ? 4 * w4 : L - 4;      // the last granule is shifted back to end at L
+                resx[k] = fbuf_load_x4(Rb, (resid && 4 * w4 < L && c < C) ? (c * HW + pix0 + w0) * 4 : kOobOffset, 0);
             }
         }
 #pragma unroll
@@ -283,7 +295,7 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
                     if constexpr (NCHW) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            CCA_LDS_ST(oimg + (16 * nt + 4 * lg + q) * PO + i, alpha * acc[a][nt][q] + addp[a][nt][q]);
+                            CCA_LDS_ST(oimg + oimg_nchw_idx<P>(16 * nt + 4 * lg + q, i), alpha * acc[a][nt][q] + addp[a][nt][q]);
                     } else {
                         lds_store_x4(oimg + (i >> 2) * GM_PP + (i & 3) * GM_CG + 16 * nt + 4 * lg, alpha * acc[a][nt]);
                     }
@@ -292,19 +304,42 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
         }
         barrier_lds_only();
         if constexpr (NCHW) {
-            // runs of W floats per channel: 2 channels x 32 lanes (4 positions each) per instruction
+            // runs of W floats per channel: 2 channels x 32 lanes (4 positions each) per instruction.  Store instructions
+            // this wave issues in this group (for the next group's counted barrier): one 16-byte store per valid channel
+            // pair (rows shorter than 4: L single stores)
+            {
+                const int crem = C - cg * GM_CG, first = 2 * wv;
+                const int nk = crem <= first ? 0 : (crem - first + 2 * GS_WAVES - 1) / (2 * GS_WAVES);
+                nstore_nchw = (nk < NSX ? nk : NSX) * (L >= 4 ? 1 : L);
+            }
+            const int crem = C - cg * GM_CG;
 #pragma unroll
             for (int k = 0; k < NSX; ++k) {
-                const int ch = 2 * (wv + GS_WAVES * k) + (lane >> 5), c = cg * GM_CG + ch, w4 = lane & 31;
-                if (4 * w4 < L && c < C) {
-                    const f32x4 u = lds_load_x4(oimg + ch * PO + 4 * w4) + resx[k];
-                    const int off = (c * HW + pix0 + 4 * w4) * 4;
-                    if (4 * w4 + 3 < L) {
-                        fbuf_store_x4(Ob, u, off, 0);
-                    } else {                                  // the last, partial granule must not reach into the next row
+                // every branch around a store is wave-uniform (scalar) and every store issued has an active lane: the
+                // counted barrier may only count instructions that really go to memory
+                if (2 * (wv + GS_WAVES * k) < crem) {
+                    const int ch = 2 * (wv + GS_WAVES * k) + (lane >> 5), c = cg * GM_CG + ch, w4 = lane & 31;
+                    const bool whole = 4 * w4 + 3 < L;
+                    if (L >= 4) {
+                        // a row of L floats = whole 4-float granules + one granule shifted back to end at L (it rewrites up to
+                        // 3 floats of its neighbour with the same values): 16-byte stores only, one instruction per channel pair
+                        const int w0 = whole ? 4 * w4 : L - 4;
+                        f32x4 u;
+                        if (whole) {
+                            u = lds_load_x4(oimg + oimg_nchw_idx<P>(ch, 4 * w4));
+                        } else {
 #pragma unroll
-                        for (int e = 0; e < 3; ++e)
-                            if (4 * w4 + e < L) fbuf_store(Ob, u[e], off + 4 * e, 0);
+                            for (int e = 0; e < 4; ++e) u[e] = CCA_LDS_LD(oimg + oimg_nchw_idx<P>(ch, (4 * w4 < L ? w0 : 0) + e));
+                        }
+                        if (4 * w4 < L && c < C) fbuf_store_x4(Ob, u + resx[k], (c * HW + pix0 + w0) * 4, 0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) {
+                            if (e < L) {
+                                if (w4 == 0 && c < C)
+                                    fbuf_store(Ob, CCA_LDS_LD(oimg + oimg_nchw_idx<P>(ch, e)) + resx[k][e], (c * HW + pix0 + e) * 4, 0);
+                            }
+                        }
                     }
                 }
             }
