@@ -555,7 +555,8 @@ def _pm(a):
 
 @pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 128, 17, 20), (1, 64, 9, 1), (1, 192, 33, 18), (1, 64, 3, 129), (1, 64, 101, 2),
                                    (2, 128, 3, 130),       # 260 column strips = one whole round of 256 + 4 cut in two
-                                   (1, 64, 2, 99)])        # the last chunks of a 100-padded strip
+                                   (1, 64, 2, 99),         # the last chunks of a 100-padded strip
+                                   (1, 512, 6, 5)])        # eight channel groups / chunks
 def test_pixel_major_bf16_path_matches_oracle(ops, shape):
     """csrc/cca_gmap.hpp through ccnet_cca_forward_pm_bf16 / ccnet_cca_backward_pm_bf16 (BASELINE configs[4]): q | k | v as
     channel slices of one packed pixel-major bf16 projection, bf16 x / y / dy / gradients, fp32 attention.  Oracle = the fp32
@@ -586,7 +587,8 @@ def test_pixel_major_bf16_path_matches_oracle(ops, shape):
     assert torch.equal(_from_bits(y0), _from_bits(bits["x"]))
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 96, 17, 20), (1, 64, 9, 1), (1, 160, 33, 18), (1, 32, 2, 99), (1, 64, 100, 3)])
+@pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 96, 17, 20), (1, 64, 9, 1), (1, 160, 33, 18), (1, 32, 2, 99), (1, 64, 100, 3),
+                                   (1, 512, 6, 5), (1, 384, 4, 7)])      # (8 and 6 channel chunks)
 def test_pixel_major_fp32_path_matches_oracle(ops, shape):
     """ccnet_cca_forward_pm_f32 / ccnet_cca_backward_pm_f32: the pixel-major family on fp32 views (one strip per workgroup; fp32
     features split into bf16 hi + lo on the fly, three products).  Oracle: the fp32 restatement; bar: the fp32 path's."""
