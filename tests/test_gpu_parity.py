@@ -772,3 +772,24 @@ def test_bench_bf16_line_has_the_contract_keys(lib, dev):
         assert key in out, key
     assert out["dtype"] == "bf16" and out["value"] > 0 and out["roofline"]["bound"] == "hbm"
     assert "pixel-major" in out["config"]["impl"]
+
+
+def test_pixel_major_cores_are_bit_identical_run_to_run(lib, dev):
+    """Counted-vmcnt barriers, register-prefetched epilogues, out-of-range DMA lanes: a race would show as run-to-run differences
+    under concurrent HBM load (tools/stress_pm.py is the long version, profiles/r02g_stress_pm.log)."""
+    import bench
+    noise = torch.randn(16 * 1024 * 1024, device=dev)
+    side = torch.cuda.Stream()
+    for wl in (bench.PixelMajorBF16Workload(lib, 2, 512, 129, 129, dev, 7), bench.PixelMajorF32Workload(lib, 2, 512, 97, 97, dev, 9),
+               bench.PixelMajorF32Workload(lib, 1, 128, 100, 61, dev, 11)):
+        wl.step()
+        torch.cuda.synchronize()
+        ref = [t.clone() for t in (wl.y, wl.dqkv, wl.dgamma, wl.A)]
+        assert all(bool(torch.isfinite(t.float()).all()) for t in ref)
+        for i in range(20):
+            if i % 2:
+                with torch.cuda.stream(side):
+                    noise.mul_(1.0001)
+            wl.step()
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip((wl.y, wl.dqkv, wl.dgamma, wl.A), ref)), i

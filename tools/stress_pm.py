@@ -1,0 +1,32 @@
+"""Repeat the pixel-major cores (bf16 all-pixel-major, fp32 with NCHW x / y / dy) under concurrent HBM load and count runs whose
+outputs differ bit-wise from the first run -- a race detector for the counted-vmcnt pipelines and the register-prefetched
+epilogues.  usage: stress_pm.py [iters]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from ccnet_amd import _lib
+lib = _lib.get_lib(); dev = torch.device('cuda')
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+noise = torch.randn(64 * 1024 * 1024, device=dev)
+side = torch.cuda.Stream()
+cases = [("bf16 (16,512,129,129)", bench.PixelMajorBF16Workload(lib, 16, 512, 129, 129, dev, 7)),
+         ("bf16 (2,512,97,97)", bench.PixelMajorBF16Workload(lib, 2, 512, 97, 97, dev, 8)),
+         ("f32 nchw (8,512,97,97)", bench.PixelMajorF32Workload(lib, 8, 512, 97, 97, dev, 9)),
+         ("f32 nchw (1,512,97,97)", bench.PixelMajorF32Workload(lib, 1, 512, 97, 97, dev, 10)),
+         ("f32 nchw (3,256,100,61)", bench.PixelMajorF32Workload(lib, 3, 256, 100, 61, dev, 11))]
+for name, wl in cases:
+    outs = lambda: (wl.y, wl.dqkv, wl.dgamma, wl.A)          # noqa: E731
+    wl.step(); torch.cuda.synchronize()
+    ref = [t.clone() for t in outs()]
+    assert all(torch.isfinite(t.float()).all() for t in ref), name
+    bad = [0, 0, 0, 0]
+    for i in range(iters):
+        if i % 2:
+            with torch.cuda.stream(side):
+                noise.mul_(1.0001)
+        wl.step()
+        torch.cuda.synchronize()
+        for j, (a, b) in enumerate(zip(outs(), ref)):
+            bad[j] += int(not torch.equal(a, b))
+    print(f"{name}: {iters} iterations, runs that differ from run 0: y {bad[0]} dqkv {bad[1]} dgamma {bad[2]} A {bad[3]}", flush=True)
