@@ -861,6 +861,31 @@ int gmap_pm(const float *T, const FT *F, const FT *resid, const float *gamma, FT
         return launch_gmap_pm<132, TRANS, FT>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
     return fail(CCNET_E_BADSHAPE, "gmap_pm: strip too long for this element type");
 }
+// dq (features k) and dk (features q) from the same dE: one launch per branch, blockIdx.y picks the job
+template <int P, typename FT>
+int launch_gmap_dual_pm(const float *dE, const FT *k, const FT *q, FT *dq, FT *dk, float *partial, int B, int Cq, int H, int W,
+                        long kbs, int kps, long qbs, int qps, long dqbs, int dqps, long dkbs, int dkps, ccnet_stream_t stream) {
+    const long pbs = (long)H * W * Cq;
+    float *pq = partial, *pk = partial + (size_t)B * pbs;
+    const GmapPlan gc = gmap_plan(B * W, Cq), gr = gmap_plan(B * H, Cq);
+    CCA_LAUNCH((cca::gmap_dual_kernel<P, false, false, FT, float>), dim3((unsigned)gc.grid, 2), dim3(cca::GS_THREADS), stream,
+               dE, k, q, (const float *)nullptr, (const float *)nullptr, pq, pk, Cq, H, W, kbs, kps, qbs, qps, 0L, 0,
+               pbs, Cq, pbs, Cq, gc.n_whole, gc.split);
+    if (int e = launch_status("gmap_dual_pm(column)")) return e;
+    CCA_LAUNCH((cca::gmap_dual_kernel<P, true, true, FT, FT>), dim3((unsigned)gr.grid, 2), dim3(cca::GS_THREADS), stream,
+               dE, k, q, (const float *)pq, (const float *)pk, dq, dk, Cq, H, W, kbs, kps, qbs, qps, pbs, Cq,
+               dqbs, dqps, dkbs, dkps, gr.n_whole, gr.split);
+    return launch_status("gmap_dual_pm(row)");
+}
+template <typename FT>
+int gmap_dual_pm(const float *dE, const FT *k, const FT *q, FT *dq, FT *dk, float *partial, int B, int Cq, int H, int W,
+                 long kbs, int kps, long qbs, int qps, long dqbs, int dqps, long dkbs, int dkps, ccnet_stream_t stream) {
+    if ((H > W ? H : W) <= 100)
+        return launch_gmap_dual_pm<100, FT>(dE, k, q, dq, dk, partial, B, Cq, H, W, kbs, kps, qbs, qps, dqbs, dqps, dkbs, dkps, stream);
+    if constexpr (PmTraits<FT>::kMaxStrip >= 132)
+        return launch_gmap_dual_pm<132, FT>(dE, k, q, dq, dk, partial, B, Cq, H, W, kbs, kps, qbs, qps, dqbs, dqps, dkbs, dkps, stream);
+    return fail(CCNET_E_BADSHAPE, "gmap_dual_pm: strip too long for this element type");
+}
 template <bool MASK, typename FT>
 int gweight_pm(const FT *X, const FT *Y, float *T, int B, int Cx, int H, int W, long xbs, int xps, long ybs, int yps,
                ccnet_stream_t stream) {
@@ -892,7 +917,7 @@ int check_pm_problem(const char *what, int B, int C, int Cq, int H, int W) {
 }
 size_t pm_workspace_bytes(int B, int C, int Cq, int H, int W, int backward) {
     if (B <= 0 || C <= 0 || Cq <= 0 || H <= 0 || W <= 0) return 0;
-    const size_t partial = (size_t)B * H * W * (C > Cq ? C : Cq) * sizeof(float);
+    const size_t partial = (size_t)B * H * W * (C > 2 * Cq ? C : 2 * Cq) * sizeof(float);     // (dq and dk partials side by side)
     return (backward ? align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W)) : 0) + partial;
 }
 
@@ -941,8 +966,8 @@ int cca_backward_pm(const char *name, const FT *dy, const FT *q, const FT *k, co
     if (int e = gmap_pm<true, FT>(A, dy, nullptr, gamma, dv, partial, B, C, H, W, dy_bs, dy_ps, 0L, 0, dv_bs, dv_ps, stream)) return e;
     // dgamma = sum A t;  dE = gamma * A * (t - sum_s A t), in place
     if (int e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, sm, B, H, W, stream, KSplit())) return e;
-    if (int e = gmap_pm<false, FT>(scratch, k, nullptr, nullptr, dq, partial, B, Cq, H, W, k_bs, k_ps, 0L, 0, dq_bs, dq_ps, stream)) return e;
-    return gmap_pm<true, FT>(scratch, q, nullptr, nullptr, dk, partial, B, Cq, H, W, q_bs, q_ps, 0L, 0, dk_bs, dk_ps, stream);
+    // the column partials of dq and dk sit side by side in the partial buffer (2 * Cq <= C channels)
+    return gmap_dual_pm<FT>(scratch, k, q, dq, dk, partial, B, Cq, H, W, k_bs, k_ps, q_bs, q_ps, dq_bs, dq_ps, dk_bs, dk_ps, stream);
 }
 }  // namespace
 }  // extern "C++"
