@@ -671,10 +671,10 @@ int ccnet_ca_strip_map_pm_f32(const float *T, const float *F, const float *adden
     do {                                                                                                                \
         if (addend) CCA_LAUNCH((cca::gmap_kernel<100, ROW_, TRANS_, true, float, float>), grid, block, stream, T, F,     \
                                addend, (const float *)nullptr, gamma, out, C, H, W, f_bs, f_ps, o_bs, o_ps, 0L, 0,      \
-                               o_bs, o_ps, gp.n_whole, gp.split);                                                       \
+                               o_bs, o_ps, gp.n_whole, gp.split, cca::GmapJob<float, float>{});                                                       \
         else        CCA_LAUNCH((cca::gmap_kernel<100, ROW_, TRANS_, false, float, float>), grid, block, stream, T, F,    \
                                addend, (const float *)nullptr, gamma, out, C, H, W, f_bs, f_ps, o_bs, o_ps, 0L, 0,      \
-                               o_bs, o_ps, gp.n_whole, gp.split);                                                       \
+                               o_bs, o_ps, gp.n_whole, gp.split, cca::GmapJob<float, float>{});                                                       \
     } while (0)
     if (row) { if (trans) CCA_GMAP(true, true); else CCA_GMAP(true, false); }
     else     { if (trans) CCA_GMAP(false, true); else CCA_GMAP(false, false); }
@@ -845,11 +845,11 @@ int launch_gmap_pm(const float *T, const FT *F, const FT *resid, const float *ga
     const GmapPlan gc = gmap_plan(B * W, C), gr = gmap_plan(B * H, C);
     CCA_LAUNCH((cca::gmap_kernel<P, false, TRANS, false, FT, float>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS),
                stream, T, F, (const float *)nullptr, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0,
-               0L, 0, pbs, C, gc.n_whole, gc.split);
+               0L, 0, pbs, C, gc.n_whole, gc.split, cca::GmapJob<FT, float>{});
     if (int e = launch_status("gmap_pm(column)")) return e;
     CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, FT, FT, NCHW>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS),
                stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C, rbs, rps, obs, ops,
-               gr.n_whole, gr.split);
+               gr.n_whole, gr.split, cca::GmapJob<FT, FT>{});
     return launch_status("gmap_pm(row)");
 }
 template <bool TRANS, typename FT>
@@ -868,13 +868,15 @@ int launch_gmap_dual_pm(const float *dE, const FT *k, const FT *q, FT *dq, FT *d
     const long pbs = (long)H * W * Cq;
     float *pq = partial, *pk = partial + (size_t)B * pbs;
     const GmapPlan gc = gmap_plan(B * W, Cq), gr = gmap_plan(B * H, Cq);
-    CCA_LAUNCH((cca::gmap_dual_kernel<P, false, false, FT, float>), dim3((unsigned)gc.grid, 2), dim3(cca::GS_THREADS), stream,
-               dE, k, q, (const float *)nullptr, (const float *)nullptr, pq, pk, Cq, H, W, kbs, kps, qbs, qps, 0L, 0,
-               pbs, Cq, pbs, Cq, gc.n_whole, gc.split);
+    const cca::GmapJob<FT, float> jc{q, nullptr, pk, qbs, pbs, qps, Cq};
+    CCA_LAUNCH((cca::gmap_kernel<P, false, false, false, FT, float, false, true>), dim3((unsigned)gc.grid, 2), dim3(cca::GS_THREADS),
+               stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
+               0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
     if (int e = launch_status("gmap_dual_pm(column)")) return e;
-    CCA_LAUNCH((cca::gmap_dual_kernel<P, true, true, FT, FT>), dim3((unsigned)gr.grid, 2), dim3(cca::GS_THREADS), stream,
-               dE, k, q, (const float *)pq, (const float *)pk, dq, dk, Cq, H, W, kbs, kps, qbs, qps, pbs, Cq,
-               dqbs, dqps, dkbs, dkps, gr.n_whole, gr.split);
+    const cca::GmapJob<FT, FT> jr{q, pk, dk, qbs, dkbs, qps, dkps};
+    CCA_LAUNCH((cca::gmap_kernel<P, true, false, true, FT, FT, false, true>), dim3((unsigned)gr.grid, 2), dim3(cca::GS_THREADS),
+               stream, dE, k, (const float *)pq, (const FT *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
+               0L, 0, dqbs, dqps, gr.n_whole, gr.split, jr);
     return launch_status("gmap_dual_pm(row)");
 }
 template <typename FT>

@@ -101,34 +101,48 @@ __device__ __forceinline__ int oimg_nchw_idx(int ch, int i) {
 // NCHW (fp32 row strips with an addend only): ``resid`` and ``out`` are NCHW tensors (batch strides rbs / obs in elements):
 // the addend slices are loaded in the accumulator layout, the output image is kept [channel][position] and leaves as runs
 // of W floats per channel -- the module's x and y never exist pixel-major.
-template <int P, typename FT, bool NCHW>
-__host__ __device__ constexpr int gmap_lds_floats() {
-    return 2 * GTile<FT>::size(P) + (NCHW ? GM_CG * (P + 4) : GTile<float>::size(P));
-}
+// DUAL (ca_backward in one launch per branch): blockIdx.y = 0 runs the job of the ordinary arguments non-transposed (dq: features
+// k), blockIdx.y = 1 runs job ``j1`` transposed (dk: features q) on the same T = dE -- twice the workgroups per launch (what
+// 1-2 images per GPU need) and half the launch boundaries.  Only the prologue differs between the two.
+template <typename FT, typename OT>
+struct GmapJob {
+    const FT *F;
+    const float *addend;
+    OT *out;
+    long fbs, obs;
+    int fps, ops;
+};
 
-template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT, bool NCHW>
-__device__ __forceinline__ void gmap_body(float *lds, int block_id, const float *__restrict__ T, const FT *__restrict__ F,
-                                          const float *__restrict__ addend, const OT *__restrict__ resid,
-                                          const float *__restrict__ gamma, OT *out,
-                                          int C, int H, int W, long fbs, int fps, long abs_, int aps,
-                                          long rbs, int rps, long obs, int ops, int n_whole, int split) {
+template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT, bool NCHW = false, bool DUAL = false>
+__global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__restrict__ T, const FT *__restrict__ F,
+                                                              const float *__restrict__ addend,
+                                                              const OT *__restrict__ resid,
+                                                              const float *__restrict__ gamma, OT *out,
+                                                              int C, int H, int W, long fbs, int fps, long abs_, int aps,
+                                                              long rbs, int rps, long obs, int ops, int n_whole, int split,
+                                                              GmapJob<FT, OT> j1) {
     constexpr bool BF = GTile<FT>::BF, OBF = std::is_same<OT, bf16_t>::value;
+    const bool trans = DUAL ? blockIdx.y != 0 : TRANS;            // (wave-uniform)
+    if (DUAL && blockIdx.y != 0) {
+        F = j1.F; addend = j1.addend; out = j1.out; fbs = j1.fbs; fps = j1.fps; obs = j1.obs; ops = j1.ops;
+    }
     constexpr int NT = (P + 15) / 16, TPW = (NT + GS_WAVES - 1) / GS_WAVES, NKS = P / 32;
     constexpr int FSZ = GTile<FT>::size(P), OSZ = GTile<float>::size(P), NPF = GTile<FT>::pieces(P);
     constexpr int SPX = OBF ? 8 : 4;                                  // pixels per store instruction
     constexpr int NSI = NCHW ? 1 : ((P + SPX - 1) / SPX + GS_WAVES - 1) / GS_WAVES;   // store instructions per wave and group (max)
     constexpr int PO = P + 4, OIMG = NCHW ? GM_CG * PO : OSZ;         // NCHW: [channel][position] image, pitch PO
     constexpr int NSX = GM_CG / 2 / GS_WAVES;                         // NCHW: store instructions per wave and group (2 channels each)
-    static_assert(!NCHW || (ROW && ADD && !OBF && !TRANS), "gmap: the NCHW epilogue belongs to the final fp32 row pass");
+    static_assert(!NCHW || (ROW && ADD && !OBF && !TRANS && !DUAL), "gmap: the NCHW epilogue belongs to the final fp32 row pass");
     static_assert(P % 4 == 0 && (2 * FSZ + OIMG) * 4 * 2 <= 163840, "gmap: two workgroups per CU");
-    static_assert(2 * FSZ + OIMG == gmap_lds_floats<P, FT, NCHW>(), "gmap: LDS size");
+    __shared__ __attribute__((aligned(16))) float lds[2 * FSZ + OIMG];
+    CCA_LDS_REGISTER(lds);
     float *const FB = lds, *const oimg = lds + 2 * FSZ;
     const int HW = H * W, S = H + W;
     const int L = ROW ? W : H, G = ROW ? H : W;
     // workgroups are dispatched in index order, two per CU: the first n_whole take a whole strip each, the remaining
     // strips (fewer than one round) are cut into `split` channel ranges so that the last round is a short one
     const int ncg = (C + GM_CG - 1) / GM_CG;
-    int id = block_id, cg0 = 0, cg1 = ncg;
+    int id = blockIdx.x, cg0 = 0, cg1 = ncg;
     if (id >= n_whole) {
         const int r = id - n_whole, part = r % split;
         id = n_whole + r / split;
@@ -169,7 +183,7 @@ __device__ __forceinline__ void gmap_body(float *lds, int block_id, const float 
             float x[8];
             if (ks < kp.nbf && 16 * t < L) {                          // wave-uniform
                 const int k0 = 32 * ks + 8 * lg;
-                if (!TRANS) {
+                if (!trans) {
                     const int base = ((pix0 + m * pstep) * S + a_off + k0) * 4;
                     const f32x4 u = fbuf_load_x4(Tb, (m < L && k0 < L) ? base : kOobOffset, 0);
                     const f32x4 v = fbuf_load_x4(Tb, (m < L && k0 + 4 < L) ? base + 16 : kOobOffset, 0);
@@ -189,7 +203,7 @@ __device__ __forceinline__ void gmap_body(float *lds, int block_id, const float 
             al[a][ks] = sp.lo;
         }
         const int kt = 32 * kp.nbf + lg;
-        at[a] = fbuf_load(Tb, (kp.tail && m < L && kt < L) ? (TRANS ? ((pix0 + kt * pstep) * S + a_off + m) * 4
+        at[a] = fbuf_load(Tb, (kp.tail && m < L && kt < L) ? (trans ? ((pix0 + kt * pstep) * S + a_off + m) * 4
                                                                      : ((pix0 + m * pstep) * S + a_off + kt) * 4) : kOobOffset, 0);
     }
 
@@ -376,39 +390,6 @@ __device__ __forceinline__ void gmap_body(float *lds, int block_id, const float 
             }
         }
     }
-}
-
-template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT, bool NCHW = false>
-__global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__restrict__ T, const FT *__restrict__ F,
-                                                              const float *__restrict__ addend,
-                                                              const OT *__restrict__ resid,
-                                                              const float *__restrict__ gamma, OT *out,
-                                                              int C, int H, int W, long fbs, int fps, long abs_, int aps,
-                                                              long rbs, int rps, long obs, int ops, int n_whole, int split) {
-    __shared__ __attribute__((aligned(16))) float lds[gmap_lds_floats<P, FT, NCHW>()];
-    CCA_LDS_REGISTER(lds);
-    gmap_body<P, ROW, TRANS, ADD, FT, OT, NCHW>(lds, blockIdx.x, T, F, addend, resid, gamma, out, C, H, W, fbs, fps, abs_, aps,
-                                                rbs, rps, obs, ops, n_whole, split);
-}
-
-// ca_backward in one launch per branch: blockIdx.y = 0 computes dq (non-transposed, features k), blockIdx.y = 1 dk
-// (transposed, features q) from the same dE -- twice the workgroups per launch (what 1-2 images per GPU need) and half the
-// launch boundaries
-template <int P, bool ROW, bool ADD, typename FT, typename OT>
-__global__ __launch_bounds__(GS_THREADS, 2) void gmap_dual_kernel(const float *__restrict__ T, const FT *__restrict__ F0,
-                                                                   const FT *__restrict__ F1, const float *__restrict__ add0,
-                                                                   const float *__restrict__ add1, OT *out0, OT *out1,
-                                                                   int C, int H, int W, long f0bs, int f0ps, long f1bs, int f1ps,
-                                                                   long abs_, int aps, long o0bs, int o0ps, long o1bs, int o1ps,
-                                                                   int n_whole, int split) {
-    __shared__ __attribute__((aligned(16))) float lds[gmap_lds_floats<P, FT, false>()];
-    CCA_LDS_REGISTER(lds);
-    if (blockIdx.y == 0)
-        gmap_body<P, ROW, false, ADD, FT, OT, false>(lds, blockIdx.x, T, F0, add0, (const OT *)nullptr, (const float *)nullptr, out0,
-                                                     C, H, W, f0bs, f0ps, abs_, aps, 0L, 0, o0bs, o0ps, n_whole, split);
-    else
-        gmap_body<P, ROW, true, ADD, FT, OT, false>(lds, blockIdx.x, T, F1, add1, (const OT *)nullptr, (const float *)nullptr, out1,
-                                                    C, H, W, f1bs, f1ps, abs_, aps, 0L, 0, o1bs, o1ps, n_whole, split);
 }
 
 // NCHW fp32 -> pixel-major fp32 (the gradient dy of an NCHW module output, ca_map_backward's features): 64 pixels x 64
