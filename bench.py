@@ -405,18 +405,20 @@ def per_step_stats(fn, iters, flush=None):
 
 
 def lib_sha16(lib):
-    with open(lib.path, "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    """identity of the build being benched: hash of the kernel sources it is compiled from (hipcc output itself is not
+    bit-reproducible; build() recompiles whenever a source is newer than the library)"""
+    from ccnet_amd import _lib
+    return _lib.kernel_source_sha16()
 
 
 def measured_traffic(lib, name="traffic_latest.json"):
     """Per-launch HBM bytes from the PMC passes (tools/pmc.sh -> tools/traffic_from_pmc.py), accepted only when
-    they were taken on the library that is being benched (sha recorded next to them); otherwise None."""
+    they were taken on a build of the kernel sources that are being benched (source hash recorded next to them); otherwise None."""
     tpath = os.path.join(ROOT, "profiles", name)
     try:
         with open(tpath) as f:
             t = json.load(f)
-        if t.get("_lib_sha16") == lib_sha16(lib):
+        if t.get("_src_sha16") == lib_sha16(lib):
             return t
     except Exception:
         pass

@@ -123,3 +123,19 @@ def get_lib() -> CcaLibrary:
         import torch  # noqa: F401  (map PyTorch's HIP runtime first, see module docstring)
         _lib = CcaLibrary(LIB_PATH)
     return _lib
+
+
+def kernel_source_sha16() -> str:
+    """sha256 prefix over the kernel sources and the C ABI header (file names + contents, sorted).  hipcc output is not
+    bit-reproducible, so measurements that must belong to "this build" (profiles/traffic_*.json) are keyed to the sources
+    the library is compiled from; __graft_entry__.build() rebuilds the library whenever a source is newer than it."""
+    import hashlib
+    root = os.path.dirname(os.path.abspath(__file__))
+    files = [os.path.join(root, "csrc", f) for f in sorted(os.listdir(os.path.join(root, "csrc")))
+             if f.endswith((".hip", ".hpp"))] + [HEADER_PATH]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

@@ -164,3 +164,20 @@ def test_product_sources_carry_no_emulator_code_and_no_env_knobs():
             assert "CCNET_EMU" not in text and "hip_emu" not in text, f
             assert "getenv" not in text, f
     assert os.path.exists(os.path.join(ROOT, "tests", "emu", "cca_platform.hpp"))
+
+
+def test_measured_traffic_is_keyed_to_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.py quotes PMC traffic only for a build of the kernel sources it was measured on."""
+    import json
+    import bench
+    from ccnet_amd import _lib
+    sha = _lib.kernel_source_sha16()
+    assert len(sha) == 16 and sha == _lib.kernel_source_sha16()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "profiles").mkdir()
+    good = {"_step_total_bytes": 123, "_src_sha16": sha}
+    (tmp_path / "profiles" / "traffic_latest.json").write_text(json.dumps(good))
+    assert bench.measured_traffic(None) == good
+    (tmp_path / "profiles" / "traffic_latest.json").write_text(json.dumps({"_step_total_bytes": 123, "_src_sha16": "0" * 16}))
+    assert bench.measured_traffic(None) is None
+    assert bench.measured_traffic(None, "missing.json") is None

@@ -6,8 +6,8 @@ reports exactly half of the bytes of a coalesced streaming read (checked here on
 reads the 58.4 MB attention tensor once: FETCH_SIZE says 29.4 MB), so fetch bytes are doubled.  WRITE_SIZE
 matched the known write volume of the same kernel (57.0 MiB vs 58.4 MB) and is used as is.
 
-The file also records the sha256 prefix of the library the counters were taken on (``_lib_sha16``: bench.py only
-quotes the traffic when it benches that same build) and the per-step total (every kernel is launched once per step).
+The file also records the sha256 prefix of the kernel sources the profiled library was built from (``_src_sha16``: bench.py
+only quotes the traffic when it benches a build of those same sources) and the per-step total (every kernel is launched once per step).
 With ``--steps N`` the profiled command ran N steps in which a kernel may be launched several times (the pixel-major bf16
 step, tools/pm_bf16_time.py: 3 warm-up + 10 timed forward/backward pairs = 13): the per-step total is then
 sum(kernel average * dispatches) / N, and ``--out`` names the file (profiles/traffic_bf16_latest.json).
@@ -43,6 +43,8 @@ for k, v in d.items():
         out[label(k) or k] = nbytes
         total += nbytes * v.get("dispatches", 1) / a.steps if a.steps else nbytes
 out["_step_total_bytes"] = int(total)
-out["_lib_sha16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+sys.path.insert(0, ROOT)
+from ccnet_amd import _lib as _cl
+out["_src_sha16"] = _cl.kernel_source_sha16()          # hipcc output is not bit-reproducible: key = the kernel sources
 json.dump(out, open(os.path.join(ROOT, "profiles", a.out), "w"), indent=1)
 print(json.dumps(out, indent=1))
