@@ -963,7 +963,7 @@ int cca_backward_pm(const char *name, const FT *dy, const FT *q, const FT *k, co
         return fail(CCNET_E_WORKSPACE, "cca_backward_pm: workspace missing or too small");
     const size_t sm = align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W));
     float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + sm);
-    // t = un-scaled dA (functions.py:110-112 through the aggregation's adjoint), dv = gamma * A^T-weighted dy
+    // t = un-scaled dA (the adjoint of the aggregation, functions.py:46-47), dv = gamma * A^T-weighted dy
     if (int e = gweight_pm<false, FT>(dy, v, scratch, B, C, H, W, dy_bs, dy_ps, v_bs, v_ps, stream)) return e;
     if (int e = gmap_pm<true, FT>(A, dy, nullptr, gamma, dv, partial, B, C, H, W, dy_bs, dy_ps, 0L, 0, dv_bs, dv_ps, stream)) return e;
     // dgamma = sum A t;  dE = gamma * A * (t - sum_s A t), in place

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
                         f32x4 v = lds_load_x4(s + 4);
                         if (ADD) v += add1[k];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {              // + the bf16 residual (x of functions.py:104)
+                        for (int e = 0; e < 4; ++e) {              // + the bf16 residual (x of functions.py:49)
                             const float lo = __builtin_bit_cast(float, res[k][e] << 16), hi = __builtin_bit_cast(float, res[k][e] & 0xffff0000u);
                             if (e < 2) { u[2 * e] += lo; u[2 * e + 1] += hi; } else { v[2 * e - 4] += lo; v[2 * e - 3] += hi; }
                         }

@@ -204,12 +204,12 @@ int ccnet_cca_backward_bf16(const uint16_t *dy, const uint16_t *q, const uint16_
 
 /* Pixel-major bf16 path (BASELINE.json configs[4], (16,512,129,129) bf16): every feature tensor is a bf16
  * (B, H*W, pixel stride) VIEW -- element (b, c, h, w) at  b * bs + (h * W + w) * ps + c  (units: elements) -- which is
- * what a channels_last tensor is, and what the reference module's 1x1 projections (cc.py:28-30) produce when they run
+ * what a channels_last tensor is, and what the reference module's 1x1 projections (functions.py:29,32,35) produce when they run
  * as one  x^T W^T  GEMM: q, k, v are then channel slices of ONE (B, H*W, 2*Cq + C) projection and no copy is made.
  * The attention tensor A (B, H, W, H+W), the scratch tensor, gamma, dgamma and every accumulation are fp32; products
  * of the bf16 features are exact on the matrix pipe; outputs are rounded to nearest even once, on store.
  * Constraints: max(H, W) <= 132, C % 8 == 0, Cq % 8 == 0, every bs / ps a multiple of 8, pointers 16-byte aligned.
- * y = gamma * (column + row aggregation) + x       (functions.py:104, cc.py:37)
+ * y = gamma * (column + row aggregation) + x       (functions.py:46-49)
  * ``workspace``: ccnet_cca_pm_bf16_workspace_bytes(..., backward) bytes (fp32 column partials; + softmax partials). */
 size_t ccnet_cca_pm_bf16_workspace_bytes(int B, int C, int Cq, int H, int W, int backward);
 int ccnet_cca_forward_pm_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v, const uint16_t *x,
