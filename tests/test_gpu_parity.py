@@ -793,3 +793,43 @@ def test_pixel_major_cores_are_bit_identical_run_to_run(lib, dev):
             wl.step()
             torch.cuda.synchronize()
             assert all(torch.equal(a, b) for a, b in zip((wl.y, wl.dqkv, wl.dgamma, wl.A), ref)), i
+
+
+def _random_pm_shapes(n, longest, align, seed):
+    rng = np.random.default_rng(seed)
+    shapes = []
+    for _ in range(n):
+        H, W = (int(rng.integers(1, longest + 1)) for _ in range(2))
+        if rng.random() < 0.3:                          # pile up on the interesting lengths
+            H = int(rng.choice([1, 4, 31, 32, 33, 96, 97, 100, longest - 1, longest]))
+        C = 8 * align * int(rng.integers(1, 5))         # C / 8 stays a multiple of the alignment
+        shapes.append((int(rng.integers(1, 3)), C, min(H, longest), min(W, longest)))
+    return shapes
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_pixel_major_family_on_random_geometries(lib, dev, dtype):
+    """Twelve random (B, C, H, W) per element type inside the family's limits (strip lengths around the tile, k-step and
+    padding boundaries; partial channel groups), forward and backward against the oracle on the same (rounded) inputs."""
+    from ccnet_amd.functions import CrissCrossPMFunction
+    bf = dtype == torch.bfloat16
+    for shape in _random_pm_shapes(12, 132 if bf else 100, 8 if bf else 4, seed=2024 + bf):
+        B, C, H, W = shape
+        cq = C // 8
+        q, k, v, x, dy = (t.to(dtype) for t in make_core_inputs(B, C, H, W, seed=B * 1000 + H * 10 + W))
+        pm = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)           # noqa: E731
+        qkv = torch.cat([pm(q), pm(k), pm(v)], dim=3).contiguous().requires_grad_(True)
+        xp = pm(x).requires_grad_(True)
+        gamma = torch.tensor([0.5], device=dev, requires_grad=True)
+        y = CrissCrossPMFunction.apply(qkv, xp, gamma, cq)
+        y.backward(pm(dy))
+        f = lambda t: t.detach().float().cpu()                              # noqa: E731
+        nchw = lambda t: f(t).permute(0, 3, 1, 2)                           # noqa: E731
+        yo, Ao = O.cca_core_forward(f(q), f(k), f(v), f(x), torch.tensor([0.5]))
+        go = O.cca_core_backward(f(dy), f(q), f(k), f(v), Ao, torch.tensor([0.5]))
+        tol = (lambda ref: 2.0 ** -8 * ref.abs() + TOL) if bf else (lambda ref: torch.full_like(ref, TOL))
+        g = qkv.grad
+        for got, ref, name in ((y, yo, "y"), (g[..., :cq], go["dq"], "dq"), (g[..., cq:2 * cq], go["dk"], "dk"),
+                               (g[..., 2 * cq:], go["dv"], "dv")):
+            assert bool(((nchw(got) - ref).abs() <= tol(ref)).all()), (shape, name, float((nchw(got) - ref).abs().max()))
+        assert abs(float(gamma.grad) - float(go["dgamma"])) < 2e-3 * max(1.0, abs(float(go["dgamma"]))), shape
