@@ -255,66 +255,75 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
         }
         // D^T[m = channel][n = strip position] = features^T x attention^T: a lane ends up with 4 consecutive channels of
         // one position (one ds_write_b128 into the pixel-major output image)
-        f32x4 acc[TPW][4];
+        // (three M tiles per wavefront = strips longer than 128: the four N tiles are accumulated two at a time, so that the
+        // accumulators -- live together with 96 fragment and up to 60 prefetch registers -- take 24 VGPRs instead of 48)
+        constexpr int NH = TPW >= 3 ? 2 : 1, NTH = 4 / NH;
 #pragma unroll
-        for (int a = 0; a < TPW; ++a)
+        for (int nh = 0; nh < NH; ++nh) {
+            f32x4 acc[TPW][NTH];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[a][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int a = 0; a < TPW; ++a)
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            if (ks < kp.nbf) {
+                for (int n = 0; n < NTH; ++n) acc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    // feature fragment: positions 32 ks + 8 lg + e of channel 16 nt + ln
-                    BfSplit fb;
-                    if constexpr (BF) {
-                        uint32_t x[8];
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (ks < kp.nbf) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) x[e] = lds_load_u16(img, gtile_bf_byte(32 * ks + 8 * lg + e, 16 * nt + ln));
-                        fb.hi = u32x4{x[0] | (x[1] << 16), x[2] | (x[3] << 16), x[4] | (x[5] << 16), x[6] | (x[7] << 16)};
-                        fb.lo = fb.hi;
-                    } else {
-                        float x[8];
+                    for (int n = 0; n < NTH; ++n) {
+                        const int nt = nh * NTH + n;
+                        // feature fragment: positions 32 ks + 8 lg + e of channel 16 nt + ln
+                        BfSplit fb;
+                        if constexpr (BF) {
+                            uint32_t x[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) x[e] = CCA_LDS_LD(img + gtile_f32_idx(32 * ks + 8 * lg + e, 16 * nt + ln));
-                        fb = bf16_split8(x);
-                    }
+                            for (int e = 0; e < 8; ++e) x[e] = lds_load_u16(img, gtile_bf_byte(32 * ks + 8 * lg + e, 16 * nt + ln));
+                            fb.hi = u32x4{x[0] | (x[1] << 16), x[2] | (x[3] << 16), x[4] | (x[5] << 16), x[6] | (x[7] << 16)};
+                            fb.lo = fb.hi;
+                        } else {
+                            float x[8];
 #pragma unroll
-                    for (int a = 0; a < TPW; ++a) {
-                        if ((wv + GS_WAVES * a) * 16 < L) {
-                            acc[a][nt] = mfma_bf16_16x16x32(fb.hi, ah[a][ks], acc[a][nt]);
-                            if (!BF) acc[a][nt] = mfma_bf16_16x16x32(fb.lo, ah[a][ks], acc[a][nt]);
-                            acc[a][nt] = mfma_bf16_16x16x32(fb.hi, al[a][ks], acc[a][nt]);
+                            for (int e = 0; e < 8; ++e) x[e] = CCA_LDS_LD(img + gtile_f32_idx(32 * ks + 8 * lg + e, 16 * nt + ln));
+                            fb = bf16_split8(x);
+                        }
+#pragma unroll
+                        for (int a = 0; a < TPW; ++a) {
+                            if ((wv + GS_WAVES * a) * 16 < L) {
+                                acc[a][n] = mfma_bf16_16x16x32(fb.hi, ah[a][ks], acc[a][n]);
+                                if (!BF) acc[a][n] = mfma_bf16_16x16x32(fb.lo, ah[a][ks], acc[a][n]);
+                                acc[a][n] = mfma_bf16_16x16x32(fb.hi, al[a][ks], acc[a][n]);
+                            }
                         }
                     }
                 }
             }
-        }
-        if (kp.tail) {
-            const int pos = 32 * kp.nbf + lg;
+            if (kp.tail) {
+                const int pos = 32 * kp.nbf + lg;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                float fbv;
-                if constexpr (BF) fbv = __builtin_bit_cast(float, lds_load_u16(img, gtile_bf_byte(pos, 16 * nt + ln)) << 16);
-                else              fbv = CCA_LDS_LD(img + gtile_f32_idx(pos, 16 * nt + ln));
+                for (int n = 0; n < NTH; ++n) {
+                    const int nt = nh * NTH + n;
+                    float fbv;
+                    if constexpr (BF) fbv = __builtin_bit_cast(float, lds_load_u16(img, gtile_bf_byte(pos, 16 * nt + ln)) << 16);
+                    else              fbv = CCA_LDS_LD(img + gtile_f32_idx(pos, 16 * nt + ln));
 #pragma unroll
-                for (int a = 0; a < TPW; ++a)
-                    if ((wv + GS_WAVES * a) * 16 < L) acc[a][nt] = mfma_16x16x4(fbv, at[a], acc[a][nt]);
+                    for (int a = 0; a < TPW; ++a)
+                        if ((wv + GS_WAVES * a) * 16 < L) acc[a][n] = mfma_16x16x4(fbv, at[a], acc[a][n]);
+                }
+                mfma_f32_result_fence();
             }
-            mfma_f32_result_fence();
-        }
 #pragma unroll
-        for (int a = 0; a < TPW; ++a) {
-            const int i = 16 * (wv + GS_WAVES * a) + ln;
-            if (i < L) {
+            for (int a = 0; a < TPW; ++a) {
+                const int i = 16 * (wv + GS_WAVES * a) + ln;
+                if (i < L) {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    if constexpr (NCHW) {
+                    for (int n = 0; n < NTH; ++n) {
+                        const int nt = nh * NTH + n;
+                        if constexpr (NCHW) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            CCA_LDS_ST(oimg + oimg_nchw_idx<P>(16 * nt + 4 * lg + q, i), alpha * acc[a][nt][q] + addp[a][nt][q]);
-                    } else {
-                        lds_store_x4(oimg + (i >> 2) * GM_PP + (i & 3) * GM_CG + 16 * nt + 4 * lg, alpha * acc[a][nt]);
+                            for (int q = 0; q < 4; ++q)
+                                CCA_LDS_ST(oimg + oimg_nchw_idx<P>(16 * nt + 4 * lg + q, i), alpha * acc[a][n][q] + addp[a][nt][q]);
+                        } else {
+                            lds_store_x4(oimg + (i >> 2) * GM_PP + (i & 3) * GM_CG + 16 * nt + 4 * lg, alpha * acc[a][n]);
+                        }
                     }
                 }
             }
