@@ -43,9 +43,6 @@ _PROTOTYPES = {
     "ccnet_ca_softmax_backward_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ccnet_ca_softmax_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, _P]),
     "ccnet_ca_map_forward_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
-    "ccnet_ca_map_forward_pm_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_long, c_int, _P]),
-    "ccnet_ca_strip_map_pm_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_long, c_int, c_long, c_int,
-                                          c_int, c_int, _P]),
     "ccnet_ca_map_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ccnet_cca_forward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ccnet_cca_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t,
@@ -75,6 +72,8 @@ _PROTOTYPES = {
     "ccnet_cca_backward_pm_nchw_f32": (c_int, [_P] * 11 + [c_int] * 5 + [c_long, c_int] * 6 + [_P, c_size_t, _P]),
     "ccnet_cca_shape_uses_mfma": (c_int, [c_int, c_int, c_int, c_int]),
     "ccnet_cca_mfma_selftest": (c_int, [_P, _P]),
+    "ccnet_cca_profile_begin": (c_int, [c_int]),
+    "ccnet_cca_profile_end": (c_int, [_P, _P, c_int, c_int]),
 }
 
 
@@ -111,6 +110,24 @@ class CcaLibrary:
     def check(self, code: int, what: str = "") -> None:
         if code != 0:
             raise CcaError(f"{what or 'ccnet_cca'} failed with code {code}: {self.last_error()}")
+
+    def profile_launches(self, fn, cap: int = 256):
+        """Run ``fn()`` with the launch profiler armed: [(kernel name, ms)] of every launch the library issued, in
+        issue order (HIP-event pairs on the launch stream; a measurement aid, see ccnet_cca_profile_begin)."""
+        self.check(self.ccnet_cca_profile_begin(cap), "profile_begin")
+        try:
+            fn()
+        finally:
+            ms = (ctypes.c_float * cap)()
+            names = ctypes.create_string_buffer(cap * 96)
+            n = self.ccnet_cca_profile_end(ms, names, 96, cap)
+        if n < 0:
+            raise CcaError(f"profile_end failed with code {n}: {self.last_error()}")
+        out = []
+        for i in range(n):
+            raw = names.raw[i * 96:(i + 1) * 96].split(b"\0", 1)[0].decode()
+            out.append((raw, float(ms[i])))
+        return out
 
 
 _lib: Optional[CcaLibrary] = None

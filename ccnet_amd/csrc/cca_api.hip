@@ -6,7 +6,6 @@
 #include "../../include/ccnet_cca.h"
 
 #include "cca_common.hpp"
-#include "cca_band.hpp"
 #include "cca_direct.hpp"
 #include "cca_gmap.hpp"
 #include "cca_map.hpp"
@@ -624,21 +623,6 @@ int ccnet_ca_map_forward_f32(const float *A, const float *v, const float *x, con
     return ca_map_forward_impl(A, v, x, gamma, out, B, C, H, W, stream, d, d, d);
 }
 
-int ccnet_ca_map_forward_pm_f32(const float *A, const float *v, const float *x, const float *gamma, float *out,
-                                int B, int C, int H, int W, long v_bs, int v_ps, ccnet_stream_t stream) {
-    if (int e = check_shape(B, C, H, W)) return e;
-    if (!A || !v || !x || !out) return fail(CCNET_E_NULLPTR, "ca_map_forward_pm: null tensor");
-    if (v_ps < C || v_bs < (long)(H * W - 1) * v_ps + C) return fail(CCNET_E_BADSHAPE, "ca_map_forward_pm: strides smaller than the tensor");
-    if ((double)H * W * v_ps >= 536870912.0) return fail(CCNET_E_BADSHAPE, "ca_map_forward_pm: per-image pixel-major view exceeds 2^29 elements");
-    if (C % 4) return fail(CCNET_E_BADSHAPE, "ca_map_forward_pm: C must be a multiple of 4");
-    const int longest = H > W ? H : W;
-    if (longest > 100) return fail(CCNET_E_BADSHAPE, "ca_map_forward_pm: strips longer than 100 are not covered by the band kernel");
-    const int nb = (H + cca::BD_R - 1) / cca::BD_R, rpb = (H + nb - 1) / nb, ncg = (C + cca::BD_CC - 1) / cca::BD_CC;
-    CCA_LAUNCH((cca::map_band_fwd_kernel<100>), dim3((unsigned)(B * ncg * nb)), dim3(cca::BD_THREADS), stream,
-               A, v, x, gamma, out, C, H, W, nb, rpb, ncg, v_bs, v_ps);
-    return launch_status("ca_map_forward_pm");
-}
-
 extern "C++" {
 namespace {
 // one strip per workgroup and two workgroups per CU: whole rounds of strips first, then the remainder cut into channel
@@ -658,29 +642,6 @@ GmapPlan gmap_plan(int strips, int C) {
 }
 }  // namespace
 }  // extern "C++"
-
-int ccnet_ca_strip_map_pm_f32(const float *T, const float *F, const float *addend, const float *gamma, float *out,
-                              int B, int C, int H, int W, long f_bs, int f_ps, long o_bs, int o_ps,
-                              int row, int trans, ccnet_stream_t stream) {
-    if (int e = check_shape(B, C, H, W)) return e;
-    if (!T || !F || !out) return fail(CCNET_E_NULLPTR, "ca_strip_map_pm: null tensor");
-    if ((H > W ? H : W) > 100 || C % 4) return fail(CCNET_E_BADSHAPE, "ca_strip_map_pm: strips <= 100, C % 4 == 0");
-    const GmapPlan gp = gmap_plan(B * (row ? H : W), C);
-    const dim3 grid((unsigned)gp.grid), block(cca::GS_THREADS);
-#define CCA_GMAP(ROW_, TRANS_)                                                                                          \
-    do {                                                                                                                \
-        if (addend) CCA_LAUNCH((cca::gmap_kernel<100, ROW_, TRANS_, true, float, float>), grid, block, stream, T, F,     \
-                               addend, (const float *)nullptr, gamma, out, C, H, W, f_bs, f_ps, o_bs, o_ps, 0L, 0,      \
-                               o_bs, o_ps, gp.n_whole, gp.split, cca::GmapJob<float, float>{});                                                       \
-        else        CCA_LAUNCH((cca::gmap_kernel<100, ROW_, TRANS_, false, float, float>), grid, block, stream, T, F,    \
-                               addend, (const float *)nullptr, gamma, out, C, H, W, f_bs, f_ps, o_bs, o_ps, 0L, 0,      \
-                               o_bs, o_ps, gp.n_whole, gp.split, cca::GmapJob<float, float>{});                                                       \
-    } while (0)
-    if (row) { if (trans) CCA_GMAP(true, true); else CCA_GMAP(true, false); }
-    else     { if (trans) CCA_GMAP(false, true); else CCA_GMAP(false, false); }
-#undef CCA_GMAP
-    return launch_status("ca_strip_map_pm");
-}
 
 int ccnet_ca_map_backward_f32(const float *dout, const float *A, const float *v, const float *gamma,
                               float *dA, float *dv, int B, int C, int H, int W, ccnet_stream_t stream) {
@@ -1075,6 +1036,18 @@ int ccnet_cca_backward_pm_nchw_f32(const float *dy, const float *q, const float 
     return cca_backward_pm<float>("cca_backward_pm_nchw_f32", dy_pm, q, k, v, A, gamma, dq, dk, dv, dgamma, scratch, B, C, Cq, H, W,
                                   pbs, C, q_bs, q_ps, k_bs, k_ps, v_bs, v_ps, dq_bs, dq_ps, dk_bs, dk_ps, dv_bs, dv_ps,
                                   workspace, base, stream);
+}
+
+/* ---- launch profiler: per-launch HIP-event durations inside a step (see cca_platform.hpp, cca_prof) ---- */
+int ccnet_cca_profile_begin(int max_launches) {
+    const char *why = cca_prof::begin(max_launches);
+    return why ? fail(CCNET_E_BADFLAGS, why) : 0;
+}
+
+int ccnet_cca_profile_end(float *ms, char *names, int name_stride, int cap) {
+    const char *why = nullptr;
+    const int n = cca_prof::end(ms, names, name_stride, cap, &why);
+    return why ? fail(CCNET_E_BADFLAGS, why) : n;            /* number of launches recorded (>= 0) */
 }
 
 int ccnet_cca_mfma_selftest(float *scratch, ccnet_stream_t stream) {

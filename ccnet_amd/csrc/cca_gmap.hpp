@@ -28,12 +28,24 @@
 // before the MFMA phase; rounded to bf16 once.  A group's stores stay in flight across the next group's barrier (counted
 // vmcnt).  Measured (profiles/r02f_*): the 512-channel launches move their bytes at 4.2 - 4.6 TB/s.
 #pragma once
-#include "cca_band.hpp"
 #include "cca_common.hpp"
 
 #include <type_traits>
 
 namespace cca {
+
+// k-step plan of a contraction of length L: nbf split-bf16 steps of 32, then (tail) one exact f32 step of 4 at 32 * nbf
+struct BandK {
+    int nbf;
+    bool tail;
+};
+__device__ __forceinline__ BandK band_ksteps(int L) {
+    const int nfull = L >> 5, rem = L & 31;
+    BandK k;
+    k.tail = rem > 0 && rem <= 4;
+    k.nbf = nfull + (rem > 4 ? 1 : 0);
+    return k;
+}
 
 constexpr int GM_CG = 64;                       // channels per group = four MFMA N tiles
 constexpr int GM_WAVES = 8;                     // gweight

@@ -123,12 +123,71 @@ __device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(
 
 }  // namespace cca
 
+// ---- launch profiler (ccnet_cca_profile_begin / _end): when armed, every launch is bracketed by a HIP-event pair on
+// ---- its own stream, so a tool can read each launch's duration INSIDE a step (bench.py: gpu_kernel_sum_ms, idle_ms)
+// ---- without an external profiler.  Disarmed (the default) it costs one relaxed atomic load per launch.
+#include <atomic>
+#include <stdio.h>
+namespace cca_prof {
+constexpr int kMaxLaunches = 256;
+struct State {
+    std::atomic<int> armed{0};
+    int n = 0, cap = 0;
+    hipEvent_t e0[kMaxLaunches], e1[kMaxLaunches];
+    const char *name[kMaxLaunches];
+};
+inline State &state() { static State s; return s; }
+inline int before(const char *name, hipStream_t stream) {
+    State &s = state();
+    if (!s.armed.load(std::memory_order_relaxed) || s.n >= s.cap) return -1;
+    const int i = s.n++;
+    s.name[i] = name;
+    (void)hipEventRecord(s.e0[i], stream);
+    return i;
+}
+inline void after(int i, hipStream_t stream) {
+    if (i >= 0) (void)hipEventRecord(state().e1[i], stream);
+}
+// arm: returns nullptr or the reason it could not
+inline const char *begin(int max_launches) {
+    State &s = state();
+    if (s.armed.load()) return "profile_begin: already armed";
+    if (max_launches <= 0 || max_launches > kMaxLaunches) return "profile_begin: 1..256 launches";
+    for (int i = s.cap; i < max_launches; ++i) {              // events are created once and kept
+        if (hipEventCreate(&s.e0[i]) != hipSuccess || hipEventCreate(&s.e1[i]) != hipSuccess) return "profile_begin: hipEventCreate failed";
+        s.cap = i + 1;
+    }
+    s.n = 0;
+    s.armed.store(1);
+    return nullptr;
+}
+// disarm, wait for the recorded launches, hand out durations and names; returns the count
+inline int end(float *ms, char *names, int name_stride, int cap, const char **why) {
+    State &s = state();
+    if (!s.armed.load()) { *why = "profile_end: not armed"; return 0; }
+    s.armed.store(0);
+    const int n = s.n < cap ? s.n : cap;
+    for (int i = 0; i < n; ++i) {
+        float t = 0.f;
+        if (hipEventSynchronize(s.e1[i]) != hipSuccess || hipEventElapsedTime(&t, s.e0[i], s.e1[i]) != hipSuccess) {
+            *why = "profile_end: reading an event pair failed";
+            return 0;
+        }
+        if (ms) ms[i] = t;
+        if (names && name_stride > 0) snprintf(names + (size_t)i * name_stride, (size_t)name_stride, "%s", s.name[i]);
+    }
+    return n;
+}
+}  // namespace cca_prof
+
 // kernel launch on a caller-given stream; a stale error of an earlier, unrelated HIP call is cleared first so that
 // launch_status() reports this launch and nothing else
 #define CCA_LAUNCH(kern, grid, block, stream, ...)                                        \
     do {                                                                                   \
         (void)hipGetLastError();                                                           \
+        const int cca_prof_i_ = cca_prof::before(#kern, (hipStream_t)(stream));            \
         hipLaunchKernelGGL(kern, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__); \
+        cca_prof::after(cca_prof_i_, (hipStream_t)(stream));                               \
     } while (0)
 
 // number of compute units of the CURRENT device (the channel splits are balanced for it)

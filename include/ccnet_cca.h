@@ -115,22 +115,6 @@ int ccnet_ca_softmax_backward_f32(const float *A, const float *dA, const float *
 int ccnet_ca_map_forward_f32(const float *A, const float *v, const float *x, const float *gamma,
                              float *out, int B, int C, int H, int W, ccnet_stream_t stream);
 
-/* ca_map_forward with the value tensor in PIXEL-MAJOR layout and both branches in ONE launch (row-band kernel,
- * csrc/cca_band.hpp): replaces functions.py:42-49 like ccnet_ca_map_forward_f32, but ``v`` is (B, H*W, v_ps) --
- * channel c of pixel p = h*W + w of image b at v[b*v_bs + p*v_ps + c] -- which is what the projection GEMM
- * (functions.py:35) emits when it is run as x^T W^T (+ bias), e.g. the value slice of one stacked (B, H*W, 2Cq+C)
- * projection.  x (residual, required) and out stay dense NCHW.  max(H, W) <= 100, C % 4 == 0. */
-int ccnet_ca_map_forward_pm_f32(const float *A, const float *v, const float *x, const float *gamma, float *out,
-                                int B, int C, int H, int W, long v_bs, int v_ps, ccnet_stream_t stream);
-
-/* One branch of a map-type contraction on PIXEL-MAJOR features (csrc/cca_gmap.hpp): per strip g of the branch
- * (row != 0: rows, else columns)  out[pixel, c] = alpha * sum P_g * F [+ addend[pixel, c]]  with the strip's attention
- * block P_g taken from T (B,H,W,H+W) as is (trans == 0: ca_map_forward / dq) or transposed (trans != 0: dv / dk).
- * F, addend and out are (B, H*W, pixel stride) fp32; addend (may be NULL) and out share strides and may alias. */
-int ccnet_ca_strip_map_pm_f32(const float *T, const float *F, const float *addend, const float *gamma, float *out,
-                              int B, int C, int H, int W, long f_bs, int f_ps, long o_bs, int o_ps,
-                              int row, int trans, ccnet_stream_t stream);
-
 /* Adjoint of the aggregation (autograd of functions.py:42-47):
  *   dA (B,H,W,H+W) = un-scaled map adjoint  (sum_c dout * v at the slot's source pixel); may be NULL
  *   dv (B,C,H,W)   = g * (A^T-weighted sums of dout), g = *gamma (1 if NULL); may be NULL */
@@ -260,6 +244,13 @@ int ccnet_cca_backward_pm_nchw_f32(const float *dy, const float *q, const float 
 /* Which kernel family serves this shape under the current impl setting: 1 = stationary MFMA strip kernels
  * (max(H,W) <= 100), 2 = windowed MFMA strip kernels (101 .. 320), 0 = any-shape kernels. */
 int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W);
+
+/* Launch profiler (a measurement aid, off by default).  Between ``begin`` and ``end`` every kernel launch the library
+ * issues is bracketed by a HIP-event pair on its stream; ``end`` disarms, waits for the recorded launches and returns
+ * their count (>= 0), filling ms[i] with launch i's duration and names + i * name_stride with its kernel name.
+ * Not re-entrant (one armed session per process); negative return = error.  Do not arm during a stream capture. */
+int ccnet_cca_profile_begin(int max_launches);
+int ccnet_cca_profile_end(float *ms, char *names, int name_stride, int cap);
 
 /* Device self-test of the MFMA fragment layout the kernels assume (asymmetric operands).
  * ``scratch`` >= 64 bytes of device memory.  The one entry point that synchronises ``stream`` (it copies

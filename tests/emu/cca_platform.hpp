@@ -161,5 +161,11 @@ __device__ inline void barrier_dma_keep() { __syncthreads(); }
 
 #define CCA_LAUNCH(kern, grid, block, stream, ...) emu::launch((grid), (block), [&]() { kern(__VA_ARGS__); })
 
+// the launch profiler measures HIP events: nothing to measure in the emulator
+namespace cca_prof {
+inline const char *begin(int) { return "profile_begin: not available in the emulator build"; }
+inline int end(float *, char *, int, int, const char **why) { *why = "profile_end: not available in the emulator build"; return 0; }
+}  // namespace cca_prof
+
 inline int cca_current_device_cus() { return 0; }      // the host default (256) applies
 inline int cca_current_device() { return 0; }

@@ -87,25 +87,6 @@ class EmuOps:
         self.lib.check(self.lib.ccnet_ca_map_forward_f32(_p(A), _p(v), _p(x), _p(gamma), _p(out), B, C, H, W, None))
         return out
 
-    def ca_map_forward_pm(self, A, v_pm, x, gamma=None, C=None):
-        """v_pm: (B, H*W, ps) pixel-major array whose first C columns are the value channels; x, out NCHW."""
-        B, C_, H, W = x.shape
-        out = np.full_like(x, np.nan)
-        self.lib.check(self.lib.ccnet_ca_map_forward_pm_f32(_p(A), _p(v_pm), _p(x), _p(gamma), _p(out), B, C_, H, W,
-                                                            v_pm.shape[1] * v_pm.shape[2], v_pm.shape[2], None))
-        return out
-
-    def strip_map_pm(self, T, F_pm, shape, row, trans, addend=None, gamma=None):
-        """one branch on pixel-major features; F_pm (B, H*W, ps); returns out (B, H*W, C) pixel-major"""
-        B, C, H, W = shape
-        out = np.full((B, H * W, C), np.nan, np.float32)
-        if addend is not None:
-            out[...] = addend
-        self.lib.check(self.lib.ccnet_ca_strip_map_pm_f32(_p(T), _p(F_pm), _p(out) if addend is not None else None, _p(gamma),
-                                                          _p(out), B, C, H, W, F_pm.shape[1] * F_pm.shape[2], F_pm.shape[2],
-                                                          H * W * C, C, int(row), int(trans), None))
-        return out
-
     def ca_map_backward(self, dout, A, v, gamma=None):
         B, C, H, W = v.shape
         dA = np.full_like(A, np.nan)

@@ -17,6 +17,10 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-3          # the north_star tolerance (max abs, fp32)
 TIGHT = 5e-5        # what exact-fp32 MFMA actually delivers on O(1) data
+# parameter-gradient bars of the golden-vector module tests: 3 x the worst error measured on MI355X (round 3,
+# profiles/r03*_pytest_gpu.log prints the per-parameter errors); until that log exists they are the round-2 bars
+PARAM_GRAD_TOL_SMALL = 5e-3      # (2,64,32,32): sums over 2048 pixels
+PARAM_GRAD_TOL_97 = 1e-2         # (1,64,97,97): sums over 9409 pixels
 DIRECT, MFMA = 1, 2
 
 
@@ -127,9 +131,11 @@ def test_config1_module_matches_reference(lib, dev):
     xd = x.to(dev).requires_grad_(True)
     y = m(xd)
     y.backward(dy.to(dev))
+    pe = {n: err(p.grad, g["grad." + n]) for n, p in m.named_parameters()}
+    print("golden cfg1_2x64x32x32 y", f"{err(y, g['y']):.1e}", "dx", f"{err(xd.grad, g['dx']):.1e}", {n: f"{e:.1e}" for n, e in pe.items()})
     assert err(y, g["y"]) < TOL and err(xd.grad, g["dx"]) < TOL
-    for n, p in m.named_parameters():
-        assert err(p.grad, g["grad." + n]) < TOL * 5, n     # weight grads sum 2048 pixels: abs 5e-3 on O(10) values
+    for n, e in pe.items():
+        assert e < PARAM_GRAD_TOL_SMALL, n     # weight grads sum <= 2048 pixels (bar = 3 x the measured worst case, r03)
 
 
 def test_fast_path_geometry_matches_live_reference_golden(lib, dev):
@@ -148,9 +154,11 @@ def test_fast_path_geometry_matches_live_reference_golden(lib, dev):
     xd = x.to(dev).requires_grad_(True)
     y = m(xd)
     y.backward(dy.to(dev))
+    pe = {n: err(p.grad, g["grad." + n]) for n, p in m.named_parameters()}
+    print("golden fast_1x64x97x97 y", f"{err(y, g['y']):.1e}", "dx", f"{err(xd.grad, g['dx']):.1e}", {n: f"{e:.1e}" for n, e in pe.items()})
     assert err(y, g["y"]) < TOL and err(xd.grad, g["dx"]) < TOL
-    for n, p in m.named_parameters():
-        assert err(p.grad, g["grad." + n]) < TOL * 10, n     # weight grads sum 9409 pixels
+    for n, e in pe.items():
+        assert e < PARAM_GRAD_TOL_97, n     # weight grads sum 9409 pixels (bar = 3 x the measured worst case, r03)
 
 
 def test_headline_shape_against_oracle_and_direct_kernels(lib, dev):
@@ -417,15 +425,18 @@ def _pm_inputs(B, C, H, W, dev, seed, qk_scale=1.0):
 
 @pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 128, 17, 20), (2, 64, 40, 33), (1, 64, 97, 97), (1, 64, 129, 70),
                                    (1, 128, 100, 132), (1, 64, 1, 9),
-                                   (1, 512, 129, 129)])     # one image of BASELINE configs[4] at its full geometry
+                                   (1, 512, 129, 129),      # one image of BASELINE configs[4] at its full geometry
+                                   (1, 512, 129, 129, "n01"),   # the same with UNSCALED N(0,1) q, k: the peaky-softmax worst case
+                                   (1, 512, 97, 97, "n01")])
 def test_pixel_major_bf16_kernels_match_oracle(lib, dev, shape):
     """BASELINE configs[4] on the pixel-major bf16 MFMA kernels (csrc/cca_gmap.hpp) at oracle-sized shapes, both
     padded strip lengths (100, 132): packed bf16 projection in, bf16 y / packed dqkv out, fp32 attention.  Oracle: the fp32
     restatement on the same bf16-rounded inputs; tolerance = the fp32 bar + one rounding of each output to bf16."""
     from ccnet_amd.functions import CrissCrossPMBF16Function
-    B, C, H, W = shape
+    unscaled = len(shape) == 5
+    B, C, H, W = shape[:4]
     cq = C // 8
-    q, k, v, x, dy, qkv, xp, dyp = _pm_inputs(B, C, H, W, dev, seed=53, qk_scale=0.35 if C >= 512 else 1.0)
+    q, k, v, x, dy, qkv, xp, dyp = _pm_inputs(B, C, H, W, dev, seed=53, qk_scale=0.35 if C >= 512 and not unscaled else 1.0)
     gamma = torch.tensor([0.5], device=dev, requires_grad=True)
     qkv.requires_grad_(True)
     xp.requires_grad_(True)
@@ -437,25 +448,31 @@ def test_pixel_major_bf16_kernels_match_oracle(lib, dev, shape):
     yo, Ao = O.cca_core_forward(f(q), f(k), f(v), f(x), f(gamma))
     go = O.cca_core_backward(f(dy), f(q), f(k), f(v), Ao, f(gamma))
     tol = lambda ref: 2.0 ** -8 * ref.abs() + TOL                           # noqa: E731
-    assert bool(((nchw(y) - yo).abs() <= tol(yo)).all())
     g = qkv.grad
-    for got, name in ((g[..., :cq], "dq"), (g[..., cq:2 * cq], "dk"), (g[..., 2 * cq:], "dv")):
-        assert bool(((nchw(got) - go[name]).abs() <= tol(go[name])).all()), name
+    pairs = (("y", nchw(y), yo), ("dq", nchw(g[..., :cq]), go["dq"]), ("dk", nchw(g[..., cq:2 * cq]), go["dk"]),
+             ("dv", nchw(g[..., 2 * cq:]), go["dv"]))
+    # reported: the worst excess over the pure output-rounding allowance 2^-8 |ref| (what the fp32 bar TOL has to cover)
+    print("pixel-major bf16 max excess over 2^-8|ref| vs oracle", shape,
+          {n: f"{float(((a - b).abs() - 2.0 ** -8 * b.abs()).max()):.1e}" for n, a, b in pairs})
+    for n, a, b in pairs:
+        assert bool(((a - b).abs() <= tol(b)).all()), n
     assert torch.equal(xp.grad, dyp)
     assert abs(float(gamma.grad) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 96, 17, 20), (2, 64, 40, 33), (1, 64, 100, 70), (1, 32, 1, 9),
-                                   (1, 512, 97, 97)])
+                                   (1, 512, 97, 97),
+                                   (1, 512, 97, 97, "n01")])    # UNSCALED N(0,1) q, k (the strips' headline test uses the same)
 def test_pixel_major_fp32_kernels_match_oracle(lib, dev, shape):
     """The pixel-major family on fp32 views (ccnet_cca_{forward,backward}_pm_f32: one strip per workgroup -- the small-batch
     path): packed fp32 projection in, y / packed dqkv out, against the oracle at the north_star bar (1e-3 max abs); the
     attention itself (exact fp32 energies) at the tight bar, the column self slot exactly 0."""
     from ccnet_amd.functions import CrissCrossPMFunction
-    B, C, H, W = shape
+    unscaled = len(shape) == 5
+    B, C, H, W = shape[:4]
     cq = C // 8
     q, k, v, x, dy = make_core_inputs(B, C, H, W, seed=57)
-    if C >= 512:
+    if C >= 512 and not unscaled:
         q, k = q * 0.35, k * 0.35
     pm = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)               # noqa: E731
     qkv = torch.cat([pm(q), pm(k), pm(v)], dim=3).contiguous().requires_grad_(True)
@@ -476,19 +493,21 @@ def test_pixel_major_fp32_kernels_match_oracle(lib, dev, shape):
     assert abs(float(gamma.grad) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
 
 
-@pytest.mark.parametrize("shape", [(1, 64, 20, 24), (2, 96, 33, 18), (1, 512, 97, 97)])
+@pytest.mark.parametrize("shape", [(1, 64, 20, 24), (2, 96, 33, 18), (1, 512, 97, 97), (1, 512, 97, 97, "default-init")])
 def test_pixel_major_fp32_module_node_matches_the_strip_node_and_the_oracle(lib, dev, shape):
     """CrissCrossPMModuleFunction (projection GEMM emitting the packed pixel-major q | k | v, core with NCHW x / y / dy, one
     autograd node) is what the module runs for small fp32 batches: same y, dx and parameter gradients as the NCHW-strip node
     (tolerance: the two families' own arithmetic), and y against the oracle at the north_star bar."""
     from ccnet_amd import CrissCrossAttention
-    B, C, H, W = shape
+    halve = len(shape) == 4                     # 5th element: the projections keep their default initialisation
+    B, C, H, W = shape[:4]
     torch.manual_seed(5)
     ms = CrissCrossAttention(C).to(dev)
     with torch.no_grad():
         ms.gamma.fill_(0.5)
         for c in (ms.query_conv, ms.key_conv):
-            c.weight.mul_(0.5)
+            if halve:
+                c.weight.mul_(0.5)
     mp = CrissCrossAttention(C).to(dev)
     mp.load_state_dict(ms.state_dict())
     ms.pixel_major_max_batch, mp.pixel_major_max_batch = 0, 1 << 30
@@ -500,11 +519,14 @@ def test_pixel_major_fp32_module_node_matches_the_strip_node_and_the_oracle(lib,
         y = m(xi)
         y.backward(dy)
         outs.append((y.detach(), xi.grad, {n: p.grad for n, p in m.named_parameters()}))
+    rel = {n: err(g, outs[1][2][n]) / max(1.0, float(g.abs().max())) for n, g in outs[0][2].items()}
+    print("pixel-major module node vs strip node", shape, "y", f"{err(outs[0][0], outs[1][0]):.1e}", "dx",
+          f"{err(outs[0][1], outs[1][1]) / max(1.0, float(outs[0][1].abs().max())):.1e}",
+          {n: f"{e:.1e}" for n, e in rel.items()})
     assert outs[1][0].is_contiguous() and err(outs[0][0], outs[1][0]) < 2e-4
     assert err(outs[0][1], outs[1][1]) < 5e-4 * max(1.0, float(outs[0][1].abs().max()))
-    for n, g in outs[0][2].items():
-        ref = float(g.abs().max())
-        assert err(g, outs[1][2][n]) < 2e-3 * max(1.0, ref), n
+    for n, e in rel.items():
+        assert e < 2e-3, n
     with torch.no_grad():
         f = lambda t: t.detach().float().cpu()                              # noqa: E731
         qo, ko, vo = (f(c(x)) for c in (ms.query_conv, ms.key_conv, ms.value_conv))
@@ -538,6 +560,22 @@ def test_pixel_major_bf16_module_route_and_full_size(lib, dev):
     for got, ref, name in ((g[..., :cq], b[0].grad, "dq"), (g[..., cq:2 * cq], b[1].grad, "dk"), (g[..., 2 * cq:], b[2].grad, "dv")):
         assert bool(((nchw(got) - ref).abs() <= tol(ref)).all()), name
     assert abs(float(ga.grad) - float(b[4].grad)) < 2e-3 * max(1.0, abs(float(b[4].grad)))
+    # images 0 and B - 1 of the full batch against the CPU ORACLE (the op has no cross-image term, so one image of the
+    # batch is a (1,512,129,129) problem): the full-size run is pinned to the oracle, not only to the other HIP family
+    f = lambda t: t.detach().float().cpu()                                  # noqa: E731
+    tolo = lambda ref: 2.0 ** -8 * ref.abs() + TOL                          # noqa: E731
+    for i in (0, B - 1):
+        sl = slice(i, i + 1)
+        qi, ki, vi, xi = (f(t[sl]) for t in b[:4])
+        yo, Ao = O.cca_core_forward(qi, ki, vi, xi, f(gamma))
+        go = O.cca_core_backward(f(dy[sl]), qi, ki, vi, Ao, f(gamma))
+        cpu = lambda t: f(t[sl]).permute(0, 3, 1, 2)                        # noqa: E731
+        pairs = (("y", cpu(ya), yo), ("dq", cpu(g[..., :cq]), go["dq"]), ("dk", cpu(g[..., cq:2 * cq]), go["dk"]),
+                 ("dv", cpu(g[..., 2 * cq:]), go["dv"]))
+        print(f"configs[4] full batch, image {i} vs oracle: max excess over 2^-8|ref|",
+              {n: f"{float(((a_ - r_).abs() - 2.0 ** -8 * r_.abs()).max()):.1e}" for n, a_, r_ in pairs})
+        for n, a_, r_ in pairs:
+            assert bool(((a_ - r_).abs() <= tolo(r_)).all()), (i, n)
     del b, ya, yb, g, qkv, xp, dyp, dy
     torch.cuda.empty_cache()
     # module route: bf16 channels_last activations

@@ -29,8 +29,13 @@ res = {}
 for k, d in sorted(agg.items()):
     res[k] = {c: sum(v) / len(v) for c, v in d.items()}
     res[k]["dispatches"] = max(len(v) for v in d.values())
+# the kernel sources the profiled library was built from, hashed NOW (at profiling time, on the box that ran it)
+sys.path.insert(0, ".")
+from ccnet_amd import _lib as _cl
+res["_src_sha16"] = _cl.kernel_source_sha16()
 json.dump(res, open(out + "/summary.json", "w"), indent=1)
 for k, d in res.items():
+    if k.startswith("_"): continue
     print(k)
     print("   ", {c: (round(v, 1) if v < 1e6 else f"{v:.4g}") for c, v in d.items()})
 PY

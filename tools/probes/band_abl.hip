@@ -1,7 +1,7 @@
 // Development probe: times map_band_fwd_kernel (csrc/cca_band.hpp) with parts of it compiled out (-DBAND_ABL=mask).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../ccnet_amd/csrc -DBAND_ABL=<mask> band_abl.hip -o band_abl_<mask>
 #include "cca_common.hpp"
-#include "cca_band.hpp"
+#include "cca_band.hpp"   // (lives next to this probe since round 3; needs -I ../../ccnet_amd/csrc)
 #include <cstdio>
 #include <cstdlib>
 #include <vector>

@@ -1,6 +1,6 @@
 #!/bin/bash
 # summarise -Rpass-analysis=kernel-resource-usage output: name vgpr agpr scratch spill lds
-cd "$(dirname "$0")/../ccnet_amd/csrc" && hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Rpass-analysis=kernel-resource-usage cca_api.hip -o libccnet_cca.so 2>&1 | python3 -c "
+cd "$(dirname "$0")/../ccnet_amd/csrc" && hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -I. -Rpass-analysis=kernel-resource-usage cca_api.hip -o /tmp/libccnet_resusage.so 2>&1 | python3 -c "
 import sys,re
 cur=None;rows={}
 for l in sys.stdin:

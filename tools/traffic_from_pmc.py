@@ -11,16 +11,17 @@ only quotes the traffic when it benches a build of those same sources) and the p
 With ``--steps N`` the profiled command ran N steps in which a kernel may be launched several times (the pixel-major bf16
 step, tools/pm_bf16_time.py: 3 warm-up + 10 timed forward/backward pairs = 13): the per-step total is then
 sum(kernel average * dispatches) / N, and ``--out`` names the file (profiles/traffic_bf16_latest.json).
-usage: traffic_from_pmc.py <summary.json> [--steps N] [--out NAME.json] [--lib libccnet_cca.so]"""
+The source hash is the one tools/pmc.sh recorded INSIDE the summary at profiling time; a summary without it, or whose hash
+differs from the working tree's kernel sources, is refused (re-profile instead of restamping).
+usage: traffic_from_pmc.py <summary.json> [--steps N] [--out NAME.json]"""
 import argparse, hashlib, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ap = argparse.ArgumentParser()
 ap.add_argument("src")
 ap.add_argument("--steps", type=int, default=0)
 ap.add_argument("--out", default="traffic_latest.json")
-ap.add_argument("--lib", default=os.path.join(ROOT, "ccnet_amd", "csrc", "libccnet_cca.so"))
 a = ap.parse_args()
-src, lib = a.src, a.lib
+src = a.src
 
 
 def label(k):
@@ -36,6 +37,13 @@ def label(k):
 
 
 d = json.load(open(src))
+sys.path.insert(0, ROOT)
+from ccnet_amd import _lib as _cl
+sha = d.pop("_src_sha16", None)
+if sha is None:
+    sys.exit(f"{src}: no _src_sha16 recorded at profiling time (tools/pmc.sh writes it); refusing to stamp it now")
+if sha != _cl.kernel_source_sha16():
+    sys.exit(f"{src}: profiled sources {sha} != working tree {_cl.kernel_source_sha16()}; re-profile")
 out, total = {}, 0
 for k, v in d.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
@@ -43,8 +51,6 @@ for k, v in d.items():
         out[label(k) or k] = nbytes
         total += nbytes * v.get("dispatches", 1) / a.steps if a.steps else nbytes
 out["_step_total_bytes"] = int(total)
-sys.path.insert(0, ROOT)
-from ccnet_amd import _lib as _cl
-out["_src_sha16"] = _cl.kernel_source_sha16()          # hipcc output is not bit-reproducible: key = the kernel sources
+out["_src_sha16"] = sha                                # recorded by tools/pmc.sh when the counters were taken
 json.dump(out, open(os.path.join(ROOT, "profiles", a.out), "w"), indent=1)
 print(json.dumps(out, indent=1))
