@@ -93,6 +93,17 @@ __device__ __forceinline__ void fbuf_load_to_lds_x4(const FBuf &b, float *lds_wa
                                              voff_bytes, soff_bytes, 0, 0);
 }
 
+// ds_read_b64_tr_b16 (gfx950 transposing LDS read): every lane passes the 8-byte-aligned LDS address of 4 consecutive
+// 16-bit elements; inside each group of 16 lanes, lane i receives element (i & 3) of the 8 bytes addressed by lane
+// 4 j + (i >> 2), j = 0..3 -- i.e. the group reads a [4 rows][16 columns] block (row r supplied as four 8-byte pieces by
+// lanes 4 r .. 4 r + 3) and lane i gets column i, rows 0..3 packed as two dwords (row 0 in the low half of the first).
+// Probed on MI355X with arbitrary per-lane addresses: tools/probes/tr16_probe.hip.  Wave-collective.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x2 lds_read_tr16_b64(const void *p) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t *)p));
+}
+
 // Workgroup barrier that orders LDS traffic only: waits for this wave's LDS operations (lgkmcnt) but NOT for
 // its outstanding global stores / loads (vmcnt).  __syncthreads() drains vmcnt as well whenever an LDS-DMA
 // has been issued, which would stall every chunk on the acknowledgement of the tile stores.

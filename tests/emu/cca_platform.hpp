@@ -148,6 +148,20 @@ __device__ inline void fbuf_load_to_lds_x4(const FBuf &b, float *lds_wave_base, 
         lds_wave_base[4 * emu::lane_id() + e] = fbuf_load(b, voff_bytes + 4 * e, soff_bytes);
 }
 
+// ds_read_b64_tr_b16: see the product header.  Lane i of each 16-lane group receives, for j = 0..3, element (i & 3) of
+// the 8 bytes addressed by lane 4 j + (i >> 2) of its group.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ inline u32x2 lds_read_tr16_b64(const void *p) {
+    const uint64_t *s = emu::wave_exchange((uint64_t)(uintptr_t)p);
+    const int l = emu::lane_id(), grp = l & ~15, i = l & 15;
+    uint16_t e[4];
+    for (int j = 0; j < 4; ++j) {
+        const uint16_t *src = (const uint16_t *)(uintptr_t)s[grp + 4 * j + (i >> 2)];
+        memcpy(&e[j], src + (i & 3), 2);
+    }
+    return u32x2{(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16)};
+}
+
 __device__ inline void barrier_lds_only() { __syncthreads(); }
 template <int KEEP>
 __device__ inline void barrier_dma_keep() { __syncthreads(); }

@@ -18,9 +18,9 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3          # the north_star tolerance (max abs, fp32)
 TIGHT = 5e-5        # what exact-fp32 MFMA actually delivers on O(1) data
 # parameter-gradient bars of the golden-vector module tests: 3 x the worst error measured on MI355X (round 3,
-# profiles/r03*_pytest_gpu.log prints the per-parameter errors); until that log exists they are the round-2 bars
-PARAM_GRAD_TOL_SMALL = 5e-3      # (2,64,32,32): sums over 2048 pixels
-PARAM_GRAD_TOL_97 = 1e-2         # (1,64,97,97): sums over 9409 pixels
+# profiles/r03a_pytest_gpu.log prints the per-parameter errors; round 2 used 5e-3 / 1e-2)
+PARAM_GRAD_TOL_SMALL = 1e-3      # (2,64,32,32): worst measured 3.4e-4 (query_conv.weight), profiles/r03a_pytest_gpu.log
+PARAM_GRAD_TOL_97 = 1.5e-3       # (1,64,97,97): worst measured 4.8e-4 (gamma), profiles/r03a_pytest_gpu.log
 DIRECT, MFMA = 1, 2
 
 
