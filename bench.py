@@ -332,6 +332,47 @@ class PixelMajorF32Workload:
         self.backward()
 
 
+class PlanesWorkload(PixelMajorF32Workload):
+    """The fp32 core on the SPLIT-PLANE path (include/ccnet_cca.h): q | k fp32 pixel-major slices of the packed projection,
+    v as bf16 hi | lo planes (split once by its producer, ccnet_cca_split_planes_f32 -- outside the core step, like the
+    projection itself; ``split_ms`` times it), x / y / dy NCHW, dy split inside the timed step, dq | dk | dv fp32 pixel-major."""
+
+    def __init__(self, lib, B, C, H, W, device, seed):
+        super().__init__(lib, B, C, H, W, device, seed)
+        Cq = C // 8
+        self.vpl = torch.empty(B, H, W, 2, C, dtype=torch.int16, device=device)
+        self.fws_bytes = lib.ccnet_cca_planes_workspace_bytes(B, C, Cq, H, W, 0)
+        self.ws_bytes = lib.ccnet_cca_planes_workspace_bytes(B, C, Cq, H, W, 1)
+        self.ws = torch.empty(max(self.fws_bytes, self.ws_bytes) // 4 + 64, device=device)
+        self.split()
+        torch.cuda.synchronize()
+
+    def split(self):
+        B, C, H, W = self.shape
+        L, cq, ct = self.lib, C // 8, self.ct
+        L.check(L.ccnet_cca_split_planes_f32(self.qkv.data_ptr() + 8 * cq, self.vpl.data_ptr(), B, C, H, W, H * W * ct, ct,
+                                             H * W * 2 * C, 2 * C, self.stream()), "split_planes")
+
+    def forward(self):
+        B, C, H, W = self.shape
+        L, cq, ct, p = self.lib, C // 8, self.ct, self.qkv.data_ptr()
+        bs = H * W * ct
+        L.check(L.ccnet_cca_forward_planes_f32(p, p + 4 * cq, self.vpl.data_ptr(), self.x.data_ptr(), self.gamma.data_ptr(),
+                                               self.y.data_ptr(), self.A.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct,
+                                               H * W * 2 * C, 2 * C, self.ws.data_ptr(), self.fws_bytes, self.stream()),
+                "cca_forward_planes")
+
+    def backward(self):
+        B, C, H, W = self.shape
+        L, cq, ct, p, g = self.lib, C // 8, self.ct, self.qkv.data_ptr(), self.dqkv.data_ptr()
+        bs = H * W * ct
+        L.check(L.ccnet_cca_backward_planes_f32(self.dy.data_ptr(), p, p + 4 * cq, self.vpl.data_ptr(), self.A.data_ptr(),
+                                                self.gamma.data_ptr(), g, g + 4 * cq, g + 8 * cq, self.dgamma.data_ptr(),
+                                                self.scratch.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct, H * W * 2 * C, 2 * C,
+                                                bs, ct, bs, ct, bs, ct, self.ws.data_ptr(), self.ws_bytes, self.stream()),
+                "cca_backward_planes")
+
+
 def bf16_config5(lib, device, shape=(16, 512, 129, 129), iters=20):
     """BASELINE.json configs[4] as an extra of the fp32 line: fwd+bwd of the pixel-major bf16 core, per-step statistics."""
     wl = PixelMajorBF16Workload(lib, *shape, device, 4321)

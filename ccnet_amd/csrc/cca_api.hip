@@ -1038,6 +1038,125 @@ int ccnet_cca_backward_pm_nchw_f32(const float *dy, const float *q, const float 
                                   workspace, base, stream);
 }
 
+/* ---- SPLIT-PLANE path (cca_gmap.hpp, bf16p_t): the fp32 core with its C-sized contraction operands (v, dy) pre-split
+ * ---- into bf16 hi | lo planes by their producers.  q, k stay fp32 pixel-major (the energies are exact fp32 products), the
+ * ---- module's x, y, dy are NCHW, dq | dk | dv leave as fp32 pixel-major views (one GEMM operand downstream). ---- */
+extern "C++" {
+namespace {
+using cca::bf16p_t;
+int check_planes_view(const char *what, long bs, int ps, int C, int H, int W) {
+    if (C % 8 || ps < 2 * C || ps % 8 || bs < (long)(H * W - 1) * ps + 2 * C || bs % 8) return fail(CCNET_E_BADSHAPE, what);
+    if ((double)H * W * ps >= 1073741824.0) return fail(CCNET_E_BADSHAPE, what);            /* 2-byte elements, 31-bit offsets */
+    return 0;
+}
+// column strips -> fp32 partial, row strips add it (+ the NCHW residual) and write the output
+template <bool TRANS, bool NCHW>
+int launch_gmap_planes(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
+                       int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
+    const long pbs = (long)H * W * C;
+    const GmapPlan gc = gmap_plan(B * W, C), gr = gmap_plan(B * H, C);
+    CCA_LAUNCH((cca::gmap_kernel<100, false, TRANS, false, bf16p_t, float>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS),
+               stream, T, F, (const float *)nullptr, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0,
+               0L, 0, pbs, C, gc.n_whole, gc.split, cca::GmapJob<bf16p_t, float>{});
+    if (int e = launch_status("gmap_planes(column)")) return e;
+    CCA_LAUNCH((cca::gmap_kernel<100, true, TRANS, true, bf16p_t, float, NCHW>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS),
+               stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C, rbs, rps, obs, ops,
+               gr.n_whole, gr.split, cca::GmapJob<bf16p_t, float>{});
+    return launch_status("gmap_planes(row)");
+}
+size_t planes_bytes(int B, int C, int H, int W) { return (size_t)B * H * W * 2 * C * 2; }
+}  // namespace
+}  // extern "C++"
+
+size_t ccnet_cca_planes_workspace_bytes(int B, int C, int Cq, int H, int W, int backward) {
+    const size_t base = pm_workspace_bytes(B, C, Cq, H, W, backward);
+    if (!base) return 0;
+    return align256(base) + (backward ? planes_bytes(B, C, H, W) : 0);                       /* + dy as planes */
+}
+
+int ccnet_cca_split_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, int src_ps,
+                               long dst_bs, int dst_ps, ccnet_stream_t stream) {
+    if (int e = check_shape(B, C, H, W)) return e;
+    if (!src || !dst) return fail(CCNET_E_NULLPTR, "split_planes: null tensor");
+    if (int e = check_pm_view<float>("split_planes: source view (fp32 pixel-major)", src_bs, src_ps, C, H, W)) return e;
+    if (int e = check_planes_view("split_planes: destination view (C % 8, pixel stride >= 2 C)", dst_bs, dst_ps, C, H, W)) return e;
+    const int hw = H * W;
+    const long items = (long)hw * (C / 8);
+    const unsigned gx = (unsigned)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
+    CCA_LAUNCH(cca::pm_split_kernel, dim3(gx, (unsigned)B), dim3(256), stream, src, (bf16p_t *)dst, C, hw, src_bs, src_ps, dst_bs, dst_ps);
+    return launch_status("split_planes");
+}
+
+int ccnet_cca_nchw_to_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, long dst_bs, int dst_ps,
+                                 ccnet_stream_t stream) {
+    if (int e = check_shape(B, C, H, W)) return e;
+    if (!src || !dst) return fail(CCNET_E_NULLPTR, "nchw_to_planes: null tensor");
+    if (src_bs < (long)C * H * W) return fail(CCNET_E_BADSHAPE, "nchw_to_planes: source batch stride");
+    if (int e = check_planes_view("nchw_to_planes: destination view (C % 8, pixel stride >= 2 C)", dst_bs, dst_ps, C, H, W)) return e;
+    const int hw = H * W;
+    CCA_LAUNCH(cca::nchw_to_planes_kernel, dim3((unsigned)(B * ((hw + 63) / 64)), (unsigned)((C + 63) / 64)), dim3(256), stream,
+               src, (bf16p_t *)dst, C, hw, src_bs, dst_bs, dst_ps);
+    return launch_status("nchw_to_planes");
+}
+
+int ccnet_cca_forward_planes_f32(const float *q, const float *k, const uint16_t *v_planes, const float *x, const float *gamma,
+                                 float *y, float *A, int B, int C, int Cq, int H, int W,
+                                 long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
+                                 void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
+    if (int e = require_both_branches("cca_forward_planes_f32")) return e;
+    if (!q || !k || !v_planes || !x || !gamma || !y || !A) return fail(CCNET_E_NULLPTR, "cca_forward_planes: null tensor");
+    if (int e = check_pm_problem<float>("cca_forward_planes: strips <= 100, C % 8 == 0, Cq % 4 == 0", B, C, Cq, H, W)) return e;
+    if (int e = check_pm_view<float>("cca_forward_planes: q view", q_bs, q_ps, Cq, H, W)) return e;
+    if (int e = check_pm_view<float>("cca_forward_planes: k view", k_bs, k_ps, Cq, H, W)) return e;
+    if (int e = check_planes_view("cca_forward_planes: v planes view", v_bs, v_ps, C, H, W)) return e;
+    if ((double)C * H * W >= 536870912.0) return fail(CCNET_E_BADSHAPE, "cca_forward_planes: image exceeds 2^29 elements");
+    if (!workspace || workspace_bytes < ccnet_cca_planes_workspace_bytes(B, C, Cq, H, W, 0))
+        return fail(CCNET_E_WORKSPACE, "cca_forward_planes: workspace missing or too small");
+    if (int e = gweight_pm<true, float>(q, k, A, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
+    if (int e = softmax_forward(A, A, B, H, W, stream)) return e;
+    const long img = (long)C * H * W;
+    return launch_gmap_planes<false, true>(A, (const bf16p_t *)v_planes, x, gamma, y, (float *)workspace, B, C, H, W, v_bs, v_ps,
+                                           img, 0, img, 0, stream);
+}
+
+int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *k, const uint16_t *v_planes, const float *A,
+                                  const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
+                                  int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps,
+                                  long v_bs, int v_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
+                                  void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
+    if (int e = require_both_branches("cca_backward_planes_f32")) return e;
+    if (!dy || !q || !k || !v_planes || !A || !gamma || !dq || !dk || !dv || !dgamma || !scratch)
+        return fail(CCNET_E_NULLPTR, "cca_backward_planes: null tensor");
+    if (int e = check_pm_problem<float>("cca_backward_planes: strips <= 100, C % 8 == 0, Cq % 4 == 0", B, C, Cq, H, W)) return e;
+    if (int e = check_pm_view<float>("cca_backward_planes: q view", q_bs, q_ps, Cq, H, W)) return e;
+    if (int e = check_pm_view<float>("cca_backward_planes: k view", k_bs, k_ps, Cq, H, W)) return e;
+    if (int e = check_planes_view("cca_backward_planes: v planes view", v_bs, v_ps, C, H, W)) return e;
+    if (int e = check_pm_view<float>("cca_backward_planes: dq view", dq_bs, dq_ps, Cq, H, W)) return e;
+    if (int e = check_pm_view<float>("cca_backward_planes: dk view", dk_bs, dk_ps, Cq, H, W)) return e;
+    if (int e = check_pm_view<float>("cca_backward_planes: dv view", dv_bs, dv_ps, C, H, W)) return e;
+    if (!workspace || workspace_bytes < ccnet_cca_planes_workspace_bytes(B, C, Cq, H, W, 1))
+        return fail(CCNET_E_WORKSPACE, "cca_backward_planes: workspace missing or too small");
+    const size_t sm = align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W));
+    const size_t base = align256(pm_workspace_bytes(B, C, Cq, H, W, 1));
+    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + sm);
+    uint16_t *dy_pl = reinterpret_cast<uint16_t *>(static_cast<char *>(workspace) + base);
+    const long dbs = (long)H * W * 2 * C;
+    // dy (NCHW, the module's gradient) -> planes, once: it is a contraction operand of four launches
+    if (int e = ccnet_cca_nchw_to_planes_f32(dy, dy_pl, B, C, H, W, (long)C * H * W, dbs, 2 * C, stream)) return e;
+    const bf16p_t *dyp = (const bf16p_t *)dy_pl, *vp = (const bf16p_t *)v_planes;
+    // t = un-scaled dA (the adjoint of the aggregation, functions.py:46-47), dv = gamma * A^T-weighted dy
+    {
+        const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
+        CCA_LAUNCH((cca::gweight_kernel<100, false, bf16p_t, false>), grid, block, stream, dyp, vp, scratch, C, H, W, dbs, 2 * C, v_bs, v_ps);
+        if (int e = launch_status("gweight_planes(dA)")) return e;
+    }
+    if (int e = launch_gmap_planes<true, false>(A, dyp, nullptr, gamma, dv, partial, B, C, H, W, dbs, 2 * C, 0L, 0, dv_bs, dv_ps, stream))
+        return e;
+    // dgamma = sum A t;  dE = gamma * A * (t - sum_s A t), in place
+    if (int e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, sm, B, H, W, stream, KSplit())) return e;
+    return gmap_dual_pm<float>(scratch, k, q, dq, dk, partial, B, Cq, H, W, k_bs, k_ps, q_bs, q_ps, dq_bs, dq_ps, dk_bs, dk_ps, stream);
+}
+
 /* ---- launch profiler: per-launch HIP-event durations inside a step (see cca_platform.hpp, cca_prof) ---- */
 int ccnet_cca_profile_begin(int max_launches) {
     const char *why = cca_prof::begin(max_launches);

@@ -73,10 +73,10 @@ struct GTile {
 // issued out of range: the DMA deposits zeros for them, so a tile is complete (and finite) after every fill
 template <typename FT>
 __device__ __forceinline__ void gtile_dma_piece(const FBuf &src, float *img, int piece, int lane, int pix0, int pstep, int n,
-                                                int ps, int c0, int C) {
+                                                int ps, int c0, int C, int plane_off = 0) {
     if constexpr (GTile<FT>::BF) {
         const int p = lane >> 3, i = 8 * piece + p, q = (lane & 7) ^ (p & 7), c = c0 + 8 * q;
-        fbuf_load_to_lds_x4(src, img + piece * GM_PB, (i < n && c < C) ? ((pix0 + i * pstep) * ps + c) * 2 : kOobOffset, 0);
+        fbuf_load_to_lds_x4(src, img + piece * GM_PB, (i < n && c < C) ? ((pix0 + i * pstep) * ps + plane_off + c) * 2 : kOobOffset, 0);
     } else {
         const int i = 4 * piece + (lane >> 4), c = c0 + 4 * ((lane & 15) ^ (i & 1));
         fbuf_load_to_lds_x4(src, img + piece * GM_PP, (i < n && c < C) ? ((pix0 + i * pstep) * ps + c) * 4 : kOobOffset, 0);
@@ -94,6 +94,47 @@ __device__ __forceinline__ int gtile_bf_byte(int j, int c) {
 }
 __device__ __forceinline__ uint32_t lds_load_u16(const float *base, int byte_off) {
     return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SPLIT PLANES: an fp32 feature tensor stored PRE-SPLIT as two bf16 planes per pixel, (B, H*W, 2, C):
+//     hi = bf16_rne(x) at [b][p][0][c],   lo = bf16_rne(x - hi) at [b][p][1][c]          (x = hi + lo + O(2^-17 |x|))
+// Same bytes as fp32, but the consumers run the bf16 matrix pipe with NO per-fragment split in their inner loops
+// ("pre-split once, consume many"): the producer of the tensor splits it once (pm_split_kernel for the value
+// slice of the projection, nchw_to_planes_kernel for the module's NCHW dy).  A pixel's 64 channels of one plane are one
+// 128-byte segment, for column strips and row strips alike.  Pointers are to the hi plane; the lo plane of a C-channel
+// tensor starts C elements later; the pixel stride (elements) is >= 2 C.
+// ---------------------------------------------------------------------------------------------------------------
+struct bf16p_t { uint16_t bits; };
+
+// "T16" tile of ONE plane: P positions x 64 channels as 1 KiB pieces of 8 positions x 128 B, no padding.  The 16-byte
+// chunk q of position p sits at chunk slot q ^ (p & 7) ^ (4 * ((p >> 3) & 1)): built for ds_read_b64_tr_b16 fragment
+// reads ([4 positions][16 channels] blocks per 16-lane group, two groups per LDS pass) -- the 8 rows a pass touches
+// (positions r and r + 8 of two neighbouring pieces, r = 0..3 or 4..7) then cover all 64 banks exactly once.
+constexpr int T16_PIECE = 256;                                                                // dwords
+__host__ __device__ constexpr int t16_pieces(int P) { return (P + 7) / 8; }
+__host__ __device__ constexpr int t16_size(int P) { return t16_pieces(P) * T16_PIECE; }      // dwords per plane tile
+__device__ __forceinline__ int t16_byte(int j, int c) {
+    const int piece = j >> 3, r = j & 7;
+    return (piece * T16_PIECE + r * 32) * 4 + ((((c >> 3) ^ r ^ ((piece & 1) << 2)) << 4) | ((c & 7) << 1));
+}
+// one DMA piece of a plane tile: positions 8 piece .. + 7 (pixels pix0 + i * pstep), channels c0 .. c0 + 63 of the plane
+// that starts ``plane_off`` elements into a pixel; ps = pixel stride in elements; lanes beyond the strip / the channel
+// count fetch out of range (zero fill)
+__device__ __forceinline__ void t16_dma_piece(const FBuf &src, float *img, int piece, int lane, int pix0, int pstep, int n,
+                                              int ps, int c0, int C, int plane_off) {
+    const int p = lane >> 3, i = 8 * piece + p, q = (lane & 7) ^ (p & 7) ^ ((piece & 1) << 2), c = c0 + 8 * q;
+    fbuf_load_to_lds_x4(src, img + piece * T16_PIECE, (i < n && c < C) ? ((pix0 + i * pstep) * ps + plane_off + c) * 2 : kOobOffset, 0);
+}
+// MFMA fragment whose K axis runs over tile positions 32 ks + 8 (lane >> 4) + e, e < 8, at channel 16 nt + (lane & 15):
+// two transposing reads (cca_platform.hpp: lane i of a 16-lane group supplies the address of row i >> 2, columns
+// 4 (i & 3) .. + 3 of a [4][16] block and receives column i)
+__device__ __forceinline__ u32x4 t16_frag(const float *tile, int ks, int nt, int lane) {
+    const int i = lane & 15, kg = lane >> 4, r = i >> 2, c = 16 * nt + 4 * (i & 3);
+    const char *b = reinterpret_cast<const char *>(tile);
+    const u32x2 lo = lds_read_tr16_b64(b + t16_byte(32 * ks + 8 * kg + r, c));
+    const u32x2 hi = lds_read_tr16_b64(b + t16_byte(32 * ks + 8 * kg + 4 + r, c));
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
 // FT: feature element, OT: output element; the addend (ADD) is fp32 pixel-major with its own strides; resid (may be
@@ -134,17 +175,21 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
                                                               long rbs, int rps, long obs, int ops, int n_whole, int split,
                                                               GmapJob<FT, OT> j1) {
     constexpr bool BF = GTile<FT>::BF, OBF = std::is_same<OT, bf16_t>::value;
+    constexpr bool PL = std::is_same<FT, bf16p_t>::value;             // split planes: hi tile | lo tile, T16 geometry
+    constexpr int TSP = t16_size(P);
     const bool trans = DUAL ? blockIdx.y != 0 : TRANS;            // (wave-uniform)
     if (DUAL && blockIdx.y != 0) {
         F = j1.F; addend = j1.addend; out = j1.out; fbs = j1.fbs; fps = j1.fps; obs = j1.obs; ops = j1.ops;
     }
     constexpr int NT = (P + 15) / 16, TPW = (NT + GS_WAVES - 1) / GS_WAVES, NKS = P / 32;
-    constexpr int FSZ = GTile<FT>::size(P), OSZ = GTile<float>::size(P), NPF = GTile<FT>::pieces(P);
+    constexpr int FSZ = PL ? 2 * TSP : GTile<FT>::size(P), OSZ = GTile<float>::size(P);
+    constexpr int NPF = PL ? 2 * t16_pieces(P) : GTile<FT>::pieces(P);
     constexpr int SPX = OBF ? 8 : 4;                                  // pixels per store instruction
     constexpr int NSI = NCHW ? 1 : ((P + SPX - 1) / SPX + GS_WAVES - 1) / GS_WAVES;   // store instructions per wave and group (max)
     constexpr int PO = P + 4, OIMG = NCHW ? GM_CG * PO : OSZ;         // NCHW: [channel][position] image, pitch PO
     constexpr int NSX = GM_CG / 2 / GS_WAVES;                         // NCHW: store instructions per wave and group (2 channels each)
     static_assert(!NCHW || (ROW && ADD && !OBF && !TRANS && !DUAL), "gmap: the NCHW epilogue belongs to the final fp32 row pass");
+    static_assert(!PL || !OBF, "gmap: split-plane features produce fp32 outputs");
     static_assert(P % 4 == 0 && (2 * FSZ + OIMG) * 4 * 2 <= 163840, "gmap: two workgroups per CU");
     __shared__ __attribute__((aligned(16))) float lds[2 * FSZ + OIMG];
     CCA_LDS_REGISTER(lds);
@@ -168,7 +213,7 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
     const int a_off = ROW ? H : 0;
 
     const FBuf Tb = make_fbuf(T + (size_t)b * HW * S, (size_t)HW * S * sizeof(float));
-    const FBuf Fb = make_fbuf(reinterpret_cast<const float *>(F + (size_t)b * fbs), ((size_t)(HW - 1) * fps + C) * sizeof(FT));
+    const FBuf Fb = make_fbuf(reinterpret_cast<const float *>(F + (size_t)b * fbs), ((size_t)(HW - 1) * fps + (PL ? 2 : 1) * C) * sizeof(FT));
     const FBuf Ob = make_fbuf(reinterpret_cast<const float *>(out + (size_t)b * obs),
                               NCHW ? (size_t)C * HW * sizeof(OT) : ((size_t)(HW - 1) * ops + C) * sizeof(OT));
     const FBuf Rb = make_fbuf(reinterpret_cast<const float *>(resid ? resid + (size_t)b * rbs : out),
@@ -178,8 +223,15 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
     const BandK kp = band_ksteps(L);
 
     auto issue_feat = [&](int cg) {
-        for (int it = wv; it < NPF; it += GS_WAVES)
-            gtile_dma_piece<FT>(Fb, FB + ((cg - cg0) & 1) * FSZ, it, lane, pix0, pstep, L, fps, cg * GM_CG, C);
+        for (int it = wv; it < NPF; it += GS_WAVES) {
+            if constexpr (PL) {
+                const int plane = it >= NPF / 2;
+                t16_dma_piece(Fb, FB + ((cg - cg0) & 1) * FSZ + plane * TSP, it - plane * (NPF / 2), lane, pix0, pstep, L, fps,
+                              cg * GM_CG, C, plane ? C : 0);
+            } else {
+                gtile_dma_piece<FT>(Fb, FB + ((cg - cg0) & 1) * FSZ, it, lane, pix0, pstep, L, fps, cg * GM_CG, C);
+            }
+        }
     };
     issue_feat(cg0);
 
@@ -285,7 +337,10 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
                         const int nt = nh * NTH + n;
                         // feature fragment: positions 32 ks + 8 lg + e of channel 16 nt + ln
                         BfSplit fb;
-                        if constexpr (BF) {
+                        if constexpr (PL) {
+                            fb.hi = t16_frag(img, ks, nt, lane);
+                            fb.lo = t16_frag(img + TSP, ks, nt, lane);
+                        } else if constexpr (BF) {
                             uint32_t x[8];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) x[e] = lds_load_u16(img, gtile_bf_byte(32 * ks + 8 * lg + e, 16 * nt + ln));
@@ -314,7 +369,9 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
                 for (int n = 0; n < NTH; ++n) {
                     const int nt = nh * NTH + n;
                     float fbv;
-                    if constexpr (BF) fbv = __builtin_bit_cast(float, lds_load_u16(img, gtile_bf_byte(pos, 16 * nt + ln)) << 16);
+                    if constexpr (PL) fbv = __builtin_bit_cast(float, lds_load_u16(img, t16_byte(pos, 16 * nt + ln)) << 16)
+                                          + __builtin_bit_cast(float, lds_load_u16(img + TSP, t16_byte(pos, 16 * nt + ln)) << 16);
+                    else if constexpr (BF) fbv = __builtin_bit_cast(float, lds_load_u16(img, gtile_bf_byte(pos, 16 * nt + ln)) << 16);
                     else              fbv = CCA_LDS_LD(img + gtile_f32_idx(pos, 16 * nt + ln));
 #pragma unroll
                     for (int a = 0; a < TPW; ++a)
@@ -442,6 +499,58 @@ __global__ __launch_bounds__(256) void nchw_to_pm_kernel(const float *__restrict
     }
 }
 
+// ---- producers of SPLIT-PLANE tensors (see bf16p_t above) ----
+__device__ __forceinline__ void planes_store8(const FBuf &Db, int off_bytes, int lo_bytes, const float (&x)[8], bool ok) {
+    const BfSplit sp = bf16_split8(x);
+    fbuf_store_x4(Db, __builtin_bit_cast(f32x4, sp.hi), ok ? off_bytes : kOobOffset, 0);
+    fbuf_store_x4(Db, __builtin_bit_cast(f32x4, sp.lo), ok ? off_bytes + lo_bytes : kOobOffset, 0);
+}
+
+// fp32 pixel-major (B, H*W, sps) channels [0, C) -> planes (B, H*W, 2, C) (pixel stride dps >= 2 C elements): the value
+// slice of the packed projection, split ONCE by its producer.  One thread = 8 channels of a pixel (32 B in, 16 + 16 B out).
+__global__ __launch_bounds__(256) void pm_split_kernel(const float *__restrict__ src, bf16p_t *__restrict__ dst, int C, int HW,
+                                                       long sbs, int sps, long dbs, int dps) {
+    const int cpp = C >> 3;                                   // 8-channel chunks per pixel
+    const int b = blockIdx.y;
+    const FBuf Sb = make_fbuf(src + (size_t)b * sbs, ((size_t)(HW - 1) * sps + C) * sizeof(float));
+    const FBuf Db = make_fbuf(reinterpret_cast<const float *>(dst + (size_t)b * dbs), ((size_t)(HW - 1) * dps + 2 * C) * 2);
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < HW * cpp; e += gridDim.x * 256) {
+        const int px = e / cpp, c = 8 * (e - px * cpp);
+        const f32x4 u = fbuf_load_x4(Sb, (px * sps + c) * 4, 0), v = fbuf_load_x4(Sb, (px * sps + c + 4) * 4, 0);
+        const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+        planes_store8(Db, (px * dps + c) * 2, C * 2, x, true);
+    }
+}
+
+// NCHW fp32 -> planes (the gradient dy of an NCHW module output): 64 pixels x 64 channels per workgroup through a padded
+// LDS tile; reads runs of 64 pixels per channel, writes 128-byte plane rows.
+__global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float *__restrict__ src, bf16p_t *__restrict__ dst, int C, int HW,
+                                                             long sbs, long dbs, int dps) {
+    __shared__ float tile[64 * 65];
+    const int ntp = (HW + 63) / 64;
+    const int b = blockIdx.x / ntp, p0 = (blockIdx.x - b * ntp) * 64, c0 = blockIdx.y * 64;
+    const FBuf Sb = make_fbuf(src + (size_t)b * sbs, (size_t)C * HW * sizeof(float));
+    const FBuf Db = make_fbuf(reinterpret_cast<const float *>(dst + (size_t)b * dbs), ((size_t)(HW - 1) * dps + 2 * C) * 2);
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int ch = (tid >> 4) + 16 * it, p4 = 4 * (tid & 15);
+        const bool ok = c0 + ch < C && p0 + p4 < HW;
+        const f32x4 v = fbuf_load_x4(Sb, ok ? ((c0 + ch) * HW + p0 + p4) * 4 : kOobOffset, 0);   // (dwords beyond the tensor read 0)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[ch * 65 + p4 + e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int px = (tid >> 3) + 32 * it, c8 = 8 * (tid & 7);
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = tile[(c8 + e) * 65 + px];
+        planes_store8(Db, ((p0 + px) * dps + c0 + c8) * 2, C * 2, x, p0 + px < HW && c0 + c8 < C);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // gweight: T[b, pixel(i, g), a_off + j] = sum_c X[pixel(i, g), c] * Y[pixel(j, g), c], bf16 pixel-major X / Y
 //   ca_forward (X = q, Y = k, K = C/8, MASK: the column self slot is -inf) and the dA half of ca_map_backward
@@ -456,10 +565,14 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
                                                                               float *__restrict__ T, int Cx, int H, int W,
                                                                               long xbs, int xps, long ybs, int yps) {
     constexpr bool BF = GTile<FT>::BF;
-    constexpr bool EXACT = !BF && MASK;          // the energies feed exp(): exact fp32 products
-    constexpr bool PRESPLIT = !BF && !MASK;      // fp32 dA: tiles are split into bf16 hi / lo images once per chunk
-    constexpr int NT = (P + 15) / 16, NTR = (NT + GM_WAVES - 1) / GM_WAVES, TSZ = GTile<FT>::size(P), NPF = GTile<FT>::pieces(P);
+    constexpr bool PL = std::is_same<FT, bf16p_t>::value;     // split planes: an operand tile = hi image | lo image (bf16 tile geometry)
+    static_assert(!(PL && MASK), "gweight: the energies are computed from fp32 q, k (exact products)");
+    constexpr bool EXACT = !BF && !PL && MASK;          // the energies feed exp(): exact fp32 products
+    constexpr bool PRESPLIT = !BF && !PL && !MASK;      // fp32 dA: tiles are split into bf16 hi / lo images once per chunk
     constexpr int TSB = GTile<bf16_t>::size(P);                       // dwords per bf16 image
+    constexpr int NPB = GTile<bf16_t>::pieces(P);
+    constexpr int NT = (P + 15) / 16, NTR = (NT + GM_WAVES - 1) / GM_WAVES;
+    constexpr int TSZ = PL ? 2 * TSB : GTile<FT>::size(P), NPF = PL ? 2 * NPB : GTile<FT>::pieces(P);
     constexpr int NBUF = SINGLE ? 1 : 2;
     constexpr int LDS = 2 * NBUF * TSZ + (PRESPLIT ? 4 * TSB : 0);
     static_assert(LDS * 4 <= 163840, "gweight: LDS");
@@ -475,15 +588,21 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
     const int ln = lane & 15, lg = lane >> 4;
     const int pix0 = row ? g * W : g, pstep = row ? 1 : W, a_off = row ? H : 0;
-    const FBuf Xb = make_fbuf(reinterpret_cast<const float *>(X + (size_t)b * xbs), ((size_t)(HW - 1) * xps + Cx) * sizeof(FT));
-    const FBuf Yb = make_fbuf(reinterpret_cast<const float *>(Y + (size_t)b * ybs), ((size_t)(HW - 1) * yps + Cx) * sizeof(FT));
+    const FBuf Xb = make_fbuf(reinterpret_cast<const float *>(X + (size_t)b * xbs), ((size_t)(HW - 1) * xps + (PL ? 2 : 1) * Cx) * sizeof(FT));
+    const FBuf Yb = make_fbuf(reinterpret_cast<const float *>(Y + (size_t)b * ybs), ((size_t)(HW - 1) * yps + (PL ? 2 : 1) * Cx) * sizeof(FT));
     const int nch = (Cx + GM_CG - 1) / GM_CG;                 // (SINGLE: the host launches this form only when nch == 1)
 
     auto issue = [&](int ch) {
         float *xb = lds + (ch % NBUF) * 2 * TSZ, *yb = xb + TSZ;
         for (int it = wv; it < 2 * NPF; it += GM_WAVES) {
-            if (it < NPF) gtile_dma_piece<FT>(Xb, xb, it, lane, pix0, pstep, L, xps, ch * GM_CG, Cx);
-            else          gtile_dma_piece<FT>(Yb, yb, it - NPF, lane, pix0, pstep, L, yps, ch * GM_CG, Cx);
+            if constexpr (PL) {
+                const int op = it >= NPF, r = it - op * NPF, plane = r >= NPB;
+                gtile_dma_piece<bf16_t>(op ? Yb : Xb, (op ? yb : xb) + plane * TSB, r - plane * NPB, lane, pix0, pstep, L,
+                                        op ? yps : xps, ch * GM_CG, Cx, plane ? Cx : 0);
+            } else {
+                if (it < NPF) gtile_dma_piece<FT>(Xb, xb, it, lane, pix0, pstep, L, xps, ch * GM_CG, Cx);
+                else          gtile_dma_piece<FT>(Yb, yb, it - NPF, lane, pix0, pstep, L, yps, ch * GM_CG, Cx);
+            }
         }
     };
     f32x4 acc[NTR][NT];
@@ -530,6 +649,7 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
             continue;
         }
         const float *xh = xb, *xl = xb, *yh = yb, *yl = yb;
+        if constexpr (PL) { xl = xb + TSB; yl = yb + TSB; }
         if constexpr (PRESPLIT) {
             // every element is split ONCE (not once per wavefront that needs it): thread -> (tensor, pixel, 8-channel chunk)
             for (int e = tid; e < 2 * P * 8; e += GM_THREADS) {

@@ -611,6 +611,85 @@ class CrissCrossPMModuleFunction(torch.autograd.Function):
                 dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma))
 
 
+def split_planes(t: torch.Tensor, c0: int, C: int) -> torch.Tensor:
+    """Channels [c0, c0 + C) of the fp32 pixel-major tensor ``t`` (B, H, W, ps) as SPLIT PLANES (B, H, W, 2, C) int16:
+    bf16 hi | lo halves of every value (include/ccnet_cca.h, "split-plane path"), produced once for all their consumers."""
+    B, H, W, ps = t.shape
+    out = torch.empty((B, H, W, 2, C), device=t.device, dtype=torch.int16)
+    lib = _lib.get_lib()
+    with torch.cuda.device(t.device):
+        lib.check(lib.ccnet_cca_split_planes_f32(t.data_ptr() + 4 * c0, out.data_ptr(), B, C, H, W, t.stride(0), t.stride(2),
+                                                 H * W * 2 * C, 2 * C, _stream()), "split_planes")
+    return out
+
+
+def planes_cover(B, C, Cq, H, W):
+    """geometry of the split-plane kernels (csrc/cca_gmap.hpp, bf16p_t)"""
+    return max(H, W) <= 100 and C % 8 == 0 and Cq % 4 == 0 and H * W * (C + 2 * Cq) < 2 ** 29
+
+
+class CrissCrossPlanesModuleFunction(torch.autograd.Function):
+    """The whole module as ONE autograd node on the SPLIT-PLANE path (fp32, no autocast), the module's own tensors NCHW:
+    the stacked projection is the GEMM ``x^T W^T`` whose (B, HW, 2Cq + C) output holds the pixel-major q | k | v; its value
+    slice is split ONCE into bf16 hi | lo planes (same bytes), which is what the aggregation (functions.py:42-47) and the
+    dA contraction of its adjoint read -- three exact bf16 products per term, no per-fragment split in any inner loop;
+    dy is split once inside the backward; q, k stay fp32 (exact energies).  ``dx = dy + W^T dqkv^T`` is one GEMM with
+    beta = 1 writing NCHW."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma):
+        x, gamma = _dev_f32("x", x), _dev_f32("gamma", gamma)
+        B, C, H, W = x.shape
+        cq, hw = wq.shape[0], H * W
+        ct = 2 * cq + C
+        w = torch.cat([wq.reshape(cq, C), wk.reshape(cq, C), wv.reshape(C, C)], 0)          # (2Cq + C, C)
+        b = torch.cat([bq, bk, bv], 0)
+        xm = x.view(B, C, hw)
+        qkv = torch.baddbmm(b.view(1, 1, -1), xm.transpose(1, 2), w.t().unsqueeze(0).expand(B, -1, -1))   # (B, HW, 2Cq + C)
+        vpl = split_planes(qkv.view(B, H, W, ct), 2 * cq, C)
+        qk = qkv                                  # q | k are read in place (channel slices of the packed projection)
+        lib = _lib.get_lib()
+        y = torch.empty_like(x)
+        A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
+        p, bs, ps = qk.data_ptr(), hw * ct, ct
+        with torch.cuda.device(x.device):
+            _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0), x.device)
+            lib.check(lib.ccnet_cca_forward_planes_f32(p, p + 4 * cq, vpl.data_ptr(), x.data_ptr(), gamma.data_ptr(),
+                                                       y.data_ptr(), A.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps,
+                                                       hw * 2 * C, 2 * C, wsp, wsn, _stream()), "cca_forward_planes")
+        ctx.save_for_backward(x, w, qk, vpl, A, gamma)
+        ctx.cq = cq
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        cq = ctx.cq
+        x, w, qk, vpl, A, gamma = ctx.saved_tensors
+        dy = _dev_f32("grad_output", dy)
+        B, C, H, W = x.shape
+        hw, ct = H * W, 2 * cq + C
+        lib = _lib.get_lib()
+        dqkv = torch.empty((B, hw, ct), device=x.device, dtype=torch.float32)
+        dgamma = torch.empty_like(gamma)
+        scratch = torch.empty_like(A)
+        p, g, bs, ps, gbs = qk.data_ptr(), dqkv.data_ptr(), hw * ct, ct, hw * ct
+        with torch.cuda.device(dy.device):
+            _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 1), dy.device)
+            lib.check(lib.ccnet_cca_backward_planes_f32(dy.data_ptr(), p, p + 4 * cq, vpl.data_ptr(), A.data_ptr(),
+                                                        gamma.data_ptr(), g, g + 4 * cq, g + 8 * cq, dgamma.data_ptr(),
+                                                        scratch.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps, hw * 2 * C, 2 * C,
+                                                        gbs, ct, gbs, ct, gbs, ct, wsp, wsn, _stream()), "cca_backward_planes")
+        xm = x.view(B, C, hw)
+        dqt = dqkv.transpose(1, 2)                                                            # (B, 2Cq + C, HW) view
+        dx = torch.baddbmm(dy.view(B, C, hw), w.t().unsqueeze(0).expand(B, -1, -1), dqt)      # dy + W^T dqkv^T  (NCHW)
+        dw = torch.bmm(dqt, xm.transpose(1, 2)).sum(0)                                        # (2Cq + C, C)
+        db = dqkv.sum(dim=(0, 1))
+        dwq, dwk, dwv = dw[:cq], dw[cq:2 * cq], dw[2 * cq:]
+        return (dx.view(B, C, H, W), dwq.reshape(cq, C, 1, 1), db[:cq], dwk.reshape(cq, C, 1, 1), db[cq:2 * cq],
+                dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma))
+
+
 def criss_cross_attention(q, k, v, x, gamma, recompute_attention=False):
     """Functional form of the fused core (``recompute_attention``: rebuild A in backward instead of keeping it)."""
     return CrissCrossFunction.apply(q, k, v, x, gamma, recompute_attention)

@@ -245,6 +245,36 @@ int ccnet_cca_backward_pm_nchw_f32(const float *dy, const float *q, const float 
  * (max(H,W) <= 100), 2 = windowed MFMA strip kernels (101 .. 320), 0 = any-shape kernels. */
 int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W);
 
+/* ---- SPLIT-PLANE path: the fp32 core with its C-sized contraction operands stored PRE-SPLIT ----
+ * A "planes" tensor is an fp32 feature tensor stored as two bf16 planes per pixel, (B, H*W, 2, C) uint16:
+ *     hi = bf16_rne(x) at [b][p][0][c],  lo = bf16_rne(x - hi) at [b][p][1][c]   (x = hi + lo + O(2^-17 |x|))
+ * -- the same bytes as fp32, pixel-major, split ONCE by the producer, so that the kernels that contract over it
+ * (functions.py:42-47 and their adjoints) run the bf16 matrix pipe with three exact products per term and no per-use split.
+ * Views: pointer to the hi plane, batch stride and pixel stride in ELEMENTS (pixel stride >= 2 C, both multiples of 8);
+ * the lo plane of a pixel starts C elements after its hi plane.  C % 8 == 0, max(H, W) <= 100.
+ *
+ * ccnet_cca_split_planes_f32: fp32 pixel-major view (e.g. the value slice of the packed projection x^T W^T) -> planes.
+ * ccnet_cca_nchw_to_planes_f32: NCHW fp32 (B, C, H, W) -> planes.
+ * ccnet_cca_forward_planes_f32 / _backward_planes_f32: functions.py:38-49 and its autograd with q, k fp32 pixel-major
+ *   views (exact fp32 energies), v as planes, the module's x / y / dy NCHW fp32, dq | dk | dv fp32 pixel-major views,
+ *   A / scratch (B,H,W,H+W) fp32 as everywhere.  Workspace: ccnet_cca_planes_workspace_bytes (backward: holds the fp32
+ *   column partial and dy as planes).  Arithmetic: energies exact fp32; every other contraction split-bf16 x3 with fp32
+ *   accumulation (the lo x lo term, 2^-18 relative, is dropped) -- the CCNET_PRECISION_* knob does not apply here. */
+size_t ccnet_cca_planes_workspace_bytes(int B, int C, int Cq, int H, int W, int backward);
+int ccnet_cca_split_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, int src_ps,
+                               long dst_bs, int dst_ps, ccnet_stream_t stream);
+int ccnet_cca_nchw_to_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, long dst_bs,
+                                 int dst_ps, ccnet_stream_t stream);
+int ccnet_cca_forward_planes_f32(const float *q, const float *k, const uint16_t *v_planes, const float *x, const float *gamma,
+                                 float *y, float *A, int B, int C, int Cq, int H, int W,
+                                 long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
+                                 void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
+int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *k, const uint16_t *v_planes, const float *A,
+                                  const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
+                                  int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps,
+                                  long v_bs, int v_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
+                                  void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
+
 /* Launch profiler (a measurement aid, off by default).  Between ``begin`` and ``end`` every kernel launch the library
  * issues is bracketed by a HIP-event pair on its stream; ``end`` disarms, waits for the recorded launches and returns
  * their count (>= 0), filling ms[i] with launch i's duration and names + i * name_stride with its kernel name.

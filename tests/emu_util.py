@@ -259,6 +259,52 @@ class EmuOps:
                                                                _p(ws), nbytes, None))
         return dqkv, dgamma
 
+    def split_planes(self, src_pm, C, c0=0):
+        """src_pm: float32 (B, H, W, ps) pixel-major; channels [c0, c0 + C) -> planes uint16 (B, H, W, 2, C)."""
+        B, H, W, ps = src_pm.shape
+        dst = np.full((B, H, W, 2, C), 0xFFFF, np.uint16)
+        self.lib.check(self.lib.ccnet_cca_split_planes_f32(src_pm.ctypes.data + 4 * c0, _p(dst), B, C, H, W, H * W * ps, ps,
+                                                           H * W * 2 * C, 2 * C, None))
+        return dst
+
+    def nchw_to_planes(self, src):
+        B, C, H, W = src.shape
+        dst = np.full((B, H, W, 2, C), 0xFFFF, np.uint16)
+        self.lib.check(self.lib.ccnet_cca_nchw_to_planes_f32(_p(src), _p(dst), B, C, H, W, C * H * W, H * W * 2 * C, 2 * C, None))
+        return dst
+
+    def cca_forward_planes(self, qkv, v_planes, x, gamma, cq):
+        """qkv: float32 (B, H, W, ct) packed pixel-major projection (q | k read from it); v_planes uint16 (B, H, W, 2, C);
+        x float32 NCHW; returns (y NCHW, A)."""
+        B, H, W, ct = qkv.shape
+        C = v_planes.shape[4]
+        y = np.full((B, C, H, W), np.nan, np.float32)
+        A = np.full((B, H, W, H + W), np.nan, np.float32)
+        nbytes = self.lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0)
+        ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
+        base, bs = qkv.ctypes.data, H * W * ct
+        self.lib.check(self.lib.ccnet_cca_forward_planes_f32(base, base + 4 * cq, _p(v_planes), _p(x), _p(gamma), _p(y), _p(A),
+                                                             B, C, cq, H, W, bs, ct, bs, ct, H * W * 2 * C, 2 * C,
+                                                             _p(ws), nbytes, None))
+        return y, A
+
+    def cca_backward_planes(self, dy, qkv, v_planes, A, gamma, cq):
+        B, H, W, ct = qkv.shape
+        C = v_planes.shape[4]
+        dqkv = np.full((B, H, W, 2 * cq + C), np.nan, np.float32)
+        dgamma = np.full(1, np.nan, np.float32)
+        scratch = np.full_like(A, np.nan)
+        nbytes = self.lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 1)
+        ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
+        base, g, bs = qkv.ctypes.data, dqkv.ctypes.data, H * W * ct
+        dct = 2 * cq + C
+        dbs = H * W * dct
+        self.lib.check(self.lib.ccnet_cca_backward_planes_f32(_p(dy), base, base + 4 * cq, _p(v_planes), _p(A), _p(gamma),
+                                                              g, g + 4 * cq, g + 8 * cq, _p(dgamma), _p(scratch),
+                                                              B, C, cq, H, W, bs, ct, bs, ct, H * W * 2 * C, 2 * C,
+                                                              dbs, dct, dbs, dct, dbs, dct, _p(ws), nbytes, None))
+        return dqkv, dgamma
+
     def mfma_selftest(self):
         scratch = np.zeros(16, np.float32)
         return self.lib.ccnet_cca_mfma_selftest(_p(scratch), None)

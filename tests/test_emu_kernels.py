@@ -595,3 +595,64 @@ def test_pixel_major_fp32_core_with_nchw_module_tensors(ops, shape):
     dqkv, dg = ops.cca_backward_pm_nchw(c["dy"], qkv, A, c["gamma"], cq)
     dqkv2, dg2 = ops.cca_backward_pm_bf16(_pm(c["dy"]), qkv, A, c["gamma"], cq)
     assert np.array_equal(dqkv, dqkv2) and np.array_equal(dg, dg2)
+
+
+def _bf16_bits_rne(x):
+    """float32 array -> bf16 bit patterns (round to nearest even), as v_cvt_pk_bf16_f32 / torch do"""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def _bf16_to_f32(bits):
+    return (bits.astype(np.uint32) << 16).view(np.float32)
+
+
+def test_split_plane_producers_are_exact_hi_lo_splits(ops):
+    """ccnet_cca_split_planes_f32 / ccnet_cca_nchw_to_planes_f32 (csrc/cca_gmap.hpp, bf16p_t): hi = bf16_rne(x),
+    lo = bf16_rne(x - hi), planes (B, H*W, 2, C); the slice form reads the value channels out of a wider projection."""
+    rng = np.random.default_rng(3)
+    B, C, H, W = 2, 72, 9, 7
+    x = (rng.standard_normal((B, C, H, W), dtype=np.float32) * np.float32(3.0))
+    x[0, 0, 0, :4] = [0.0, 1.0, -2.5, 3.0e-20]
+    hi = _bf16_bits_rne(x)
+    lo = _bf16_bits_rne(x - _bf16_to_f32(hi))
+    want = np.stack([_pm(hi), _pm(lo)], axis=3)                    # (B, H, W, 2, C)
+    got = ops.nchw_to_planes(x)
+    assert np.array_equal(got, want)
+    wide = np.full((B, H, W, C + 24), 9.0, np.float32)
+    wide[..., 16:16 + C] = _pm(x)
+    got2 = ops.split_planes(wide, C, c0=16)
+    assert np.array_equal(got2, want)
+    err = np.abs(_bf16_to_f32(want[..., 0, :]).astype(np.float64) + _bf16_to_f32(want[..., 1, :]) - _pm(x))
+    assert float((err / np.maximum(np.abs(_pm(x)), 1e-30)).max()) < 2.0 ** -16
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 96, 17, 20), (1, 64, 9, 1), (1, 160, 33, 18), (1, 64, 2, 99), (1, 64, 100, 3),
+                                   (1, 64, 3, 97), (2, 128, 3, 130 // 2), (1, 512, 6, 5)])
+def test_split_plane_core_matches_the_fp32_pixel_major_core_and_the_oracle(ops, shape):
+    """ccnet_cca_{forward,backward}_planes_f32: v and dy enter the kernels as bf16 hi | lo planes (split once by their
+    producers), fragments come out of LDS by transposing reads, three bf16 MFMAs per term.  The arithmetic is the fp32
+    pixel-major family's (same split, same products), so y / dq / dk / dv must agree with it to fp32 summation noise, and
+    with the oracle at the fp32 bar; the attention tensor is bit-identical (same energies kernel)."""
+    B, C, H, W = shape
+    cq = C // 8
+    c = rand_case(*shape, seed=51)
+    qkv = np.ascontiguousarray(np.concatenate([_pm(c["q"]), _pm(c["k"]), _pm(c["v"])], axis=3))
+    vpl = ops.split_planes(qkv, C, c0=2 * cq)
+    y, A = ops.cca_forward_planes(qkv, vpl, c["x"], c["gamma"], cq)
+    y2, A2 = ops.cca_forward_pm_nchw(qkv, c["x"], c["gamma"], cq)
+    assert np.array_equal(A, A2)
+    assert np.all(A[:, np.arange(H), :, np.arange(H)] == 0)
+    assert maxerr(y, y2) < 2e-6 * max(1.0, float(np.abs(y2).max()))
+    yo, Ao = O.cca_core_forward(T(c["q"]), T(c["k"]), T(c["v"]), T(c["x"]), T(c["gamma"]))
+    assert maxerr(y, yo.numpy()) < 2e-4 * max(1.0, float(yo.abs().max()))
+    dqkv, dg = ops.cca_backward_planes(c["dy"], qkv, vpl, A, c["gamma"], cq)
+    dqkv2, dg2 = ops.cca_backward_pm_nchw(c["dy"], qkv, A, c["gamma"], cq)
+    assert maxerr(dqkv, dqkv2) < 5e-6 * max(1.0, float(np.abs(dqkv2).max()))
+    go = O.cca_core_backward(T(c["dy"]), T(c["q"]), T(c["k"]), T(c["v"]), Ao, T(c["gamma"]))
+    nchw = lambda a: np.transpose(a, (0, 3, 1, 2))                                 # noqa: E731
+    for name, got in (("dq", dqkv[..., :cq]), ("dk", dqkv[..., cq:2 * cq]), ("dv", dqkv[..., 2 * cq:])):
+        assert maxerr(nchw(got), go[name].numpy()) < 5e-4 * max(1.0, float(go[name].abs().max())), name
+    assert abs(float(dg[0]) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
+    y3, _ = ops.cca_forward_planes(qkv, vpl, c["x"], c["gamma"], cq)
+    assert np.array_equal(y, y3)                                                    # run-to-run bit identity

@@ -534,6 +534,81 @@ def test_pixel_major_fp32_module_node_matches_the_strip_node_and_the_oracle(lib,
     assert err(outs[1][0], yo) < TOL
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 20, 24), (2, 96, 33, 18), (1, 64, 100, 3), (2, 512, 97, 97, "default-init")])
+def test_split_plane_module_node_matches_the_oracle_and_the_other_nodes(lib, dev, shape):
+    """CrissCrossPlanesModuleFunction (v and dy enter the kernels pre-split into bf16 hi | lo planes, fragments by
+    transposing LDS reads): y against the oracle at the north_star bar with the projections at their DEFAULT initialisation
+    (unscaled q, k), y / dx / all 7 parameter gradients against the pixel-major fp32 node (same arithmetic: fp32 summation
+    noise only) and the NCHW-strip node."""
+    from ccnet_amd import CrissCrossAttention
+    from ccnet_amd.functions import CrissCrossPlanesModuleFunction, CrissCrossPMModuleFunction
+    B, C, H, W = shape[:4]
+    torch.manual_seed(7)
+    m = CrissCrossAttention(C).to(dev)
+    with torch.no_grad():
+        m.gamma.fill_(0.5)
+    x = torch.randn(B, C, H, W, device=dev)
+    dy = torch.randn(B, C, H, W, device=dev)
+    outs = {}
+    for name, fn in (("planes", CrissCrossPlanesModuleFunction), ("pm", CrissCrossPMModuleFunction)):
+        m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        y = fn.apply(xi, m.query_conv.weight, m.query_conv.bias, m.key_conv.weight, m.key_conv.bias,
+                     m.value_conv.weight, m.value_conv.bias, m.gamma)
+        y.backward(dy)
+        outs[name] = (y.detach(), xi.grad, {n: p.grad.clone() for n, p in m.named_parameters()})
+    a, b = outs["planes"], outs["pm"]
+    rel = {n: err(g, b[2][n]) / max(1.0, float(g.abs().max())) for n, g in a[2].items()}
+    print("split-plane node vs pixel-major fp32 node", shape, "y", f"{err(a[0], b[0]):.1e}", "dx",
+          f"{err(a[1], b[1]) / max(1.0, float(b[1].abs().max())):.1e}", {n: f"{e:.1e}" for n, e in rel.items()})
+    assert a[0].is_contiguous() and err(a[0], b[0]) < 2e-5
+    assert err(a[1], b[1]) < 5e-5 * max(1.0, float(b[1].abs().max()))
+    for n, e in rel.items():
+        assert e < 2e-4, n
+    with torch.no_grad():
+        f = lambda t: t.detach().float().cpu()                              # noqa: E731
+        qo, ko, vo = (f(c(x)) for c in (m.query_conv, m.key_conv, m.value_conv))
+    yo, Ao = O.cca_core_forward(qo, ko, vo, f(x), torch.tensor([0.5]))
+    go = O.cca_core_backward(f(dy), qo, ko, vo, Ao, torch.tensor([0.5]))
+    print("split-plane node vs oracle", shape, "y", f"{err(a[0], yo):.1e}", "dgamma",
+          f"{abs(float(a[2]['gamma']) - float(go['dgamma'])):.1e}")
+    assert err(a[0], yo) < TOL
+    assert abs(float(a[2]["gamma"]) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
+
+
+def test_split_plane_core_at_the_headline_shape_against_the_oracle(lib, dev):
+    """(8,512,97,97) fp32 -- BASELINE.json configs[1] -- through the split-plane C ABI (unscaled N(0,1) q, k: the
+    peaky-softmax worst case): y, dq, dk, dv vs the CPU oracle image by image at the north_star bar; run-to-run bit
+    identity; the producers' planes reproduce their input to 2^-16."""
+    import bench
+    B, C, H, W = 8, 512, 97, 97
+    cq = C // 8
+    wl = bench.PlanesWorkload(lib, B, C, H, W, dev, 4321)
+    wl.step()
+    torch.cuda.synchronize()
+    y1, g1 = wl.y.clone(), wl.dqkv.clone()
+    wl.step()
+    torch.cuda.synchronize()
+    assert torch.equal(y1, wl.y) and torch.equal(g1, wl.dqkv)
+    nchw = lambda t: t.permute(0, 3, 1, 2).contiguous().cpu()               # noqa: E731
+    q, k, v = nchw(wl.qkv[..., :cq]), nchw(wl.qkv[..., cq:2 * cq]), nchw(wl.qkv[..., 2 * cq:])
+    pl = wl.vpl.view(torch.bfloat16).float()
+    rec = nchw(pl[:, :, :, 0] + pl[:, :, :, 1])
+    assert float(((rec - v).abs() / v.abs().clamp_min(1e-30)).max()) < 2.0 ** -16
+    worst = {}
+    for i in (0, B - 1):
+        sl = slice(i, i + 1)
+        yo, Ao = O.cca_core_forward(q[sl], k[sl], v[sl], wl.x[sl].cpu(), torch.tensor([0.5]))
+        go = O.cca_core_backward(wl.dy[sl].cpu(), q[sl], k[sl], v[sl], Ao, torch.tensor([0.5]))
+        e = {"y": err(wl.y[sl], yo), "A": err(wl.A[sl], Ao), "dq": err(nchw(wl.dqkv[sl][..., :cq]), go["dq"]),
+             "dk": err(nchw(wl.dqkv[sl][..., cq:2 * cq]), go["dk"]), "dv": err(nchw(wl.dqkv[sl][..., 2 * cq:]), go["dv"])}
+        for n, val in e.items():
+            worst[n] = max(worst.get(n, 0.0), val)
+    print("split-plane headline max-abs errors vs oracle (images 0 and 7):", {n: f"{e:.1e}" for n, e in worst.items()})
+    assert all(e < TOL for e in worst.values()), worst
+    assert worst["A"] < TIGHT
+
+
 def test_pixel_major_bf16_module_route_and_full_size(lib, dev):
     """The module takes bf16 activations through the pixel-major kernels (channels_last in, channels_last out), and at
     BASELINE configs[4]'s full size (16,512,129,129) the path agrees with the fp32 strip kernels on the same bf16-rounded

@@ -74,8 +74,7 @@ def code_object_kernels(lib_path, tmp_path):
             cur = kernels.setdefault(val, {})
         elif key == "name":
             cur = None if not val.startswith("_Z") else cur
-        elif cur is not None and key in ("private_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count", "vgpr_count",
-                                        "group_segment_fixed_size"):
+        elif cur is not None and key in ("private_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count", "vgpr_count"):
             cur[key] = int(val)
     return kernels
 

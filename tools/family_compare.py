@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""A/B of the fp32 core families at one shape on this GPU: NCHW strips, pixel-major fp32 (NCHW x / y / dy), split planes.
+Per family: fwd+bwd ms (eager, HIP events), the per-launch durations inside a step (library launch profiler) and -- for
+the plane path -- parity of its outputs against the pixel-major fp32 family on the same inputs.
+usage: family_compare.py [B C H W]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from ccnet_amd import _lib  # noqa: E402
+
+B, C, H, W = (int(a) for a in sys.argv[1:5]) if len(sys.argv) >= 5 else (8, 512, 97, 97)
+lib = _lib.get_lib()
+dev = torch.device("cuda:0")
+fams = [("nchw-strips", bench.CoreWorkload), ("pixel-major-f32", bench.PixelMajorF32Workload), ("planes", bench.PlanesWorkload)]
+res = {}
+for name, cls in fams:
+    wl = cls(lib, B, C, H, W, dev, 1234)
+    for _ in range(5):
+        wl.step()
+    torch.cuda.synchronize()
+    ms = bench.time_region(wl.step, 30)
+    fwd, bwd = bench.time_region(wl.forward, 20), bench.time_region(wl.backward, 20)
+    rec = lib.profile_launches(lambda: [wl.step() for _ in range(5)])
+    n = len(rec) // 5
+    print(f"== {name} ({B},{C},{H},{W}): step {ms:.4f} ms  fwd {fwd:.4f}  bwd {bwd:.4f}  launches {n}  "
+          f"event sum {sum(t for _, t in rec) / 5:.4f}")
+    for i in range(n):
+        print(f"     {sum(rec[r * n + i][1] for r in range(5)) / 5 * 1e3:8.1f} us  {rec[i][0][:110]}")
+    if name == "planes":
+        print(f"     split of v (producer side, outside the step): {bench.time_region(wl.split, 20) * 1e3:.1f} us")
+    res[name] = wl
+a, b = res["planes"], res["pixel-major-f32"]
+a.step(); b.step()
+torch.cuda.synchronize()
+for nm in ("y", "dqkv", "A", "dgamma"):
+    d = (getattr(a, nm) - getattr(b, nm)).abs().max().item()
+    print(f"planes vs pixel-major-f32: max |d {nm}| = {d:.3e}   (max |ref| {getattr(b, nm).abs().max().item():.3e})")
