@@ -77,6 +77,7 @@ _PROTOTYPES = {
     "ccnet_cca_backward_planes_f32": (c_int, [_P] * 11 + [c_int] * 5 + [c_long, c_int] * 6 + [_P, c_size_t, _P]),
     "ccnet_cca_shape_uses_mfma": (c_int, [c_int, c_int, c_int, c_int]),
     "ccnet_cca_mfma_selftest": (c_int, [_P, _P]),
+    "ccnet_cca_set_option": (c_int, [c_char_p, c_int]),
     "ccnet_cca_profile_begin": (c_int, [c_int]),
     "ccnet_cca_profile_end": (c_int, [_P, _P, c_int, c_int]),
 }

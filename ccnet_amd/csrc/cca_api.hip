@@ -37,6 +37,10 @@ std::atomic<int> g_map_bf16{1};
 // The affinity kernel (ca_forward, K = C/8) always runs exact f32: its energies feed exp().
 std::atomic<int> g_weight_bf16{1};
 
+// development / A-B options (ccnet_cca_set_option): "planes_ring" 1 (default) = the split-plane passes with a pixel-major
+// output run gmap3_kernel (three-tile ring, stores from the accumulators), 0 = gmap_kernel (two tiles, output image in LDS)
+std::atomic<int> g_planes_ring{1};
+
 int fail(int code, const char *what) {
     char buf[256];
     snprintf(buf, sizeof(buf), "ccnet_cca: %s (code %d)", what, code);
@@ -1050,15 +1054,34 @@ int check_planes_view(const char *what, long bs, int ps, int C, int H, int W) {
     return 0;
 }
 // column strips -> fp32 partial, row strips add it (+ the NCHW residual) and write the output
+template <bool TRANS>
+int launch_gmap3_planes(const float *T, const bf16p_t *F, const float *gamma, float *out, float *partial, int B, int C, int H, int W,
+                        long fbs, int fps, long obs, int ops, bool row_too, ccnet_stream_t stream) {
+    const long pbs = (long)H * W * C;
+    const GmapPlan gc = gmap_plan(B * W, C), gr = gmap_plan(B * H, C);
+    CCA_LAUNCH((cca::gmap3_kernel<100, false, TRANS, false>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS), stream, T, F,
+               (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0, pbs, C, gc.n_whole, gc.split);
+    if (int e = launch_status("gmap3_planes(column)")) return e;
+    if (!row_too) return 0;
+    CCA_LAUNCH((cca::gmap3_kernel<100, true, TRANS, true>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS), stream, T, F,
+               (const float *)partial, gamma, out, C, H, W, fbs, fps, pbs, C, obs, ops, gr.n_whole, gr.split);
+    return launch_status("gmap3_planes(row)");
+}
 template <bool TRANS, bool NCHW>
 int launch_gmap_planes(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
                        int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
     const long pbs = (long)H * W * C;
     const GmapPlan gc = gmap_plan(B * W, C), gr = gmap_plan(B * H, C);
+    const bool ring = g_planes_ring.load() != 0;
+    if (ring) {
+        if (int e = launch_gmap3_planes<TRANS>(T, F, gamma, out, partial, B, C, H, W, fbs, fps, obs, ops, !NCHW, stream)) return e;
+        if (!NCHW) return 0;
+    } else {
     CCA_LAUNCH((cca::gmap_kernel<100, false, TRANS, false, bf16p_t, float>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS),
                stream, T, F, (const float *)nullptr, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0,
                0L, 0, pbs, C, gc.n_whole, gc.split, cca::GmapJob<bf16p_t, float>{});
     if (int e = launch_status("gmap_planes(column)")) return e;
+    }
     CCA_LAUNCH((cca::gmap_kernel<100, true, TRANS, true, bf16p_t, float, NCHW>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS),
                stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C, rbs, rps, obs, ops,
                gr.n_whole, gr.split, cca::GmapJob<bf16p_t, float>{});
@@ -1155,6 +1178,12 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
     // dgamma = sum A t;  dE = gamma * A * (t - sum_s A t), in place
     if (int e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, sm, B, H, W, stream, KSplit())) return e;
     return gmap_dual_pm<float>(scratch, k, q, dq, dk, partial, B, Cq, H, W, k_bs, k_ps, q_bs, q_ps, dq_bs, dq_ps, dk_bs, dk_ps, stream);
+}
+
+int ccnet_cca_set_option(const char *name, int value) {
+    if (!name) return fail(CCNET_E_NULLPTR, "set_option: null name");
+    if (std::string(name) == "planes_ring") return g_planes_ring.exchange(value);
+    return fail(CCNET_E_BADFLAGS, "set_option: unknown option");
 }
 
 /* ---- launch profiler: per-launch HIP-event durations inside a step (see cca_platform.hpp, cca_prof) ---- */

@@ -76,10 +76,10 @@ __device__ __forceinline__ void gtile_dma_piece(const FBuf &src, float *img, int
                                                 int ps, int c0, int C, int plane_off = 0) {
     if constexpr (GTile<FT>::BF) {
         const int p = lane >> 3, i = 8 * piece + p, q = (lane & 7) ^ (p & 7), c = c0 + 8 * q;
-        fbuf_load_to_lds_x4(src, img + piece * GM_PB, (i < n && c < C) ? ((pix0 + i * pstep) * ps + plane_off + c) * 2 : kOobOffset, 0);
+        fbuf_load_to_lds_x4_uncounted(src, img + piece * GM_PB, (i < n && c < C) ? ((pix0 + i * pstep) * ps + plane_off + c) * 2 : kOobOffset);
     } else {
         const int i = 4 * piece + (lane >> 4), c = c0 + 4 * ((lane & 15) ^ (i & 1));
-        fbuf_load_to_lds_x4(src, img + piece * GM_PP, (i < n && c < C) ? ((pix0 + i * pstep) * ps + c) * 4 : kOobOffset, 0);
+        fbuf_load_to_lds_x4_uncounted(src, img + piece * GM_PP, (i < n && c < C) ? ((pix0 + i * pstep) * ps + c) * 4 : kOobOffset);
     }
 }
 // fp32 tiles: 4 pixels x 64 channels per 1 KiB DMA piece; the 16-byte chunk q of pixel p sits at chunk position
@@ -124,7 +124,7 @@ __device__ __forceinline__ int t16_byte(int j, int c) {
 __device__ __forceinline__ void t16_dma_piece(const FBuf &src, float *img, int piece, int lane, int pix0, int pstep, int n,
                                               int ps, int c0, int C, int plane_off) {
     const int p = lane >> 3, i = 8 * piece + p, q = (lane & 7) ^ (p & 7) ^ ((piece & 1) << 2), c = c0 + 8 * q;
-    fbuf_load_to_lds_x4(src, img + piece * T16_PIECE, (i < n && c < C) ? ((pix0 + i * pstep) * ps + plane_off + c) * 2 : kOobOffset, 0);
+    fbuf_load_to_lds_x4_uncounted(src, img + piece * T16_PIECE, (i < n && c < C) ? ((pix0 + i * pstep) * ps + plane_off + c) * 2 : kOobOffset);
 }
 // MFMA fragment whose K axis runs over tile positions 32 ks + 8 (lane >> 4) + e, e < 8, at channel 16 nt + (lane & 15):
 // two transposing reads (cca_platform.hpp: lane i of a 16-lane group supplies the address of row i >> 2, columns
@@ -467,6 +467,202 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
                 }
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gmap3: the same strip contraction as gmap_kernel on SPLIT-PLANE features with a pixel-major fp32 output, restructured
+// for MEMORY-LEVEL PARALLELISM.  Measured (profiles/r03b_family_compare.txt): pre-splitting the features changed the
+// gmap launches by 2 % -- they are bound by the ONE feature tile a workgroup has in flight (a group's iteration lasts one
+// loaded memory latency, ~4 us, however little it computes).  Here a workgroup keeps a ring of THREE feature tiles (two
+// in flight while one is consumed), and the results leave STRAIGHT FROM THE ACCUMULATORS: the swapped MFMA leaves a lane
+// with 4 consecutive channels of one position = one 16-byte store, the four N tiles of a pixel row are stored back to
+// back by the same wavefront (256 contiguous bytes per pixel), so there is no output image in LDS, no second barrier per
+// group, and the LDS that image used is the third ring slot (79,872 B: still two workgroups per CU).  The addend of the
+// row pass is prefetched in the accumulator layout one group ahead.  One counted barrier per group: every wait names
+// exactly how many of this wavefront's newer vector-memory operations (ring fills, addend prefetch, stores) may stay in
+// flight -- they complete in issue order.
+// ---------------------------------------------------------------------------------------------------------------
+template <int P, bool ROW, bool TRANS, bool ADD>
+__global__ __launch_bounds__(GS_THREADS, 2) void gmap3_kernel(const float *__restrict__ T, const bf16p_t *__restrict__ F,
+                                                               const float *__restrict__ addend, const float *__restrict__ gamma,
+                                                               float *__restrict__ out, int C, int H, int W, long fbs, int fps,
+                                                               long abs_, int aps, long obs, int ops, int n_whole, int split) {
+    constexpr int NT = (P + 15) / 16, TPW = (NT + GS_WAVES - 1) / GS_WAVES, NKS = P / 32;
+    constexpr int TSP = t16_size(P), FSZ = 2 * TSP, NPF = 2 * t16_pieces(P), NBUF = 3;
+    static_assert(P % 4 == 0 && NBUF * FSZ * 4 * 2 <= 163840, "gmap3: two workgroups per CU");
+    // (the ring fills are LDS-DMAs the compiler does not see -- fbuf_load_to_lds_x4_uncounted, cca_platform.hpp: with the
+    // builtin form it drained the fills of the next two tiles before every group's first transposing read)
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * FSZ];
+    CCA_LDS_REGISTER(lds);
+    const int HW = H * W, S = H + W;
+    const int L = ROW ? W : H, G = ROW ? H : W;
+    const int ncg = (C + GM_CG - 1) / GM_CG;
+    int id = blockIdx.x, cg0 = 0, cg1 = ncg;
+    if (id >= n_whole) {
+        const int r = id - n_whole, part = r % split;
+        id = n_whole + r / split;
+        cg0 = part * ncg / split;
+        cg1 = (part + 1) * ncg / split;
+    }
+    const int b = id / G, g = id - b * G;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
+    const int ln = lane & 15, lg = lane >> 4;
+    const int pix0 = ROW ? g * W : g, pstep = ROW ? 1 : W;
+    const int a_off = ROW ? H : 0;
+
+    const FBuf Tb = make_fbuf(T + (size_t)b * HW * S, (size_t)HW * S * sizeof(float));
+    const FBuf Fb = make_fbuf(reinterpret_cast<const float *>(F + (size_t)b * fbs), ((size_t)(HW - 1) * fps + 2 * C) * 2);
+    const FBuf Ob = make_fbuf(out + (size_t)b * obs, ((size_t)(HW - 1) * ops + C) * sizeof(float));
+    const FBuf Db = make_fbuf(ADD ? addend + (size_t)b * abs_ : T, ADD ? ((size_t)(HW - 1) * aps + C) * sizeof(float) : 4);
+    const float alpha = gamma ? gamma[0] : 1.f;
+    const BandK kp = band_ksteps(L);
+
+    // ring fill of group cg: every piece of both planes is issued whatever the strip length (zero fill beyond it), so a
+    // wavefront issues exactly npw instructions per tile
+    const int npw = (NPF - wv + GS_WAVES - 1) / GS_WAVES;
+    auto issue_feat = [&](int cg, float *dst) {
+#pragma unroll
+        for (int k = 0; k < (NPF + GS_WAVES - 1) / GS_WAVES; ++k) {
+            const int it = wv + GS_WAVES * k;
+            if (it < NPF) {                                                  // (wave-uniform)
+                const int plane = it >= NPF / 2;
+                t16_dma_piece(Fb, dst + plane * TSP, it - plane * (NPF / 2), lane, pix0, pstep, L, fps, cg * GM_CG, C, plane ? C : 0);
+            }
+        }
+    };
+    issue_feat(cg0, lds);
+    if (cg0 + 1 < cg1) issue_feat(cg0 + 1, lds + FSZ);
+
+    // the strip's attention block -> MFMA fragments in registers (as gmap_kernel)
+    u32x4 ah[TPW][NKS], al[TPW][NKS];
+    float at[TPW];
+#pragma unroll
+    for (int a = 0; a < TPW; ++a) {
+        const int t = wv + GS_WAVES * a, m = 16 * t + ln;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            float x[8];
+            if (ks < kp.nbf && 16 * t < L) {                          // wave-uniform
+                const int k0 = 32 * ks + 8 * lg;
+                if (!TRANS) {
+                    const int base = ((pix0 + m * pstep) * S + a_off + k0) * 4;
+                    const f32x4 u = fbuf_load_x4(Tb, (m < L && k0 < L) ? base : kOobOffset, 0);
+                    const f32x4 v = fbuf_load_x4(Tb, (m < L && k0 + 4 < L) ? base + 16 : kOobOffset, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { x[e] = k0 + e < L ? u[e] : 0.f; x[4 + e] = k0 + 4 + e < L ? v[e] : 0.f; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        x[e] = fbuf_load(Tb, (m < L && k0 + e < L) ? ((pix0 + (k0 + e) * pstep) * S + a_off + m) * 4 : kOobOffset, 0);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = 0.f;
+            }
+            const BfSplit sp = bf16_split8(x);
+            ah[a][ks] = sp.hi;
+            al[a][ks] = sp.lo;
+        }
+        const int kt = 32 * kp.nbf + lg;
+        at[a] = fbuf_load(Tb, (kp.tail && m < L && kt < L) ? (TRANS ? ((pix0 + kt * pstep) * S + a_off + m) * 4
+                                                                     : ((pix0 + m * pstep) * S + a_off + kt) * 4) : kOobOffset, 0);
+    }
+
+    // stores / addend loads of a group: one 16-byte access per owned M tile and N tile whose channels exist (both
+    // conditions wave-uniform, every instruction issued has valid lanes: only such instructions may be counted)
+    int ntile_w = 0;
+#pragma unroll
+    for (int a = 0; a < TPW; ++a) ntile_w += (wv + GS_WAVES * a) * 16 < L ? 1 : 0;
+    auto nnt = [&](int cg) { const int rem = C - cg * GM_CG; return rem >= GM_CG ? 4 : (rem + 15) / 16; };
+    auto nacc = [&](int cg) { return (cg >= cg0 && cg < cg1) ? ntile_w * nnt(cg) : 0; };   // per-wave accesses of a group
+    f32x4 addp[ADD ? 2 : 1][ADD ? TPW : 1][4];
+    auto load_addend = [&](int cg, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+        if constexpr (ADD) {
+#pragma unroll
+            for (int a = 0; a < TPW; ++a) {
+                const int i = 16 * (wv + GS_WAVES * a) + ln;
+                if ((wv + GS_WAVES * a) * 16 < L) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int c = cg * GM_CG + 16 * nt + 4 * lg;
+                        if (cg * GM_CG + 16 * nt < C)
+                            addp[slot][a][nt] = fbuf_load_x4(Db, (i < L && c < C) ? ((pix0 + i * pstep) * aps + c) * 4 : kOobOffset, 0);
+                    }
+                }
+            }
+        }
+    };
+    load_addend(cg0, std::integral_constant<int, 0>{});
+
+    // one group; SL = which half of the addend registers holds its addend (compile time: a dynamically indexed register
+    // array would live in scratch memory)
+    auto group = [&](int cg, auto slot_c) {
+        constexpr int SL = decltype(slot_c)::value;
+        const float *img = lds + ((cg - cg0) % NBUF) * FSZ;
+        float *nxt = lds + ((cg + 2 - cg0) % NBUF) * FSZ;                     // ring slot of tile cg + 2 (= the slot of tile cg - 1)
+        // tile cg landed and every wavefront is done with tile cg - 1.  This wavefront's vector-memory operations issued
+        // AFTER the fill of tile cg, oldest first: stores(cg - 2), addend(cg), fill(cg + 1), stores(cg - 1) -- they may stay in
+        // flight.  (First group: the prologue's loads are drained anyway.)
+        if (cg == cg0) barrier_dma_keep<0>();
+        else           barrier_dma_keep_n(nacc(cg - 2) + (ADD ? nacc(cg) : 0) + (cg + 1 < cg1 ? npw : 0) + nacc(cg - 1));
+        if (ADD && cg + 1 < cg1) load_addend(cg + 1, std::integral_constant<int, SL ^ 1>{});
+        if (cg + 2 < cg1) issue_feat(cg + 2, nxt);
+        f32x4 acc[TPW][4];
+#pragma unroll
+        for (int a = 0; a < TPW; ++a)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks < kp.nbf) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const u32x4 fh = t16_frag(img, ks, nt, lane), fl = t16_frag(img + TSP, ks, nt, lane);
+#pragma unroll
+                    for (int a = 0; a < TPW; ++a) {
+                        if ((wv + GS_WAVES * a) * 16 < L) {
+                            acc[a][nt] = mfma_bf16_16x16x32(fh, ah[a][ks], acc[a][nt]);
+                            acc[a][nt] = mfma_bf16_16x16x32(fl, ah[a][ks], acc[a][nt]);
+                            acc[a][nt] = mfma_bf16_16x16x32(fh, al[a][ks], acc[a][nt]);
+                        }
+                    }
+                }
+            }
+        }
+        if (kp.tail) {
+            const int pos = 32 * kp.nbf + lg;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const float fbv = __builtin_bit_cast(float, lds_load_u16(img, t16_byte(pos, 16 * nt + ln)) << 16)
+                                + __builtin_bit_cast(float, lds_load_u16(img + TSP, t16_byte(pos, 16 * nt + ln)) << 16);
+#pragma unroll
+                for (int a = 0; a < TPW; ++a)
+                    if ((wv + GS_WAVES * a) * 16 < L) acc[a][nt] = mfma_16x16x4(fbv, at[a], acc[a][nt]);
+            }
+            mfma_f32_result_fence();
+        }
+        // D^T[m = channel][n = position]: lane (ln, lg) holds channels 16 nt + 4 lg .. + 3 of position 16 t + ln
+#pragma unroll
+        for (int a = 0; a < TPW; ++a) {
+            const int i = 16 * (wv + GS_WAVES * a) + ln;
+            if ((wv + GS_WAVES * a) * 16 < L) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int c = cg * GM_CG + 16 * nt + 4 * lg;
+                    if (cg * GM_CG + 16 * nt < C) {
+                        f32x4 u = alpha * acc[a][nt];
+                        if constexpr (ADD) u += addp[SL][a][nt];
+                        fbuf_store_x4(Ob, u, (i < L && c < C) ? ((pix0 + i * pstep) * ops + c) * 4 : kOobOffset, 0);
+                    }
+                }
+            }
+        }
+    };
+    for (int cg = cg0; cg < cg1; cg += 2) {
+        group(cg, std::integral_constant<int, 0>{});
+        if (cg + 1 < cg1) group(cg + 1, std::integral_constant<int, 1>{});
     }
 }
 

@@ -104,6 +104,21 @@ __device__ __forceinline__ u32x2 lds_read_tr16_b64(const void *p) {
     return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t *)p));
 }
 
+// LDS-DMA that the COMPILER DOES NOT SEE (inline asm; same instruction as fbuf_load_to_lds_x4 with soffset 0).  hipcc
+// tracks builtin LDS-DMAs as LDS stores and protects later LDS reads it cannot prove disjoint from them with a
+// `s_waitcnt vmcnt` of its own -- for the transposing reads and the 16-bit gathers of cca_gmap.hpp that wait drained the
+// fill of the NEXT tile before every group's first fragment read (ISA: vmcnt(0) / vmcnt(#newer loads); tools/isa_waits.py),
+// i.e. the double buffer never overlapped anything.  An asm statement is opaque: no wait is inserted for it and it is not in
+// the compiler's vmcnt bookkeeping (its waits for other loads become slightly stricter, never weaker: completion is in issue
+// order).  The kernel itself waits with counted barriers (barrier_dma_keep*) before reading a tile -- as it always did.
+// M0 (LDS destination base) is saved and restored inside the statement (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void fbuf_load_to_lds_x4_uncounted(const FBuf &b, float *lds_wave_base, int voff_bytes) {
+    const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff_bytes), "s"(lds_addr), "s"(b) : "memory");
+}
+
 // Workgroup barrier that orders LDS traffic only: waits for this wave's LDS operations (lgkmcnt) but NOT for
 // its outstanding global stores / loads (vmcnt).  __syncthreads() drains vmcnt as well whenever an LDS-DMA
 // has been issued, which would stall every chunk on the acknowledgement of the tile stores.

@@ -275,6 +275,11 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
                                   long v_bs, int v_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
                                   void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
 
+/* Development / A-B switches by name (returns the previous value, < 0 for an unknown name); defaults are what ships:
+ *   "planes_ring"  1 = split-plane passes with a pixel-major output keep a ring of three feature tiles and store straight
+ *                      from the accumulators (gmap3_kernel), 0 = two tiles + output image in LDS (gmap_kernel). */
+int ccnet_cca_set_option(const char *name, int value);
+
 /* Launch profiler (a measurement aid, off by default).  Between ``begin`` and ``end`` every kernel launch the library
  * issues is bracketed by a HIP-event pair on its stream; ``end`` disarms, waits for the recorded launches and returns
  * their count (>= 0), filling ms[i] with launch i's duration and names + i * name_stride with its kernel name.

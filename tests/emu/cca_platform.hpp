@@ -148,6 +148,10 @@ __device__ inline void fbuf_load_to_lds_x4(const FBuf &b, float *lds_wave_base, 
         lds_wave_base[4 * emu::lane_id() + e] = fbuf_load(b, voff_bytes + 4 * e, soff_bytes);
 }
 
+__device__ inline void fbuf_load_to_lds_x4_uncounted(const FBuf &b, float *lds_wave_base, int voff_bytes) {
+    fbuf_load_to_lds_x4(b, lds_wave_base, voff_bytes, 0);
+}
+
 // ds_read_b64_tr_b16: see the product header.  Lane i of each 16-lane group receives, for j = 0..3, element (i & 3) of
 // the 8 bytes addressed by lane 4 j + (i >> 2) of its group.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));

@@ -227,12 +227,19 @@ const unsigned char *wave_exchange_bytes(const void *mine, size_t nbytes) {
 void lds_register(void *base, size_t bytes) {
     // first caller of the block wins; it runs before any other fiber touches LDS, and the
     // kernel follows the registration with a __syncthreads().
+    // (a kernel may register several __shared__ arrays: each is poisoned once per block, by its first caller)
+    static void *seen[8];
+    static int nseen = 0;
+    if (!lds_base) nseen = 0;                                // first registration of this block
+    for (int i = 0; i < nseen; ++i)
+        if (seen[i] == base) return;
+    if (nseen < 8) seen[nseen++] = base;
     if (!lds_base) {
         lds_base = base;
         lds_bytes = bytes;
-        uint32_t *p = static_cast<uint32_t *>(lds_base);
-        for (size_t i = 0; i < lds_bytes / 4; ++i) p[i] = 0x7fc0dead;
     }
+    uint32_t *p = static_cast<uint32_t *>(base);
+    for (size_t i = 0; i < bytes / 4; ++i) p[i] = 0x7fc0dead;
 }
 
 static void note(const void *addr, int site, bool write) {

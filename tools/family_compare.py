@@ -15,9 +15,11 @@ from ccnet_amd import _lib  # noqa: E402
 B, C, H, W = (int(a) for a in sys.argv[1:5]) if len(sys.argv) >= 5 else (8, 512, 97, 97)
 lib = _lib.get_lib()
 dev = torch.device("cuda:0")
-fams = [("nchw-strips", bench.CoreWorkload), ("pixel-major-f32", bench.PixelMajorF32Workload), ("planes", bench.PlanesWorkload)]
+fams = [("nchw-strips", bench.CoreWorkload), ("pixel-major-f32", bench.PixelMajorF32Workload),
+        ("planes-noring", bench.PlanesWorkload), ("planes", bench.PlanesWorkload)]
 res = {}
 for name, cls in fams:
+    lib.ccnet_cca_set_option(b"planes_ring", 0 if name == "planes-noring" else 1)
     wl = cls(lib, B, C, H, W, dev, 1234)
     for _ in range(5):
         wl.step()
@@ -30,12 +32,17 @@ for name, cls in fams:
           f"event sum {sum(t for _, t in rec) / 5:.4f}")
     for i in range(n):
         print(f"     {sum(rec[r * n + i][1] for r in range(5)) / 5 * 1e3:8.1f} us  {rec[i][0][:110]}")
-    if name == "planes":
+    if name.startswith("planes"):
         print(f"     split of v (producer side, outside the step): {bench.time_region(wl.split, 20) * 1e3:.1f} us")
     res[name] = wl
-a, b = res["planes"], res["pixel-major-f32"]
-a.step(); b.step()
-torch.cuda.synchronize()
-for nm in ("y", "dqkv", "A", "dgamma"):
-    d = (getattr(a, nm) - getattr(b, nm)).abs().max().item()
-    print(f"planes vs pixel-major-f32: max |d {nm}| = {d:.3e}   (max |ref| {getattr(b, nm).abs().max().item():.3e})")
+b = res["pixel-major-f32"]
+b.step()
+for fam, ring in (("planes-noring", 0), ("planes", 1)):
+    a = res[fam]
+    lib.ccnet_cca_set_option(b"planes_ring", ring)
+    a.step()
+    torch.cuda.synchronize()
+    for nm in ("y", "dqkv", "A", "dgamma"):
+        d = (getattr(a, nm) - getattr(b, nm)).abs().max().item()
+        print(f"{fam} vs pixel-major-f32: max |d {nm}| = {d:.3e}   (max |ref| {getattr(b, nm).abs().max().item():.3e})")
+lib.ccnet_cca_set_option(b"planes_ring", 1)
