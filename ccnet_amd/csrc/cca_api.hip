@@ -37,8 +37,9 @@ std::atomic<int> g_map_bf16{1};
 // The affinity kernel (ca_forward, K = C/8) always runs exact f32: its energies feed exp().
 std::atomic<int> g_weight_bf16{1};
 
-// development / A-B options (ccnet_cca_set_option): "planes_ring" 1 (default) = the split-plane passes with a pixel-major
-// output run gmap3_kernel (three-tile ring, stores from the accumulators), 0 = gmap_kernel (two tiles, output image in LDS)
+// development / A-B options (ccnet_cca_set_option): "planes_ring" 0 = gmap_kernel (two tiles, output image in LDS) for every
+// split-plane pass, 1 = the passes with a pixel-major output run gmap3_kernel (three-tile ring, stores from the accumulators,
+// two workgroups per CU), 2 = as 1 with the column passes on the two-tile / three-workgroups-per-CU form
 std::atomic<int> g_planes_ring{1};
 
 int fail(int code, const char *what) {
@@ -634,13 +635,24 @@ namespace {
 struct GmapPlan {
     int grid, n_whole, split;
 };
-GmapPlan gmap_plan(int strips, int C) {
-    const int cus = 2 * num_cus(), ncg = (C + cca::GM_CG - 1) / cca::GM_CG;
+// ``per_cu`` workgroups fit a CU.  The remainder strips are cut into the number of channel ranges that minimises the
+// estimated length of the last phase: ceil(parts / slots) sub-rounds of (channel groups per part + prologue) -- the
+// prologue (a strip's attention block) costs about one channel group of traffic.  (Round 2 used floor(slots / rem), which
+// left 264 remainder strips of the headline shape uncut: a second round at half occupancy.)
+GmapPlan gmap_plan(int strips, int C, int per_cu = 2) {
+    const int slots = per_cu * num_cus(), ncg = (C + cca::GM_CG - 1) / cca::GM_CG;
     GmapPlan p;
-    p.n_whole = strips / cus * cus;
+    p.n_whole = strips / slots * slots;
     const int rem = strips - p.n_whole;
-    int split = rem ? cus / rem : 1;
-    p.split = split < 1 ? 1 : (split > ncg ? ncg : split);
+    p.split = 1;
+    if (rem) {
+        double best = 1e30;
+        for (int s = 1; s <= ncg; ++s) {
+            const int parts = rem * s, rounds = (parts + slots - 1) / slots;
+            const double cost = rounds * ((ncg + s - 1) / s + 1.0);
+            if (cost < best - 1e-9) { best = cost; p.split = s; }
+        }
+    }
     p.grid = p.n_whole + rem * p.split;
     return p;
 }
@@ -1058,9 +1070,17 @@ template <bool TRANS>
 int launch_gmap3_planes(const float *T, const bf16p_t *F, const float *gamma, float *out, float *partial, int B, int C, int H, int W,
                         long fbs, int fps, long obs, int ops, bool row_too, ccnet_stream_t stream) {
     const long pbs = (long)H * W * C;
-    const GmapPlan gc = gmap_plan(B * W, C), gr = gmap_plan(B * H, C);
-    CCA_LAUNCH((cca::gmap3_kernel<100, false, TRANS, false>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS), stream, T, F,
-               (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0, pbs, C, gc.n_whole, gc.split);
+    const GmapPlan gr = gmap_plan(B * H, C);
+    const int ring = g_planes_ring.load();
+    if (ring == 2) {                        // three workgroups per CU, two ring slots
+        const GmapPlan gc = gmap_plan(B * W, C, 3);
+        CCA_LAUNCH((cca::gmap3_kernel<100, false, TRANS, false, 2, 3>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS), stream, T, F,
+                   (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0, pbs, C, gc.n_whole, gc.split);
+    } else {
+        const GmapPlan gc = gmap_plan(B * W, C);
+        CCA_LAUNCH((cca::gmap3_kernel<100, false, TRANS, false>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS), stream, T, F,
+                   (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0, pbs, C, gc.n_whole, gc.split);
+    }
     if (int e = launch_status("gmap3_planes(column)")) return e;
     if (!row_too) return 0;
     CCA_LAUNCH((cca::gmap3_kernel<100, true, TRANS, true>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS), stream, T, F,

@@ -483,14 +483,17 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
 // exactly how many of this wavefront's newer vector-memory operations (ring fills, addend prefetch, stores) may stay in
 // flight -- they complete in issue order.
 // ---------------------------------------------------------------------------------------------------------------
-template <int P, bool ROW, bool TRANS, bool ADD>
-__global__ __launch_bounds__(GS_THREADS, 2) void gmap3_kernel(const float *__restrict__ T, const bf16p_t *__restrict__ F,
+// NBUF ring slots (fills run NBUF - 1 tiles ahead), WPC workgroups per CU: <3, 2> keeps two tiles in flight per workgroup;
+// <2, 3> trades one of them for a third workgroup per CU (53,248 B of LDS, <= 168 VGPRs) -- 768 slots for the 776 strips
+// of a branch at the headline shape, where 512 slots left the second round half empty (profiles/r03c_family_compare.txt).
+template <int P, bool ROW, bool TRANS, bool ADD, int NBUF = 3, int WPC = 2>
+__global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__restrict__ T, const bf16p_t *__restrict__ F,
                                                                const float *__restrict__ addend, const float *__restrict__ gamma,
                                                                float *__restrict__ out, int C, int H, int W, long fbs, int fps,
                                                                long abs_, int aps, long obs, int ops, int n_whole, int split) {
     constexpr int NT = (P + 15) / 16, TPW = (NT + GS_WAVES - 1) / GS_WAVES, NKS = P / 32;
-    constexpr int TSP = t16_size(P), FSZ = 2 * TSP, NPF = 2 * t16_pieces(P), NBUF = 3;
-    static_assert(P % 4 == 0 && NBUF * FSZ * 4 * 2 <= 163840, "gmap3: two workgroups per CU");
+    constexpr int TSP = t16_size(P), FSZ = 2 * TSP, NPF = 2 * t16_pieces(P), D = NBUF - 1;
+    static_assert(P % 4 == 0 && NBUF * FSZ * 4 * WPC <= 163840 && (NBUF == 2 || NBUF == 3), "gmap3: LDS of WPC workgroups per CU");
     // (the ring fills are LDS-DMAs the compiler does not see -- fbuf_load_to_lds_x4_uncounted, cca_platform.hpp: with the
     // builtin form it drained the fills of the next two tiles before every group's first transposing read)
     __shared__ __attribute__((aligned(16))) float lds[NBUF * FSZ];
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap3_kernel(const float *__res
         }
     };
     issue_feat(cg0, lds);
-    if (cg0 + 1 < cg1) issue_feat(cg0 + 1, lds + FSZ);
+    if (D > 1 && cg0 + 1 < cg1) issue_feat(cg0 + 1, lds + FSZ);
 
     // the strip's attention block -> MFMA fragments in registers (as gmap_kernel)
     u32x4 ah[TPW][NKS], al[TPW][NKS];
@@ -601,14 +604,16 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap3_kernel(const float *__res
     auto group = [&](int cg, auto slot_c) {
         constexpr int SL = decltype(slot_c)::value;
         const float *img = lds + ((cg - cg0) % NBUF) * FSZ;
-        float *nxt = lds + ((cg + 2 - cg0) % NBUF) * FSZ;                     // ring slot of tile cg + 2 (= the slot of tile cg - 1)
+        float *nxt = lds + ((cg + D - cg0) % NBUF) * FSZ;                     // ring slot of tile cg + D (= the slot of tile cg - 1)
         // tile cg landed and every wavefront is done with tile cg - 1.  This wavefront's vector-memory operations issued
-        // AFTER the fill of tile cg, oldest first: stores(cg - 2), addend(cg), fill(cg + 1), stores(cg - 1) -- they may stay in
-        // flight.  (First group: the prologue's loads are drained anyway.)
+        // AFTER the fill of tile cg may stay in flight; oldest first (an iteration issues addend(c + 1), fill(c + D), stores(c)):
+        //   D = 2: stores(cg - 2), addend(cg), fill(cg + 1), stores(cg - 1)        D = 1: stores(cg - 1)
+        // (First group: the prologue's loads are drained anyway.)
         if (cg == cg0) barrier_dma_keep<0>();
-        else           barrier_dma_keep_n(nacc(cg - 2) + (ADD ? nacc(cg) : 0) + (cg + 1 < cg1 ? npw : 0) + nacc(cg - 1));
+        else if (D == 2) barrier_dma_keep_n(nacc(cg - 2) + (ADD ? nacc(cg) : 0) + (cg + 1 < cg1 ? npw : 0) + nacc(cg - 1));
+        else             barrier_dma_keep_n(nacc(cg - 1));
         if (ADD && cg + 1 < cg1) load_addend(cg + 1, std::integral_constant<int, SL ^ 1>{});
-        if (cg + 2 < cg1) issue_feat(cg + 2, nxt);
+        if (cg + D < cg1) issue_feat(cg + D, nxt);
         f32x4 acc[TPW][4];
 #pragma unroll
         for (int a = 0; a < TPW; ++a)

@@ -16,10 +16,11 @@ B, C, H, W = (int(a) for a in sys.argv[1:5]) if len(sys.argv) >= 5 else (8, 512,
 lib = _lib.get_lib()
 dev = torch.device("cuda:0")
 fams = [("nchw-strips", bench.CoreWorkload), ("pixel-major-f32", bench.PixelMajorF32Workload),
-        ("planes-noring", bench.PlanesWorkload), ("planes", bench.PlanesWorkload)]
+        ("planes-noring", bench.PlanesWorkload), ("planes", bench.PlanesWorkload), ("planes-3wg", bench.PlanesWorkload)]
+RING = {"planes-noring": 0, "planes": 1, "planes-3wg": 2}
 res = {}
 for name, cls in fams:
-    lib.ccnet_cca_set_option(b"planes_ring", 0 if name == "planes-noring" else 1)
+    lib.ccnet_cca_set_option(b"planes_ring", RING.get(name, 1))
     wl = cls(lib, B, C, H, W, dev, 1234)
     for _ in range(5):
         wl.step()
@@ -37,7 +38,7 @@ for name, cls in fams:
     res[name] = wl
 b = res["pixel-major-f32"]
 b.step()
-for fam, ring in (("planes-noring", 0), ("planes", 1)):
+for fam, ring in RING.items():
     a = res[fam]
     lib.ccnet_cca_set_option(b"planes_ring", ring)
     a.step()
