@@ -491,6 +491,66 @@ def launch_accounting(lib, wl, graph, steps=20):
     return out
 
 
+def planes_launch_bytes(B, C, H, W):
+    """Algorithmic (compulsory) bytes of every launch of one split-plane step, in issue order: what the launch must read and
+    write once, from the tensor sizes of SURVEY 8(d) (feature C-sized 4*P*C, Cq-sized 4*P*Cq, attention-shaped 4*P*S)."""
+    P, S, Cq = B * H * W, H + W, C // 8
+    fc, fq, att = 4 * P * C, 4 * P * Cq, 4 * P * S
+    return [
+        ("energies q.k (both branches)", 2 * fq + att),
+        ("softmax", 2 * att),
+        ("aggregation, column pass (v, A/2 -> partial)", 2 * fc + att // 2),
+        ("aggregation, row pass (v, A/2, partial, x -> y NCHW)", 4 * fc + att // 2),
+        ("dy NCHW -> planes", 2 * fc),
+        ("dA = dy.v (both branches)", 2 * fc + att),
+        ("dv, column pass (dy, A/2 -> partial)", 2 * fc + att // 2),
+        ("dv, row pass (dy, A/2, partial -> dv)", 3 * fc + att // 2),
+        ("softmax backward", 3 * att),
+        ("dgamma reduction", 0),
+        ("dq | dk, column pass", att // 2 + 4 * fq),
+        ("dq | dk, row pass", att // 2 + 6 * fq),
+    ]
+
+
+def planes_roofline(lib, wl, step_ms, launch_ms):
+    """Op-level roofline of the split-plane step + its dominant launch (timed INSIDE the step by the launch profiler)."""
+    B, C, H, W = wl.shape
+    nbytes = core_bytes(B, C, H, W)
+    ach = nbytes / (step_ms * 1e-3) / 1e9
+    traffic = measured_traffic(lib, "traffic_planes_latest.json")
+    obj = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(ach / HBM_COPY_GBS, 4),
+           "level": "op (one core fwd+bwd)", "algorithmic_bytes": nbytes, "step_ms": round(step_ms, 4),
+           "traffic": (traffic or {}).get("_step_total_bytes")}
+    table = planes_launch_bytes(B, C, H, W)
+    if len(launch_ms) == len(table):
+        rows = [{"launch": what, "kernel": name, "ms": ms, "bytes": nb} for (what, nb), (name, ms) in zip(table, launch_ms)]
+        obj["launches"] = [{"launch": r["launch"], "ms": r["ms"], "algorithmic_bytes": r["bytes"],
+                            "achieved_gbs": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1) if r["ms"] > 0 else None} for r in rows]
+        dom = max(rows, key=lambda r: r["ms"])
+        obj["dominant_kernel"] = {"kernel": dom["kernel"], "launch": dom["launch"], "kernel_ms": round(dom["ms"], 4),
+                                  "algorithmic_bytes": dom["bytes"],
+                                  "achieved_gbs": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
+                                  "frac": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "how": "HIP-event pair around the launch inside eager steps (ccnet_cca_profile_*)",
+                                  "traffic": (traffic or {}).get(dom["kernel"])}
+    return obj
+
+
+def strips_family_summary(lib, B, C, H, W, device):
+    """The same core on the NCHW strip kernels (q, k, v NCHW), for the family choice: eager step + in-step launch durations."""
+    wl = CoreWorkload(lib, B, C, H, W, device, 1234)
+    for _ in range(3):
+        wl.step()
+    out = {"ms_per_step": round(time_region(wl.step, 20), 4)}
+    rec = lib.profile_launches(lambda: [wl.step() for _ in range(3)])
+    n = len(rec) // 3
+    out["launch_ms"] = [[rec[i][0].replace("cca::", ""), round(sum(rec[r * n + i][1] for r in range(3)) / 3, 4)] for i in range(n)]
+    del wl
+    torch.cuda.empty_cache()
+    return out
+
+
 def lib_sha16(lib):
     """identity of the build being benched: hash of the kernel sources it is compiled from (hipcc output itself is not
     bit-reproducible; build() recompiles whenever a source is newer than the library)"""
@@ -772,8 +832,16 @@ def small_batch_ms(lib, C, H, W, device, batches=(1, 2), iters=30):
         pm[f"B{B}_ms"] = round(time_region(wl.step, iters), 4)
         del wl
     out["pixel_major_family"] = pm
-    out["what"] = ("fp32 core fwd+bwd; pixel_major_family = ccnet_cca_*_pm_nchw_f32 (one workgroup per strip; q | k | v are "
-                   "slices of the packed pixel-major projection, x / y / dy NCHW, dy transposed inside the step)")
+    pl = {}
+    for B in tuple(batches):
+        wl = PlanesWorkload(lib, B, C, H, W, device, 277 + B)
+        wl.step()
+        pl[f"B{B}_ms"] = round(time_region(wl.step, iters), 4)
+        del wl
+    out["split_plane_family"] = pl
+    out["what"] = ("fp32 core fwd+bwd, eager; B1_ms / B2_ms = NCHW strip kernels; pixel_major_family = ccnet_cca_*_pm_nchw_f32 (one "
+                   "workgroup per strip; q | k | v slices of the packed pixel-major projection, x / y / dy NCHW, dy transposed inside "
+                   "the step); split_plane_family = ccnet_cca_*_planes_f32 (the module's default route)")
     torch.cuda.empty_cache()
     return out
 
@@ -808,6 +876,9 @@ def main(argv=None, workload_factory=None):
     ap.add_argument("--train-batch", type=int, default=1, help="images per GPU in the train leg (engine.py:88: 8/world)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--prewarm-s", type=float, default=0.5, help="untimed pre-run (seconds) before the warm-up steps")
+    ap.add_argument("--family", default="planes", choices=("planes", "strips"),
+                    help="f32 core: planes (default) = split-plane path (q | k fp32 pixel-major, v as bf16 hi | lo planes, x / y / dy "
+                         "NCHW; what the module runs); strips = NCHW strip kernels (q, k, v NCHW)")
     ap.add_argument("--launch", default="graph", choices=("graph", "eager"),
                     help="graph (default): the step's launches are captured once into a hipGraph and the timed region replays "
                          "it (the task's 'capture launch-bound inner loops in hipGraphs'); eager: two C-ABI calls per step")
@@ -857,7 +928,9 @@ def main(argv=None, workload_factory=None):
             sys.exit("bench.py: --backend gloo needs --workload-factory (tests); the product path is HIP-only")
         from ccnet_amd import _lib
         lib = _lib.get_lib()
-        wl = (PixelMajorBF16Workload if bf16 else CoreWorkload)(lib, B, C, H, W, device, shard_seed(1234, rank))
+        use_planes = (not bf16 and args.family == "planes" and max(H, W) <= 100 and C % 8 == 0)
+        cls = PixelMajorBF16Workload if bf16 else PlanesWorkload if use_planes else CoreWorkload
+        wl = cls(lib, B, C, H, W, device, shard_seed(1234, rank))
 
     grads = torch.zeros(CCA_PARAM_FLOATS(C), device=device) if args.allreduce_grads else None
 
@@ -904,6 +977,7 @@ def main(argv=None, workload_factory=None):
     value = aggregate_value(nbytes, args.steps, world, secs)
     ms = secs / args.steps * 1e3
     impl = "injected" if lib is None else ("pixel-major bf16 mfma" if bf16 else
+                                           "split-plane mfma (v, dy pre-split into bf16 hi|lo planes)" if isinstance(wl, PlanesWorkload) else
                                            "mfma-strip" if lib.ccnet_cca_shape_uses_mfma(B, C, H, W) else "direct")
     out = {
         "metric": metric_label(C, H, W),
@@ -914,7 +988,9 @@ def main(argv=None, workload_factory=None):
                                 f"pixel-major features, fp32 attention / softmax / accumulate), ({B},{C},{H},{W}) per GPU"
                                 if bf16 else
                                 f"BASELINE.json configs[1]: single-op CrissCrossAttention core fwd+bwd, "
-                                f"({B},{C},{H},{W}) fp32 per GPU, R=1"),
+                                f"({B},{C},{H},{W}) fp32 per GPU, R=1"
+                                + ("; q | k fp32 pixel-major slices of the packed projection, v pre-split into bf16 hi|lo planes by "
+                                   "its producer, x / y / dy NCHW fp32, dq | dk | dv fp32 pixel-major" if isinstance(wl, PlanesWorkload) else "")),
                    "per_gpu_batch": B, "global_batch": B * world, "shape": [B, C, H, W],
                    "parallelism": f"batch-sharded x{world} (no data-path collective"
                                   + (", + all-reduce of the 7 parameter gradients per step)" if grads is not None else ")"),
@@ -949,10 +1025,15 @@ def main(argv=None, workload_factory=None):
         bwd_ms = time_region(wl.backward, 10)
         out["fwd_ms"], out["bwd_ms"] = round(fwd_ms, 4), round(bwd_ms, 4)
         out.update(launch_accounting(lib, wl, graph))
-        roof, rows = roofline_object(wl, ms)
-        out["roofline"] = roof
-        out["kernels_ms"] = {r["kernel"]: round(r["ms"], 4) for r in rows}
-        out["stages_ms"] = {k: round(v, 4) for k, v in roofline_object.stages.items()}
+        if isinstance(wl, PlanesWorkload):
+            out["roofline"] = planes_roofline(lib, wl, ms, out.get("launch_ms", []))
+            out["producer_split_ms"] = round(time_region(wl.split, 20), 4)
+            out["strips_family"] = strips_family_summary(lib, B, C, H, W, device)
+        else:
+            roof, rows = roofline_object(wl, ms)
+            out["roofline"] = roof
+            out["kernels_ms"] = {r["kernel"]: round(r["ms"], 4) for r in rows}
+            out["stages_ms"] = {k: round(v, 4) for k, v in roofline_object.stages.items()}
         for key, fn in (("bf16_config5", lambda: bf16_config5(lib, device)),
                         ("small_batch_core_ms", lambda: small_batch_ms(lib, C, H, W, device)),
                         ("rcca_head_R2_2048x97x97", lambda: rcca_head_ms(device)),

@@ -37,6 +37,7 @@ _PROTOTYPES = {
     "ccnet_cca_get_impl": (c_int, []),
     "ccnet_cca_set_branch_mask": (c_int, [c_int]),
     "ccnet_cca_set_precision": (c_int, [c_int]),
+    "ccnet_cca_get_precision": (c_int, []),
     "ccnet_ca_forward_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ccnet_ca_backward_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ccnet_ca_softmax_forward_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),

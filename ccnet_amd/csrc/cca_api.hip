@@ -40,7 +40,7 @@ std::atomic<int> g_weight_bf16{1};
 // development / A-B options (ccnet_cca_set_option): "planes_ring" 0 = gmap_kernel (two tiles, output image in LDS) for every
 // split-plane pass, 1 = the passes with a pixel-major output run gmap3_kernel (three-tile ring, stores from the accumulators,
 // two workgroups per CU), 2 = as 1 with the column passes on the two-tile / three-workgroups-per-CU form
-std::atomic<int> g_planes_ring{1};
+std::atomic<int> g_planes_ring{2};
 
 int fail(int code, const char *what) {
     char buf[256];
@@ -537,6 +537,10 @@ int ccnet_cca_set_precision(int precision) {
     if (precision == CCNET_PRECISION_DEFAULT) { g_map_bf16.store(1); g_weight_bf16.store(1); }
     if (precision == CCNET_PRECISION_BF16X3)  { g_map_bf16.store(2); g_weight_bf16.store(1); }
     return prev;
+}
+int ccnet_cca_get_precision(void) {
+    const int mb = g_map_bf16.load(), wb = g_weight_bf16.load();
+    return mb == 2 ? CCNET_PRECISION_BF16X3 : (mb == 1 || wb ? CCNET_PRECISION_DEFAULT : CCNET_PRECISION_F32);
 }
 int ccnet_cca_set_branch_mask(int mask) {
     if (mask >= 1 && mask <= 3) return g_branch_mask.exchange(mask);

@@ -715,23 +715,24 @@ class CrissCrossAttention(nn.Module):
     #: strides; set False (class or instance) for three separate convolutions exactly as functions.py:29-35.
     fuse_projections = True
 
-    #: fp32, no autocast: run projection + core + their backward as one autograd node (``CrissCrossModuleFunction``:
-    #: the input gradient ``dy + W^T dqkv`` is a single GEMM with beta = 1); False keeps torch's conv2d autograd.
+    #: fp32, no autocast: run projection + core + their backward as one autograd node (the input gradient
+    #: ``dy + W^T dqkv`` is a single GEMM with beta = 1); False keeps torch's conv2d autograd.
     fuse_module_backward = True
 
     #: activation memory (networks/ccnet.py:118-119 applies the module R times): when True the
     #: (B,H,W,H+W) attention tensor is NOT kept for backward -- it is recomputed from q, k (one affinity + softmax
-    #: launch pair, ~8 % of a fwd+bwd) -- so an application holds q, k, v only.  Under torch.no_grad() / eval nothing is
-    #: kept either way.
+    #: launch pair, ~8 % of a fwd+bwd) -- so an application holds q, k, v only.  A feature of the NCHW strip nodes: the
+    #: pixel-major / split-plane routes are skipped while it is set.  Under torch.no_grad() / eval nothing is kept either way.
     recompute_attention = False
 
-    #: fp32 channels_last inputs run on the pixel-major family (one workgroup per strip; x as (B, H, W, C) is then a free
-    #: view and nothing is copied).
+    #: fp32 NCHW inputs (no autocast, strips <= 100): the SPLIT-PLANE node (``CrissCrossPlanesModuleFunction``: q | k | v out
+    #: of one GEMM pixel-major, v and dy pre-split into bf16 hi | lo planes, x / y / dy NCHW).  Measured on MI355X, core
+    #: fwd+bwd at (8,512,97,97): 0.83 ms vs 0.87 ms on the NCHW strips of the same box (profiles/r03d_family_compare.txt).
+    split_planes = True
+    #: fp32 channels_last inputs run on the pixel-major family (x as (B, H, W, C) is then a free view: nothing is copied).
     pixel_major_for_channels_last = True
-    #: NCHW fp32 inputs with at most this many images run on the pixel-major family through ``CrissCrossPMModuleFunction``
-    #: (q | k | v pixel-major out of the projection GEMM, x / y / dy left NCHW).  Measured on MI355X at (B,512,97,97), core
-    #: fwd+bwd: B = 1 0.16 vs 0.265 ms on the NCHW strips, B = 2 0.24 vs 0.358 ms, B = 8 0.82 vs 0.85 ms (all-pixel-major
-    #: boundary); module fwd+bwd B = 1 0.505 vs 0.548, B = 2 0.718 vs 0.806, B = 4 1.229 vs 1.316, B = 8 2.31 vs 2.30 ms.  0 = never.
+    #: with ``split_planes`` off: NCHW fp32 inputs with at most this many images run on the pixel-major fp32 node
+    #: (``CrissCrossPMModuleFunction``, round 2: B = 1 0.16 vs 0.265 ms on the NCHW strips).  0 = never.
     pixel_major_max_batch = 4
 
     #: bf16 inputs: strips <= 132 (C, C/8 divisible by 8) run on the pixel-major bf16 MFMA kernels; geometries outside
@@ -739,69 +740,96 @@ class CrissCrossAttention(nn.Module):
     #: through fp32 copies on the fp32 MFMA kernels.
     native_bf16 = True
 
+    #: route name -> what runs (``route(x)`` picks one; ``forward`` only dispatches on it)
+    ROUTES = {
+        "bf16-pixel-major": "one x^T W^T projection + pixel-major bf16 MFMA kernels (BASELINE configs[4])",
+        "bf16-any-shape": "three convolutions + the any-shape bf16-I/O entry points (strips beyond every strip kernel)",
+        "f32-channels-last": "one x^T W^T projection + pixel-major fp32 kernels, channels_last in / out",
+        "f32-planes": "one autograd node: projection GEMM, v / dy as bf16 hi | lo planes, NCHW x / y / dy",
+        "f32-pixel-major": "one autograd node: projection GEMM emitting pixel-major q | k | v, NCHW x / y / dy",
+        "f32-strips-node": "one autograd node on the NCHW strip kernels (honours recompute_attention)",
+        "packed-strips": "stacked conv2d + NCHW strip kernels through channel-slice strides (any float dtype, autocast)",
+        "separate-strips": "three convolutions + NCHW strip / windowed / any-shape kernels (functions.py:29-35 as written)",
+    }
+
+    def route(self, x):
+        """Which implementation ``forward`` runs for this input (a key of ``ROUTES``).  The pixel-major and split-plane
+        routes always compute split-bf16 x3 (exact fp32 energies): they are skipped while the process-wide knobs pin exact
+        fp32 arithmetic (``ccnet_cca_set_precision(CCNET_PRECISION_F32)``) or the any-shape kernels (``CCNET_IMPL_DIRECT``),
+        while ``recompute_attention`` is set (they keep the attention tensor) and while ``fuse_projections`` is off."""
+        B, C, H, W = x.shape
+        cq = self.query_conv.out_channels
+        lib = _lib.get_lib()
+        knobs_ok = (lib.ccnet_cca_get_precision() != _lib.CCNET_PRECISION_F32 and lib.ccnet_cca_get_impl() != _lib.CCNET_IMPL_DIRECT)
+        fast_ok = knobs_ok and self.fuse_projections and not self.recompute_attention
+        if x.dtype == torch.bfloat16 and self.native_bf16:
+            if (fast_ok and (self._fusable(x) or (torch.is_autocast_enabled() and self._fusable()))   # (autocast casts W for linear)
+                    and pm_bf16_covers(B, C, cq, H, W)):
+                return "bf16-pixel-major"
+            if not self._strip_kernels_cover(x):
+                return "bf16-any-shape"
+        if x.dtype == torch.float32 and not torch.is_autocast_enabled() and self._fusable(x):
+            cl = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+            if fast_ok and pm_covers(torch.float32, B, C, cq, H, W):
+                if cl and self.pixel_major_for_channels_last:
+                    return "f32-channels-last"
+                if not cl and self.fuse_module_backward:
+                    if self.split_planes and planes_cover(B, C, cq, H, W):
+                        return "f32-planes"
+                    if B <= self.pixel_major_max_batch:
+                        return "f32-pixel-major"
+            if self.fuse_projections and self.fuse_module_backward:
+                return "f32-strips-node"
+        if self.fuse_projections and self._fusable():
+            return "packed-strips"
+        return "separate-strips"
+
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError(
                 "CrissCrossAttention (ccnet_amd): input is on the CPU. This module runs its attention core as HIP "
                 "kernels on an AMD GPU and has no CPU fallback; move the module and its input to the device.")
-        if (x.dtype == torch.bfloat16 and self.native_bf16
-                and (self._fusable(x) or (torch.is_autocast_enabled() and self._fusable()))   # (autocast casts W for linear)
-                and pm_bf16_covers(x.shape[0], x.shape[1], self.query_conv.out_channels, x.shape[2], x.shape[3])):
-            # bf16 activations (BASELINE configs[4]): pixel-major bf16 kernels.  x as (B, H, W, C) is a free view of a
-            # channels_last tensor (one transposing copy otherwise); query | key | value are ONE GEMM x^T W^T whose
-            # output the kernels read through channel-slice strides; y comes back in x's memory format.
-            cq = self.query_conv.out_channels
+        r = self.route(x)
+        cq = self.query_conv.out_channels
+        params = (self.query_conv.weight, self.query_conv.bias, self.key_conv.weight, self.key_conv.bias,
+                  self.value_conv.weight, self.value_conv.bias)
+        if r == "bf16-pixel-major":
+            # x as (B, H, W, C) is a free view of a channels_last tensor (one transposing copy otherwise); query | key | value
+            # are ONE GEMM x^T W^T whose output the kernels read through channel-slice strides; y comes back in x's memory format
             xp = x.permute(0, 2, 3, 1)
-            w = torch.cat([self.query_conv.weight, self.key_conv.weight, self.value_conv.weight], 0).flatten(1)
-            b = torch.cat([self.query_conv.bias, self.key_conv.bias, self.value_conv.bias], 0)
-            qkv = torch.nn.functional.linear(xp, w, b).to(torch.bfloat16)
+            qkv = torch.nn.functional.linear(xp, self._stacked_weight().flatten(1), self._stacked_bias()).to(torch.bfloat16)
             y = CrissCrossPMBF16Function.apply(qkv, xp, self.gamma.float(), cq).permute(0, 3, 1, 2)
-            # memory format follows the input: NCHW-contiguous in -> NCHW-contiguous out (one transposing copy each way)
             return y if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() else y.contiguous()
-        if x.dtype == torch.bfloat16 and self.native_bf16 and not self._strip_kernels_cover(x):
-            # bf16 activations at a geometry the fp32 MFMA strip kernels do not cover: run the bf16-I/O entry points
-            # (fp32 attention / softmax / accumulation inside) instead of materialising fp32 copies of every tensor
+        if r == "bf16-any-shape":
             q, k, v = self.query_conv(x), self.key_conv(x), self.value_conv(x)
             return CrissCrossBF16Function.apply(q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16),
                                                 x, self.gamma.float())
-        if (x.dtype == torch.float32 and not torch.is_autocast_enabled() and self._fusable(x)
-                and pm_covers(torch.float32, x.shape[0], x.shape[1], self.query_conv.out_channels, x.shape[2], x.shape[3])):
-            cl = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
-            if cl and self.pixel_major_for_channels_last:
-                # channels_last in, channels_last out: x as (B, H, W, C) is a free view, the projection one GEMM x^T W^T
-                cq = self.query_conv.out_channels
-                xp = x.permute(0, 2, 3, 1)
-                w = torch.cat([self.query_conv.weight, self.key_conv.weight, self.value_conv.weight], 0).flatten(1)
-                b = torch.cat([self.query_conv.bias, self.key_conv.bias, self.value_conv.bias], 0)
-                return CrissCrossPMFunction.apply(torch.nn.functional.linear(xp, w, b), xp, self.gamma, cq).permute(0, 3, 1, 2)
-            if (not cl and self.fuse_module_backward and not self.recompute_attention
-                    and x.shape[0] <= self.pixel_major_max_batch):
-                # NCHW in, NCHW out, one autograd node, one workgroup per strip (CCNet's own recipe is 1 image per GPU)
-                return CrissCrossPMModuleFunction.apply(x, self.query_conv.weight, self.query_conv.bias,
-                                                        self.key_conv.weight, self.key_conv.bias,
-                                                        self.value_conv.weight, self.value_conv.bias, self.gamma)
-        if (self.fuse_projections and self.fuse_module_backward and self._fusable(x) and x.dtype == torch.float32
-                and not torch.is_autocast_enabled()):
-            return CrissCrossModuleFunction.apply(x, self.query_conv.weight, self.query_conv.bias,
-                                                  self.key_conv.weight, self.key_conv.bias,
-                                                  self.value_conv.weight, self.value_conv.bias, self.gamma,
-                                                  self.recompute_attention)
-        if self.fuse_projections and self._fusable():
-            # one GEMM for functions.py:29,32,35: the three 1x1 convolutions share their input, so their
-            # weights are stacked row-wise (parameters and state_dict keys stay the reference's three convs)
-            w = torch.cat([self.query_conv.weight, self.key_conv.weight, self.value_conv.weight], 0)
-            b = torch.cat([self.query_conv.bias, self.key_conv.bias, self.value_conv.bias], 0)
-            qkv = torch.nn.functional.conv2d(x, w, b)
-            cq = self.query_conv.out_channels
-            # half inputs, or fp32 inputs whose projections autocast turned into bf16: the kernels compute in fp32
+        if r == "f32-channels-last":
+            xp = x.permute(0, 2, 3, 1)
+            qkv = torch.nn.functional.linear(xp, self._stacked_weight().flatten(1), self._stacked_bias())
+            return CrissCrossPMFunction.apply(qkv, xp, self.gamma, cq).permute(0, 3, 1, 2)
+        if r == "f32-planes":
+            return CrissCrossPlanesModuleFunction.apply(x, *params, self.gamma)
+        if r == "f32-pixel-major":
+            return CrissCrossPMModuleFunction.apply(x, *params, self.gamma)
+        if r == "f32-strips-node":
+            return CrissCrossModuleFunction.apply(x, *params, self.gamma, self.recompute_attention)
+        if r == "packed-strips":
+            # one GEMM for functions.py:29,32,35 (parameters and state_dict keys stay the reference's three convs); half
+            # inputs, or fp32 inputs whose projections autocast turned into bf16: the kernels compute in fp32
+            qkv = torch.nn.functional.conv2d(x, self._stacked_weight(), self._stacked_bias())
             return CrissCrossPackedFunction.apply(qkv.float(), x.float(), self.gamma.float(), cq,
                                                   self.recompute_attention).to(x.dtype)
-        proj_query = self.query_conv(x)
-        proj_key = self.key_conv(x)
-        proj_value = self.value_conv(x)
+        proj_query, proj_key, proj_value = self.query_conv(x), self.key_conv(x), self.value_conv(x)
         out = CrissCrossFunction.apply(proj_query.float(), proj_key.float(), proj_value.float(),
                                        x.float(), self.gamma.float(), self.recompute_attention)
         return out.to(x.dtype)
+
+    def _stacked_weight(self):
+        return torch.cat([self.query_conv.weight, self.key_conv.weight, self.value_conv.weight], 0)
+
+    def _stacked_bias(self):
+        return torch.cat([self.query_conv.bias, self.key_conv.bias, self.value_conv.bias], 0)
 
     @staticmethod
     def _strip_kernels_cover(x):

@@ -55,8 +55,13 @@ extern "C" {
 #define CCNET_IMPL_DIRECT  1           /* one-thread-per-output kernels, any shape */
 #define CCNET_IMPL_MFMA    2           /* MFMA strip kernels only (max(H,W) <= 320), error beyond */
 
-/* Arithmetic of the strip kernels.  The affinity (ca_forward), the softmax and the dq/dk kernels always run
- * exact fp32 (the f32 MFMA is bit-identical to an fmaf chain).  The three C-sized contractions may instead split
+/* Arithmetic of the NCHW STRIP kernels (ccnet_ca_*_f32, ccnet_cca_*_f32, *_strided_f32, *_ws_f32).  The affinity
+ * (ca_forward), the softmax and the dq/dk kernels of that family always run exact fp32 (the f32 MFMA is bit-identical
+ * to an fmaf chain).  The PIXEL-MAJOR and SPLIT-PLANE entry points (*_pm_*, *_planes_*) are not governed by this knob:
+ * they compute the energies in exact fp32 and EVERY other contraction (dq / dk included) as split-bf16 x3 -- callers that
+ * pin CCNET_PRECISION_F32 or CCNET_IMPL_DIRECT for validation must call the strip / direct entry points; the Python module
+ * reads the two knobs (ccnet_cca_get_precision / ccnet_cca_get_impl) and routes accordingly.
+ * The three C-sized contractions of the strip family may split
  * every fp32 operand into bf16 hi + lo and evaluate the products on the bf16 matrix pipe with fp32 accumulation
  * (relative error ~2^-17 per product; measured max-abs error at (8,512,97,97): 2e-4 on dq/dk, 3e-5 on y/dv,
  * inside the 1e-3 fp32 parity bar):
@@ -84,6 +89,7 @@ int         ccnet_cca_set_impl(int impl);          /* returns the previous setti
 int         ccnet_cca_get_impl(void);
 int         ccnet_cca_set_branch_mask(int mask);   /* returns the previous mask */
 int         ccnet_cca_set_precision(int precision);/* returns the previous setting */
+int         ccnet_cca_get_precision(void);
 
 /* Affinity: replaces functions.py:30-34 (layout shuffles), :38 (bmm + INF), :39 (bmm), :40 (cat
  * [+ Softmax when CCNET_CA_SOFTMAX]).  out (B,H,W,H+W). */
@@ -276,8 +282,11 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
                                   void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
 
 /* Development / A-B switches by name (returns the previous value, < 0 for an unknown name); defaults are what ships:
- *   "planes_ring"  1 = split-plane passes with a pixel-major output keep a ring of three feature tiles and store straight
- *                      from the accumulators (gmap3_kernel), 0 = two tiles + output image in LDS (gmap_kernel). */
+ *   "planes_ring"  which kernels run the split-plane passes that have a pixel-major output:
+ *                  2 (default) gmap3_kernel -- stores straight from the accumulators; column passes with two ring slots and
+ *                    three workgroups per CU, row passes with three ring slots and two workgroups per CU;
+ *                  1 gmap3_kernel, three ring slots / two workgroups per CU everywhere;
+ *                  0 gmap_kernel (two feature tiles + an output image in LDS). */
 int ccnet_cca_set_option(const char *name, int value);
 
 /* Launch profiler (a measurement aid, off by default).  Between ``begin`` and ``end`` every kernel launch the library

@@ -282,7 +282,7 @@ def test_fused_projection_matches_three_separate_convolutions(lib, dev, shape):
     B, C, H, W = shape
     torch.manual_seed(5)
     m = CrissCrossAttention(C).to(dev)
-    m.pixel_major_max_batch = 0              # this test is about the NCHW strip family (the pixel-major node has its own)
+    m.pixel_major_max_batch, m.split_planes = 0, False   # this test is about the NCHW strip family (the other nodes have their own)
     with torch.no_grad():
         m.gamma.fill_(0.7)
     assert m.fuse_projections and m._fusable()
@@ -511,6 +511,8 @@ def test_pixel_major_fp32_module_node_matches_the_strip_node_and_the_oracle(lib,
     mp = CrissCrossAttention(C).to(dev)
     mp.load_state_dict(ms.state_dict())
     ms.pixel_major_max_batch, mp.pixel_major_max_batch = 0, 1 << 30
+    ms.split_planes = mp.split_planes = False
+    assert ms.route(torch.empty(B, C, H, W, device=dev)) == "f32-strips-node" and mp.route(torch.empty(B, C, H, W, device=dev)) == "f32-pixel-major"
     x = torch.randn(B, C, H, W, device=dev)
     dy = torch.randn(B, C, H, W, device=dev)
     outs = []
@@ -822,7 +824,7 @@ def test_recompute_attention_matches_saved_attention_and_keeps_less(lib, dev):
             m = CrissCrossAttention(C).to(dev)
             m.fuse_module_backward = fused
             m.recompute_attention = rec
-            m.pixel_major_max_batch = 0           # (recompute is a feature of the NCHW strip nodes; keep both runs on them)
+            m.pixel_major_max_batch, m.split_planes = 0, False   # (recompute is a feature of the NCHW strip nodes; keep both runs on them)
             with torch.no_grad():
                 m.gamma.fill_(0.5)
             xd = x.clone().requires_grad_(True)

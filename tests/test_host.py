@@ -226,3 +226,54 @@ def test_measured_traffic_is_keyed_to_the_kernel_sources(tmp_path, monkeypatch):
     (tmp_path / "profiles" / "traffic_latest.json").write_text(json.dumps({"_step_total_bytes": 123, "_src_sha16": "0" * 16}))
     assert bench.measured_traffic(None) is None
     assert bench.measured_traffic(None, "missing.json") is None
+
+
+def test_module_routing_table(device_lib_path):
+    """``CrissCrossAttention.forward`` is ONE routing table.  ``route`` is a pure function of the input's
+    dtype / layout / shape, the module's flags and the two process-wide knobs; enumerate it (no kernel is launched: the
+    tensors are meta-free CPU stand-ins carrying only dtype, strides and shape)."""
+    from ccnet_amd import CrissCrossAttention, _lib
+    lib = _lib.get_lib()
+    m = CrissCrossAttention(64)
+    nchw = lambda B, H, W, dt=torch.float32: torch.empty(B, 64, H, W, dtype=dt)                       # noqa: E731
+    cl = lambda B, H, W, dt=torch.float32: nchw(B, H, W, dt).contiguous(memory_format=torch.channels_last)   # noqa: E731
+    assert set(m.ROUTES) >= {m.route(nchw(1, 8, 8))}
+    table = {
+        ("f32 NCHW 97x97 B=8", lambda: m.route(nchw(8, 97, 97))): "f32-planes",
+        ("f32 NCHW 97x97 B=1", lambda: m.route(nchw(1, 97, 97))): "f32-planes",
+        ("f32 NCHW 129x129 (beyond the plane kernels)", lambda: m.route(nchw(2, 129, 129))): "f32-strips-node",
+        ("f32 channels_last", lambda: m.route(cl(2, 33, 18))): "f32-channels-last",
+    }
+    for (what, fn), want in table.items():
+        assert fn() == want, what
+    m.to(torch.bfloat16)
+    assert m.route(cl(2, 129, 129, torch.bfloat16)) == "bf16-pixel-major"
+    assert m.route(nchw(1, 330, 9, torch.bfloat16)) == "bf16-any-shape"
+    assert m.route(nchw(1, 200, 9, torch.bfloat16)) == "packed-strips"           # windowed fp32 kernels through fp32 copies
+    m.to(torch.float32)
+    m.split_planes = False
+    assert m.route(nchw(2, 97, 97)) == "f32-pixel-major" and m.route(nchw(8, 97, 97)) == "f32-strips-node"
+    m.split_planes = True
+    m.recompute_attention = True                     # (ADVICE r2: the flag must not be silently ignored)
+    assert m.route(nchw(2, 97, 97)) == "f32-strips-node" and m.route(cl(2, 33, 18)) == "f32-strips-node"
+    m.recompute_attention = False
+    m.fuse_projections = False
+    assert m.route(nchw(2, 97, 97)) == "separate-strips"
+    m.fuse_projections = True
+    m.fuse_module_backward = False
+    assert m.route(nchw(2, 97, 97)) == "packed-strips"
+    m.fuse_module_backward = True
+    prev = lib.ccnet_cca_set_precision(_lib.CCNET_PRECISION_F32)                 # (ADVICE r2: the knobs are honoured)
+    try:
+        assert lib.ccnet_cca_get_precision() == _lib.CCNET_PRECISION_F32
+        assert m.route(nchw(2, 97, 97)) == "f32-strips-node" and m.route(cl(2, 33, 18)) == "f32-strips-node"
+    finally:
+        lib.ccnet_cca_set_precision(prev)
+    previ = lib.ccnet_cca_set_impl(_lib.CCNET_IMPL_DIRECT)
+    try:
+        assert m.route(nchw(2, 97, 97)) == "f32-strips-node"
+    finally:
+        lib.ccnet_cca_set_impl(previ)
+    assert m.route(nchw(2, 97, 97)) == "f32-planes"
+    m.query_conv = torch.nn.Conv2d(64, 8, 3, padding=1)                           # a swapped-out projection: nothing is bypassed
+    assert m.route(nchw(2, 97, 97)) == "separate-strips"
