@@ -1086,7 +1086,9 @@ int launch_gmap3_planes(const float *T, const bf16p_t *F, const float *gamma, fl
                    (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0, pbs, C, gc.n_whole, gc.split);
     }
     if (int e = launch_status("gmap3_planes(column)")) return e;
-    if (!row_too) return 0;
+    // (row passes: the accumulator-layout addend prefetch of gmap3 is still slower than gmap_kernel's output image --
+    // 121 vs 103 us at the headline shape, profiles/r03e_bench.json -- so only "planes_ring" 1 uses it there)
+    if (!row_too || ring != 1) return 0;
     CCA_LAUNCH((cca::gmap3_kernel<100, true, TRANS, true>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS), stream, T, F,
                (const float *)partial, gamma, out, C, H, W, fbs, fps, pbs, C, obs, ops, gr.n_whole, gr.split);
     return launch_status("gmap3_planes(row)");
@@ -1096,10 +1098,10 @@ int launch_gmap_planes(const float *T, const bf16p_t *F, const float *resid, con
                        int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
     const long pbs = (long)H * W * C;
     const GmapPlan gc = gmap_plan(B * W, C), gr = gmap_plan(B * H, C);
-    const bool ring = g_planes_ring.load() != 0;
+    const int ring = g_planes_ring.load();
     if (ring) {
         if (int e = launch_gmap3_planes<TRANS>(T, F, gamma, out, partial, B, C, H, W, fbs, fps, obs, ops, !NCHW, stream)) return e;
-        if (!NCHW) return 0;
+        if (!NCHW && ring == 1) return 0;
     } else {
     CCA_LAUNCH((cca::gmap_kernel<100, false, TRANS, false, bf16p_t, float>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS),
                stream, T, F, (const float *)nullptr, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0,

@@ -770,11 +770,15 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
     static_assert(!(PL && MASK), "gweight: the energies are computed from fp32 q, k (exact products)");
     constexpr bool EXACT = !BF && !PL && MASK;          // the energies feed exp(): exact fp32 products
     constexpr bool PRESPLIT = !BF && !PL && !MASK;      // fp32 dA: tiles are split into bf16 hi / lo images once per chunk
-    constexpr int TSB = GTile<bf16_t>::size(P);                       // dwords per bf16 image
-    constexpr int NPB = GTile<bf16_t>::pieces(P);
+    // split planes: T16 tile geometry (unpadded 1 KiB pieces, cca_gmap's plane tiles) so that THREE stages of X hi | X lo |
+    // Y hi | Y lo fit the 160 KB (159,744 B at P = 100): two stages in flight while one is multiplied (with two stages the
+    // launch ran at 4.2 TB/s, bound by the one stage a CU had in flight: profiles/r03e_bench.json)
+    constexpr int TSB = PL ? t16_size(P) : GTile<bf16_t>::size(P);   // dwords per bf16 image
+    constexpr int NPB = PL ? t16_pieces(P) : GTile<bf16_t>::pieces(P);
     constexpr int NT = (P + 15) / 16, NTR = (NT + GM_WAVES - 1) / GM_WAVES;
     constexpr int TSZ = PL ? 2 * TSB : GTile<FT>::size(P), NPF = PL ? 2 * NPB : GTile<FT>::pieces(P);
-    constexpr int NBUF = SINGLE ? 1 : 2;
+    constexpr int NBUF = SINGLE ? 1 : (PL && 3 * 2 * 2 * TSB * 4 <= 163840) ? 3 : 2;
+    constexpr int D = NBUF > 1 ? NBUF - 1 : 1;                        // fills run D stages ahead
     constexpr int LDS = 2 * NBUF * TSZ + (PRESPLIT ? 4 * TSB : 0);
     static_assert(LDS * 4 <= 163840, "gweight: LDS");
     __shared__ __attribute__((aligned(16))) float lds[LDS];
@@ -798,8 +802,8 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
         for (int it = wv; it < 2 * NPF; it += GM_WAVES) {
             if constexpr (PL) {
                 const int op = it >= NPF, r = it - op * NPF, plane = r >= NPB;
-                gtile_dma_piece<bf16_t>(op ? Yb : Xb, (op ? yb : xb) + plane * TSB, r - plane * NPB, lane, pix0, pstep, L,
-                                        op ? yps : xps, ch * GM_CG, Cx, plane ? Cx : 0);
+                t16_dma_piece(op ? Yb : Xb, (op ? yb : xb) + plane * TSB, r - plane * NPB, lane, pix0, pstep, L,
+                              op ? yps : xps, ch * GM_CG, Cx, plane ? Cx : 0);
             } else {
                 if (it < NPF) gtile_dma_piece<FT>(Xb, xb, it, lane, pix0, pstep, L, xps, ch * GM_CG, Cx);
                 else          gtile_dma_piece<FT>(Yb, yb, it - NPF, lane, pix0, pstep, L, yps, ch * GM_CG, Cx);
@@ -814,17 +818,23 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
     // bf16 fragment = the 8 consecutive channels 32 kk + 8 lg .. + 7 of one pixel = one 16-byte chunk (chunk q of pixel p
     // at chunk position q ^ (p & 7)) of a bf16 image
     auto frag = [&](const float *tile, int pixel_, int kk) {
-        const int pixel = pixel_ < 8 * GTile<bf16_t>::pieces(P) ? pixel_ : 0;      // (tile rows beyond the strip: results unused)
+        const int pixel = pixel_ < 8 * NPB ? pixel_ : 0;                            // (tile rows beyond the strip: results unused)
         const int chunk = 4 * kk + lg;
+        if constexpr (PL) return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(tile) + t16_byte(pixel, 8 * chunk));
         const int off = (pixel >> 3) * GM_PB + (pixel & 7) * 32 + ((chunk ^ (pixel & 7)) << 2);
         return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint32_t *>(tile) + off);
     };
     float *const img = lds + 2 * NBUF * TSZ;     // PRESPLIT: X_hi | X_lo | Y_hi | Y_lo
+    // this wavefront's pieces per stage (every piece is issued whatever the strip length: zero fill beyond it)
+    const int npw = (2 * NPF - wv + GM_WAVES - 1) / GM_WAVES;
     issue(0);
+    if (D > 1 && nch > 1) issue(1);
     for (int ch = 0; ch < nch; ++ch) {
         const float *xb = lds + (ch % NBUF) * 2 * TSZ, *yb = xb + TSZ;
-        barrier_dma_keep<0>();
-        if (ch + 1 < nch) issue(ch + 1);
+        // stage ch landed, every wavefront is done with stage ch - 1; the D - 1 stages issued after it may stay in flight
+        if (D > 1 && ch + 1 < nch) barrier_dma_keep_n(npw);
+        else                       barrier_dma_keep<0>();
+        if (ch + D < nch) issue(ch + D);
         if constexpr (EXACT) {
             // v_mfma_f32_16x16x4_f32 (bit-identical to an fmaf chain), 16 k-steps of 4 channels; lane (ln, lg) holds
             // channel 4 ks + lg of pixel ln of its tile

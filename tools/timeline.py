@@ -22,9 +22,12 @@ for f in files:
 rows.sort()
 if not rows:
     sys.exit("no cca:: kernels in the trace")
-# a step starts at every occurrence of the kernel that is launched first (the most frequent first-after-a-long-gap name:
-# simply the name of the first cca kernel of the trace)
-first = rows[0][2]
+# a step starts at the first kernel that is launched once per step: take the most common launch count among the kernel
+# names (once-per-step kernels outnumber the ones a step launches twice; set-up kernels run once in the whole trace)
+import collections
+counts = collections.Counter(r[2] for r in rows)
+per_step = collections.Counter(counts.values()).most_common(1)[0][0]
+first = next(r[2] for r in rows if counts[r[2]] == per_step)
 starts = [i for i, r in enumerate(rows) if r[2] == first]
 # keep only complete steps with the most common length
 lens = [b - a for a, b in zip(starts, starts[1:])]
