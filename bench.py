@@ -253,8 +253,8 @@ class PixelMajorBF16Workload:
         self.A = torch.empty(B, H, W, H + W, device=device)
         self.scratch = torch.empty_like(self.A)
         self.dgamma = torch.empty(1, device=device)
-        self.fws_bytes = lib.ccnet_cca_pm_bf16_workspace_bytes(B, C, Cq, H, W, 0)
-        self.ws_bytes = lib.ccnet_cca_pm_bf16_workspace_bytes(B, C, Cq, H, W, 1)
+        self.fws_bytes = lib.ccnet_cca_pm_workspace_bytes(B, C, Cq, H, W, 0)
+        self.ws_bytes = lib.ccnet_cca_pm_workspace_bytes(B, C, Cq, H, W, 1)
         self.ws = torch.empty(max(self.fws_bytes, self.ws_bytes) // 4 + 64, device=device)
 
     def stream(self):
@@ -284,10 +284,11 @@ class PixelMajorBF16Workload:
         self.backward()
 
 
-class PixelMajorF32Workload:
-    """The fp32 core on the pixel-major family with the module's boundary: q | k | v = channel slices of the packed pixel-major
-    projection, x / y / dy NCHW (ccnet_cca_forward_pm_nchw_f32 + ccnet_cca_backward_pm_nchw_f32; the transposition of dy is
-    inside the timed step)."""
+class PlanesWorkload:
+    """The fp32 core on the SPLIT-PLANE path (include/ccnet_cca.h): q | k fp32 pixel-major slices of the packed projection,
+    v as bf16 hi | lo planes (split once by its producer, ccnet_cca_split_planes_f32 -- outside the core step, like the
+    projection itself; ``producer_split_ms`` times it), x / y / dy NCHW, dy split inside the timed step, dq | dk | dv fp32
+    pixel-major."""
 
     def __init__(self, lib, B, C, H, W, device, seed):
         self.lib, self.shape = lib, (B, C, H, W)
@@ -302,50 +303,19 @@ class PixelMajorF32Workload:
         self.A = torch.empty(B, H, W, H + W, device=device)
         self.scratch = torch.empty_like(self.A)
         self.dgamma = torch.empty(1, device=device)
-        self.fws_bytes = lib.ccnet_cca_pm_nchw_f32_workspace_bytes(B, C, Cq, H, W, 0)
-        self.ws_bytes = lib.ccnet_cca_pm_nchw_f32_workspace_bytes(B, C, Cq, H, W, 1)
-        self.ws = torch.empty(max(self.fws_bytes, self.ws_bytes) // 4 + 64, device=device)
-
-    def stream(self):
-        return torch.cuda.current_stream().cuda_stream
-
-    def forward(self):
-        B, C, H, W = self.shape
-        L, cq, ct, p = self.lib, C // 8, self.ct, self.qkv.data_ptr()
-        bs = H * W * ct
-        L.check(L.ccnet_cca_forward_pm_nchw_f32(p, p + 4 * cq, p + 8 * cq, self.x.data_ptr(), self.gamma.data_ptr(),
-                                                self.y.data_ptr(), self.A.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct, bs, ct,
-                                                self.ws.data_ptr(), self.fws_bytes, self.stream()), "cca_forward_pm_nchw")
-
-    def backward(self):
-        B, C, H, W = self.shape
-        L, cq, ct, p, g = self.lib, C // 8, self.ct, self.qkv.data_ptr(), self.dqkv.data_ptr()
-        bs = H * W * ct
-        L.check(L.ccnet_cca_backward_pm_nchw_f32(self.dy.data_ptr(), p, p + 4 * cq, p + 8 * cq, self.A.data_ptr(),
-                                                 self.gamma.data_ptr(), g, g + 4 * cq, g + 8 * cq, self.dgamma.data_ptr(),
-                                                 self.scratch.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct, bs, ct,
-                                                 bs, ct, bs, ct, bs, ct, self.ws.data_ptr(), self.ws_bytes, self.stream()),
-                "cca_backward_pm_nchw")
-
-    def step(self):
-        self.forward()
-        self.backward()
-
-
-class PlanesWorkload(PixelMajorF32Workload):
-    """The fp32 core on the SPLIT-PLANE path (include/ccnet_cca.h): q | k fp32 pixel-major slices of the packed projection,
-    v as bf16 hi | lo planes (split once by its producer, ccnet_cca_split_planes_f32 -- outside the core step, like the
-    projection itself; ``split_ms`` times it), x / y / dy NCHW, dy split inside the timed step, dq | dk | dv fp32 pixel-major."""
-
-    def __init__(self, lib, B, C, H, W, device, seed):
-        super().__init__(lib, B, C, H, W, device, seed)
-        Cq = C // 8
         self.vpl = torch.empty(B, H, W, 2, C, dtype=torch.int16, device=device)
         self.fws_bytes = lib.ccnet_cca_planes_workspace_bytes(B, C, Cq, H, W, 0)
         self.ws_bytes = lib.ccnet_cca_planes_workspace_bytes(B, C, Cq, H, W, 1)
         self.ws = torch.empty(max(self.fws_bytes, self.ws_bytes) // 4 + 64, device=device)
         self.split()
         torch.cuda.synchronize()
+
+    def stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def step(self):
+        self.forward()
+        self.backward()
 
     def split(self):
         B, C, H, W = self.shape
@@ -825,13 +795,6 @@ def small_batch_ms(lib, C, H, W, device, batches=(1, 2), iters=30):
         wl.step()
         out[f"B{B}_ms"] = round(time_region(wl.step, iters), 4)
         del wl
-    pm = {}
-    for B in tuple(batches) + (8,):
-        wl = PixelMajorF32Workload(lib, B, C, H, W, device, 177 + B)
-        wl.step()
-        pm[f"B{B}_ms"] = round(time_region(wl.step, iters), 4)
-        del wl
-    out["pixel_major_family"] = pm
     pl = {}
     for B in tuple(batches):
         wl = PlanesWorkload(lib, B, C, H, W, device, 277 + B)
@@ -839,9 +802,9 @@ def small_batch_ms(lib, C, H, W, device, batches=(1, 2), iters=30):
         pl[f"B{B}_ms"] = round(time_region(wl.step, iters), 4)
         del wl
     out["split_plane_family"] = pl
-    out["what"] = ("fp32 core fwd+bwd, eager; B1_ms / B2_ms = NCHW strip kernels; pixel_major_family = ccnet_cca_*_pm_nchw_f32 (one "
-                   "workgroup per strip; q | k | v slices of the packed pixel-major projection, x / y / dy NCHW, dy transposed inside "
-                   "the step); split_plane_family = ccnet_cca_*_planes_f32 (the module's default route)")
+    out["what"] = ("fp32 core fwd+bwd, eager; B1_ms / B2_ms = NCHW strip kernels; split_plane_family = ccnet_cca_*_planes_f32 (one "
+                   "workgroup per strip; q | k slices of the packed pixel-major projection, v / dy as bf16 hi|lo planes, x / y / dy "
+                   "NCHW: the module's default route)")
     torch.cuda.empty_cache()
     return out
 

@@ -686,12 +686,6 @@ int ccnet_cca_forward_ws_f32(const float *q, const float *k, const float *v, con
     return ca_map_forward_impl(A, v, x, gamma, y, B, C, H, W, stream, v_bs, d, d);
 }
 
-int ccnet_cca_forward_strided_f32(const float *q, const float *k, const float *v, const float *x, const float *gamma,
-                                  float *y, float *A, int B, int C, int Cq, int H, int W,
-                                  long q_bs, long k_bs, long v_bs, ccnet_stream_t stream) {
-    return ccnet_cca_forward_ws_f32(q, k, v, x, gamma, y, A, B, C, Cq, H, W, q_bs, k_bs, v_bs, nullptr, 0, stream);
-}
-
 int ccnet_cca_attention_strided_f32(const float *q, const float *k, float *A, int B, int Cq, int H, int W,
                                     long q_bs, long k_bs, ccnet_stream_t stream) {
     if (int e = require_both_branches("cca_attention")) return e;
@@ -703,8 +697,8 @@ int ccnet_cca_attention_strided_f32(const float *q, const float *k, float *A, in
 
 int ccnet_cca_forward_f32(const float *q, const float *k, const float *v, const float *x, const float *gamma,
                           float *y, float *A, int B, int C, int Cq, int H, int W, ccnet_stream_t stream) {
-    return ccnet_cca_forward_strided_f32(q, k, v, x, gamma, y, A, B, C, Cq, H, W,
-                                         (long)Cq * H * W, (long)Cq * H * W, (long)C * H * W, stream);
+    return ccnet_cca_forward_ws_f32(q, k, v, x, gamma, y, A, B, C, Cq, H, W,
+                                    (long)Cq * H * W, (long)Cq * H * W, (long)C * H * W, nullptr, 0, stream);
 }
 
 int ccnet_cca_backward_strided_f32(const float *dy, const float *q, const float *k, const float *v, const float *A,
@@ -745,62 +739,6 @@ int ccnet_cca_backward_f32(const float *dy, const float *q, const float *k, cons
     return ccnet_cca_backward_strided_f32(dy, q, k, v, A, gamma, dq, dk, dv, dgamma, scratch, workspace,
                                           workspace_bytes, B, C, Cq, H, W, dq_, dq_, dc, dq_, dq_, dc, stream);
 }
-
-/* ---- bf16 feature I/O (BASELINE configs[4]): bf16 q, k, v, x, y, dy, dq, dk, dv; fp32 attention, softmax,
- * ---- accumulation, gamma.  Served by the any-shape kernels (one thread per output). ---- */
-int ccnet_cca_forward_bf16(const uint16_t *q_, const uint16_t *k_, const uint16_t *v_, const uint16_t *x_,
-                           const float *gamma, uint16_t *y_, float *A, int B, int C, int Cq, int H, int W,
-                           ccnet_stream_t stream) {
-    if (int e = require_both_branches("cca_forward_bf16")) return e;
-    if (!q_ || !k_ || !v_ || !x_ || !gamma || !y_ || !A) return fail(CCNET_E_NULLPTR, "cca_forward_bf16: null tensor");
-    if (int e = check_shape(B, C, H, W)) return e;
-    if (int e = check_shape(B, Cq, H, W)) return e;
-    using cca::bf16_t;
-    const bf16_t *q = (const bf16_t *)q_, *k = (const bf16_t *)k_, *v = (const bf16_t *)v_, *x = (const bf16_t *)x_;
-    bf16_t *y = (bf16_t *)y_;
-    const long dq_ = (long)Cq * H * W, dc = (long)C * H * W;
-    const size_t na = (size_t)B * H * W * (H + W), nf = (size_t)B * C * H * W;
-    CCA_LAUNCH((cca::direct_weight_kernel<true, bf16_t>), dim3(direct_grid(na)), dim3(cca::D_BLOCK), stream,
-               q, k, A, Cq, H, W, na, dq_, dq_);
-    if (int e = launch_status("cca_forward_bf16(energy)")) return e;
-    if (int e = softmax_forward(A, A, B, H, W, stream)) return e;
-    CCA_LAUNCH((cca::direct_map_kernel<bf16_t>), dim3(direct_grid(nf)), dim3(cca::D_BLOCK), stream,
-               (const float *)A, v, x, gamma, y, C, H, W, nf, dc, dc, dc);
-    return launch_status("cca_forward_bf16(aggregate)");
-}
-
-int ccnet_cca_backward_bf16(const uint16_t *dy_, const uint16_t *q_, const uint16_t *k_, const uint16_t *v_,
-                            const float *A, const float *gamma, uint16_t *dq_, uint16_t *dk_, uint16_t *dv_,
-                            float *dgamma, float *scratch, void *workspace, size_t workspace_bytes,
-                            int B, int C, int Cq, int H, int W, ccnet_stream_t stream) {
-    if (int e = require_both_branches("cca_backward_bf16")) return e;
-    if (!dy_ || !q_ || !k_ || !v_ || !A || !gamma || !dq_ || !dk_ || !dv_ || !dgamma || !scratch)
-        return fail(CCNET_E_NULLPTR, "cca_backward_bf16: null tensor");
-    if (int e = check_shape(B, C, H, W)) return e;
-    if (int e = check_shape(B, Cq, H, W)) return e;
-    using cca::bf16_t;
-    const bf16_t *dy = (const bf16_t *)dy_, *q = (const bf16_t *)q_, *k = (const bf16_t *)k_, *v = (const bf16_t *)v_;
-    bf16_t *dq = (bf16_t *)dq_, *dk = (bf16_t *)dk_, *dv = (bf16_t *)dv_;
-    const long sq = (long)Cq * H * W, sc = (long)C * H * W;
-    const size_t na = (size_t)B * H * W * (H + W), nf = (size_t)B * C * H * W, nq = (size_t)B * Cq * H * W;
-    // t = un-scaled dA into scratch, dv = gamma * (A^T-weighted sums of dy)
-    CCA_LAUNCH((cca::direct_weight_kernel<false, bf16_t>), dim3(direct_grid(na)), dim3(cca::D_BLOCK), stream,
-               dy, v, scratch, C, H, W, na, sc, sc);
-    if (int e = launch_status("cca_backward_bf16(dA)")) return e;
-    CCA_LAUNCH((cca::direct_mapT_kernel<bf16_t>), dim3(direct_grid(nf)), dim3(cca::D_BLOCK), stream,
-               A, dy, gamma, dv, C, H, W, nf, sc, sc);
-    if (int e = launch_status("cca_backward_bf16(dv)")) return e;
-    // dgamma = sum A*t ; dE = gamma * A * (t - sum_s A t), in place
-    if (int e = ccnet_ca_softmax_backward_f32(A, scratch, gamma, scratch, dgamma, workspace, workspace_bytes,
-                                              B, H, W, stream)) return e;
-    CCA_LAUNCH((cca::direct_map_kernel<bf16_t>), dim3(direct_grid(nq)), dim3(cca::D_BLOCK), stream,
-               (const float *)scratch, k, (const bf16_t *)nullptr, (const float *)nullptr, dq, Cq, H, W, nq, sq, 0L, sq);
-    if (int e = launch_status("cca_backward_bf16(dq)")) return e;
-    CCA_LAUNCH((cca::direct_mapT_kernel<bf16_t>), dim3(direct_grid(nq)), dim3(cca::D_BLOCK), stream,
-               (const float *)scratch, q, (const float *)nullptr, dk, Cq, H, W, nq, sq, sq);
-    return launch_status("cca_backward_bf16(dk)");
-}
-
 
 /* ---- pixel-major paths (cca_gmap.hpp): features as (B, H*W, pixel stride) views, fp32 attention ---- */
 extern "C++" {
@@ -955,10 +893,7 @@ int cca_backward_pm(const char *name, const FT *dy, const FT *q, const FT *k, co
 }  // namespace
 }  // extern "C++"
 
-size_t ccnet_cca_pm_bf16_workspace_bytes(int B, int C, int Cq, int H, int W, int backward) {
-    return pm_workspace_bytes(B, C, Cq, H, W, backward);
-}
-size_t ccnet_cca_pm_f32_workspace_bytes(int B, int C, int Cq, int H, int W, int backward) {
+size_t ccnet_cca_pm_workspace_bytes(int B, int C, int Cq, int H, int W, int backward) {
     return pm_workspace_bytes(B, C, Cq, H, W, backward);
 }
 
@@ -998,64 +933,6 @@ int ccnet_cca_backward_pm_f32(const float *dy, const float *q, const float *k, c
     return cca_backward_pm<float>("cca_backward_pm_f32", dy, q, k, v, A, gamma, dq, dk, dv, dgamma, scratch, B, C, Cq, H, W,
                                   dy_bs, dy_ps, q_bs, q_ps, k_bs, k_ps, v_bs, v_ps, dq_bs, dq_ps, dk_bs, dk_ps, dv_bs, dv_ps,
                                   workspace, workspace_bytes, stream);
-}
-
-/* ---- the same fp32 core with the module's own tensors left NCHW: x, y, dy are (B, C, H, W) fp32, q | k | v (dq | dk | dv)
- * ---- pixel-major views (the packed projection).  y leaves the final row pass as runs of W floats per channel; dy is
- * ---- brought pixel-major once (workspace) because it is a contraction operand of the column strips. ---- */
-size_t ccnet_cca_pm_nchw_f32_workspace_bytes(int B, int C, int Cq, int H, int W, int backward) {
-    const size_t base = pm_workspace_bytes(B, C, Cq, H, W, backward);
-    if (!base) return 0;
-    return align256(base) + (backward ? (size_t)B * H * W * C * sizeof(float) : 0);
-}
-
-int ccnet_nchw_to_pm_f32(const float *src, float *dst, int B, int C, int H, int W, long src_bs, long dst_bs, int dst_ps,
-                         ccnet_stream_t stream) {
-    if (int e = check_shape(B, C, H, W)) return e;
-    if (!src || !dst) return fail(CCNET_E_NULLPTR, "nchw_to_pm: null tensor");
-    if (dst_ps < C || dst_ps % 4 || dst_bs % 4 || src_bs < (long)C * H * W || (double)H * W * dst_ps >= 536870912.0)
-        return fail(CCNET_E_BADSHAPE, "nchw_to_pm: strides");
-    const int hw = H * W;
-    CCA_LAUNCH(cca::nchw_to_pm_kernel, dim3((unsigned)(B * ((hw + 63) / 64)), (unsigned)((C + 63) / 64)), dim3(256), stream,
-               src, dst, C, hw, src_bs, dst_bs, dst_ps);
-    return launch_status("nchw_to_pm");
-}
-
-int ccnet_cca_forward_pm_nchw_f32(const float *q, const float *k, const float *v, const float *x, const float *gamma,
-                                  float *y, float *A, int B, int C, int Cq, int H, int W,
-                                  long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
-                                  void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
-    if (int e = require_both_branches("cca_forward_pm_nchw_f32")) return e;
-    if (!q || !k || !v || !x || !gamma || !y || !A) return fail(CCNET_E_NULLPTR, "cca_forward_pm_nchw: null tensor");
-    if (int e = check_pm_problem<float>("cca_forward_pm_nchw: strips <= 100, C % 4 == 0, Cq % 4 == 0", B, C, Cq, H, W)) return e;
-    if (int e = check_pm_view<float>("cca_forward_pm_nchw: q view", q_bs, q_ps, Cq, H, W)) return e;
-    if (int e = check_pm_view<float>("cca_forward_pm_nchw: k view", k_bs, k_ps, Cq, H, W)) return e;
-    if (int e = check_pm_view<float>("cca_forward_pm_nchw: v view", v_bs, v_ps, C, H, W)) return e;
-    if ((double)C * H * W >= 536870912.0) return fail(CCNET_E_BADSHAPE, "cca_forward_pm_nchw: image exceeds 2^29 elements");
-    if (!workspace || workspace_bytes < ccnet_cca_pm_nchw_f32_workspace_bytes(B, C, Cq, H, W, 0))
-        return fail(CCNET_E_WORKSPACE, "cca_forward_pm_nchw: workspace missing or too small");
-    if (int e = gweight_pm<true, float>(q, k, A, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
-    if (int e = softmax_forward(A, A, B, H, W, stream)) return e;
-    const long img = (long)C * H * W;
-    return launch_gmap_pm<100, false, float, true>(A, v, x, gamma, y, (float *)workspace, B, C, H, W, v_bs, v_ps, img, 0, img, 0, stream);
-}
-
-int ccnet_cca_backward_pm_nchw_f32(const float *dy, const float *q, const float *k, const float *v, const float *A,
-                                   const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
-                                   int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps,
-                                   long v_bs, int v_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
-                                   void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
-    if (!dy) return fail(CCNET_E_NULLPTR, "cca_backward_pm_nchw: null tensor");
-    if (int e = check_pm_problem<float>("cca_backward_pm_nchw: strips <= 100, C % 4 == 0, Cq % 4 == 0", B, C, Cq, H, W)) return e;
-    const size_t need = ccnet_cca_pm_nchw_f32_workspace_bytes(B, C, Cq, H, W, 1);
-    if (!workspace || workspace_bytes < need) return fail(CCNET_E_WORKSPACE, "cca_backward_pm_nchw: workspace missing or too small");
-    const size_t base = align256(pm_workspace_bytes(B, C, Cq, H, W, 1));
-    float *dy_pm = reinterpret_cast<float *>(static_cast<char *>(workspace) + base);
-    const long pbs = (long)H * W * C;
-    if (int e = ccnet_nchw_to_pm_f32(dy, dy_pm, B, C, H, W, (long)C * H * W, pbs, C, stream)) return e;
-    return cca_backward_pm<float>("cca_backward_pm_nchw_f32", dy_pm, q, k, v, A, gamma, dq, dk, dv, dgamma, scratch, B, C, Cq, H, W,
-                                  pbs, C, q_bs, q_ps, k_bs, k_ps, v_bs, v_ps, dq_bs, dq_ps, dk_bs, dk_ps, dv_bs, dv_ps,
-                                  workspace, base, stream);
 }
 
 /* ---- SPLIT-PLANE path (cca_gmap.hpp, bf16p_t): the fp32 core with its C-sized contraction operands (v, dy) pre-split

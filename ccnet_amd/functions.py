@@ -28,7 +28,7 @@ from torch.nn import Softmax
 from . import _lib
 from ._lib import CCNET_CA_ENERGY, CCNET_CA_SOFTMAX
 
-__all__ = ["INF", "CA_Weight", "CA_Map", "CrissCrossFunction", "CrissCrossPackedFunction", "CrissCrossBF16Function", "CrissCrossModuleFunction", "ca_weight", "ca_map", "ca_softmax",
+__all__ = ["INF", "CA_Weight", "CA_Map", "CrissCrossFunction", "CrissCrossPackedFunction", "CrissCrossModuleFunction", "ca_weight", "ca_map", "ca_softmax",
            "criss_cross_attention", "CrissCrossAttention"]
 
 
@@ -276,7 +276,7 @@ class CrissCrossPackedFunction(torch.autograd.Function):
     """Fused core on a PACKED projection: ``qkv`` is the (B, 2*Cq + C, H, W) output of one 1x1 convolution whose
     weight is the row-wise concatenation of query_conv / key_conv / value_conv (functions.py:29,32,35).  The
     kernels read q, k, v as channel slices of it through the batch-stride arguments of
-    ``ccnet_cca_forward_strided_f32`` (include/ccnet_cca.h) -- no split copies -- and the backward writes dq, dk,
+    ``ccnet_cca_forward_ws_f32`` (include/ccnet_cca.h) -- no split copies -- and the backward writes dq, dk,
     dv straight into the slices of one ``dqkv`` tensor, which is what the fused convolution's backward consumes."""
 
     @staticmethod
@@ -335,58 +335,6 @@ class CrissCrossPackedFunction(torch.autograd.Function):
         return dqkv, dy, dgamma.view_as(gamma), None, None
 
 
-def _dev_bf16(name: str, t: torch.Tensor) -> torch.Tensor:
-    if not isinstance(t, torch.Tensor) or not t.is_cuda:
-        raise RuntimeError(f"{name}: expected a bfloat16 tensor on an AMD GPU (there is no CPU fallback)")
-    if t.dtype != torch.bfloat16:
-        raise RuntimeError(f"{name}: expected bfloat16, got {t.dtype}")
-    return t.contiguous()
-
-
-class CrissCrossBF16Function(torch.autograd.Function):
-    """Fused core with bf16 feature tensors (BASELINE configs[4]): q, k, v, x -> y in bf16, the attention, its
-    softmax, every accumulation and gamma in fp32 (``ccnet_cca_forward_bf16`` / ``ccnet_cca_backward_bf16``)."""
-
-    @staticmethod
-    def forward(ctx, q, k, v, x, gamma):
-        q, k, v, x = _dev_bf16("query", q), _dev_bf16("key", k), _dev_bf16("value", v), _dev_bf16("x", x)
-        gamma = _dev_f32("gamma", gamma)
-        _check_qk(q, k)
-        _same_device(q, k, v, x, gamma)
-        B, C, H, W = v.shape
-        if x.shape != v.shape or q.shape[0] != B or tuple(q.shape[2:]) != (H, W):
-            raise RuntimeError(f"shape mismatch: q {tuple(q.shape)}, v {tuple(v.shape)}, x {tuple(x.shape)}")
-        lib = _lib.get_lib()
-        y = torch.empty_like(x)
-        A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
-            lib.check(lib.ccnet_cca_forward_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), x.data_ptr(),
-                                                 gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
-                                                 B, C, q.shape[1], H, W, _stream()), "cca_forward_bf16")
-        ctx.save_for_backward(q, k, v, A, gamma)
-        return y
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, dy):
-        q, k, v, A, gamma = ctx.saved_tensors
-        dy = _dev_bf16("grad_output", dy)
-        B, C, H, W = v.shape
-        lib = _lib.get_lib()
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        dgamma = torch.empty_like(gamma)
-        scratch = torch.empty_like(A)
-        nbytes = lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
-        ws = torch.empty((nbytes + 3) // 4, device=v.device, dtype=torch.float32)
-        with torch.cuda.device(v.device):
-            lib.check(lib.ccnet_cca_backward_bf16(dy.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
-                                                  A.data_ptr(), gamma.data_ptr(), dq.data_ptr(), dk.data_ptr(),
-                                                  dv.data_ptr(), dgamma.data_ptr(), scratch.data_ptr(),
-                                                  ws.data_ptr(), nbytes, B, C, q.shape[1], H, W, _stream()),
-                      "cca_backward_bf16")
-        return dq, dk, dv, dy, dgamma.view_as(gamma)
-
-
 _PM_DTYPES = {torch.bfloat16: (2, 8, 132, "bf16"), torch.float32: (4, 4, 100, "f32")}   # bytes, alignment (elements), max strip
 
 
@@ -443,7 +391,7 @@ class CrissCrossPMFunction(torch.autograd.Function):
         lib = _lib.get_lib()
         y = torch.empty((B, H, W, C), device=x.device, dtype=qkv.dtype)
         A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
-        _ws, ws_ptr, nbytes = _workspace(lib.ccnet_cca_pm_bf16_workspace_bytes(B, C, cq, H, W, 0), x.device)
+        _ws, ws_ptr, nbytes = _workspace(lib.ccnet_cca_pm_workspace_bytes(B, C, cq, H, W, 0), x.device)
         p = qkv.data_ptr()
         fwd = getattr(lib, "ccnet_cca_forward_pm_" + tag)
         with torch.cuda.device(x.device):
@@ -467,7 +415,7 @@ class CrissCrossPMFunction(torch.autograd.Function):
         dqkv = torch.empty((B, H, W, ct), device=qkv.device, dtype=qkv.dtype)
         dgamma = torch.empty_like(gamma)
         scratch = torch.empty_like(A)
-        _ws, ws_ptr, nbytes = _workspace(lib.ccnet_cca_pm_bf16_workspace_bytes(B, C, cq, H, W, 1), qkv.device)
+        _ws, ws_ptr, nbytes = _workspace(lib.ccnet_cca_pm_workspace_bytes(B, C, cq, H, W, 1), qkv.device)
         p, g = qkv.data_ptr(), dqkv.data_ptr()
         bs, ps = qkv.stride(0), qkv.stride(2)
         bwd = getattr(lib, "ccnet_cca_backward_pm_" + tag)
@@ -550,65 +498,6 @@ class CrissCrossModuleFunction(torch.autograd.Function):
         dwq, dwk, dwv = dw[:cq], dw[cq:2 * cq], dw[2 * cq:]
         return (dx.view(B, C, H, W), dwq.reshape(cq, C, 1, 1), db[:cq], dwk.reshape(cq, C, 1, 1), db[cq:2 * cq],
                 dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma), None)
-
-
-class CrissCrossPMModuleFunction(torch.autograd.Function):
-    """The whole module as ONE autograd node on the pixel-major family with the module's own tensors left NCHW (fp32, no
-    autocast): the stacked projection is the GEMM ``x^T W^T`` (x read through its (B, C, HW) view as the transposed operand:
-    no copy) whose (B, HW, 2Cq + C) output IS the packed pixel-major q | k | v; the core (``ccnet_cca_*_pm_nchw_f32``) reads x,
-    writes y and reads dy as NCHW tensors; ``dx = dy + W^T dqkv^T`` is one GEMM with beta = 1 writing NCHW.  One workgroup per
-    strip: the path for 1-2 images per GPU, and since round 2 no slower than the NCHW strips at 8."""
-
-    @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma):
-        x, gamma = _dev_f32("x", x), _dev_f32("gamma", gamma)
-        B, C, H, W = x.shape
-        cq, hw = wq.shape[0], H * W
-        ct = 2 * cq + C
-        w = torch.cat([wq.reshape(cq, C), wk.reshape(cq, C), wv.reshape(C, C)], 0)          # (2Cq + C, C)
-        b = torch.cat([bq, bk, bv], 0)
-        xm = x.view(B, C, hw)
-        qkv = torch.baddbmm(b.view(1, 1, -1), xm.transpose(1, 2), w.t().unsqueeze(0).expand(B, -1, -1))   # (B, HW, 2Cq + C)
-        lib = _lib.get_lib()
-        y = torch.empty_like(x)
-        A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
-        p, bs = qkv.data_ptr(), hw * ct
-        with torch.cuda.device(x.device):
-            _ws, wsp, wsn = _workspace(lib.ccnet_cca_pm_nchw_f32_workspace_bytes(B, C, cq, H, W, 0), x.device)
-            lib.check(lib.ccnet_cca_forward_pm_nchw_f32(p, p + 4 * cq, p + 8 * cq, x.data_ptr(), gamma.data_ptr(),
-                                                        y.data_ptr(), A.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct, bs, ct,
-                                                        wsp, wsn, _stream()), "cca_forward_pm_nchw")
-        ctx.save_for_backward(x, w, qkv, A, gamma)
-        ctx.cq = cq
-        return y
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, dy):
-        cq = ctx.cq
-        x, w, qkv, A, gamma = ctx.saved_tensors
-        dy = _dev_f32("grad_output", dy)
-        B, C, H, W = x.shape
-        hw, ct = H * W, 2 * cq + C
-        lib = _lib.get_lib()
-        dqkv = torch.empty_like(qkv)
-        dgamma = torch.empty_like(gamma)
-        scratch = torch.empty_like(A)
-        p, g, bs = qkv.data_ptr(), dqkv.data_ptr(), hw * ct
-        with torch.cuda.device(dy.device):
-            _ws, wsp, wsn = _workspace(lib.ccnet_cca_pm_nchw_f32_workspace_bytes(B, C, cq, H, W, 1), dy.device)
-            lib.check(lib.ccnet_cca_backward_pm_nchw_f32(dy.data_ptr(), p, p + 4 * cq, p + 8 * cq, A.data_ptr(),
-                                                         gamma.data_ptr(), g, g + 4 * cq, g + 8 * cq, dgamma.data_ptr(),
-                                                         scratch.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct, bs, ct,
-                                                         bs, ct, bs, ct, bs, ct, wsp, wsn, _stream()), "cca_backward_pm_nchw")
-        xm = x.view(B, C, hw)
-        dqt = dqkv.transpose(1, 2)                                                            # (B, 2Cq + C, HW) view
-        dx = torch.baddbmm(dy.view(B, C, hw), w.t().unsqueeze(0).expand(B, -1, -1), dqt)      # dy + W^T dqkv^T  (NCHW)
-        dw = torch.bmm(dqt, xm.transpose(1, 2)).sum(0)                                        # (2Cq + C, C)
-        db = dqkv.sum(dim=(0, 1))
-        dwq, dwk, dwv = dw[:cq], dw[cq:2 * cq], dw[2 * cq:]
-        return (dx.view(B, C, H, W), dwq.reshape(cq, C, 1, 1), db[:cq], dwk.reshape(cq, C, 1, 1), db[cq:2 * cq],
-                dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma))
 
 
 def split_planes(t: torch.Tensor, c0: int, C: int) -> torch.Tensor:
@@ -731,22 +620,16 @@ class CrissCrossAttention(nn.Module):
     split_planes = True
     #: fp32 channels_last inputs run on the pixel-major family (x as (B, H, W, C) is then a free view: nothing is copied).
     pixel_major_for_channels_last = True
-    #: with ``split_planes`` off: NCHW fp32 inputs with at most this many images run on the pixel-major fp32 node
-    #: (``CrissCrossPMModuleFunction``, round 2: B = 1 0.16 vs 0.265 ms on the NCHW strips).  0 = never.
-    pixel_major_max_batch = 4
-
-    #: bf16 inputs: strips <= 132 (C, C/8 divisible by 8) run on the pixel-major bf16 MFMA kernels; geometries outside
-    #: every strip kernel (strips longer than 320) use the any-shape bf16-I/O entry points; the rest is computed
-    #: through fp32 copies on the fp32 MFMA kernels.
+    #: bf16 inputs: strips <= 132 (C, C/8 divisible by 8) run on the pixel-major bf16 MFMA kernels; every other geometry is
+    #: computed through fp32 copies on the fp32 kernels (round 2 also had any-shape bf16-I/O kernels for strips > 320:
+    #: 793 ms at configs[4], removed from the library in round 3).
     native_bf16 = True
 
     #: route name -> what runs (``route(x)`` picks one; ``forward`` only dispatches on it)
     ROUTES = {
         "bf16-pixel-major": "one x^T W^T projection + pixel-major bf16 MFMA kernels (BASELINE configs[4])",
-        "bf16-any-shape": "three convolutions + the any-shape bf16-I/O entry points (strips beyond every strip kernel)",
         "f32-channels-last": "one x^T W^T projection + pixel-major fp32 kernels, channels_last in / out",
         "f32-planes": "one autograd node: projection GEMM, v / dy as bf16 hi | lo planes, NCHW x / y / dy",
-        "f32-pixel-major": "one autograd node: projection GEMM emitting pixel-major q | k | v, NCHW x / y / dy",
         "f32-strips-node": "one autograd node on the NCHW strip kernels (honours recompute_attention)",
         "packed-strips": "stacked conv2d + NCHW strip kernels through channel-slice strides (any float dtype, autocast)",
         "separate-strips": "three convolutions + NCHW strip / windowed / any-shape kernels (functions.py:29-35 as written)",
@@ -766,8 +649,6 @@ class CrissCrossAttention(nn.Module):
             if (fast_ok and (self._fusable(x) or (torch.is_autocast_enabled() and self._fusable()))   # (autocast casts W for linear)
                     and pm_bf16_covers(B, C, cq, H, W)):
                 return "bf16-pixel-major"
-            if not self._strip_kernels_cover(x):
-                return "bf16-any-shape"
         if x.dtype == torch.float32 and not torch.is_autocast_enabled() and self._fusable(x):
             cl = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
             if fast_ok and pm_covers(torch.float32, B, C, cq, H, W):
@@ -776,8 +657,6 @@ class CrissCrossAttention(nn.Module):
                 if not cl and self.fuse_module_backward:
                     if self.split_planes and planes_cover(B, C, cq, H, W):
                         return "f32-planes"
-                    if B <= self.pixel_major_max_batch:
-                        return "f32-pixel-major"
             if self.fuse_projections and self.fuse_module_backward:
                 return "f32-strips-node"
         if self.fuse_projections and self._fusable():
@@ -800,18 +679,12 @@ class CrissCrossAttention(nn.Module):
             qkv = torch.nn.functional.linear(xp, self._stacked_weight().flatten(1), self._stacked_bias()).to(torch.bfloat16)
             y = CrissCrossPMBF16Function.apply(qkv, xp, self.gamma.float(), cq).permute(0, 3, 1, 2)
             return y if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() else y.contiguous()
-        if r == "bf16-any-shape":
-            q, k, v = self.query_conv(x), self.key_conv(x), self.value_conv(x)
-            return CrissCrossBF16Function.apply(q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16),
-                                                x, self.gamma.float())
         if r == "f32-channels-last":
             xp = x.permute(0, 2, 3, 1)
             qkv = torch.nn.functional.linear(xp, self._stacked_weight().flatten(1), self._stacked_bias())
             return CrissCrossPMFunction.apply(qkv, xp, self.gamma, cq).permute(0, 3, 1, 2)
         if r == "f32-planes":
             return CrissCrossPlanesModuleFunction.apply(x, *params, self.gamma)
-        if r == "f32-pixel-major":
-            return CrissCrossPMModuleFunction.apply(x, *params, self.gamma)
         if r == "f32-strips-node":
             return CrissCrossModuleFunction.apply(x, *params, self.gamma, self.recompute_attention)
         if r == "packed-strips":

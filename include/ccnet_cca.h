@@ -137,14 +137,14 @@ int ccnet_ca_map_backward_f32(const float *dout, const float *A, const float *v,
 size_t ccnet_cca_forward_workspace_bytes(int B, int C, int Cq, int H, int W);
 size_t ccnet_cca_backward_workspace_bytes(int B, int C, int Cq, int H, int W);
 
-/* ccnet_cca_forward_strided_f32 with the optional workspace described above. */
+/* The strided forward (see "strided forms" above), with the optional workspace described above (NULL / 0: unsplit). */
 int ccnet_cca_forward_ws_f32(const float *q, const float *k, const float *v, const float *x, const float *gamma,
                              float *y, float *A, int B, int C, int Cq, int H, int W,
                              long q_bs, long k_bs, long v_bs, void *workspace, size_t workspace_bytes,
                              ccnet_stream_t stream);
 
 /* The attention tensor alone: A = softmax(ca_forward(q, k)) with q, k addressed through batch strides (channel
- * slices of a stacked projection).  This is what ccnet_cca_forward_strided_f32 leaves in ``A``; the host calls it in
+ * slices of a stacked projection).  This is what ccnet_cca_forward_ws_f32 leaves in ``A``; the host calls it in
  * the backward pass when it chose NOT to keep A between forward and backward (recompute instead of save:
  * SURVEY.md 8(f) rank 4, networks/ccnet.py:118-119 -- R applications of the module hold R attention tensors). */
 int ccnet_cca_attention_strided_f32(const float *q, const float *k, float *A, int B, int Cq, int H, int W,
@@ -168,29 +168,12 @@ int ccnet_cca_backward_f32(const float *dy, const float *q, const float *k, cons
  * ``*_bs`` arguments are the distance between consecutive batch elements in ELEMENTS (dense tensor: C*H*W;
  * a slice of the fused projection: (2*Cq+C)*H*W).  Base pointers must be 4-byte aligned.  x, y, dy, A and
  * scratch stay dense.  A stride below C*H*W returns CCNET_E_BADSHAPE. */
-int ccnet_cca_forward_strided_f32(const float *q, const float *k, const float *v, const float *x,
-                                  const float *gamma, float *y, float *A,
-                                  int B, int C, int Cq, int H, int W,
-                                  long q_bs, long k_bs, long v_bs, ccnet_stream_t stream);
 int ccnet_cca_backward_strided_f32(const float *dy, const float *q, const float *k, const float *v,
                                    const float *A, const float *gamma, float *dq, float *dk, float *dv,
                                    float *dgamma, float *scratch, void *workspace, size_t workspace_bytes,
                                    int B, int C, int Cq, int H, int W,
                                    long q_bs, long k_bs, long v_bs, long dq_bs, long dk_bs, long dv_bs,
                                    ccnet_stream_t stream);
-
-/* bf16 feature I/O (BASELINE.json configs[4]: "bf16 mixed-precision CrissCrossAttention with fp32 softmax
- * accumulate"): q, k, v, x, y, dy, dq, dk, dv are bf16 (raw 16-bit patterns, NCHW contiguous); the attention
- * tensor A, the scratch buffer, gamma, dgamma and every accumulation stay fp32; outputs are rounded to nearest
- * even once, on store.  Same semantics and argument order as ccnet_cca_forward_f32 / ccnet_cca_backward_f32.
- * This round they run on the any-shape kernels (correct for every H, W; the MFMA strip kernels are fp32-only). */
-int ccnet_cca_forward_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v, const uint16_t *x,
-                           const float *gamma, uint16_t *y, float *A,
-                           int B, int C, int Cq, int H, int W, ccnet_stream_t stream);
-int ccnet_cca_backward_bf16(const uint16_t *dy, const uint16_t *q, const uint16_t *k, const uint16_t *v,
-                            const float *A, const float *gamma, uint16_t *dq, uint16_t *dk, uint16_t *dv,
-                            float *dgamma, float *scratch, void *workspace, size_t workspace_bytes,
-                            int B, int C, int Cq, int H, int W, ccnet_stream_t stream);
 
 /* Pixel-major bf16 path (BASELINE.json configs[4], (16,512,129,129) bf16): every feature tensor is a bf16
  * (B, H*W, pixel stride) VIEW -- element (b, c, h, w) at  b * bs + (h * W + w) * ps + c  (units: elements) -- which is
@@ -200,8 +183,8 @@ int ccnet_cca_backward_bf16(const uint16_t *dy, const uint16_t *q, const uint16_
  * of the bf16 features are exact on the matrix pipe; outputs are rounded to nearest even once, on store.
  * Constraints: max(H, W) <= 132, C % 8 == 0, Cq % 8 == 0, every bs / ps a multiple of 8, pointers 16-byte aligned.
  * y = gamma * (column + row aggregation) + x       (functions.py:46-49)
- * ``workspace``: ccnet_cca_pm_bf16_workspace_bytes(..., backward) bytes (fp32 column partials; + softmax partials). */
-size_t ccnet_cca_pm_bf16_workspace_bytes(int B, int C, int Cq, int H, int W, int backward);
+ * ``workspace``: ccnet_cca_pm_workspace_bytes(..., backward) bytes (fp32 column partials; + softmax partials). */
+size_t ccnet_cca_pm_workspace_bytes(int B, int C, int Cq, int H, int W, int backward);      /* (bf16 and fp32 views alike) */
 int ccnet_cca_forward_pm_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v, const uint16_t *x,
                               const float *gamma, uint16_t *y, float *A, int B, int C, int Cq, int H, int W,
                               long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long x_bs, int x_ps,
@@ -217,8 +200,8 @@ int ccnet_cca_backward_pm_bf16(const uint16_t *dy, const uint16_t *q, const uint
 /* The same core on fp32 pixel-major views (strips <= 100, C % 4 == 0, Cq % 4 == 0, every bs / ps a multiple of 4): one
  * strip per workgroup instead of 8 per workgroup -- 26x more workgroups per launch, which is what 1-2 images per GPU
  * need.  fp32 features are split into bf16 hi + lo on the fly (the three-product form of DESIGN.md 3.7);
- * same arguments and semantics as the bf16 pair. */
-size_t ccnet_cca_pm_f32_workspace_bytes(int B, int C, int Cq, int H, int W, int backward);
+ * same arguments, semantics and workspace as the bf16 pair.  (What the module runs for channels_last fp32 inputs; NCHW fp32
+ * inputs take the split-plane path below.) */
 int ccnet_cca_forward_pm_f32(const float *q, const float *k, const float *v, const float *x,
                              const float *gamma, float *y, float *A, int B, int C, int Cq, int H, int W,
                              long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long x_bs, int x_ps,
@@ -229,23 +212,6 @@ int ccnet_cca_backward_pm_f32(const float *dy, const float *q, const float *k, c
                               long dy_bs, int dy_ps, long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
                               long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
                               void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
-
-/* ... and with the module's own tensors left NCHW: x, y, dy are (B, C, H, W) fp32 contiguous, q | k | v and dq | dk | dv stay
- * pixel-major views (the packed x^T W^T projection and its gradient).  y is written by the final row pass as runs of W
- * floats per channel; dy -- a contraction operand of the column strips -- is brought pixel-major once, inside the
- * workspace (ccnet_nchw_to_pm_f32 is that transposition on its own).  Nothing of the module is copied on the host side. */
-size_t ccnet_cca_pm_nchw_f32_workspace_bytes(int B, int C, int Cq, int H, int W, int backward);
-int ccnet_nchw_to_pm_f32(const float *src, float *dst, int B, int C, int H, int W, long src_bs, long dst_bs, int dst_ps,
-                         ccnet_stream_t stream);
-int ccnet_cca_forward_pm_nchw_f32(const float *q, const float *k, const float *v, const float *x, const float *gamma,
-                                  float *y, float *A, int B, int C, int Cq, int H, int W,
-                                  long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
-                                  void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
-int ccnet_cca_backward_pm_nchw_f32(const float *dy, const float *q, const float *k, const float *v, const float *A,
-                                   const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
-                                   int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps,
-                                   long v_bs, int v_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
-                                   void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
 
 /* Which kernel family serves this shape under the current impl setting: 1 = stationary MFMA strip kernels
  * (max(H,W) <= 100), 2 = windowed MFMA strip kernels (101 .. 320), 0 = any-shape kernels. */

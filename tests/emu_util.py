@@ -154,8 +154,8 @@ class EmuOps:
         A = np.full((B, H, W, H + W), np.nan, np.float32)
         hw, bs = H * W * 4, (2 * cq + C) * H * W
         base = qkv.ctypes.data
-        self.lib.check(self.lib.ccnet_cca_forward_strided_f32(base, base + cq * hw, base + 2 * cq * hw, _p(x), _p(gamma),
-                                                              _p(y), _p(A), B, C, cq, H, W, bs, bs, bs, None))
+        self.lib.check(self.lib.ccnet_cca_forward_ws_f32(base, base + cq * hw, base + 2 * cq * hw, _p(x), _p(gamma),
+                                                         _p(y), _p(A), B, C, cq, H, W, bs, bs, bs, None, 0, None))
         return y, A
 
     def cca_backward_packed(self, dy, qkv, A, gamma, cq):
@@ -173,27 +173,6 @@ class EmuOps:
                                                                bs, bs, bs, bs, bs, bs, None))
         return dqkv, dgamma
 
-    def cca_forward_bf16(self, q, k, v, x, gamma):
-        """q, k, v, x: uint16 arrays holding bf16 bit patterns; returns (y bits, A fp32)."""
-        B, C, H, W = v.shape
-        y = np.zeros_like(v)
-        A = np.full((B, H, W, H + W), np.nan, np.float32)
-        self.lib.check(self.lib.ccnet_cca_forward_bf16(_p(q), _p(k), _p(v), _p(x), _p(gamma), _p(y), _p(A),
-                                                       B, C, q.shape[1], H, W, None))
-        return y, A
-
-    def cca_backward_bf16(self, dy, q, k, v, A, gamma):
-        B, C, H, W = v.shape
-        dq, dk, dv = np.zeros_like(q), np.zeros_like(k), np.zeros_like(v)
-        dgamma = np.full(1, np.nan, np.float32)
-        scratch = np.full_like(A, np.nan)
-        nbytes = self.lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
-        ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
-        self.lib.check(self.lib.ccnet_cca_backward_bf16(_p(dy), _p(q), _p(k), _p(v), _p(A), _p(gamma), _p(dq), _p(dk),
-                                                        _p(dv), _p(dgamma), _p(scratch), _p(ws), nbytes,
-                                                        B, C, q.shape[1], H, W, None))
-        return dq, dk, dv, dgamma
-
     def cca_forward_pm_bf16(self, qkv, x, gamma, cq):
         """qkv: uint16 (B, H, W, 2*cq + C) packed pixel-major projection (q | k | v channel slices, bf16 bit patterns),
         x: uint16 (B, H, W, ps >= C); returns (y bits (B, H, W, C), A fp32).  float32 arrays take the fp32 entry points."""
@@ -204,7 +183,7 @@ class EmuOps:
         f32 = qkv.dtype == np.float32
         es = 4 if f32 else 2
         fwd = self.lib.ccnet_cca_forward_pm_f32 if f32 else self.lib.ccnet_cca_forward_pm_bf16
-        nbytes = self.lib.ccnet_cca_pm_bf16_workspace_bytes(B, C, cq, H, W, 0)
+        nbytes = self.lib.ccnet_cca_pm_workspace_bytes(B, C, cq, H, W, 0)
         ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
         base, bs = qkv.ctypes.data, H * W * ct
         self.lib.check(fwd(base, base + es * cq, base + 2 * es * cq, _p(x), _p(gamma), _p(y), _p(A),
@@ -219,7 +198,7 @@ class EmuOps:
         dqkv = np.zeros_like(qkv)
         dgamma = np.full(1, np.nan, np.float32)
         scratch = np.full_like(A, np.nan)
-        nbytes = self.lib.ccnet_cca_pm_bf16_workspace_bytes(B, C, cq, H, W, 1)
+        nbytes = self.lib.ccnet_cca_pm_workspace_bytes(B, C, cq, H, W, 1)
         ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
         base, g, bs = qkv.ctypes.data, dqkv.ctypes.data, H * W * ct
         f32 = qkv.dtype == np.float32
@@ -229,34 +208,6 @@ class EmuOps:
                                                            g, g + es * cq, g + 2 * es * cq, _p(dgamma), _p(scratch),
                                                            B, C, cq, H, W, H * W * C, C, bs, ct, bs, ct, bs, ct,
                                                            bs, ct, bs, ct, bs, ct, _p(ws), nbytes, None))
-        return dqkv, dgamma
-
-    def cca_forward_pm_nchw(self, qkv, x, gamma, cq):
-        """qkv: float32 (B, H, W, 2*cq + C) packed pixel-major projection; x: float32 NCHW; returns (y NCHW, A)."""
-        B, H, W, ct = qkv.shape
-        C = ct - 2 * cq
-        y = np.full((B, C, H, W), np.nan, np.float32)
-        A = np.full((B, H, W, H + W), np.nan, np.float32)
-        nbytes = self.lib.ccnet_cca_pm_nchw_f32_workspace_bytes(B, C, cq, H, W, 0)
-        ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
-        base, bs = qkv.ctypes.data, H * W * ct
-        self.lib.check(self.lib.ccnet_cca_forward_pm_nchw_f32(base, base + 4 * cq, base + 8 * cq, _p(x), _p(gamma), _p(y), _p(A),
-                                                              B, C, cq, H, W, bs, ct, bs, ct, bs, ct, _p(ws), nbytes, None))
-        return y, A
-
-    def cca_backward_pm_nchw(self, dy, qkv, A, gamma, cq):
-        B, H, W, ct = qkv.shape
-        C = ct - 2 * cq
-        dqkv = np.full_like(qkv, np.nan)
-        dgamma = np.full(1, np.nan, np.float32)
-        scratch = np.full_like(A, np.nan)
-        nbytes = self.lib.ccnet_cca_pm_nchw_f32_workspace_bytes(B, C, cq, H, W, 1)
-        ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
-        base, g, bs = qkv.ctypes.data, dqkv.ctypes.data, H * W * ct
-        self.lib.check(self.lib.ccnet_cca_backward_pm_nchw_f32(_p(dy), base, base + 4 * cq, base + 8 * cq, _p(A), _p(gamma),
-                                                               g, g + 4 * cq, g + 8 * cq, _p(dgamma), _p(scratch),
-                                                               B, C, cq, H, W, bs, ct, bs, ct, bs, ct, bs, ct, bs, ct, bs, ct,
-                                                               _p(ws), nbytes, None))
         return dqkv, dgamma
 
     def split_planes(self, src_pm, C, c0=0):

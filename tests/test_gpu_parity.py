@@ -282,7 +282,7 @@ def test_fused_projection_matches_three_separate_convolutions(lib, dev, shape):
     B, C, H, W = shape
     torch.manual_seed(5)
     m = CrissCrossAttention(C).to(dev)
-    m.pixel_major_max_batch, m.split_planes = 0, False   # this test is about the NCHW strip family (the other nodes have their own)
+    m.split_planes = False   # this test is about the NCHW strip family (the other nodes have their own)
     with torch.no_grad():
         m.gamma.fill_(0.7)
     assert m.fuse_projections and m._fusable()
@@ -357,62 +357,23 @@ def _bf16_core_inputs(B, C, H, W, dev, seed):
     return q, k, v, x, dy
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 5, 6), (1, 24, 17, 20), (2, 64, 40, 33), (1, 32, 129, 70)])
-def test_bf16_io_matches_oracle_on_the_same_rounded_inputs(lib, dev, shape):
-    """BASELINE configs[4] at oracle-sized shapes: bf16 q/k/v/x/dy -> bf16 y/dq/dk/dv, fp32 inside.  Oracle: the
-    fp32 restatement on the same bf16-rounded inputs.  Tolerance re-stated: the fp32 path's 1e-3 before the final
-    rounding, plus one rounding of the output to bf16 (<= 2^-8 relative)."""
-    from ccnet_amd.functions import CrissCrossBF16Function
-    B, C, H, W = shape
-    q, k, v, x, dy = _bf16_core_inputs(B, C, H, W, dev, seed=51)
-    gamma = torch.tensor([0.5], device=dev)
-    leaves = [t.clone().requires_grad_(True) for t in (q, k, v, x)] + [gamma.clone().requires_grad_(True)]
-    y = CrissCrossBF16Function.apply(*leaves)
-    assert y.dtype == torch.bfloat16
-    y.backward(dy)
-    f = lambda t: t.detach().float().cpu()                                  # noqa: E731
-    yo, Ao = O.cca_core_forward(f(q), f(k), f(v), f(x), f(gamma))
-    go = O.cca_core_backward(f(dy), f(q), f(k), f(v), Ao, f(gamma))
-    tol = lambda ref: 2.0 ** -8 * ref.abs() + TOL                           # noqa: E731
-    assert bool(((f(y) - yo).abs() <= tol(yo)).all())
-    for got, name in zip(leaves[:3], ("dq", "dk", "dv")):
-        assert bool(((f(got.grad) - go[name]).abs() <= tol(go[name])).all()), name
-    assert torch.equal(leaves[3].grad, dy)                                  # dx of the core is dy (functions.py:49)
-    assert abs(float(leaves[4].grad) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
-
-
-def test_bf16_config5_full_size_against_the_fp32_path(lib, dev):
-    """BASELINE configs[4] at its full size (16,512,129,129): too large for the CPU oracle, so the bf16-I/O entry
-    points are compared with the fp32 entry points (checked against the oracle elsewhere; at this size the windowed
-    long-strip kernels) on the same bf16-rounded inputs; they must agree to one bf16 rounding of each output.  The
-    module uses the native bf16 path only where no strip kernel covers the geometry."""
-    from ccnet_amd import CrissCrossAttention, criss_cross_attention
-    from ccnet_amd.functions import CrissCrossBF16Function
-    lib.ccnet_cca_set_impl(0)
-    B, C, H, W = 16, 512, 129, 129
-    q, k, v, x, dy = _bf16_core_inputs(B, C, H, W, dev, seed=61)
-    q, k = q * 0.35, k * 0.35                                               # keep the softmax from saturating
-    gamma = torch.tensor([0.5], device=dev)
-    a = [t.clone().requires_grad_(True) for t in (q, k, v, x)] + [gamma.clone().requires_grad_(True)]
-    ya = CrissCrossBF16Function.apply(*a)
-    ya.backward(dy)
-    b = [t.float().requires_grad_(True) for t in (q, k, v, x)] + [gamma.clone().requires_grad_(True)]
-    yb = criss_cross_attention(*b)
-    yb.backward(dy.float())
-    tol = lambda ref: 2.0 ** -8 * ref.abs() + 2e-4                          # noqa: E731
-    assert bool(((ya.float() - yb).abs() <= tol(yb)).all())
-    for i, name in enumerate(("dq", "dk", "dv")):
-        assert bool(((a[i].grad.float() - b[i].grad).abs() <= tol(b[i].grad)).all()), name
-    assert abs(float(a[4].grad) - float(b[4].grad)) < 2e-3 * max(1.0, abs(float(b[4].grad)))
-    del a, b, ya, yb
+def test_bf16_module_beyond_every_strip_kernel_runs_through_fp32_copies(lib, dev):
+    """bf16 activations at a geometry no bf16 / MFMA kernel covers (strips > 320): the module computes through fp32 copies
+    on the any-shape fp32 kernels and hands back bf16 (round 2's any-shape bf16-I/O kernels were removed from the library)."""
+    from ccnet_amd import CrissCrossAttention
     m = CrissCrossAttention(64).to(dev).to(torch.bfloat16)
     assert m._strip_kernels_cover(torch.empty(1, 64, 129, 129)) and not m._strip_kernels_cover(torch.empty(1, 64, 321, 20))
     with torch.no_grad():
         m.gamma.fill_(0.5)
-    xm = torch.randn(1, 64, 330, 9, device=dev, dtype=torch.bfloat16, requires_grad=True)     # beyond every strip kernel
+    xm = torch.randn(1, 64, 330, 9, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    assert m.route(xm) == "packed-strips"
     ym = m(xm)
     ym.sum().backward()
     assert ym.dtype == torch.bfloat16 and m.gamma.grad is not None and xm.grad is not None
+    mf = CrissCrossAttention(64).to(dev)
+    mf.load_state_dict({k: v.float() for k, v in m.state_dict().items()})
+    yf = mf(xm.detach().float())
+    assert err(ym.float(), yf) < 2.0 ** -7 * float(yf.abs().max()) + 2e-2
 
 
 def _pm_inputs(B, C, H, W, dev, seed, qk_scale=1.0):
@@ -493,57 +454,14 @@ def test_pixel_major_fp32_kernels_match_oracle(lib, dev, shape):
     assert abs(float(gamma.grad) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
 
 
-@pytest.mark.parametrize("shape", [(1, 64, 20, 24), (2, 96, 33, 18), (1, 512, 97, 97), (1, 512, 97, 97, "default-init")])
-def test_pixel_major_fp32_module_node_matches_the_strip_node_and_the_oracle(lib, dev, shape):
-    """CrissCrossPMModuleFunction (projection GEMM emitting the packed pixel-major q | k | v, core with NCHW x / y / dy, one
-    autograd node) is what the module runs for small fp32 batches: same y, dx and parameter gradients as the NCHW-strip node
-    (tolerance: the two families' own arithmetic), and y against the oracle at the north_star bar."""
-    from ccnet_amd import CrissCrossAttention
-    halve = len(shape) == 4                     # 5th element: the projections keep their default initialisation
-    B, C, H, W = shape[:4]
-    torch.manual_seed(5)
-    ms = CrissCrossAttention(C).to(dev)
-    with torch.no_grad():
-        ms.gamma.fill_(0.5)
-        for c in (ms.query_conv, ms.key_conv):
-            if halve:
-                c.weight.mul_(0.5)
-    mp = CrissCrossAttention(C).to(dev)
-    mp.load_state_dict(ms.state_dict())
-    ms.pixel_major_max_batch, mp.pixel_major_max_batch = 0, 1 << 30
-    ms.split_planes = mp.split_planes = False
-    assert ms.route(torch.empty(B, C, H, W, device=dev)) == "f32-strips-node" and mp.route(torch.empty(B, C, H, W, device=dev)) == "f32-pixel-major"
-    x = torch.randn(B, C, H, W, device=dev)
-    dy = torch.randn(B, C, H, W, device=dev)
-    outs = []
-    for m in (ms, mp):
-        xi = x.clone().requires_grad_(True)
-        y = m(xi)
-        y.backward(dy)
-        outs.append((y.detach(), xi.grad, {n: p.grad for n, p in m.named_parameters()}))
-    rel = {n: err(g, outs[1][2][n]) / max(1.0, float(g.abs().max())) for n, g in outs[0][2].items()}
-    print("pixel-major module node vs strip node", shape, "y", f"{err(outs[0][0], outs[1][0]):.1e}", "dx",
-          f"{err(outs[0][1], outs[1][1]) / max(1.0, float(outs[0][1].abs().max())):.1e}",
-          {n: f"{e:.1e}" for n, e in rel.items()})
-    assert outs[1][0].is_contiguous() and err(outs[0][0], outs[1][0]) < 2e-4
-    assert err(outs[0][1], outs[1][1]) < 5e-4 * max(1.0, float(outs[0][1].abs().max()))
-    for n, e in rel.items():
-        assert e < 2e-3, n
-    with torch.no_grad():
-        f = lambda t: t.detach().float().cpu()                              # noqa: E731
-        qo, ko, vo = (f(c(x)) for c in (ms.query_conv, ms.key_conv, ms.value_conv))
-    yo, _ = O.cca_core_forward(qo, ko, vo, f(x), torch.tensor([0.5]))
-    assert err(outs[1][0], yo) < TOL
-
-
 @pytest.mark.parametrize("shape", [(1, 64, 20, 24), (2, 96, 33, 18), (1, 64, 100, 3), (2, 512, 97, 97, "default-init")])
 def test_split_plane_module_node_matches_the_oracle_and_the_other_nodes(lib, dev, shape):
     """CrissCrossPlanesModuleFunction (v and dy enter the kernels pre-split into bf16 hi | lo planes, fragments by
-    transposing LDS reads): y against the oracle at the north_star bar with the projections at their DEFAULT initialisation
-    (unscaled q, k), y / dx / all 7 parameter gradients against the pixel-major fp32 node (same arithmetic: fp32 summation
-    noise only) and the NCHW-strip node."""
+    transposing LDS reads) -- the module's default route for fp32 NCHW inputs: y against the oracle at the north_star bar
+    with the projections at their DEFAULT initialisation (unscaled q, k), y / dx / all 7 parameter gradients against the
+    NCHW-strip node (different kernels, different arithmetic for dq / dk: bar = 3x the measured difference)."""
     from ccnet_amd import CrissCrossAttention
-    from ccnet_amd.functions import CrissCrossPlanesModuleFunction, CrissCrossPMModuleFunction
+    from ccnet_amd.functions import CrissCrossModuleFunction, CrissCrossPlanesModuleFunction
     B, C, H, W = shape[:4]
     torch.manual_seed(7)
     m = CrissCrossAttention(C).to(dev)
@@ -551,22 +469,23 @@ def test_split_plane_module_node_matches_the_oracle_and_the_other_nodes(lib, dev
         m.gamma.fill_(0.5)
     x = torch.randn(B, C, H, W, device=dev)
     dy = torch.randn(B, C, H, W, device=dev)
+    assert m.route(x) == "f32-planes"
     outs = {}
-    for name, fn in (("planes", CrissCrossPlanesModuleFunction), ("pm", CrissCrossPMModuleFunction)):
+    for name, fn, extra in (("planes", CrissCrossPlanesModuleFunction, ()), ("strips", CrissCrossModuleFunction, (False,))):
         m.zero_grad(set_to_none=True)
         xi = x.clone().requires_grad_(True)
         y = fn.apply(xi, m.query_conv.weight, m.query_conv.bias, m.key_conv.weight, m.key_conv.bias,
-                     m.value_conv.weight, m.value_conv.bias, m.gamma)
+                     m.value_conv.weight, m.value_conv.bias, m.gamma, *extra)
         y.backward(dy)
         outs[name] = (y.detach(), xi.grad, {n: p.grad.clone() for n, p in m.named_parameters()})
-    a, b = outs["planes"], outs["pm"]
+    a, b = outs["planes"], outs["strips"]
     rel = {n: err(g, b[2][n]) / max(1.0, float(g.abs().max())) for n, g in a[2].items()}
-    print("split-plane node vs pixel-major fp32 node", shape, "y", f"{err(a[0], b[0]):.1e}", "dx",
+    print("split-plane node vs NCHW-strip node", shape, "y", f"{err(a[0], b[0]):.1e}", "dx",
           f"{err(a[1], b[1]) / max(1.0, float(b[1].abs().max())):.1e}", {n: f"{e:.1e}" for n, e in rel.items()})
-    assert a[0].is_contiguous() and err(a[0], b[0]) < 2e-5
-    assert err(a[1], b[1]) < 5e-5 * max(1.0, float(b[1].abs().max()))
+    assert a[0].is_contiguous() and err(a[0], b[0]) < 2e-4
+    assert err(a[1], b[1]) < 5e-4 * max(1.0, float(b[1].abs().max()))
     for n, e in rel.items():
-        assert e < 2e-4, n
+        assert e < 3e-3, n
     with torch.no_grad():
         f = lambda t: t.detach().float().cpu()                              # noqa: E731
         qo, ko, vo = (f(c(x)) for c in (m.query_conv, m.key_conv, m.value_conv))
@@ -824,7 +743,7 @@ def test_recompute_attention_matches_saved_attention_and_keeps_less(lib, dev):
             m = CrissCrossAttention(C).to(dev)
             m.fuse_module_backward = fused
             m.recompute_attention = rec
-            m.pixel_major_max_batch, m.split_planes = 0, False   # (recompute is a feature of the NCHW strip nodes; keep both runs on them)
+            m.split_planes = False   # (recompute is a feature of the NCHW strip nodes; keep both runs on them)
             with torch.no_grad():
                 m.gamma.fill_(0.5)
             xd = x.clone().requires_grad_(True)
@@ -895,8 +814,8 @@ def test_pixel_major_cores_are_bit_identical_run_to_run(lib, dev):
     import bench
     noise = torch.randn(16 * 1024 * 1024, device=dev)
     side = torch.cuda.Stream()
-    for wl in (bench.PixelMajorBF16Workload(lib, 2, 512, 129, 129, dev, 7), bench.PixelMajorF32Workload(lib, 2, 512, 97, 97, dev, 9),
-               bench.PixelMajorF32Workload(lib, 1, 128, 100, 61, dev, 11)):
+    for wl in (bench.PixelMajorBF16Workload(lib, 2, 512, 129, 129, dev, 7), bench.PlanesWorkload(lib, 2, 512, 97, 97, dev, 9),
+               bench.PlanesWorkload(lib, 1, 128, 100, 61, dev, 11), bench.PlanesWorkload(lib, 8, 512, 97, 97, dev, 12)):
         wl.step()
         torch.cuda.synchronize()
         ref = [t.clone() for t in (wl.y, wl.dqkv, wl.dgamma, wl.A)]

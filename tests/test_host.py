@@ -248,11 +248,11 @@ def test_module_routing_table(device_lib_path):
         assert fn() == want, what
     m.to(torch.bfloat16)
     assert m.route(cl(2, 129, 129, torch.bfloat16)) == "bf16-pixel-major"
-    assert m.route(nchw(1, 330, 9, torch.bfloat16)) == "bf16-any-shape"
+    assert m.route(nchw(1, 330, 9, torch.bfloat16)) == "packed-strips"           # any-shape fp32 kernels through fp32 copies
     assert m.route(nchw(1, 200, 9, torch.bfloat16)) == "packed-strips"           # windowed fp32 kernels through fp32 copies
     m.to(torch.float32)
     m.split_planes = False
-    assert m.route(nchw(2, 97, 97)) == "f32-pixel-major" and m.route(nchw(8, 97, 97)) == "f32-strips-node"
+    assert m.route(nchw(2, 97, 97)) == "f32-strips-node" and m.route(nchw(8, 97, 97)) == "f32-strips-node"
     m.split_planes = True
     m.recompute_attention = True                     # (the flag must not be silently ignored)
     assert m.route(nchw(2, 97, 97)) == "f32-strips-node" and m.route(cl(2, 33, 18)) == "f32-strips-node"

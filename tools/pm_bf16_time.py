@@ -20,7 +20,7 @@ y, dqkv = torch.empty_like(x), torch.empty_like(qkv)
 A = torch.empty(B, H, W, H + W, device=dev)
 scr = torch.empty_like(A)
 dg = torch.empty(1, device=dev)
-nf, nb = L.ccnet_cca_pm_bf16_workspace_bytes(B, C, cq, H, W, 0), L.ccnet_cca_pm_bf16_workspace_bytes(B, C, cq, H, W, 1)
+nf, nb = L.ccnet_cca_pm_workspace_bytes(B, C, cq, H, W, 0), L.ccnet_cca_pm_workspace_bytes(B, C, cq, H, W, 1)
 ws = torch.empty(max(nf, nb) // 4 + 64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 p, gq, bs = qkv.data_ptr(), dqkv.data_ptr(), H * W * ct

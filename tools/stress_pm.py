@@ -1,4 +1,4 @@
-"""Repeat the pixel-major cores (bf16 all-pixel-major, fp32 with NCHW x / y / dy) under concurrent HBM load and count runs whose
+"""Repeat the pixel-major bf16 core and the split-plane fp32 core (NCHW x / y / dy) under concurrent HBM load and count runs whose
 outputs differ bit-wise from the first run -- a race detector for the counted-vmcnt pipelines and the register-prefetched
 epilogues.  usage: stress_pm.py [iters]"""
 import os, sys
@@ -12,9 +12,9 @@ noise = torch.randn(64 * 1024 * 1024, device=dev)
 side = torch.cuda.Stream()
 cases = [("bf16 (16,512,129,129)", bench.PixelMajorBF16Workload(lib, 16, 512, 129, 129, dev, 7)),
          ("bf16 (2,512,97,97)", bench.PixelMajorBF16Workload(lib, 2, 512, 97, 97, dev, 8)),
-         ("f32 nchw (8,512,97,97)", bench.PixelMajorF32Workload(lib, 8, 512, 97, 97, dev, 9)),
-         ("f32 nchw (1,512,97,97)", bench.PixelMajorF32Workload(lib, 1, 512, 97, 97, dev, 10)),
-         ("f32 nchw (3,256,100,61)", bench.PixelMajorF32Workload(lib, 3, 256, 100, 61, dev, 11))]
+         ("f32 planes (8,512,97,97)", bench.PlanesWorkload(lib, 8, 512, 97, 97, dev, 9)),
+         ("f32 planes (1,512,97,97)", bench.PlanesWorkload(lib, 1, 512, 97, 97, dev, 10)),
+         ("f32 planes (3,256,100,61)", bench.PlanesWorkload(lib, 3, 256, 100, 61, dev, 11))]
 for name, wl in cases:
     outs = lambda: (wl.y, wl.dqkv, wl.dgamma, wl.A)          # noqa: E731
     wl.step(); torch.cuda.synchronize()

@@ -8,6 +8,8 @@ matched the known write volume of the same kernel (57.0 MiB vs 58.4 MB) and is u
 
 The file also records the sha256 prefix of the kernel sources the profiled library was built from (``_src_sha16``: bench.py
 only quotes the traffic when it benches a build of those same sources) and the per-step total (every kernel is launched once per step).
+``--per-dispatch``: a kernel that a step launches more than once (the split-plane step launches gmap3_kernel<.., 2, 3> for the
+forward and the dv column pass) is accounted per dispatch: the per-step total is sum(average * dispatches) / steps.
 With ``--steps N`` the profiled command ran N steps in which a kernel may be launched several times (the pixel-major bf16
 step, tools/pm_bf16_time.py: 3 warm-up + 10 timed forward/backward pairs = 13): the per-step total is then
 sum(kernel average * dispatches) / N, and ``--out`` names the file (profiles/traffic_bf16_latest.json).
