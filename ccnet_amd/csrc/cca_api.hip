@@ -41,6 +41,8 @@ std::atomic<int> g_weight_bf16{1};
 // split-plane pass, 1 = the passes with a pixel-major output run gmap3_kernel (three-tile ring, stores from the accumulators,
 // two workgroups per CU), 2 = as 1 with the column passes on the two-tile / three-workgroups-per-CU form
 std::atomic<int> g_planes_ring{2};
+// "planes_stream" 1 (default) = the split-plane dA contraction runs the persistent gweight_stream_kernel, 0 = gweight_kernel
+std::atomic<int> g_planes_stream{1};
 
 int fail(int code, const char *what) {
     char buf[256];
@@ -1071,7 +1073,14 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
     if (int e = ccnet_cca_nchw_to_planes_f32(dy, dy_pl, B, C, H, W, (long)C * H * W, dbs, 2 * C, stream)) return e;
     const bf16p_t *dyp = (const bf16p_t *)dy_pl, *vp = (const bf16p_t *)v_planes;
     // t = un-scaled dA (the adjoint of the aggregation, functions.py:46-47), dv = gamma * A^T-weighted dy
-    {
+    if (const int ps = g_planes_stream.load()) {
+        // persistent: one workgroup per CU walks the strips of both branches, its ring runs across strip boundaries
+        // (option values > 1 cap the number of workgroups: tests make one workgroup walk many strips)
+        const int nstrips = B * (H + W), cus = ps > 1 ? ps : num_cus();
+        const dim3 grid((unsigned)(nstrips < cus ? nstrips : cus)), block(cca::GM_THREADS);
+        CCA_LAUNCH((cca::gweight_stream_kernel<100>), grid, block, stream, dyp, vp, scratch, C, B, H, W, dbs, 2 * C, v_bs, v_ps);
+        if (int e = launch_status("gweight_stream(dA)")) return e;
+    } else {
         const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
         CCA_LAUNCH((cca::gweight_kernel<100, false, bf16p_t, false>), grid, block, stream, dyp, vp, scratch, C, H, W, dbs, 2 * C, v_bs, v_ps);
         if (int e = launch_status("gweight_planes(dA)")) return e;
@@ -1086,6 +1095,7 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
 int ccnet_cca_set_option(const char *name, int value) {
     if (!name) return fail(CCNET_E_NULLPTR, "set_option: null name");
     if (std::string(name) == "planes_ring") return g_planes_ring.exchange(value);
+    if (std::string(name) == "planes_stream") return g_planes_stream.exchange(value);
     return fail(CCNET_E_BADFLAGS, "set_option: unknown option");
 }
 

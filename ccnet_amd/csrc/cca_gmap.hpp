@@ -922,4 +922,139 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// gweight_stream: the dA contraction (T = X_g Y_g^T per strip, K = all channels) on SPLIT-PLANE operands as a PERSISTENT
+// kernel.  gweight_kernel runs one workgroup per strip and one workgroup per CU (three stages of X hi | X lo | Y hi | Y lo
+// fill the LDS): every strip then pays its first fill (nothing to multiply meanwhile) and its 37 KB of result stores (nothing
+// in flight behind them) alone on its CU -- 169 us at the headline shape of which ~117 us is streaming at the CU's share of
+// HBM (profiles/r03g_bench.json, r03g_pmc_step_summary.json).  Here a workgroup walks strips first, first + grid, ... and its
+// ring of stages runs ACROSS strip boundaries: while the last chunks of one strip are multiplied the first stages of the next
+// are landing, and the result stores of a strip drain behind the next strip's fills.  Counted barriers as everywhere: the
+// result stores are buffer stores issued only under wave-uniform conditions that leave at least one lane in range, so they
+// can be counted (a fully out-of-range store retires early and would break the in-order count).
+// ---------------------------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(GM_THREADS, 1) void gweight_stream_kernel(const bf16p_t *__restrict__ X, const bf16p_t *__restrict__ Y,
+                                                                        float *__restrict__ T, int Cx, int B, int H, int W,
+                                                                        long xbs, int xps, long ybs, int yps) {
+    constexpr int TSB = t16_size(P), NPB = t16_pieces(P);                 // one plane tile: dwords, 1 KiB pieces
+    constexpr int NT = (P + 15) / 16, NTR = (NT + GM_WAVES - 1) / GM_WAVES;
+    constexpr int STG = 4 * TSB, NPS = 4 * NPB, NBUF = 3, D = NBUF - 1;   // stage = X hi | X lo | Y hi | Y lo
+    static_assert(NBUF * STG * 4 <= 163840, "gweight_stream: three stages must fit the LDS");
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * STG];
+    CCA_LDS_REGISTER(lds);
+    const int HW = H * W, S = H + W;
+    const int nstrips = B * S, first = blockIdx.x, step = gridDim.x;
+    const int nloc = first < nstrips ? (nstrips - first + step - 1) / step : 0;
+    const int nch = (Cx + GM_CG - 1) / GM_CG, total = nloc * nch;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
+    const int ln = lane & 15, lg = lane >> 4;
+
+    struct Strip { int b, L, pix0, pstep, a_off; };
+    auto strip_of = [&](int n) {                                            // the strip stage n belongs to
+        const int sidx = first + (n / nch) * step;
+        const int b = sidx / S, r = sidx - b * S;
+        const bool row = r >= W;
+        const int g = row ? r - W : r;
+        return Strip{b, row ? W : H, row ? g * W : g, row ? 1 : W, row ? H : 0};
+    };
+    const int npw = (NPS - wv + GM_WAVES - 1) / GM_WAVES;                   // this wavefront's pieces per stage (all are issued)
+    auto issue = [&](int n) {
+        const Strip st = strip_of(n);
+        const int ch = n % nch;
+        const FBuf Xb = make_fbuf(reinterpret_cast<const float *>(X + (size_t)st.b * xbs), ((size_t)(HW - 1) * xps + 2 * Cx) * 2);
+        const FBuf Yb = make_fbuf(reinterpret_cast<const float *>(Y + (size_t)st.b * ybs), ((size_t)(HW - 1) * yps + 2 * Cx) * 2);
+        float *dst = lds + (n % NBUF) * STG;
+#pragma unroll
+        for (int k = 0; k < (NPS + GM_WAVES - 1) / GM_WAVES; ++k) {
+            const int it = wv + GM_WAVES * k;
+            if (it < NPS) {                                                 // (wave-uniform)
+                const int op = it >= 2 * NPB, r = it - op * 2 * NPB, plane = r >= NPB;
+                t16_dma_piece(op ? Yb : Xb, dst + (2 * op + plane) * TSB, r - plane * NPB, lane, st.pix0, st.pstep, st.L,
+                              op ? yps : xps, ch * GM_CG, Cx, plane ? Cx : 0);
+            }
+        }
+    };
+    // result stores this wavefront issues for a strip of length L: one per (owned tile row, q, key tile) that has a lane in range
+    auto nstores = [&](int L) {
+        int rows = 0;
+#pragma unroll
+        for (int a = 0; a < NTR; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rows += 16 * (wv + GM_WAVES * a) + q < L ? 1 : 0;
+        return rows * ((L + 15) / 16);
+    };
+    auto stores_after = [&](int m) {                                        // stores issued at the end of iteration m
+        return (m >= 0 && m % nch == nch - 1) ? nstores(strip_of(m).L) : 0;
+    };
+    auto frag = [&](const float *tile, int pixel_, int kk) {               // 8 consecutive channels of one position: 16 bytes
+        const int pixel = pixel_ < 8 * NPB ? pixel_ : 0;
+        return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(tile) + t16_byte(pixel, 8 * (4 * kk + lg)));
+    };
+
+    if (total == 0) return;
+    issue(0);
+    if (total > 1) issue(1);
+    f32x4 acc[NTR][NT];
+    Strip cur = strip_of(0);
+    for (int n = 0; n < total; ++n) {
+        const int ch = n % nch;
+        // stage n landed, every wavefront is done with stage n - 1.  Issued after the fill of stage n, oldest first:
+        // stores(n - 2), fill(n + 1), stores(n - 1) -- they may stay in flight.
+        if (n == 0) barrier_dma_keep<0>();
+        else        barrier_dma_keep_n(stores_after(n - 2) + (n + 1 < total ? npw : 0) + stores_after(n - 1));
+        if (n + D < total) issue(n + D);
+        if (ch == 0) {
+            cur = strip_of(n);
+#pragma unroll
+            for (int a = 0; a < NTR; ++a)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int L = cur.L;
+        const float *xh = lds + (n % NBUF) * STG, *xl = xh + TSB, *yh = xh + 2 * TSB, *yl = xh + 3 * TSB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {                                    // two k-steps of 32 channels
+            u32x4 ah[NTR], al[NTR];
+#pragma unroll
+            for (int a = 0; a < NTR; ++a) {
+                ah[a] = frag(xh, 16 * (wv + GM_WAVES * a) + ln, kk);
+                al[a] = frag(xl, 16 * (wv + GM_WAVES * a) + ln, kk);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (t * 16 < L) {
+                    const u32x4 bh = frag(yh, 16 * t + ln, kk), bl = frag(yl, 16 * t + ln, kk);
+#pragma unroll
+                    for (int a = 0; a < NTR; ++a)
+                        if ((wv + GM_WAVES * a) * 16 < L) {
+                            acc[a][t] = mfma_bf16_16x16x32(ah[a], bh, acc[a][t]);
+                            acc[a][t] = mfma_bf16_16x16x32(ah[a], bl, acc[a][t]);
+                            acc[a][t] = mfma_bf16_16x16x32(al[a], bh, acc[a][t]);
+                        }
+                }
+            }
+        }
+        if (ch == nch - 1) {
+            // D[m = query position 16 ti + 4 lg + q][n = key position 16 t + ln] -> T rows (64-byte runs per query)
+            const FBuf Tb = make_fbuf(T + (size_t)cur.b * HW * S, (size_t)HW * S * sizeof(float));
+#pragma unroll
+            for (int a = 0; a < NTR; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (16 * (wv + GM_WAVES * a) + q < L) {                 // (wave-uniform: lanes lg = 0 are in range)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            if (t * 16 < L) {                               // (wave-uniform: lanes ln = 0 are in range)
+                                const int i = 16 * (wv + GM_WAVES * a) + 4 * lg + q, j = 16 * t + ln;
+                                fbuf_store(Tb, acc[a][t][q], (i < L && j < L) ? ((cur.pix0 + i * cur.pstep) * S + cur.a_off + j) * 4 : kOobOffset, 0);
+                            }
+                        }
+                    }
+                }
+        }
+    }
+}
+
+
 }  // namespace cca

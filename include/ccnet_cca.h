@@ -252,7 +252,10 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
  *                  2 (default) gmap3_kernel -- stores straight from the accumulators; column passes with two ring slots and
  *                    three workgroups per CU, row passes with three ring slots and two workgroups per CU;
  *                  1 gmap3_kernel, three ring slots / two workgroups per CU everywhere;
- *                  0 gmap_kernel (two feature tiles + an output image in LDS). */
+ *                  0 gmap_kernel (two feature tiles + an output image in LDS).
+ *   "planes_stream" 1 (default) the split-plane dA contraction is the persistent gweight_stream_kernel (one workgroup per CU
+ *                    walks the strips, its three-stage ring runs across strip boundaries); 0 gweight_kernel (one workgroup
+ *                    per strip); k > 1: persistent with at most k workgroups (tests). */
 int ccnet_cca_set_option(const char *name, int value);
 
 /* Launch profiler (a measurement aid, off by default).  Between ``begin`` and ``end`` every kernel launch the library

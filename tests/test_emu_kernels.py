@@ -607,3 +607,27 @@ def test_split_plane_core_matches_the_fp32_pixel_major_core_and_the_oracle(ops, 
     assert abs(float(dg[0]) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
     y3, _ = ops.cca_forward_planes(qkv, vpl, c["x"], c["gamma"], cq)
     assert np.array_equal(y, y3)                                                    # run-to-run bit identity
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 5, 6), (1, 192, 17, 20), (1, 64, 3, 97)])
+def test_streaming_dA_kernel_walks_many_strips_per_workgroup(ops, shape):
+    """gweight_stream_kernel (persistent dA contraction of the split-plane backward): with the workgroup count capped at 3 every
+    workgroup walks several strips of both branches and both lengths, its ring of stages crossing the strip boundaries; the
+    result must be bit-identical to the one-workgroup-per-strip kernel (same products, same accumulation order)."""
+    B, C, H, W = shape
+    cq = max(C // 8, 4)
+    c = rand_case(B, C, H, W, seed=61)
+    rng = np.random.default_rng(5)
+    qk = rng.standard_normal((B, 2 * cq, H, W), dtype=np.float32) * np.float32(0.3)
+    qkv = np.ascontiguousarray(np.concatenate([_pm(qk), _pm(c["v"])], axis=3))
+    vpl = ops.split_planes(qkv, C, c0=2 * cq)
+    y, A = ops.cca_forward_planes(qkv, vpl, c["x"], c["gamma"], cq)
+    outs = []
+    for opt in (0, 3, 1):
+        prev = ops.lib.ccnet_cca_set_option(b"planes_stream", opt)
+        try:
+            outs.append(ops.cca_backward_planes(c["dy"], qkv, vpl, A, c["gamma"], cq))
+        finally:
+            ops.lib.ccnet_cca_set_option(b"planes_stream", prev)
+    for dqkv, dg in outs[1:]:
+        assert np.array_equal(dqkv, outs[0][0]) and np.array_equal(dg, outs[0][1])

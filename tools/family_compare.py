@@ -15,12 +15,13 @@ from ccnet_amd import _lib  # noqa: E402
 B, C, H, W = (int(a) for a in sys.argv[1:5]) if len(sys.argv) >= 5 else (8, 512, 97, 97)
 lib = _lib.get_lib()
 dev = torch.device("cuda:0")
-fams = [("nchw-strips", bench.CoreWorkload),
-        ("planes-noring", bench.PlanesWorkload), ("planes", bench.PlanesWorkload), ("planes-3wg", bench.PlanesWorkload)]
-RING = {"planes-noring": 0, "planes": 1, "planes-3wg": 2}
+fams = [("nchw-strips", bench.CoreWorkload), ("planes-noring", bench.PlanesWorkload), ("planes", bench.PlanesWorkload),
+        ("planes-3wg", bench.PlanesWorkload), ("planes-3wg-nostream", bench.PlanesWorkload)]
+RING = {"planes-noring": 0, "planes": 1, "planes-3wg": 2, "planes-3wg-nostream": 2}
 res = {}
 for name, cls in fams:
     lib.ccnet_cca_set_option(b"planes_ring", RING.get(name, 1))
+    lib.ccnet_cca_set_option(b"planes_stream", 0 if name.endswith("nostream") else 1)
     wl = cls(lib, B, C, H, W, dev, 1234)
     for _ in range(5):
         wl.step()
@@ -42,9 +43,11 @@ b.step()
 for fam, ring in RING.items():
     a = res[fam]
     lib.ccnet_cca_set_option(b"planes_ring", ring)
+    lib.ccnet_cca_set_option(b"planes_stream", 0 if fam.endswith("nostream") else 1)
     a.step()
     torch.cuda.synchronize()
     for nm in ("y", "dqkv", "A", "dgamma"):
         d = (getattr(a, nm) - getattr(b, nm)).abs().max().item()
         print(f"{fam} vs planes-noring: max |d {nm}| = {d:.3e}   (max |ref| {getattr(b, nm).abs().max().item():.3e})")
-lib.ccnet_cca_set_option(b"planes_ring", 1)
+lib.ccnet_cca_set_option(b"planes_ring", 2)
+lib.ccnet_cca_set_option(b"planes_stream", 1)
