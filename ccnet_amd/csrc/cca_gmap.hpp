@@ -114,16 +114,21 @@ struct bf16p_t { uint16_t bits; };
 constexpr int T16_PIECE = 256;                                                                // dwords
 __host__ __device__ constexpr int t16_pieces(int P) { return (P + 7) / 8; }
 __host__ __device__ constexpr int t16_size(int P) { return t16_pieces(P) * T16_PIECE; }      // dwords per plane tile
+// FLIP = false drops the piece-parity term: the layout for tiles that are read by ROWS (ds_read_b128 of 8 consecutive channels
+// of 16 consecutive positions, the K-contiguous fragments of the dA contraction) -- with the flip, positions p and p + 12 of a
+// b128 lane group meet on the same banks (50 % LDS conflict cycles in gweight, profiles/r03g_pmc_step_summary.json).
+template <bool FLIP = true>
 __device__ __forceinline__ int t16_byte(int j, int c) {
     const int piece = j >> 3, r = j & 7;
-    return (piece * T16_PIECE + r * 32) * 4 + ((((c >> 3) ^ r ^ ((piece & 1) << 2)) << 4) | ((c & 7) << 1));
+    return (piece * T16_PIECE + r * 32) * 4 + ((((c >> 3) ^ r ^ (FLIP ? (piece & 1) << 2 : 0)) << 4) | ((c & 7) << 1));
 }
 // one DMA piece of a plane tile: positions 8 piece .. + 7 (pixels pix0 + i * pstep), channels c0 .. c0 + 63 of the plane
 // that starts ``plane_off`` elements into a pixel; ps = pixel stride in elements; lanes beyond the strip / the channel
 // count fetch out of range (zero fill)
+template <bool FLIP = true>
 __device__ __forceinline__ void t16_dma_piece(const FBuf &src, float *img, int piece, int lane, int pix0, int pstep, int n,
                                               int ps, int c0, int C, int plane_off) {
-    const int p = lane >> 3, i = 8 * piece + p, q = (lane & 7) ^ (p & 7) ^ ((piece & 1) << 2), c = c0 + 8 * q;
+    const int p = lane >> 3, i = 8 * piece + p, q = (lane & 7) ^ (p & 7) ^ (FLIP ? (piece & 1) << 2 : 0), c = c0 + 8 * q;
     fbuf_load_to_lds_x4_uncounted(src, img + piece * T16_PIECE, (i < n && c < C) ? ((pix0 + i * pstep) * ps + plane_off + c) * 2 : kOobOffset);
 }
 // MFMA fragment whose K axis runs over tile positions 32 ks + 8 (lane >> 4) + e, e < 8, at channel 16 nt + (lane & 15):
@@ -802,7 +807,7 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
         for (int it = wv; it < 2 * NPF; it += GM_WAVES) {
             if constexpr (PL) {
                 const int op = it >= NPF, r = it - op * NPF, plane = r >= NPB;
-                t16_dma_piece(op ? Yb : Xb, (op ? yb : xb) + plane * TSB, r - plane * NPB, lane, pix0, pstep, L,
+                t16_dma_piece<false>(op ? Yb : Xb, (op ? yb : xb) + plane * TSB, r - plane * NPB, lane, pix0, pstep, L,
                               op ? yps : xps, ch * GM_CG, Cx, plane ? Cx : 0);
             } else {
                 if (it < NPF) gtile_dma_piece<FT>(Xb, xb, it, lane, pix0, pstep, L, xps, ch * GM_CG, Cx);
@@ -820,7 +825,7 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
     auto frag = [&](const float *tile, int pixel_, int kk) {
         const int pixel = pixel_ < 8 * NPB ? pixel_ : 0;                            // (tile rows beyond the strip: results unused)
         const int chunk = 4 * kk + lg;
-        if constexpr (PL) return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(tile) + t16_byte(pixel, 8 * chunk));
+        if constexpr (PL) return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(tile) + t16_byte<false>(pixel, 8 * chunk));
         const int off = (pixel >> 3) * GM_PB + (pixel & 7) * 32 + ((chunk ^ (pixel & 7)) << 2);
         return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint32_t *>(tile) + off);
     };
@@ -970,7 +975,7 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gweight_stream_kernel(const bf1
             const int it = wv + GM_WAVES * k;
             if (it < NPS) {                                                 // (wave-uniform)
                 const int op = it >= 2 * NPB, r = it - op * 2 * NPB, plane = r >= NPB;
-                t16_dma_piece(op ? Yb : Xb, dst + (2 * op + plane) * TSB, r - plane * NPB, lane, st.pix0, st.pstep, st.L,
+                t16_dma_piece<false>(op ? Yb : Xb, dst + (2 * op + plane) * TSB, r - plane * NPB, lane, st.pix0, st.pstep, st.L,
                               op ? yps : xps, ch * GM_CG, Cx, plane ? Cx : 0);
             }
         }
@@ -989,7 +994,7 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gweight_stream_kernel(const bf1
     };
     auto frag = [&](const float *tile, int pixel_, int kk) {               // 8 consecutive channels of one position: 16 bytes
         const int pixel = pixel_ < 8 * NPB ? pixel_ : 0;
-        return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(tile) + t16_byte(pixel, 8 * (4 * kk + lg)));
+        return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(tile) + t16_byte<false>(pixel, 8 * (4 * kk + lg)));
     };
 
     if (total == 0) return;
