@@ -764,9 +764,16 @@ int launch_gmap_pm(const float *T, const FT *F, const FT *resid, const float *ga
                    int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
     const long pbs = (long)H * W * C;
     const GmapPlan gc = gmap_plan(B * W, C), gr = gmap_plan(B * H, C);
-    CCA_LAUNCH((cca::gmap_kernel<P, false, TRANS, false, FT, float>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS),
-               stream, T, F, (const float *)nullptr, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0,
-               0L, 0, pbs, C, gc.n_whole, gc.split, cca::GmapJob<FT, float>{});
+    if (std::is_same<FT, bf16_t>::value && g_planes_ring.load() != 0) {
+        // bf16 features: the column pass on the ring kernel (three feature tiles, stores from the accumulators)
+        if constexpr (std::is_same<FT, bf16_t>::value)
+            CCA_LAUNCH((cca::gmap3_kernel<P, false, TRANS, false, 3, 2, bf16_t>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS), stream,
+                       T, F, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0, pbs, C, gc.n_whole, gc.split);
+    } else {
+        CCA_LAUNCH((cca::gmap_kernel<P, false, TRANS, false, FT, float>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS),
+                   stream, T, F, (const float *)nullptr, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0,
+                   0L, 0, pbs, C, gc.n_whole, gc.split, cca::GmapJob<FT, float>{});
+    }
     if (int e = launch_status("gmap_pm(column)")) return e;
     CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, FT, FT, NCHW>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS),
                stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C, rbs, rps, obs, ops,
@@ -812,6 +819,18 @@ int gmap_dual_pm(const float *dE, const FT *k, const FT *q, FT *dq, FT *dk, floa
 template <bool MASK, typename FT>
 int gweight_pm(const FT *X, const FT *Y, float *T, int B, int Cx, int H, int W, long xbs, int xps, long ybs, int yps,
                ccnet_stream_t stream) {
+    if constexpr (!MASK && std::is_same<FT, bf16_t>::value) {
+        // bf16 dA at strips 101 .. 132 (BASELINE configs[4]): the persistent kernel (four-stage ring across strip boundaries).
+        // (Its 100-position bf16 instantiation comes out of hipcc with 256 VGPRs + 13 spilled whatever the launch bound, so
+        // shorter strips stay on gweight_kernel.)
+        const int ps = g_planes_stream.load();
+        if (ps && (H > W ? H : W) > 100) {
+            const int nstrips = B * (H + W), cus = ps > 1 ? ps : num_cus();
+            const dim3 sgrid((unsigned)(nstrips < cus ? nstrips : cus)), sblock(cca::GM_THREADS);
+            CCA_LAUNCH((cca::gweight_stream_kernel<132, bf16_t>), sgrid, sblock, stream, X, Y, T, Cx, B, H, W, xbs, xps, ybs, yps);
+            return launch_status("gweight_stream(bf16)");
+        }
+    }
     const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
     const bool single = Cx <= cca::GM_CG;           // one chunk: the single-buffered form (more workgroups per CU)
 #define CCA_GWEIGHT(P_)                                                                                                   \

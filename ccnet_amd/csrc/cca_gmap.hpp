@@ -491,13 +491,17 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
 // NBUF ring slots (fills run NBUF - 1 tiles ahead), WPC workgroups per CU: <3, 2> keeps two tiles in flight per workgroup;
 // <2, 3> trades one of them for a third workgroup per CU (53,248 B of LDS, <= 168 VGPRs) -- 768 slots for the 776 strips
 // of a branch at the headline shape, where 512 slots left the second round half empty (profiles/r03c_family_compare.txt).
-template <int P, bool ROW, bool TRANS, bool ADD, int NBUF = 3, int WPC = 2>
-__global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__restrict__ T, const bf16p_t *__restrict__ F,
+// FT = bf16p_t (split planes: hi | lo tiles, three products) or bf16_t (bf16 features, BASELINE configs[4]: one tile, the two
+// products with the attention's hi and lo halves); the output is fp32 pixel-major either way (the column partial).
+template <int P, bool ROW, bool TRANS, bool ADD, int NBUF = 3, int WPC = 2, typename FT = bf16p_t>
+__global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__restrict__ T, const FT *__restrict__ F,
                                                                const float *__restrict__ addend, const float *__restrict__ gamma,
                                                                float *__restrict__ out, int C, int H, int W, long fbs, int fps,
                                                                long abs_, int aps, long obs, int ops, int n_whole, int split) {
     constexpr int NT = (P + 15) / 16, TPW = (NT + GS_WAVES - 1) / GS_WAVES, NKS = P / 32;
-    constexpr int TSP = t16_size(P), FSZ = 2 * TSP, NPF = 2 * t16_pieces(P), D = NBUF - 1;
+    constexpr int NPL = std::is_same<FT, bf16p_t>::value ? 2 : 1;       // planes per feature tile
+    static_assert(NPL == 2 || std::is_same<FT, bf16_t>::value, "gmap3: bf16p_t or bf16_t features");
+    constexpr int TSP = t16_size(P), FSZ = NPL * TSP, NPF = NPL * t16_pieces(P), D = NBUF - 1;
     static_assert(P % 4 == 0 && NBUF * FSZ * 4 * WPC <= 163840 && (NBUF == 2 || NBUF == 3), "gmap3: LDS of WPC workgroups per CU");
     // (the ring fills are LDS-DMAs the compiler does not see -- fbuf_load_to_lds_x4_uncounted, cca_platform.hpp: with the
     // builtin form it drained the fills of the next two tiles before every group's first transposing read)
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
     const int a_off = ROW ? H : 0;
 
     const FBuf Tb = make_fbuf(T + (size_t)b * HW * S, (size_t)HW * S * sizeof(float));
-    const FBuf Fb = make_fbuf(reinterpret_cast<const float *>(F + (size_t)b * fbs), ((size_t)(HW - 1) * fps + 2 * C) * 2);
+    const FBuf Fb = make_fbuf(reinterpret_cast<const float *>(F + (size_t)b * fbs), ((size_t)(HW - 1) * fps + NPL * C) * 2);
     const FBuf Ob = make_fbuf(out + (size_t)b * obs, ((size_t)(HW - 1) * ops + C) * sizeof(float));
     const FBuf Db = make_fbuf(ADD ? addend + (size_t)b * abs_ : T, ADD ? ((size_t)(HW - 1) * aps + C) * sizeof(float) : 4);
     const float alpha = gamma ? gamma[0] : 1.f;
@@ -534,8 +538,8 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
         for (int k = 0; k < (NPF + GS_WAVES - 1) / GS_WAVES; ++k) {
             const int it = wv + GS_WAVES * k;
             if (it < NPF) {                                                  // (wave-uniform)
-                const int plane = it >= NPF / 2;
-                t16_dma_piece(Fb, dst + plane * TSP, it - plane * (NPF / 2), lane, pix0, pstep, L, fps, cg * GM_CG, C, plane ? C : 0);
+                const int plane = it >= NPF / NPL;
+                t16_dma_piece(Fb, dst + plane * TSP, it - plane * (NPF / NPL), lane, pix0, pstep, L, fps, cg * GM_CG, C, plane ? C : 0);
             }
         }
     };
@@ -629,12 +633,14 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
             if (ks < kp.nbf) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    const u32x4 fh = t16_frag(img, ks, nt, lane), fl = t16_frag(img + TSP, ks, nt, lane);
+                    const u32x4 fh = t16_frag(img, ks, nt, lane);
+                    u32x4 fl = fh;
+                    if constexpr (NPL == 2) fl = t16_frag(img + TSP, ks, nt, lane);
 #pragma unroll
                     for (int a = 0; a < TPW; ++a) {
                         if ((wv + GS_WAVES * a) * 16 < L) {
                             acc[a][nt] = mfma_bf16_16x16x32(fh, ah[a][ks], acc[a][nt]);
-                            acc[a][nt] = mfma_bf16_16x16x32(fl, ah[a][ks], acc[a][nt]);
+                            if constexpr (NPL == 2) acc[a][nt] = mfma_bf16_16x16x32(fl, ah[a][ks], acc[a][nt]);
                             acc[a][nt] = mfma_bf16_16x16x32(fh, al[a][ks], acc[a][nt]);
                         }
                     }
@@ -645,8 +651,8 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
             const int pos = 32 * kp.nbf + lg;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const float fbv = __builtin_bit_cast(float, lds_load_u16(img, t16_byte(pos, 16 * nt + ln)) << 16)
-                                + __builtin_bit_cast(float, lds_load_u16(img + TSP, t16_byte(pos, 16 * nt + ln)) << 16);
+                float fbv = __builtin_bit_cast(float, lds_load_u16(img, t16_byte(pos, 16 * nt + ln)) << 16);
+                if constexpr (NPL == 2) fbv += __builtin_bit_cast(float, lds_load_u16(img + TSP, t16_byte(pos, 16 * nt + ln)) << 16);
 #pragma unroll
                 for (int a = 0; a < TPW; ++a)
                     if ((wv + GS_WAVES * a) * 16 < L) acc[a][nt] = mfma_16x16x4(fbv, at[a], acc[a][nt]);
@@ -938,13 +944,19 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
 // result stores are buffer stores issued only under wave-uniform conditions that leave at least one lane in range, so they
 // can be counted (a fully out-of-range store retires early and would break the in-order count).
 // ---------------------------------------------------------------------------------------------------------------
-template <int P>
-__global__ __launch_bounds__(GM_THREADS, 1) void gweight_stream_kernel(const bf16p_t *__restrict__ X, const bf16p_t *__restrict__ Y,
+// FT = bf16p_t (split planes, three products per term) or bf16_t (bf16 features of BASELINE configs[4]: exact single products)
+// (launch bound "4 waves per SIMD": a REGISTER bound of 128 -- the LDS ring admits one workgroup per CU anyway; without it the
+// bf16 / P = 100 instantiation came out with 256 VGPRs and 13 spilled)
+template <int P, typename FT = bf16p_t>
+__global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT *__restrict__ X, const FT *__restrict__ Y,
                                                                         float *__restrict__ T, int Cx, int B, int H, int W,
                                                                         long xbs, int xps, long ybs, int yps) {
+    constexpr int NPL = std::is_same<FT, bf16p_t>::value ? 2 : 1;        // planes per operand
+    static_assert(NPL == 2 || std::is_same<FT, bf16_t>::value, "gweight_stream: bf16p_t or bf16_t operands");
     constexpr int TSB = t16_size(P), NPB = t16_pieces(P);                 // one plane tile: dwords, 1 KiB pieces
     constexpr int NT = (P + 15) / 16, NTR = (NT + GM_WAVES - 1) / GM_WAVES;
-    constexpr int STG = 4 * TSB, NPS = 4 * NPB, NBUF = 3, D = NBUF - 1;   // stage = X hi | X lo | Y hi | Y lo
+    constexpr int STG = 2 * NPL * TSB, NPS = 2 * NPL * NPB;               // stage = X (hi | lo) | Y (hi | lo)
+    constexpr int NBUF = 4 * STG * 4 <= 163840 ? 4 : 3, D = NBUF - 1;     // as many stages as fit: D of them in flight
     static_assert(NBUF * STG * 4 <= 163840, "gweight_stream: three stages must fit the LDS");
     __shared__ __attribute__((aligned(16))) float lds[NBUF * STG];
     CCA_LDS_REGISTER(lds);
@@ -967,15 +979,15 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gweight_stream_kernel(const bf1
     auto issue = [&](int n) {
         const Strip st = strip_of(n);
         const int ch = n % nch;
-        const FBuf Xb = make_fbuf(reinterpret_cast<const float *>(X + (size_t)st.b * xbs), ((size_t)(HW - 1) * xps + 2 * Cx) * 2);
-        const FBuf Yb = make_fbuf(reinterpret_cast<const float *>(Y + (size_t)st.b * ybs), ((size_t)(HW - 1) * yps + 2 * Cx) * 2);
+        const FBuf Xb = make_fbuf(reinterpret_cast<const float *>(X + (size_t)st.b * xbs), ((size_t)(HW - 1) * xps + NPL * Cx) * 2);
+        const FBuf Yb = make_fbuf(reinterpret_cast<const float *>(Y + (size_t)st.b * ybs), ((size_t)(HW - 1) * yps + NPL * Cx) * 2);
         float *dst = lds + (n % NBUF) * STG;
 #pragma unroll
         for (int k = 0; k < (NPS + GM_WAVES - 1) / GM_WAVES; ++k) {
             const int it = wv + GM_WAVES * k;
             if (it < NPS) {                                                 // (wave-uniform)
-                const int op = it >= 2 * NPB, r = it - op * 2 * NPB, plane = r >= NPB;
-                t16_dma_piece<false>(op ? Yb : Xb, dst + (2 * op + plane) * TSB, r - plane * NPB, lane, st.pix0, st.pstep, st.L,
+                const int op = it >= NPL * NPB, r = it - op * NPL * NPB, plane = r >= NPB;
+                t16_dma_piece<false>(op ? Yb : Xb, dst + (NPL * op + plane) * TSB, r - plane * NPB, lane, st.pix0, st.pstep, st.L,
                               op ? yps : xps, ch * GM_CG, Cx, plane ? Cx : 0);
             }
         }
@@ -998,16 +1010,24 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gweight_stream_kernel(const bf1
     };
 
     if (total == 0) return;
-    issue(0);
-    if (total > 1) issue(1);
+#pragma unroll
+    for (int n = 0; n < D; ++n)
+        if (n < total) issue(n);
     f32x4 acc[NTR][NT];
     Strip cur = strip_of(0);
     for (int n = 0; n < total; ++n) {
         const int ch = n % nch;
-        // stage n landed, every wavefront is done with stage n - 1.  Issued after the fill of stage n, oldest first:
-        // stores(n - 2), fill(n + 1), stores(n - 1) -- they may stay in flight.
-        if (n == 0) barrier_dma_keep<0>();
-        else        barrier_dma_keep_n(stores_after(n - 2) + (n + 1 < total ? npw : 0) + stores_after(n - 1));
+        // stage n landed, every wavefront is done with stage n - 1.  Issued after the fill of stage n, oldest first (iteration m
+        // issues fill(m + D), then stores(m)): stores(n - D), fill(n + 1), stores(n - D + 1), ..., fill(n + D - 1), stores(n - 1)
+        // -- they may stay in flight.
+        if (n == 0) {
+            barrier_dma_keep<0>();
+        } else {
+            int keep = 0;
+#pragma unroll
+            for (int d = 1; d <= D; ++d) keep += stores_after(n - d) + (d < D && n + d < total ? npw : 0);
+            barrier_dma_keep_n(keep);
+        }
         if (n + D < total) issue(n + D);
         if (ch == 0) {
             cur = strip_of(n);
@@ -1017,25 +1037,29 @@ __global__ __launch_bounds__(GM_THREADS, 1) void gweight_stream_kernel(const bf1
                 for (int t = 0; t < NT; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         const int L = cur.L;
-        const float *xh = lds + (n % NBUF) * STG, *xl = xh + TSB, *yh = xh + 2 * TSB, *yl = xh + 3 * TSB;
+        const float *xh = lds + (n % NBUF) * STG, *xl = xh + (NPL - 1) * TSB, *yh = xh + NPL * TSB, *yl = yh + (NPL - 1) * TSB;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {                                    // two k-steps of 32 channels
             u32x4 ah[NTR], al[NTR];
 #pragma unroll
             for (int a = 0; a < NTR; ++a) {
                 ah[a] = frag(xh, 16 * (wv + GM_WAVES * a) + ln, kk);
-                al[a] = frag(xl, 16 * (wv + GM_WAVES * a) + ln, kk);
+                if constexpr (NPL == 2) al[a] = frag(xl, 16 * (wv + GM_WAVES * a) + ln, kk);
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (t * 16 < L) {
-                    const u32x4 bh = frag(yh, 16 * t + ln, kk), bl = frag(yl, 16 * t + ln, kk);
+                    const u32x4 bh = frag(yh, 16 * t + ln, kk);
+                    u32x4 bl = bh;
+                    if constexpr (NPL == 2) bl = frag(yl, 16 * t + ln, kk);
 #pragma unroll
                     for (int a = 0; a < NTR; ++a)
                         if ((wv + GM_WAVES * a) * 16 < L) {
                             acc[a][t] = mfma_bf16_16x16x32(ah[a], bh, acc[a][t]);
-                            acc[a][t] = mfma_bf16_16x16x32(ah[a], bl, acc[a][t]);
-                            acc[a][t] = mfma_bf16_16x16x32(al[a], bh, acc[a][t]);
+                            if constexpr (NPL == 2) {
+                                acc[a][t] = mfma_bf16_16x16x32(ah[a], bl, acc[a][t]);
+                                acc[a][t] = mfma_bf16_16x16x32(al[a], bh, acc[a][t]);
+                            }
                         }
                 }
             }
