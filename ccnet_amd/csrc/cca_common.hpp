@@ -238,14 +238,15 @@ __device__ __forceinline__ void strip_dma_channel(const FBuf &src, float *dst, i
         }
 }
 
-// counted barrier with a run-time (wave-uniform) count
+// counted barrier with a run-time (wave-uniform) count.  The vmcnt field holds 0 .. 63; a count above 63 waits with 63
+// (keeping FEWER operations in flight than allowed is always safe), a negative one drains.
 __device__ __forceinline__ void barrier_dma_keep_n(int n) {
+    if (n > 63) n = 63;
     switch (n) {
 #define CCA_KEEP(N_) case N_: barrier_dma_keep<N_>(); break;
-        CCA_KEEP(0) CCA_KEEP(1) CCA_KEEP(2) CCA_KEEP(3) CCA_KEEP(4) CCA_KEEP(5) CCA_KEEP(6) CCA_KEEP(7) CCA_KEEP(8) CCA_KEEP(9)
-        CCA_KEEP(10) CCA_KEEP(11) CCA_KEEP(12) CCA_KEEP(13) CCA_KEEP(14) CCA_KEEP(15) CCA_KEEP(16) CCA_KEEP(17) CCA_KEEP(18)
-        CCA_KEEP(19) CCA_KEEP(20) CCA_KEEP(21) CCA_KEEP(22) CCA_KEEP(23) CCA_KEEP(24) CCA_KEEP(25) CCA_KEEP(26) CCA_KEEP(27)
-        CCA_KEEP(28) CCA_KEEP(29) CCA_KEEP(30) CCA_KEEP(31) CCA_KEEP(32)
+#define CCA_KEEP8(B_) CCA_KEEP(B_) CCA_KEEP(B_ + 1) CCA_KEEP(B_ + 2) CCA_KEEP(B_ + 3) CCA_KEEP(B_ + 4) CCA_KEEP(B_ + 5) CCA_KEEP(B_ + 6) CCA_KEEP(B_ + 7)
+        CCA_KEEP8(0) CCA_KEEP8(8) CCA_KEEP8(16) CCA_KEEP8(24) CCA_KEEP8(32) CCA_KEEP8(40) CCA_KEEP8(48) CCA_KEEP8(56)
+#undef CCA_KEEP8
 #undef CCA_KEEP
         default: barrier_dma_keep<0>(); break;
     }
