@@ -819,18 +819,8 @@ int gmap_dual_pm(const float *dE, const FT *k, const FT *q, FT *dq, FT *dk, floa
 template <bool MASK, typename FT>
 int gweight_pm(const FT *X, const FT *Y, float *T, int B, int Cx, int H, int W, long xbs, int xps, long ybs, int yps,
                ccnet_stream_t stream) {
-    if constexpr (!MASK && std::is_same<FT, bf16_t>::value) {
-        // bf16 dA at strips 101 .. 132 (BASELINE configs[4]): the persistent kernel (four-stage ring across strip boundaries).
-        // (Its 100-position bf16 instantiation comes out of hipcc with 256 VGPRs + 13 spilled whatever the launch bound, so
-        // shorter strips stay on gweight_kernel.)
-        const int ps = g_planes_stream.load();
-        if (ps && (H > W ? H : W) > 100) {
-            const int nstrips = B * (H + W), cus = ps > 1 ? ps : num_cus();
-            const dim3 sgrid((unsigned)(nstrips < cus ? nstrips : cus)), sblock(cca::GM_THREADS);
-            CCA_LAUNCH((cca::gweight_stream_kernel<132, bf16_t>), sgrid, sblock, stream, X, Y, T, Cx, B, H, W, xbs, xps, ybs, yps);
-            return launch_status("gweight_stream(bf16)");
-        }
-    }
+    // (bf16 dA stays on gweight_kernel: the persistent gweight_stream_kernel<132, bf16_t> measured 350 us against 301 us at
+    // configs[4] -- profiles/r03j_bf16_compare.txt -- wavefront 0 owns two of the nine tile rows and every barrier waits for it)
     const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
     const bool single = Cx <= cca::GM_CG;           // one chunk: the single-buffered form (more workgroups per CU)
 #define CCA_GWEIGHT(P_)                                                                                                   \

@@ -631,24 +631,3 @@ def test_streaming_dA_kernel_walks_many_strips_per_workgroup(ops, shape):
             ops.lib.ccnet_cca_set_option(b"planes_stream", prev)
     for dqkv, dg in outs[1:]:
         assert np.array_equal(dqkv, outs[0][0]) and np.array_equal(dg, outs[0][1])
-
-
-@pytest.mark.parametrize("shape", [(2, 64, 5, 101), (1, 128, 3, 132), (1, 64, 101, 2)])
-def test_streaming_dA_kernel_on_bf16_features(ops, shape):
-    """the persistent dA kernel with bf16 operands (BASELINE configs[4] path: strips 101 .. 132, four ring stages): capped at
-    three workgroups vs one workgroup per strip vs the non-persistent kernel -- bit-identical backward outputs."""
-    B, C, H, W = shape
-    cq = C // 8
-    c = rand_case(*shape, seed=63)
-    bits = lambda a: _bf16_bits_rne(a)                                              # noqa: E731
-    qkv = np.ascontiguousarray(np.concatenate([bits(_pm(c["q"])), bits(_pm(c["k"])), bits(_pm(c["v"]))], axis=3))
-    y, A = ops.cca_forward_pm_bf16(qkv, bits(_pm(c["x"])), c["gamma"], cq)
-    outs = []
-    for opt in (0, 3, 1):
-        prev = ops.lib.ccnet_cca_set_option(b"planes_stream", opt)
-        try:
-            outs.append(ops.cca_backward_pm_bf16(bits(_pm(c["dy"])), qkv, A, c["gamma"], cq))
-        finally:
-            ops.lib.ccnet_cca_set_option(b"planes_stream", prev)
-    for dqkv, dg in outs[1:]:
-        assert np.array_equal(dqkv, outs[0][0]) and np.array_equal(dg, outs[0][1])
