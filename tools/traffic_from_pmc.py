@@ -22,6 +22,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("src")
 ap.add_argument("--steps", type=int, default=0)
 ap.add_argument("--out", default="traffic_latest.json")
+ap.add_argument("--exclude", default="", help="comma-separated kernel-name fragments left out of the per-step total (e.g. the "
+                                              "producer-side pm_split_kernel of the split-plane workload, which runs outside the step)")
 a = ap.parse_args()
 src = a.src
 
@@ -47,7 +49,10 @@ if sha is None:
 if sha != _cl.kernel_source_sha16():
     sys.exit(f"{src}: profiled sources {sha} != working tree {_cl.kernel_source_sha16()}; re-profile")
 out, total = {}, 0
+skip = [e for e in a.exclude.split(",") if e]
 for k, v in d.items():
+    if any(e in k for e in skip):
+        continue
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         nbytes = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
         out[label(k) or k] = nbytes
