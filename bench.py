@@ -891,7 +891,7 @@ def main(argv=None, workload_factory=None):
             sys.exit("bench.py: --backend gloo needs --workload-factory (tests); the product path is HIP-only")
         from ccnet_amd import _lib
         lib = _lib.get_lib()
-        use_planes = (not bf16 and args.family == "planes" and max(H, W) <= 100 and C % 8 == 0)
+        use_planes = (not bf16 and args.family == "planes" and max(H, W) <= 132 and C % 8 == 0)
         cls = PixelMajorBF16Workload if bf16 else PlanesWorkload if use_planes else CoreWorkload
         wl = cls(lib, B, C, H, W, device, shard_seed(1234, rank))
 

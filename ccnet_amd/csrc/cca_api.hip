@@ -957,13 +957,28 @@ int check_planes_view(const char *what, long bs, int ps, int C, int H, int W) {
     if ((double)H * W * ps >= 1073741824.0) return fail(CCNET_E_BADSHAPE, what);            /* 2-byte elements, 31-bit offsets */
     return 0;
 }
+int check_planes_problem(const char *what, int B, int C, int Cq, int H, int W) {
+    if (int e = check_shape(B, C, H, W)) return e;
+    if (int e = check_shape(B, Cq, H, W)) return e;
+    if ((H > W ? H : W) > 132 || C % 8 || Cq % 4) return fail(CCNET_E_BADSHAPE, what);
+    return 0;
+}
 // column strips -> fp32 partial, row strips add it (+ the NCHW residual) and write the output
-template <bool TRANS>
+// P = 100: column passes on the ring kernel (two slots, three workgroups per CU by default), row passes on gmap_kernel with two
+// workgroups per CU.  P = 132 (strips 101 .. 132): the ring kernel with two slots and two workgroups per CU, the row passes with
+// ONE workgroup per CU (two plane tiles + the output image are 104 KB).
+template <int P, bool TRANS>
 int launch_gmap3_planes(const float *T, const bf16p_t *F, const float *gamma, float *out, float *partial, int B, int C, int H, int W,
                         long fbs, int fps, long obs, int ops, bool row_too, ccnet_stream_t stream) {
     const long pbs = (long)H * W * C;
     const GmapPlan gr = gmap_plan(B * H, C);
     const int ring = g_planes_ring.load();
+    if constexpr (P > 100) {
+        const GmapPlan gc = gmap_plan(B * W, C);
+        CCA_LAUNCH((cca::gmap3_kernel<P, false, TRANS, false, 2, 2>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS), stream, T, F,
+                   (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0, pbs, C, gc.n_whole, gc.split);
+        return launch_status("gmap3_planes(column)");
+    } else {
     if (ring == 2) {                        // three workgroups per CU, two ring slots
         const GmapPlan gc = gmap_plan(B * W, C, 3);
         CCA_LAUNCH((cca::gmap3_kernel<100, false, TRANS, false, 2, 3>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS), stream, T, F,
@@ -980,26 +995,65 @@ int launch_gmap3_planes(const float *T, const bf16p_t *F, const float *gamma, fl
     CCA_LAUNCH((cca::gmap3_kernel<100, true, TRANS, true>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS), stream, T, F,
                (const float *)partial, gamma, out, C, H, W, fbs, fps, pbs, C, obs, ops, gr.n_whole, gr.split);
     return launch_status("gmap3_planes(row)");
+    }
+}
+template <int P, bool TRANS, bool NCHW>
+int launch_gmap_planes_p(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
+                         int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
+    constexpr int WPC = P > 100 ? 1 : 2;
+    const long pbs = (long)H * W * C;
+    const GmapPlan gc = gmap_plan(B * W, C), gr = gmap_plan(B * H, C, WPC);
+    const int ring = P > 100 ? 2 : g_planes_ring.load();
+    if (ring) {
+        if (int e = launch_gmap3_planes<P, TRANS>(T, F, gamma, out, partial, B, C, H, W, fbs, fps, obs, ops, !NCHW, stream)) return e;
+        if (!NCHW && ring == 1) return 0;
+    } else {
+        if constexpr (P <= 100) {
+            CCA_LAUNCH((cca::gmap_kernel<100, false, TRANS, false, bf16p_t, float>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS),
+                       stream, T, F, (const float *)nullptr, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0,
+                       0L, 0, pbs, C, gc.n_whole, gc.split, cca::GmapJob<bf16p_t, float>{});
+            if (int e = launch_status("gmap_planes(column)")) return e;
+        }
+    }
+    CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, bf16p_t, float, NCHW, false, WPC>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS),
+               stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C, rbs, rps, obs, ops,
+               gr.n_whole, gr.split, cca::GmapJob<bf16p_t, float>{});
+    return launch_status("gmap_planes(row)");
 }
 template <bool TRANS, bool NCHW>
 int launch_gmap_planes(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
                        int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
-    const long pbs = (long)H * W * C;
-    const GmapPlan gc = gmap_plan(B * W, C), gr = gmap_plan(B * H, C);
-    const int ring = g_planes_ring.load();
-    if (ring) {
-        if (int e = launch_gmap3_planes<TRANS>(T, F, gamma, out, partial, B, C, H, W, fbs, fps, obs, ops, !NCHW, stream)) return e;
-        if (!NCHW && ring == 1) return 0;
-    } else {
-    CCA_LAUNCH((cca::gmap_kernel<100, false, TRANS, false, bf16p_t, float>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS),
-               stream, T, F, (const float *)nullptr, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0,
-               0L, 0, pbs, C, gc.n_whole, gc.split, cca::GmapJob<bf16p_t, float>{});
-    if (int e = launch_status("gmap_planes(column)")) return e;
-    }
-    CCA_LAUNCH((cca::gmap_kernel<100, true, TRANS, true, bf16p_t, float, NCHW>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS),
-               stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C, rbs, rps, obs, ops,
-               gr.n_whole, gr.split, cca::GmapJob<bf16p_t, float>{});
-    return launch_status("gmap_planes(row)");
+    if ((H > W ? H : W) <= 100)
+        return launch_gmap_planes_p<100, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+    return launch_gmap_planes_p<132, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+}
+// strips 101 .. 132 with fp32 q | k: the energies and dq | dk kernels of the pixel-major fp32 family at 132 positions (one
+// workgroup per CU for the latter: fp32 tiles)
+int gweight_energies_f32(const float *q, const float *k, float *A, int B, int Cq, int H, int W, long qbs, int qps, long kbs, int kps,
+                         ccnet_stream_t stream) {
+    if ((H > W ? H : W) <= 100) return gweight_pm<true, float>(q, k, A, B, Cq, H, W, qbs, qps, kbs, kps, stream);
+    const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
+    if (Cq <= cca::GM_CG) CCA_LAUNCH((cca::gweight_kernel<132, true, float, true>), grid, block, stream, q, k, A, Cq, H, W, qbs, qps, kbs, kps);
+    else                  CCA_LAUNCH((cca::gweight_kernel<132, true, float, false>), grid, block, stream, q, k, A, Cq, H, W, qbs, qps, kbs, kps);
+    return launch_status("gweight_energies(132)");
+}
+int gmap_dual_f32(const float *dE, const float *k, const float *q, float *dq, float *dk, float *partial, int B, int Cq, int H, int W,
+                  long kbs, int kps, long qbs, int qps, long dqbs, int dqps, long dkbs, int dkps, ccnet_stream_t stream) {
+    if ((H > W ? H : W) <= 100)
+        return gmap_dual_pm<float>(dE, k, q, dq, dk, partial, B, Cq, H, W, kbs, kps, qbs, qps, dqbs, dqps, dkbs, dkps, stream);
+    const long pbs = (long)H * W * Cq;
+    float *pq = partial, *pk = partial + (size_t)B * pbs;
+    const GmapPlan gc = gmap_plan(B * W, Cq, 1), gr = gmap_plan(B * H, Cq, 1);
+    const cca::GmapJob<float, float> jc{q, nullptr, pk, qbs, pbs, qps, Cq};
+    CCA_LAUNCH((cca::gmap_kernel<132, false, false, false, float, float, false, true, 1>), dim3((unsigned)gc.grid, 2), dim3(cca::GS_THREADS),
+               stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
+               0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
+    if (int e = launch_status("gmap_dual_f32(column, 132)")) return e;
+    const cca::GmapJob<float, float> jr{q, pk, dk, qbs, dkbs, qps, dkps};
+    CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, float, float, false, true, 1>), dim3((unsigned)gr.grid, 2), dim3(cca::GS_THREADS),
+               stream, dE, k, (const float *)pq, (const float *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
+               0L, 0, dqbs, dqps, gr.n_whole, gr.split, jr);
+    return launch_status("gmap_dual_f32(row, 132)");
 }
 size_t planes_bytes(int B, int C, int H, int W) { return (size_t)B * H * W * 2 * C * 2; }
 }  // namespace
@@ -1042,14 +1096,14 @@ int ccnet_cca_forward_planes_f32(const float *q, const float *k, const uint16_t 
                                  void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
     if (int e = require_both_branches("cca_forward_planes_f32")) return e;
     if (!q || !k || !v_planes || !x || !gamma || !y || !A) return fail(CCNET_E_NULLPTR, "cca_forward_planes: null tensor");
-    if (int e = check_pm_problem<float>("cca_forward_planes: strips <= 100, C % 8 == 0, Cq % 4 == 0", B, C, Cq, H, W)) return e;
+    if (int e = check_planes_problem("cca_forward_planes: strips <= 132, C % 8 == 0, Cq % 4 == 0", B, C, Cq, H, W)) return e;
     if (int e = check_pm_view<float>("cca_forward_planes: q view", q_bs, q_ps, Cq, H, W)) return e;
     if (int e = check_pm_view<float>("cca_forward_planes: k view", k_bs, k_ps, Cq, H, W)) return e;
     if (int e = check_planes_view("cca_forward_planes: v planes view", v_bs, v_ps, C, H, W)) return e;
     if ((double)C * H * W >= 536870912.0) return fail(CCNET_E_BADSHAPE, "cca_forward_planes: image exceeds 2^29 elements");
     if (!workspace || workspace_bytes < ccnet_cca_planes_workspace_bytes(B, C, Cq, H, W, 0))
         return fail(CCNET_E_WORKSPACE, "cca_forward_planes: workspace missing or too small");
-    if (int e = gweight_pm<true, float>(q, k, A, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
+    if (int e = gweight_energies_f32(q, k, A, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
     if (int e = softmax_forward(A, A, B, H, W, stream)) return e;
     const long img = (long)C * H * W;
     return launch_gmap_planes<false, true>(A, (const bf16p_t *)v_planes, x, gamma, y, (float *)workspace, B, C, H, W, v_bs, v_ps,
@@ -1064,7 +1118,7 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
     if (int e = require_both_branches("cca_backward_planes_f32")) return e;
     if (!dy || !q || !k || !v_planes || !A || !gamma || !dq || !dk || !dv || !dgamma || !scratch)
         return fail(CCNET_E_NULLPTR, "cca_backward_planes: null tensor");
-    if (int e = check_pm_problem<float>("cca_backward_planes: strips <= 100, C % 8 == 0, Cq % 4 == 0", B, C, Cq, H, W)) return e;
+    if (int e = check_planes_problem("cca_backward_planes: strips <= 132, C % 8 == 0, Cq % 4 == 0", B, C, Cq, H, W)) return e;
     if (int e = check_pm_view<float>("cca_backward_planes: q view", q_bs, q_ps, Cq, H, W)) return e;
     if (int e = check_pm_view<float>("cca_backward_planes: k view", k_bs, k_ps, Cq, H, W)) return e;
     if (int e = check_planes_view("cca_backward_planes: v planes view", v_bs, v_ps, C, H, W)) return e;
@@ -1082,7 +1136,11 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
     if (int e = ccnet_cca_nchw_to_planes_f32(dy, dy_pl, B, C, H, W, (long)C * H * W, dbs, 2 * C, stream)) return e;
     const bf16p_t *dyp = (const bf16p_t *)dy_pl, *vp = (const bf16p_t *)v_planes;
     // t = un-scaled dA (the adjoint of the aggregation, functions.py:46-47), dv = gamma * A^T-weighted dy
-    if (const int ps = g_planes_stream.load()) {
+    if ((H > W ? H : W) > 100) {
+        const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
+        CCA_LAUNCH((cca::gweight_kernel<132, false, bf16p_t, false>), grid, block, stream, dyp, vp, scratch, C, H, W, dbs, 2 * C, v_bs, v_ps);
+        if (int e = launch_status("gweight_planes(dA, 132)")) return e;
+    } else if (const int ps = g_planes_stream.load()) {
         // persistent: one workgroup per CU walks the strips of both branches, its ring runs across strip boundaries
         // (option values > 1 cap the number of workgroups: tests make one workgroup walk many strips)
         const int nstrips = B * (H + W), cus = ps > 1 ? ps : num_cus();
@@ -1098,7 +1156,7 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
         return e;
     // dgamma = sum A t;  dE = gamma * A * (t - sum_s A t), in place
     if (int e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, sm, B, H, W, stream, KSplit())) return e;
-    return gmap_dual_pm<float>(scratch, k, q, dq, dk, partial, B, Cq, H, W, k_bs, k_ps, q_bs, q_ps, dq_bs, dq_ps, dk_bs, dk_ps, stream);
+    return gmap_dual_f32(scratch, k, q, dq, dk, partial, B, Cq, H, W, k_bs, k_ps, q_bs, q_ps, dq_bs, dq_ps, dk_bs, dk_ps, stream);
 }
 
 int ccnet_cca_set_option(const char *name, int value) {

@@ -171,8 +171,10 @@ struct GmapJob {
     int fps, ops;
 };
 
-template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT, bool NCHW = false, bool DUAL = false>
-__global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__restrict__ T, const FT *__restrict__ F,
+// WPC: workgroups per CU the LDS budget is checked for (2 everywhere except the 132-position kernels on fp32 / split-plane
+// features, whose two feature tiles + output image take 104 KB: one workgroup per CU)
+template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT, bool NCHW = false, bool DUAL = false, int WPC = 2>
+__global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__restrict__ T, const FT *__restrict__ F,
                                                               const float *__restrict__ addend,
                                                               const OT *__restrict__ resid,
                                                               const float *__restrict__ gamma, OT *out,
@@ -192,10 +194,11 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
     constexpr int SPX = OBF ? 8 : 4;                                  // pixels per store instruction
     constexpr int NSI = NCHW ? 1 : ((P + SPX - 1) / SPX + GS_WAVES - 1) / GS_WAVES;   // store instructions per wave and group (max)
     constexpr int PO = P + 4, OIMG = NCHW ? GM_CG * PO : OSZ;         // NCHW: [channel][position] image, pitch PO
-    constexpr int NSX = GM_CG / 2 / GS_WAVES;                         // NCHW: store instructions per wave and group (2 channels each)
+    constexpr int CPI = P <= 128 ? 2 : 1, LPC = kWave / CPI;          // NCHW: channels per store instruction, lanes per channel (4 positions each)
+    constexpr int NSX = GM_CG / CPI / GS_WAVES;                       // NCHW: store instructions per wave and group
     static_assert(!NCHW || (ROW && ADD && !OBF && !TRANS && !DUAL), "gmap: the NCHW epilogue belongs to the final fp32 row pass");
     static_assert(!PL || !OBF, "gmap: split-plane features produce fp32 outputs");
-    static_assert(P % 4 == 0 && (2 * FSZ + OIMG) * 4 * 2 <= 163840, "gmap: two workgroups per CU");
+    static_assert(P % 4 == 0 && (2 * FSZ + OIMG) * 4 * WPC <= 163840, "gmap: LDS of WPC workgroups per CU");
     __shared__ __attribute__((aligned(16))) float lds[2 * FSZ + OIMG];
     CCA_LDS_REGISTER(lds);
     float *const FB = lds, *const oimg = lds + 2 * FSZ;
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
             }
 #pragma unroll
             for (int k = 0; k < NSX; ++k) {                 // residual in the store layout: 4 positions of channel c
-                const int c = cg * GM_CG + 2 * (wv + GS_WAVES * k) + (lane >> 5), w4 = lane & 31;
+                const int c = cg * GM_CG + CPI * (wv + GS_WAVES * k) + (lane / LPC), w4 = lane & (LPC - 1);
                 const int w0 = (4 * w4 + 3 < L || L < 4) ? 4 * w4 : L - 4;      // the last granule is shifted back to end at L
                 resx[k] = fbuf_load_x4(Rb, (resid && 4 * w4 < L && c < C) ? (c * HW + pix0 + w0) * 4 : kOobOffset, 0);
             }
@@ -404,12 +407,12 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
         }
         barrier_lds_only();
         if constexpr (NCHW) {
-            // runs of W floats per channel: 2 channels x 32 lanes (4 positions each) per instruction.  Store instructions
-            // this wave issues in this group (for the next group's counted barrier): one 16-byte store per valid channel
-            // pair (rows shorter than 4: L single stores)
+            // runs of W floats per channel: CPI channels x LPC lanes (4 positions each) per instruction (2 x 32 up to 128
+            // positions, 1 x 64 beyond).  Store instructions this wave issues in this group (for the next group's counted
+            // barrier): one 16-byte store per valid channel set (rows shorter than 4: L single stores)
             {
-                const int crem = C - cg * GM_CG, first = 2 * wv;
-                const int nk = crem <= first ? 0 : (crem - first + 2 * GS_WAVES - 1) / (2 * GS_WAVES);
+                const int crem = C - cg * GM_CG, first = CPI * wv;
+                const int nk = crem <= first ? 0 : (crem - first + CPI * GS_WAVES - 1) / (CPI * GS_WAVES);
                 nstore_nchw = (nk < NSX ? nk : NSX) * (L >= 4 ? 1 : L);
             }
             const int crem = C - cg * GM_CG;
@@ -417,8 +420,8 @@ __global__ __launch_bounds__(GS_THREADS, 2) void gmap_kernel(const float *__rest
             for (int k = 0; k < NSX; ++k) {
                 // every branch around a store is wave-uniform (scalar) and every store issued has an active lane: the
                 // counted barrier may only count instructions that really go to memory
-                if (2 * (wv + GS_WAVES * k) < crem) {
-                    const int ch = 2 * (wv + GS_WAVES * k) + (lane >> 5), c = cg * GM_CG + ch, w4 = lane & 31;
+                if (CPI * (wv + GS_WAVES * k) < crem) {
+                    const int ch = CPI * (wv + GS_WAVES * k) + (lane / LPC), c = cg * GM_CG + ch, w4 = lane & (LPC - 1);
                     const bool whole = 4 * w4 + 3 < L;
                     if (L >= 4) {
                         // a row of L floats = whole 4-float granules + one granule shifted back to end at L (it rewrites up to

@@ -514,7 +514,7 @@ def split_planes(t: torch.Tensor, c0: int, C: int) -> torch.Tensor:
 
 def planes_cover(B, C, Cq, H, W):
     """geometry of the split-plane kernels (csrc/cca_gmap.hpp, bf16p_t)"""
-    return max(H, W) <= 100 and C % 8 == 0 and Cq % 4 == 0 and H * W * (C + 2 * Cq) < 2 ** 29
+    return max(H, W) <= 132 and C % 8 == 0 and Cq % 4 == 0 and H * W * (C + 2 * Cq) < 2 ** 29
 
 
 class CrissCrossPlanesModuleFunction(torch.autograd.Function):
@@ -614,7 +614,7 @@ class CrissCrossAttention(nn.Module):
     #: pixel-major / split-plane routes are skipped while it is set.  Under torch.no_grad() / eval nothing is kept either way.
     recompute_attention = False
 
-    #: fp32 NCHW inputs (no autocast, strips <= 100): the SPLIT-PLANE node (``CrissCrossPlanesModuleFunction``: q | k | v out
+    #: fp32 NCHW inputs (no autocast, strips <= 132): the SPLIT-PLANE node (``CrissCrossPlanesModuleFunction``: q | k | v out
     #: of one GEMM pixel-major, v and dy pre-split into bf16 hi | lo planes, x / y / dy NCHW).  Measured on MI355X, core
     #: fwd+bwd at (8,512,97,97): 0.83 ms vs 0.87 ms on the NCHW strips of the same box (profiles/r03d_family_compare.txt).
     split_planes = True
@@ -651,12 +651,10 @@ class CrissCrossAttention(nn.Module):
                 return "bf16-pixel-major"
         if x.dtype == torch.float32 and not torch.is_autocast_enabled() and self._fusable(x):
             cl = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
-            if fast_ok and pm_covers(torch.float32, B, C, cq, H, W):
-                if cl and self.pixel_major_for_channels_last:
-                    return "f32-channels-last"
-                if not cl and self.fuse_module_backward:
-                    if self.split_planes and planes_cover(B, C, cq, H, W):
-                        return "f32-planes"
+            if fast_ok and cl and self.pixel_major_for_channels_last and pm_covers(torch.float32, B, C, cq, H, W):
+                return "f32-channels-last"
+            if fast_ok and not cl and self.fuse_module_backward and self.split_planes and planes_cover(B, C, cq, H, W):
+                return "f32-planes"
             if self.fuse_projections and self.fuse_module_backward:
                 return "f32-strips-node"
         if self.fuse_projections and self._fusable():

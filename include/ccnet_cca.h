@@ -223,7 +223,9 @@ int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W);
  * -- the same bytes as fp32, pixel-major, split ONCE by the producer, so that the kernels that contract over it
  * (functions.py:42-47 and their adjoints) run the bf16 matrix pipe with three exact products per term and no per-use split.
  * Views: pointer to the hi plane, batch stride and pixel stride in ELEMENTS (pixel stride >= 2 C, both multiples of 8);
- * the lo plane of a pixel starts C elements after its hi plane.  C % 8 == 0, max(H, W) <= 100.
+ * the lo plane of a pixel starts C elements after its hi plane.  C % 8 == 0, max(H, W) <= 132 (strips up to 100 run the
+ * kernels tuned for the headline geometry; 101 .. 132 -- the 129 x 129 map of BASELINE configs[4] in fp32 -- the same kernels
+ * padded to 132 positions, the row passes with one workgroup per CU).
  *
  * ccnet_cca_split_planes_f32: fp32 pixel-major view (e.g. the value slice of the packed projection x^T W^T) -> planes.
  * ccnet_cca_nchw_to_planes_f32: NCHW fp32 (B, C, H, W) -> planes.

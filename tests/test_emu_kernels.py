@@ -579,7 +579,8 @@ def test_split_plane_producers_are_exact_hi_lo_splits(ops):
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 96, 17, 20), (1, 64, 9, 1), (1, 160, 33, 18), (1, 64, 2, 99), (1, 64, 100, 3),
-                                   (1, 64, 3, 97), (2, 128, 3, 130 // 2), (1, 512, 6, 5)])
+                                   (1, 64, 3, 97), (2, 128, 3, 130 // 2), (1, 512, 6, 5),
+                                   (1, 64, 101, 2), (1, 64, 3, 129), (1, 128, 2, 132)])     # strips 101 .. 132: the 132-position kernels
 def test_split_plane_core_matches_the_fp32_pixel_major_core_and_the_oracle(ops, shape):
     """ccnet_cca_{forward,backward}_planes_f32: v and dy enter the kernels as bf16 hi | lo planes (split once by their
     producers), fragments come out of LDS by transposing reads, three bf16 MFMAs per term.  The arithmetic is the fp32
@@ -591,16 +592,19 @@ def test_split_plane_core_matches_the_fp32_pixel_major_core_and_the_oracle(ops, 
     qkv = np.ascontiguousarray(np.concatenate([_pm(c["q"]), _pm(c["k"]), _pm(c["v"])], axis=3))
     vpl = ops.split_planes(qkv, C, c0=2 * cq)
     y, A = ops.cca_forward_planes(qkv, vpl, c["x"], c["gamma"], cq)
-    y2, A2 = ops.cca_forward_pm_bf16(qkv, _pm(c["x"]), c["gamma"], cq)            # fp32 qkv: the all-pixel-major fp32 entry points
     nchw = lambda a: np.transpose(a, (0, 3, 1, 2))                                 # noqa: E731
-    assert np.array_equal(A, A2)
+    long_strips = max(H, W) > 100                  # (the fp32 pixel-major entry points stop at 100 positions)
+    if not long_strips:
+        y2, A2 = ops.cca_forward_pm_bf16(qkv, _pm(c["x"]), c["gamma"], cq)        # fp32 qkv: the all-pixel-major fp32 entry points
+        assert np.array_equal(A, A2)
+        assert maxerr(y, nchw(y2)) < 2e-6 * max(1.0, float(np.abs(y2).max()))
     assert np.all(A[:, np.arange(H), :, np.arange(H)] == 0)
-    assert maxerr(y, nchw(y2)) < 2e-6 * max(1.0, float(np.abs(y2).max()))
     yo, Ao = O.cca_core_forward(T(c["q"]), T(c["k"]), T(c["v"]), T(c["x"]), T(c["gamma"]))
     assert maxerr(y, yo.numpy()) < 2e-4 * max(1.0, float(yo.abs().max()))
     dqkv, dg = ops.cca_backward_planes(c["dy"], qkv, vpl, A, c["gamma"], cq)
-    dqkv2, dg2 = ops.cca_backward_pm_bf16(_pm(c["dy"]), qkv, A, c["gamma"], cq)
-    assert maxerr(dqkv, dqkv2) < 5e-6 * max(1.0, float(np.abs(dqkv2).max()))
+    if not long_strips:
+        dqkv2, dg2 = ops.cca_backward_pm_bf16(_pm(c["dy"]), qkv, A, c["gamma"], cq)
+        assert maxerr(dqkv, dqkv2) < 5e-6 * max(1.0, float(np.abs(dqkv2).max()))
     go = O.cca_core_backward(T(c["dy"]), T(c["q"]), T(c["k"]), T(c["v"]), Ao, T(c["gamma"]))
     for name, got in (("dq", dqkv[..., :cq]), ("dk", dqkv[..., cq:2 * cq]), ("dv", dqkv[..., 2 * cq:])):
         assert maxerr(nchw(got), go[name].numpy()) < 5e-4 * max(1.0, float(go[name].abs().max())), name

@@ -454,7 +454,8 @@ def test_pixel_major_fp32_kernels_match_oracle(lib, dev, shape):
     assert abs(float(gamma.grad) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
 
 
-@pytest.mark.parametrize("shape", [(1, 64, 20, 24), (2, 96, 33, 18), (1, 64, 100, 3), (2, 512, 97, 97, "default-init")])
+@pytest.mark.parametrize("shape", [(1, 64, 20, 24), (2, 96, 33, 18), (1, 64, 100, 3), (2, 512, 97, 97, "default-init"),
+                                   (1, 128, 129, 101), (1, 512, 129, 129)])       # strips 101 .. 132: the 132-position kernels
 def test_split_plane_module_node_matches_the_oracle_and_the_other_nodes(lib, dev, shape):
     """CrissCrossPlanesModuleFunction (v and dy enter the kernels pre-split into bf16 hi | lo planes, fragments by
     transposing LDS reads) -- the module's default route for fp32 NCHW inputs: y against the oracle at the north_star bar

@@ -241,7 +241,8 @@ def test_module_routing_table(device_lib_path):
     table = {
         ("f32 NCHW 97x97 B=8", lambda: m.route(nchw(8, 97, 97))): "f32-planes",
         ("f32 NCHW 97x97 B=1", lambda: m.route(nchw(1, 97, 97))): "f32-planes",
-        ("f32 NCHW 129x129 (beyond the plane kernels)", lambda: m.route(nchw(2, 129, 129))): "f32-strips-node",
+        ("f32 NCHW 129x129 (plane kernels padded to 132 positions)", lambda: m.route(nchw(2, 129, 129))): "f32-planes",
+        ("f32 NCHW 129x257 (beyond the plane kernels)", lambda: m.route(nchw(2, 129, 257))): "f32-strips-node",
         ("f32 channels_last", lambda: m.route(cl(2, 33, 18))): "f32-channels-last",
     }
     for (what, fn), want in table.items():
