@@ -1016,7 +1016,14 @@ def main(argv=None, workload_factory=None):
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, H, W, args.cpu_budget)
     if extras and not args.no_train:
-        # every rank takes part (DDP + SyncBN collectives); rank 0 keeps the result
+        # every rank takes part (DDP + SyncBN collectives); rank 0 keeps the result.  Ranks 1.. wait HERE (not inside the train
+        # leg's first collective) while rank 0 finishes its rank-0-only extras, and a failure of rank 0 up to this point is
+        # agreed on before anybody enters DDP
+        if use_dist:
+            ok = torch.ones(1, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok) < 1:
+                sys.exit("bench.py: a rank failed before the train leg")
         del wl
         torch.cuda.empty_cache()
         try:
