@@ -43,6 +43,11 @@ std::atomic<int> g_weight_bf16{1};
 std::atomic<int> g_planes_ring{2};
 // "planes_stream" 1 (default) = the split-plane dA contraction runs the persistent gweight_stream_kernel, 0 = gweight_kernel
 std::atomic<int> g_planes_stream{1};
+// "planes_overlap": the dv passes of the pixel-major / split-plane backwards run on the library's side stream; 2 = from before
+// dA on, 1 = next to softmax-backward and dq | dk only, 0 = everything on the caller's stream; -1 (default) = what measured best
+// per family: 2 on split planes (0.821 -> 0.776 -> 0.760 ms at the headline shape), 1 on the bf16 / fp32 pixel-major entries
+// (configs[4] bf16: 1.917 -> 1.903, but 1.959 with 2: its one-workgroup-per-strip dA shares the CUs badly)
+std::atomic<int> g_planes_overlap{-1};
 
 int fail(int code, const char *what) {
     char buf[256];
@@ -849,9 +854,29 @@ int check_pm_problem(const char *what, int B, int C, int Cq, int H, int W) {
 }
 size_t pm_workspace_bytes(int B, int C, int Cq, int H, int W, int backward) {
     if (B <= 0 || C <= 0 || Cq <= 0 || H <= 0 || W <= 0) return 0;
-    const size_t partial = (size_t)B * H * W * (C > 2 * Cq ? C : 2 * Cq) * sizeof(float);     // (dq and dk partials side by side)
-    return (backward ? align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W)) : 0) + partial;
+    // forward: the column partial of the aggregation.  backward: softmax-backward's slabs | the column partial of dv | the
+    // column partials of dq and dk side by side (a region of their own: those launches may run next to the dv passes)
+    const size_t px = (size_t)B * H * W * sizeof(float);
+    if (!backward) return px * C;
+    return align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W)) + align256(px * C) + px * 2 * Cq;
 }
+float *partial_qk_of(float *partial, int B, int C, int H, int W) {
+    return reinterpret_cast<float *>(reinterpret_cast<char *>(partial) + align256((size_t)B * H * W * C * sizeof(float)));
+}
+// fork / join of the library's side stream around the launches of a backward that are independent of the caller's chain
+// ("planes_overlap": 0 = never fork, 1 = dv next to softmax-backward and dq | dk, 2 = dv next to dA as well)
+struct SideFork {
+    hipStream_t main, side = nullptr;
+    explicit SideFork(ccnet_stream_t m) : main((hipStream_t)m) {}
+    void fork() { if (!side) side = cca_side::fork(main); }
+    ccnet_stream_t stream() const { return side ? (ccnet_stream_t)side : (ccnet_stream_t)main; }
+    // every path out of the backward joins (a capture must not end forked)
+    int join(int e) {
+        if (side && !cca_side::join(main) && !e) e = fail(1, "cca_backward: joining the side stream failed");
+        side = nullptr;
+        return e;
+    }
+};
 
 template <typename FT>
 int cca_forward_pm(const char *name, const FT *q, const FT *k, const FT *v, const FT *x, const float *gamma, FT *y, float *A,
@@ -894,12 +919,19 @@ int cca_backward_pm(const char *name, const FT *dy, const FT *q, const FT *k, co
     const size_t sm = align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W));
     float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + sm);
     // t = un-scaled dA (the adjoint of the aggregation, functions.py:46-47), dv = gamma * A^T-weighted dy
-    if (int e = gweight_pm<false, FT>(dy, v, scratch, B, C, H, W, dy_bs, dy_ps, v_bs, v_ps, stream)) return e;
-    if (int e = gmap_pm<true, FT>(A, dy, nullptr, gamma, dv, partial, B, C, H, W, dy_bs, dy_ps, 0L, 0, dv_bs, dv_ps, stream)) return e;
+    // dv (two C-sized, HBM-bound passes) is independent of the chain dA -> dE -> dq | dk: it runs on the side stream
+    const int overlap = g_planes_overlap.load() < 0 ? 1 : g_planes_overlap.load();
+    SideFork sf(stream);
+    if (overlap == 2) sf.fork();
+    int e = gweight_pm<false, FT>(dy, v, scratch, B, C, H, W, dy_bs, dy_ps, v_bs, v_ps, stream);
+    if (overlap == 1) sf.fork();
+    if (!e) e = gmap_pm<true, FT>(A, dy, nullptr, gamma, dv, partial, B, C, H, W, dy_bs, dy_ps, 0L, 0, dv_bs, dv_ps, sf.stream());
     // dgamma = sum A t;  dE = gamma * A * (t - sum_s A t), in place
-    if (int e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, sm, B, H, W, stream, KSplit())) return e;
-    // the column partials of dq and dk sit side by side in the partial buffer (2 * Cq <= C channels)
-    return gmap_dual_pm<FT>(scratch, k, q, dq, dk, partial, B, Cq, H, W, k_bs, k_ps, q_bs, q_ps, dq_bs, dq_ps, dk_bs, dk_ps, stream);
+    if (!e) e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, sm, B, H, W, stream, KSplit());
+    // the column partials of dq and dk sit side by side in their own region
+    if (!e) e = gmap_dual_pm<FT>(scratch, k, q, dq, dk, partial_qk_of(partial, B, C, H, W), B, Cq, H, W, k_bs, k_ps, q_bs, q_ps,
+                                 dq_bs, dq_ps, dk_bs, dk_ps, stream);
+    return sf.join(e);
 }
 }  // namespace
 }  // extern "C++"
@@ -1135,34 +1167,43 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
     // dy (NCHW, the module's gradient) -> planes, once: it is a contraction operand of four launches
     if (int e = ccnet_cca_nchw_to_planes_f32(dy, dy_pl, B, C, H, W, (long)C * H * W, dbs, 2 * C, stream)) return e;
     const bf16p_t *dyp = (const bf16p_t *)dy_pl, *vp = (const bf16p_t *)v_planes;
+    // dv (two C-sized, HBM-bound passes) is independent of the chain dA -> dE -> dq | dk: it runs on the library's side stream
+    // next to that chain and joins before this function returns
+    const int overlap = g_planes_overlap.load() < 0 ? 2 : g_planes_overlap.load();
+    SideFork sf(stream);
+    if (overlap == 2) sf.fork();
     // t = un-scaled dA (the adjoint of the aggregation, functions.py:46-47), dv = gamma * A^T-weighted dy
+    int e = 0;
     if ((H > W ? H : W) > 100) {
         const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
         CCA_LAUNCH((cca::gweight_kernel<132, false, bf16p_t, false>), grid, block, stream, dyp, vp, scratch, C, H, W, dbs, 2 * C, v_bs, v_ps);
-        if (int e = launch_status("gweight_planes(dA, 132)")) return e;
+        e = launch_status("gweight_planes(dA, 132)");
     } else if (const int ps = g_planes_stream.load()) {
         // persistent: one workgroup per CU walks the strips of both branches, its ring runs across strip boundaries
         // (option values > 1 cap the number of workgroups: tests make one workgroup walk many strips)
         const int nstrips = B * (H + W), cus = ps > 1 ? ps : num_cus();
         const dim3 grid((unsigned)(nstrips < cus ? nstrips : cus)), block(cca::GM_THREADS);
         CCA_LAUNCH((cca::gweight_stream_kernel<100>), grid, block, stream, dyp, vp, scratch, C, B, H, W, dbs, 2 * C, v_bs, v_ps);
-        if (int e = launch_status("gweight_stream(dA)")) return e;
+        e = launch_status("gweight_stream(dA)");
     } else {
         const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
         CCA_LAUNCH((cca::gweight_kernel<100, false, bf16p_t, false>), grid, block, stream, dyp, vp, scratch, C, H, W, dbs, 2 * C, v_bs, v_ps);
-        if (int e = launch_status("gweight_planes(dA)")) return e;
+        e = launch_status("gweight_planes(dA)");
     }
-    if (int e = launch_gmap_planes<true, false>(A, dyp, nullptr, gamma, dv, partial, B, C, H, W, dbs, 2 * C, 0L, 0, dv_bs, dv_ps, stream))
-        return e;
+    if (overlap == 1) sf.fork();
+    if (!e) e = launch_gmap_planes<true, false>(A, dyp, nullptr, gamma, dv, partial, B, C, H, W, dbs, 2 * C, 0L, 0, dv_bs, dv_ps, sf.stream());
     // dgamma = sum A t;  dE = gamma * A * (t - sum_s A t), in place
-    if (int e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, sm, B, H, W, stream, KSplit())) return e;
-    return gmap_dual_f32(scratch, k, q, dq, dk, partial, B, Cq, H, W, k_bs, k_ps, q_bs, q_ps, dq_bs, dq_ps, dk_bs, dk_ps, stream);
+    if (!e) e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, sm, B, H, W, stream, KSplit());
+    if (!e) e = gmap_dual_f32(scratch, k, q, dq, dk, partial_qk_of(partial, B, C, H, W), B, Cq, H, W, k_bs, k_ps, q_bs, q_ps,
+                              dq_bs, dq_ps, dk_bs, dk_ps, stream);
+    return sf.join(e);
 }
 
 int ccnet_cca_set_option(const char *name, int value) {
     if (!name) return fail(CCNET_E_NULLPTR, "set_option: null name");
     if (std::string(name) == "planes_ring") return g_planes_ring.exchange(value);
     if (std::string(name) == "planes_stream") return g_planes_stream.exchange(value);
+    if (std::string(name) == "planes_overlap") return g_planes_overlap.exchange(value);
     return fail(CCNET_E_BADFLAGS, "set_option: unknown option");
 }
 

@@ -153,6 +153,7 @@ __device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(
 // ---- its own stream, so a tool can read each launch's duration INSIDE a step (bench.py: gpu_kernel_sum_ms, idle_ms)
 // ---- without an external profiler.  Disarmed (the default) it costs one relaxed atomic load per launch.
 #include <atomic>
+#include <mutex>
 #include <stdio.h>
 namespace cca_prof {
 constexpr int kMaxLaunches = 256;
@@ -205,6 +206,51 @@ inline int end(float *ms, char *names, int name_stride, int cap, const char **wh
     return n;
 }
 }  // namespace cca_prof
+
+// A library-owned second stream per device for launches that are independent of the caller's chain (the dv passes next to
+// softmax-backward -> dq | dk of the split-plane backward): fork() makes the side stream wait for everything the caller's
+// stream holds so far and hands it out, join() makes the caller's stream wait for the side stream.  Event record / wait pairs
+// only: under stream capture the side stream joins the capture and comes back before it ends, i.e. the step stays one graph.
+namespace cca_side {
+struct Dev {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+inline Dev *dev_state() {
+    static Dev devs[64];
+    static std::mutex mu;
+    const int d = [] { int x = 0; return hipGetDevice(&x) == hipSuccess && x >= 0 && x < 64 ? x : -1; }();
+    if (d < 0) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    Dev &v = devs[d];
+    if (!v.s) {
+        hipStream_t s = nullptr;
+        hipEvent_t f = nullptr, j = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&f, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&j, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        v.fork = f; v.join = j; v.s = s;
+    }
+    return &v;
+}
+// nullptr when the side stream cannot be had (the caller then stays on its own stream)
+inline hipStream_t fork(hipStream_t main) {
+    Dev *v = dev_state();
+    if (!v) return nullptr;
+    if (hipEventRecord(v->fork, main) != hipSuccess || hipStreamWaitEvent(v->s, v->fork, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return v->s;
+}
+inline bool join(hipStream_t main) {
+    Dev *v = dev_state();
+    return v && hipEventRecord(v->join, v->s) == hipSuccess && hipStreamWaitEvent(main, v->join, 0) == hipSuccess;
+}
+}  // namespace cca_side
 
 // kernel launch on a caller-given stream; a stale error of an earlier, unrelated HIP call is cleared first so that
 // launch_status() reports this launch and nothing else

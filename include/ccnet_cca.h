@@ -257,7 +257,12 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
  *                  0 gmap_kernel (two feature tiles + an output image in LDS).
  *   "planes_stream" 1 (default) the split-plane dA contraction is the persistent gweight_stream_kernel (one workgroup per CU
  *                    walks the strips, its three-stage ring runs across strip boundaries); 0 gweight_kernel (one workgroup
- *                    per strip); k > 1: persistent with at most k workgroups (tests). */
+ *                    per strip); k > 1: persistent with at most k workgroups (tests).
+ *   "planes_overlap" the backwards of the pixel-major / split-plane entries run their two dv passes on a library-owned side
+ *                    stream (forked from ``stream`` by an event, joined before the call returns: the caller's stream sees
+ *                    one ordered operation and a stream capture stays one graph): 2 next to dA, softmax-backward and
+ *                    dq | dk; 1 next to softmax-backward and dq | dk only; 0 everything on ``stream``; -1 (default) what
+ *                    measured best per family (2 on split planes, 1 on the bf16 / fp32 pixel-major entries). */
 int ccnet_cca_set_option(const char *name, int value);
 
 /* Launch profiler (a measurement aid, off by default).  Between ``begin`` and ``end`` every kernel launch the library

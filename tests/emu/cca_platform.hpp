@@ -185,5 +185,11 @@ inline const char *begin(int) { return "profile_begin: not available in the emul
 inline int end(float *, char *, int, int, const char **why) { *why = "profile_end: not available in the emulator build"; return 0; }
 }  // namespace cca_prof
 
+// the emulator runs every launch to completion: there is nothing to overlap, the "side stream" is the caller's
+namespace cca_side {
+inline hipStream_t fork(hipStream_t) { return nullptr; }
+inline bool join(hipStream_t) { return true; }
+}  // namespace cca_side
+
 inline int cca_current_device_cus() { return 0; }      // the host default (256) applies
 inline int cca_current_device() { return 0; }

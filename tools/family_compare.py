@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the fp32 core families at one shape on this GPU: NCHW strips vs split planes under the three "planes_ring" options.
+"""A/B of the fp32 core families at one shape on this GPU: NCHW strips vs split planes under its options (ring kernels, persistent dA, dv on the side stream).
 Per family: fwd+bwd ms (eager, HIP events), the per-launch durations inside a step (library launch profiler) and the
 agreement of the plane variants with each other on the same inputs.
 usage: family_compare.py [B C H W]"""
@@ -15,13 +15,21 @@ from ccnet_amd import _lib  # noqa: E402
 B, C, H, W = (int(a) for a in sys.argv[1:5]) if len(sys.argv) >= 5 else (8, 512, 97, 97)
 lib = _lib.get_lib()
 dev = torch.device("cuda:0")
-fams = [("nchw-strips", bench.CoreWorkload), ("planes-noring", bench.PlanesWorkload), ("planes", bench.PlanesWorkload),
-        ("planes-3wg", bench.PlanesWorkload), ("planes-3wg-nostream", bench.PlanesWorkload)]
-RING = {"planes-noring": 0, "planes": 1, "planes-3wg": 2, "planes-3wg-nostream": 2}
+fams = [("nchw-strips", bench.CoreWorkload), ("planes-noring", bench.PlanesWorkload), ("planes-3wg-nostream", bench.PlanesWorkload),
+        ("planes-3wg-nooverlap", bench.PlanesWorkload), ("planes-3wg-overlap1", bench.PlanesWorkload),
+        ("planes-3wg", bench.PlanesWorkload)]
+RING = {"planes-noring": 0, "planes-3wg": 2, "planes-3wg-nostream": 2, "planes-3wg-nooverlap": 2, "planes-3wg-overlap1": 2}
+
+
+def set_options(name):
+    lib.ccnet_cca_set_option(b"planes_ring", RING.get(name, 2))
+    lib.ccnet_cca_set_option(b"planes_stream", 0 if name.endswith("nostream") else 1)
+    lib.ccnet_cca_set_option(b"planes_overlap", 0 if name.endswith("nooverlap") or name.endswith("noring") else 1 if name.endswith("overlap1") else -1)
+
+
 res = {}
 for name, cls in fams:
-    lib.ccnet_cca_set_option(b"planes_ring", RING.get(name, 1))
-    lib.ccnet_cca_set_option(b"planes_stream", 0 if name.endswith("nostream") else 1)
+    set_options(name)
     wl = cls(lib, B, C, H, W, dev, 1234)
     for _ in range(5):
         wl.step()
@@ -38,16 +46,14 @@ for name, cls in fams:
         print(f"     split of v (producer side, outside the step): {bench.time_region(wl.split, 20) * 1e3:.1f} us")
     res[name] = wl
 b = res["planes-noring"]
-lib.ccnet_cca_set_option(b"planes_ring", 0)
+set_options("planes-noring")
 b.step()
 for fam, ring in RING.items():
     a = res[fam]
-    lib.ccnet_cca_set_option(b"planes_ring", ring)
-    lib.ccnet_cca_set_option(b"planes_stream", 0 if fam.endswith("nostream") else 1)
+    set_options(fam)
     a.step()
     torch.cuda.synchronize()
     for nm in ("y", "dqkv", "A", "dgamma"):
         d = (getattr(a, nm) - getattr(b, nm)).abs().max().item()
         print(f"{fam} vs planes-noring: max |d {nm}| = {d:.3e}   (max |ref| {getattr(b, nm).abs().max().item():.3e})")
-lib.ccnet_cca_set_option(b"planes_ring", 2)
-lib.ccnet_cca_set_option(b"planes_stream", 1)
+set_options("planes-3wg")      # the shipped defaults
