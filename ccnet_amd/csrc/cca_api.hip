@@ -984,8 +984,8 @@ int ccnet_cca_backward_pm_f32(const float *dy, const float *q, const float *k, c
 extern "C++" {
 namespace {
 using cca::bf16p_t;
-int check_planes_view(const char *what, long bs, int ps, int C, int H, int W) {
-    if (C % 8 || ps < 2 * C || ps % 8 || bs < (long)(H * W - 1) * ps + 2 * C || bs % 8) return fail(CCNET_E_BADSHAPE, what);
+int check_planes_view(const char *what, long bs, int ps, int C, int H, int W, int nplanes = 2) {
+    if (C % 8 || ps < nplanes * C || ps % 8 || bs < (long)(H * W - 1) * ps + nplanes * C || bs % 8) return fail(CCNET_E_BADSHAPE, what);
     if ((double)H * W * ps >= 1073741824.0) return fail(CCNET_E_BADSHAPE, what);            /* 2-byte elements, 31-bit offsets */
     return 0;
 }
@@ -994,6 +994,14 @@ int check_planes_problem(const char *what, int B, int C, int Cq, int H, int W) {
     if (int e = check_shape(B, Cq, H, W)) return e;
     if ((H > W ? H : W) > 132 || C % 8 || Cq % 4) return fail(CCNET_E_BADSHAPE, what);
     return 0;
+}
+// CCNET_PLANES_* -> where the halves go inside a pixel's row (false: unknown layout)
+bool plane_layout(int layout, int C, cca::PlaneLayout *pl) {
+    if (layout == CCNET_PLANES_HL) *pl = cca::PlaneLayout{C, 0, 2 * C};
+    else if (layout == CCNET_PLANES_HLH) *pl = cca::PlaneLayout{C, 2 * C, 3 * C};
+    else if (layout == CCNET_PLANES_HHL) *pl = cca::PlaneLayout{2 * C, C, 3 * C};
+    else return false;
+    return true;
 }
 // column strips -> fp32 partial, row strips add it (+ the NCHW residual) and write the output
 // P = 100: column passes on the ring kernel (two slots, three workgroups per CU by default), row passes on gmap_kernel with two
@@ -1098,27 +1106,31 @@ size_t ccnet_cca_planes_workspace_bytes(int B, int C, int Cq, int H, int W, int 
 }
 
 int ccnet_cca_split_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, int src_ps,
-                               long dst_bs, int dst_ps, ccnet_stream_t stream) {
+                               long dst_bs, int dst_ps, int layout, ccnet_stream_t stream) {
     if (int e = check_shape(B, C, H, W)) return e;
     if (!src || !dst) return fail(CCNET_E_NULLPTR, "split_planes: null tensor");
+    cca::PlaneLayout pl;
+    if (!plane_layout(layout, C, &pl)) return fail(CCNET_E_BADFLAGS, "split_planes: layout is one of CCNET_PLANES_*");
     if (int e = check_pm_view<float>("split_planes: source view (fp32 pixel-major)", src_bs, src_ps, C, H, W)) return e;
-    if (int e = check_planes_view("split_planes: destination view (C % 8, pixel stride >= 2 C)", dst_bs, dst_ps, C, H, W)) return e;
+    if (int e = check_planes_view("split_planes: destination view (C % 8, pixel stride >= planes * C)", dst_bs, dst_ps, C, H, W, pl.width / C)) return e;
     const int hw = H * W;
     const long items = (long)hw * (C / 8);
     const unsigned gx = (unsigned)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
-    CCA_LAUNCH(cca::pm_split_kernel, dim3(gx, (unsigned)B), dim3(256), stream, src, (bf16p_t *)dst, C, hw, src_bs, src_ps, dst_bs, dst_ps);
+    CCA_LAUNCH(cca::pm_split_kernel, dim3(gx, (unsigned)B), dim3(256), stream, src, (bf16p_t *)dst, C, hw, src_bs, src_ps, dst_bs, dst_ps, pl);
     return launch_status("split_planes");
 }
 
 int ccnet_cca_nchw_to_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, long dst_bs, int dst_ps,
-                                 ccnet_stream_t stream) {
+                                 int layout, ccnet_stream_t stream) {
     if (int e = check_shape(B, C, H, W)) return e;
     if (!src || !dst) return fail(CCNET_E_NULLPTR, "nchw_to_planes: null tensor");
+    cca::PlaneLayout pl;
+    if (!plane_layout(layout, C, &pl)) return fail(CCNET_E_BADFLAGS, "nchw_to_planes: layout is one of CCNET_PLANES_*");
     if (src_bs < (long)C * H * W) return fail(CCNET_E_BADSHAPE, "nchw_to_planes: source batch stride");
-    if (int e = check_planes_view("nchw_to_planes: destination view (C % 8, pixel stride >= 2 C)", dst_bs, dst_ps, C, H, W)) return e;
+    if (int e = check_planes_view("nchw_to_planes: destination view (C % 8, pixel stride >= planes * C)", dst_bs, dst_ps, C, H, W, pl.width / C)) return e;
     const int hw = H * W;
     CCA_LAUNCH(cca::nchw_to_planes_kernel, dim3((unsigned)(B * ((hw + 63) / 64)), (unsigned)((C + 63) / 64)), dim3(256), stream,
-               src, (bf16p_t *)dst, C, hw, src_bs, dst_bs, dst_ps);
+               src, (bf16p_t *)dst, C, hw, src_bs, dst_bs, dst_ps, pl);
     return launch_status("nchw_to_planes");
 }
 
@@ -1165,7 +1177,7 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
     uint16_t *dy_pl = reinterpret_cast<uint16_t *>(static_cast<char *>(workspace) + base);
     const long dbs = (long)H * W * 2 * C;
     // dy (NCHW, the module's gradient) -> planes, once: it is a contraction operand of four launches
-    if (int e = ccnet_cca_nchw_to_planes_f32(dy, dy_pl, B, C, H, W, (long)C * H * W, dbs, 2 * C, stream)) return e;
+    if (int e = ccnet_cca_nchw_to_planes_f32(dy, dy_pl, B, C, H, W, (long)C * H * W, dbs, 2 * C, CCNET_PLANES_HL, stream)) return e;
     const bf16p_t *dyp = (const bf16p_t *)dy_pl, *vp = (const bf16p_t *)v_planes;
     // dv (two C-sized, HBM-bound passes) is independent of the chain dA -> dE -> dq | dk: it runs on the library's side stream
     // next to that chain and joins before this function returns

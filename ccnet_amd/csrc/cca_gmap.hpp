@@ -715,37 +715,41 @@ __global__ __launch_bounds__(256) void nchw_to_pm_kernel(const float *__restrict
 }
 
 // ---- producers of SPLIT-PLANE tensors (see bf16p_t above) ----
-__device__ __forceinline__ void planes_store8(const FBuf &Db, int off_bytes, int lo_bytes, const float (&x)[8], bool ok) {
+// PlaneLayout: where the halves of a pixel's C values go inside its dps-element row -- hi at 0, lo at ``lo`` elements, and
+// (three-plane rows for K-concatenated split-bf16 GEMMs, include/ccnet_cca.h CCNET_PLANES_*) a second copy of hi at ``hi2``
+struct PlaneLayout { int lo, hi2, width; };
+__device__ __forceinline__ void planes_store8(const FBuf &Db, int off_bytes, const PlaneLayout &pl, const float (&x)[8], bool ok) {
     const BfSplit sp = bf16_split8(x);
     fbuf_store_x4(Db, __builtin_bit_cast(f32x4, sp.hi), ok ? off_bytes : kOobOffset, 0);
-    fbuf_store_x4(Db, __builtin_bit_cast(f32x4, sp.lo), ok ? off_bytes + lo_bytes : kOobOffset, 0);
+    fbuf_store_x4(Db, __builtin_bit_cast(f32x4, sp.lo), ok ? off_bytes + 2 * pl.lo : kOobOffset, 0);
+    if (pl.hi2 > 0) fbuf_store_x4(Db, __builtin_bit_cast(f32x4, sp.hi), ok ? off_bytes + 2 * pl.hi2 : kOobOffset, 0);
 }
 
 // fp32 pixel-major (B, H*W, sps) channels [0, C) -> planes (B, H*W, 2, C) (pixel stride dps >= 2 C elements): the value
 // slice of the packed projection, split ONCE by its producer.  One thread = 8 channels of a pixel (32 B in, 16 + 16 B out).
 __global__ __launch_bounds__(256) void pm_split_kernel(const float *__restrict__ src, bf16p_t *__restrict__ dst, int C, int HW,
-                                                       long sbs, int sps, long dbs, int dps) {
+                                                       long sbs, int sps, long dbs, int dps, PlaneLayout pl) {
     const int cpp = C >> 3;                                   // 8-channel chunks per pixel
     const int b = blockIdx.y;
     const FBuf Sb = make_fbuf(src + (size_t)b * sbs, ((size_t)(HW - 1) * sps + C) * sizeof(float));
-    const FBuf Db = make_fbuf(reinterpret_cast<const float *>(dst + (size_t)b * dbs), ((size_t)(HW - 1) * dps + 2 * C) * 2);
+    const FBuf Db = make_fbuf(reinterpret_cast<const float *>(dst + (size_t)b * dbs), ((size_t)(HW - 1) * dps + pl.width) * 2);
     for (int e = blockIdx.x * 256 + threadIdx.x; e < HW * cpp; e += gridDim.x * 256) {
         const int px = e / cpp, c = 8 * (e - px * cpp);
         const f32x4 u = fbuf_load_x4(Sb, (px * sps + c) * 4, 0), v = fbuf_load_x4(Sb, (px * sps + c + 4) * 4, 0);
         const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
-        planes_store8(Db, (px * dps + c) * 2, C * 2, x, true);
+        planes_store8(Db, (px * dps + c) * 2, pl, x, true);
     }
 }
 
 // NCHW fp32 -> planes (the gradient dy of an NCHW module output): 64 pixels x 64 channels per workgroup through a padded
 // LDS tile; reads runs of 64 pixels per channel, writes 128-byte plane rows.
 __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float *__restrict__ src, bf16p_t *__restrict__ dst, int C, int HW,
-                                                             long sbs, long dbs, int dps) {
+                                                             long sbs, long dbs, int dps, PlaneLayout pl) {
     __shared__ float tile[64 * 65];
     const int ntp = (HW + 63) / 64;
     const int b = blockIdx.x / ntp, p0 = (blockIdx.x - b * ntp) * 64, c0 = blockIdx.y * 64;
     const FBuf Sb = make_fbuf(src + (size_t)b * sbs, (size_t)C * HW * sizeof(float));
-    const FBuf Db = make_fbuf(reinterpret_cast<const float *>(dst + (size_t)b * dbs), ((size_t)(HW - 1) * dps + 2 * C) * 2);
+    const FBuf Db = make_fbuf(reinterpret_cast<const float *>(dst + (size_t)b * dbs), ((size_t)(HW - 1) * dps + pl.width) * 2);
     const int tid = threadIdx.x;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -762,7 +766,7 @@ __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float *__rest
         float x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = tile[(c8 + e) * 65 + px];
-        planes_store8(Db, ((p0 + px) * dps + c0 + c8) * 2, C * 2, x, p0 + px < HW && c0 + c8 < C);
+        planes_store8(Db, ((p0 + px) * dps + c0 + c8) * 2, pl, x, p0 + px < HW && c0 + c8 < C);
     }
 }
 

@@ -500,16 +500,39 @@ class CrissCrossModuleFunction(torch.autograd.Function):
                 dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma), None)
 
 
-def split_planes(t: torch.Tensor, c0: int, C: int) -> torch.Tensor:
-    """Channels [c0, c0 + C) of the fp32 pixel-major tensor ``t`` (B, H, W, ps) as SPLIT PLANES (B, H, W, 2, C) int16:
-    bf16 hi | lo halves of every value (include/ccnet_cca.h, "split-plane path"), produced once for all their consumers."""
+PLANES_HL, PLANES_HLH, PLANES_HHL = 2, 3, 4          # include/ccnet_cca.h CCNET_PLANES_*
+
+
+def split_planes(t: torch.Tensor, c0: int, C: int, layout: int = PLANES_HL, dtype=torch.int16) -> torch.Tensor:
+    """Channels [c0, c0 + C) of the fp32 pixel-major tensor ``t`` (B, H, W, ps) as SPLIT PLANES (B, H, W, n, C):
+    bf16 hi | lo halves of every value (include/ccnet_cca.h, "split-plane path"), produced once for all their consumers
+    (``layout`` HLH / HHL: the three-plane rows of a K-concatenated split-bf16 GEMM; ``dtype`` bfloat16 for those)."""
     B, H, W, ps = t.shape
-    out = torch.empty((B, H, W, 2, C), device=t.device, dtype=torch.int16)
+    n = 2 if layout == PLANES_HL else 3
+    out = torch.empty((B, H, W, n, C), device=t.device, dtype=dtype)
     lib = _lib.get_lib()
     with torch.cuda.device(t.device):
         lib.check(lib.ccnet_cca_split_planes_f32(t.data_ptr() + 4 * c0, out.data_ptr(), B, C, H, W, t.stride(0), t.stride(2),
-                                                 H * W * 2 * C, 2 * C, _stream()), "split_planes")
+                                                 H * W * n * C, n * C, layout, _stream()), "split_planes")
     return out
+
+
+def nchw_to_planes(x: torch.Tensor, layout: int = PLANES_HL, dtype=torch.int16) -> torch.Tensor:
+    """fp32 NCHW (B, C, H, W) -> planes (B, H, W, n, C) (transposed and split in one pass, csrc/cca_gmap.hpp)."""
+    B, C, H, W = x.shape
+    n = 2 if layout == PLANES_HL else 3
+    out = torch.empty((B, H, W, n, C), device=x.device, dtype=dtype)
+    lib = _lib.get_lib()
+    with torch.cuda.device(x.device):
+        lib.check(lib.ccnet_cca_nchw_to_planes_f32(x.data_ptr(), out.data_ptr(), B, C, H, W, C * H * W, H * W * n * C, n * C,
+                                                   layout, _stream()), "nchw_to_planes")
+    return out
+
+
+def _split_weight(w: torch.Tensor):
+    """fp32 (N, K) -> bf16 halves (hi, lo) with w = hi + lo + O(2^-17 |w|)"""
+    hi = w.to(torch.bfloat16)
+    return hi, (w - hi.float()).to(torch.bfloat16)
 
 
 def planes_cover(B, C, Cq, H, W):
@@ -523,18 +546,31 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
     slice is split ONCE into bf16 hi | lo planes (same bytes), which is what the aggregation (functions.py:42-47) and the
     dA contraction of its adjoint read -- three exact bf16 products per term, no per-fragment split in any inner loop;
     dy is split once inside the backward; q, k stay fp32 (exact energies).  ``dx = dy + W^T dqkv^T`` is one GEMM with
-    beta = 1 writing NCHW."""
+    beta = 1 writing NCHW.
+
+    ``split_gemm``: the three projection GEMMs (functions.py:29-35 and their adjoints) run split-bf16 x3 as well -- ONE stock
+    bf16 -> fp32 GEMM each on K-concatenated three-plane operands (x.w ~ xh.wh + xh.wl + xl.wh: rows [xh | xh | xl] of x
+    against [wh | wl | wh] of the stacked weight, K = 3C; the adjoints pair [dh | dl | dh] of dqkv with [wh | wh | wl] and,
+    row by row over 3 B HW rows, with x's planes for the weight gradient).  The planes are written by the library's
+    producers (one pass over x, one over dqkv); fp32 accumulation, relative error ~1e-5 (the lo x lo term is dropped)."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma):
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma, split_gemm=False):
         x, gamma = _dev_f32("x", x), _dev_f32("gamma", gamma)
         B, C, H, W = x.shape
         cq, hw = wq.shape[0], H * W
         ct = 2 * cq + C
         w = torch.cat([wq.reshape(cq, C), wk.reshape(cq, C), wv.reshape(C, C)], 0)          # (2Cq + C, C)
         b = torch.cat([bq, bk, bv], 0)
-        xm = x.view(B, C, hw)
-        qkv = torch.baddbmm(b.view(1, 1, -1), xm.transpose(1, 2), w.t().unsqueeze(0).expand(B, -1, -1))   # (B, HW, 2Cq + C)
+        x3 = None
+        if split_gemm:
+            x3 = nchw_to_planes(x, PLANES_HHL, torch.bfloat16)                              # (B, H, W, 3, C): xh | xh | xl
+            wh, wl = _split_weight(w)
+            qkv = torch.mm(x3.view(B * hw, 3 * C), torch.cat([wh, wl, wh], 1).t(), out_dtype=torch.float32)
+            qkv = qkv.add_(b).view(B, hw, ct)
+        else:
+            xm = x.view(B, C, hw)
+            qkv = torch.baddbmm(b.view(1, 1, -1), xm.transpose(1, 2), w.t().unsqueeze(0).expand(B, -1, -1))   # (B, HW, 2Cq + C)
         vpl = split_planes(qkv.view(B, H, W, ct), 2 * cq, C)
         qk = qkv                                  # q | k are read in place (channel slices of the packed projection)
         lib = _lib.get_lib()
@@ -546,7 +582,10 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
             lib.check(lib.ccnet_cca_forward_planes_f32(p, p + 4 * cq, vpl.data_ptr(), x.data_ptr(), gamma.data_ptr(),
                                                        y.data_ptr(), A.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps,
                                                        hw * 2 * C, 2 * C, wsp, wsn, _stream()), "cca_forward_planes")
-        ctx.save_for_backward(x, w, qk, vpl, A, gamma)
+        if x3 is not None:
+            ctx.save_for_backward(x, w, qk, vpl, A, gamma, x3)
+        else:
+            ctx.save_for_backward(x, w, qk, vpl, A, gamma)
         ctx.cq = cq
         return y
 
@@ -554,7 +593,8 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, dy):
         cq = ctx.cq
-        x, w, qk, vpl, A, gamma = ctx.saved_tensors
+        x, w, qk, vpl, A, gamma = ctx.saved_tensors[:6]
+        x3 = ctx.saved_tensors[6] if len(ctx.saved_tensors) > 6 else None
         dy = _dev_f32("grad_output", dy)
         B, C, H, W = x.shape
         hw, ct = H * W, 2 * cq + C
@@ -569,14 +609,23 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
                                                         gamma.data_ptr(), g, g + 4 * cq, g + 8 * cq, dgamma.data_ptr(),
                                                         scratch.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps, hw * 2 * C, 2 * C,
                                                         gbs, ct, gbs, ct, gbs, ct, wsp, wsn, _stream()), "cca_backward_planes")
-        xm = x.view(B, C, hw)
-        dqt = dqkv.transpose(1, 2)                                                            # (B, 2Cq + C, HW) view
-        dx = torch.baddbmm(dy.view(B, C, hw), w.t().unsqueeze(0).expand(B, -1, -1), dqt)      # dy + W^T dqkv^T  (NCHW)
-        dw = torch.bmm(dqt, xm.transpose(1, 2)).sum(0)                                        # (2Cq + C, C)
         db = dqkv.sum(dim=(0, 1))
+        if x3 is not None:
+            d3 = split_planes(dqkv.view(B, H, W, ct), 0, ct, PLANES_HLH, torch.bfloat16)      # (B, H, W, 3, ct): dh | dl | dh
+            wh, wl = _split_weight(w)
+            w3t = torch.cat([wh.t(), wh.t(), wl.t()], 1)                                      # (C, 3 ct)
+            dx = torch.bmm(w3t.unsqueeze(0).expand(B, -1, -1), d3.view(B, hw, 3 * ct).transpose(1, 2),
+                           out_dtype=torch.float32).add_(dy.view(B, C, hw))                   # dy + W^T dqkv^T  (NCHW)
+            # rows (dh, xh), (dl, xh), (dh, xl) of every pixel: the three products, contracted over 3 HW rows per image
+            dw = torch.bmm(d3.view(B, 3 * hw, ct).transpose(1, 2), x3.view(B, 3 * hw, C), out_dtype=torch.float32).sum(0)
+        else:
+            xm = x.view(B, C, hw)
+            dqt = dqkv.transpose(1, 2)                                                        # (B, 2Cq + C, HW) view
+            dx = torch.baddbmm(dy.view(B, C, hw), w.t().unsqueeze(0).expand(B, -1, -1), dqt)  # dy + W^T dqkv^T  (NCHW)
+            dw = torch.bmm(dqt, xm.transpose(1, 2)).sum(0)                                    # (2Cq + C, C)
         dwq, dwk, dwv = dw[:cq], dw[cq:2 * cq], dw[2 * cq:]
         return (dx.view(B, C, H, W), dwq.reshape(cq, C, 1, 1), db[:cq], dwk.reshape(cq, C, 1, 1), db[cq:2 * cq],
-                dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma))
+                dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma), None)
 
 
 def criss_cross_attention(q, k, v, x, gamma, recompute_attention=False):
@@ -618,6 +667,13 @@ class CrissCrossAttention(nn.Module):
     #: of one GEMM pixel-major, v and dy pre-split into bf16 hi | lo planes, x / y / dy NCHW).  Measured on MI355X, core
     #: fwd+bwd at (8,512,97,97): 0.83 ms vs 0.87 ms on the NCHW strips of the same box (profiles/r03d_family_compare.txt).
     split_planes = True
+    #: the split-plane node also runs its three projection GEMMs split-bf16 x3 (one bf16 -> fp32 GEMM each on three-plane
+    #: operands, fp32 accumulate, ~1e-5 relative): fwd 496 -> 278, dx 488 -> 265, dW 508 -> 325 us at (8,512,97,97)
+    #: (profiles/r03p_split_gemm_probe2.txt) for two extra producer passes.  False = fp32 GEMMs (torch's default fp32 path).
+    split_bf16_projections = True
+    #: ... from this many pixels per call on (module fwd+bwd at 512 channels, 97 x 97: B = 8 2.23 -> 1.92 ms, B = 4 1.21 -> 1.11,
+    #: B = 2 0.70 -> 0.75, B = 1 0.59 -> 0.74: below ~30k pixels the step is bound by host launches and the extra ops cost more)
+    split_bf16_min_pixels = 32768
     #: fp32 channels_last inputs run on the pixel-major family (x as (B, H, W, C) is then a free view: nothing is copied).
     pixel_major_for_channels_last = True
     #: bf16 inputs: strips <= 132 (C, C/8 divisible by 8) run on the pixel-major bf16 MFMA kernels; every other geometry is
@@ -682,7 +738,8 @@ class CrissCrossAttention(nn.Module):
             qkv = torch.nn.functional.linear(xp, self._stacked_weight().flatten(1), self._stacked_bias())
             return CrissCrossPMFunction.apply(qkv, xp, self.gamma, cq).permute(0, 3, 1, 2)
         if r == "f32-planes":
-            return CrissCrossPlanesModuleFunction.apply(x, *params, self.gamma)
+            split_gemm = self.split_bf16_projections and x.shape[0] * x.shape[2] * x.shape[3] >= self.split_bf16_min_pixels
+            return CrissCrossPlanesModuleFunction.apply(x, *params, self.gamma, split_gemm)
         if r == "f32-strips-node":
             return CrissCrossModuleFunction.apply(x, *params, self.gamma, self.recompute_attention)
         if r == "packed-strips":

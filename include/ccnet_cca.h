@@ -229,16 +229,24 @@ int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W);
  *
  * ccnet_cca_split_planes_f32: fp32 pixel-major view (e.g. the value slice of the packed projection x^T W^T) -> planes.
  * ccnet_cca_nchw_to_planes_f32: NCHW fp32 (B, C, H, W) -> planes.
+ *   ``layout`` of both: CCNET_PLANES_HL = hi | lo as above (what the core consumes).  The THREE-plane rows are operands of
+ *   K-concatenated split-bf16 GEMMs on a stock bf16 -> fp32 GEMM (the projections either side of the core, functions.py:29-35:
+ *   x.w ~ xh.wh + xh.wl + xl.wh is ONE GEMM with K = 3C on rows [xh | xh | xl] x [wh | wl | wh]): CCNET_PLANES_HLH =
+ *   hi | lo | hi, CCNET_PLANES_HHL = hi | hi | lo (pixel stride >= 3 C).  Paired row by row, HLH x HHL gives the three
+ *   products as well (the weight gradient as one GEMM over 3 B H W rows).
  * ccnet_cca_forward_planes_f32 / _backward_planes_f32: functions.py:38-49 and its autograd with q, k fp32 pixel-major
  *   views (exact fp32 energies), v as planes, the module's x / y / dy NCHW fp32, dq | dk | dv fp32 pixel-major views,
  *   A / scratch (B,H,W,H+W) fp32 as everywhere.  Workspace: ccnet_cca_planes_workspace_bytes (backward: holds the fp32
  *   column partial and dy as planes).  Arithmetic: energies exact fp32; every other contraction split-bf16 x3 with fp32
  *   accumulation (the lo x lo term, 2^-18 relative, is dropped) -- the CCNET_PRECISION_* knob does not apply here. */
 size_t ccnet_cca_planes_workspace_bytes(int B, int C, int Cq, int H, int W, int backward);
+#define CCNET_PLANES_HL 2
+#define CCNET_PLANES_HLH 3
+#define CCNET_PLANES_HHL 4
 int ccnet_cca_split_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, int src_ps,
-                               long dst_bs, int dst_ps, ccnet_stream_t stream);
+                               long dst_bs, int dst_ps, int layout, ccnet_stream_t stream);
 int ccnet_cca_nchw_to_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, long dst_bs,
-                                 int dst_ps, ccnet_stream_t stream);
+                                 int dst_ps, int layout, ccnet_stream_t stream);
 int ccnet_cca_forward_planes_f32(const float *q, const float *k, const uint16_t *v_planes, const float *x, const float *gamma,
                                  float *y, float *A, int B, int C, int Cq, int H, int W,
                                  long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,

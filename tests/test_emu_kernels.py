@@ -576,6 +576,14 @@ def test_split_plane_producers_are_exact_hi_lo_splits(ops):
     assert np.array_equal(got2, want)
     err = np.abs(_bf16_to_f32(want[..., 0, :]).astype(np.float64) + _bf16_to_f32(want[..., 1, :]) - _pm(x))
     assert float((err / np.maximum(np.abs(_pm(x)), 1e-30)).max()) < 2.0 ** -16
+    # three-plane rows (operands of the K-concatenated split-bf16 GEMMs): hi | lo | hi and hi | hi | lo
+    h, l = _pm(hi), _pm(lo)
+    for layout, order in ((3, (h, l, h)), (4, (h, h, l))):
+        want3 = np.stack(order, axis=3)
+        assert np.array_equal(ops.nchw_to_planes(x, layout), want3)
+        assert np.array_equal(ops.split_planes(wide, C, c0=16, layout=layout), want3)
+    with pytest.raises(RuntimeError):
+        ops.split_planes(wide, C, c0=16, layout=5)
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 96, 17, 20), (1, 64, 9, 1), (1, 160, 33, 18), (1, 64, 2, 99), (1, 64, 100, 3),

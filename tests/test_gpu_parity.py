@@ -472,21 +472,26 @@ def test_split_plane_module_node_matches_the_oracle_and_the_other_nodes(lib, dev
     dy = torch.randn(B, C, H, W, device=dev)
     assert m.route(x) == "f32-planes"
     outs = {}
-    for name, fn, extra in (("planes", CrissCrossPlanesModuleFunction, ()), ("strips", CrissCrossModuleFunction, (False,))):
+    for name, fn, extra in (("planes", CrissCrossPlanesModuleFunction, (False,)), ("planes+split-gemm", CrissCrossPlanesModuleFunction, (True,)),
+                            ("strips", CrissCrossModuleFunction, (False,))):
         m.zero_grad(set_to_none=True)
         xi = x.clone().requires_grad_(True)
         y = fn.apply(xi, m.query_conv.weight, m.query_conv.bias, m.key_conv.weight, m.key_conv.bias,
                      m.value_conv.weight, m.value_conv.bias, m.gamma, *extra)
         y.backward(dy)
         outs[name] = (y.detach(), xi.grad, {n: p.grad.clone() for n, p in m.named_parameters()})
-    a, b = outs["planes"], outs["strips"]
-    rel = {n: err(g, b[2][n]) / max(1.0, float(g.abs().max())) for n, g in a[2].items()}
-    print("split-plane node vs NCHW-strip node", shape, "y", f"{err(a[0], b[0]):.1e}", "dx",
-          f"{err(a[1], b[1]) / max(1.0, float(b[1].abs().max())):.1e}", {n: f"{e:.1e}" for n, e in rel.items()})
-    assert a[0].is_contiguous() and err(a[0], b[0]) < 2e-4
-    assert err(a[1], b[1]) < 5e-4 * max(1.0, float(b[1].abs().max()))
-    for n, e in rel.items():
-        assert e < 3e-3, n
+    b = outs["strips"]
+    # the node with fp32 projection GEMMs, and the module's default: split-bf16 x3 projections as well (same bars)
+    for variant in ("planes", "planes+split-gemm"):
+        a = outs[variant]
+        rel = {n: err(g, b[2][n]) / max(1.0, float(g.abs().max())) for n, g in a[2].items()}
+        print(f"split-plane node ({variant}) vs NCHW-strip node", shape, "y", f"{err(a[0], b[0]):.1e}", "dx",
+              f"{err(a[1], b[1]) / max(1.0, float(b[1].abs().max())):.1e}", {n: f"{e:.1e}" for n, e in rel.items()})
+        assert a[0].is_contiguous() and err(a[0], b[0]) < 2e-4
+        assert err(a[1], b[1]) < 5e-4 * max(1.0, float(b[1].abs().max()))
+        for n, e in rel.items():
+            assert e < 3e-3, n
+    assert m.split_bf16_projections                                          # (what m(x) runs)
     with torch.no_grad():
         f = lambda t: t.detach().float().cpu()                              # noqa: E731
         qo, ko, vo = (f(c(x)) for c in (m.query_conv, m.key_conv, m.value_conv))

@@ -1,5 +1,5 @@
 """module fwd+bwd (projections + core + autograd) at several batch sizes, one autograd node each, NCHW fp32 tensors: NCHW strip
-family vs split-plane family (the default route), and the pixel-major family on channels_last tensors"""
+family vs split-plane family with fp32 and with split-bf16 projection GEMMs (the default route), and the pixel-major family on channels_last tensors"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,10 +9,10 @@ dev = torch.device("cuda:0")
 C, H, W = 512, 97, 97
 for B in (1, 2, 4, 8):
     row, ys = [], []
-    for planes, cl in ((False, False), (True, False), (False, True)):
+    for planes, cl, sg in ((False, False, False), (True, False, False), (False, True, False), (True, False, True)):
         torch.manual_seed(0)
         m = CrissCrossAttention(C).to(dev)
-        m.split_planes = planes
+        m.split_planes, m.split_bf16_projections = planes, sg
         with torch.no_grad():
             m.gamma.fill_(0.5)
         x = torch.randn(B, C, H, W, device=dev)
@@ -28,6 +28,8 @@ for B in (1, 2, 4, 8):
         ys.append((y.detach().clone(), x.grad.clone(), m.value_conv.weight.grad.clone()))
         row.append(bench.time_region(one, 20))
     d = [float((a - b).abs().max()) for a, b in zip(ys[0], ys[1])]
-    print(f"B={B}: module fwd+bwd  NCHW-strip node {row[0]:.3f} ms | split-plane node (default) {row[1]:.3f} ms | pixel-major "
-          f"family, channels_last tensors {row[2]:.3f} ms   (max |diff| strip vs split-plane: y {d[0]:.1e} dx {d[1]:.1e} "
-          f"dWv {d[2]:.1e})", flush=True)
+    d3 = [float((a - b).abs().max()) for a, b in zip(ys[0], ys[3])]
+    print(f"B={B}: module fwd+bwd  NCHW-strip node {row[0]:.3f} ms | split-plane node, fp32 GEMMs {row[1]:.3f} ms | split-plane node + "
+          f"split-bf16 GEMMs (default) {row[3]:.3f} ms | pixel-major family, channels_last tensors {row[2]:.3f} ms   (max |diff| vs "
+          f"strip node: fp32 GEMMs y {d[0]:.1e} dx {d[1]:.1e} dWv {d[2]:.1e}; split GEMMs y {d3[0]:.1e} dx {d3[1]:.1e} dWv {d3[2]:.1e})",
+          flush=True)

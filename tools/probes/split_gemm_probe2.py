@@ -40,6 +40,18 @@ for name, fn in (("mm + bias add", lambda: torch.mm(X3.view(B * hw, 3 * C), W3.t
     except Exception as e:
         print(f"fwd {name} failed: {str(e)[:200]}")
 
+# two GEMMs on the two-plane layout the library's producers already emit ([xh | xl], 2C per pixel): K = 2C, then K = C with beta = 1
+X2 = torch.cat([xh, xl], dim=2).contiguous().view(B * hw, 2 * C)
+W2 = torch.cat([wh, wh], dim=1).contiguous()
+def two_gemms():
+    g1 = torch.addmm(bias, X2, W2.t(), out_dtype=torch.float32)
+    return torch.addmm(g1, X2[:, :C], wl.t(), out_dtype=torch.float32)
+try:
+    y = two_gemms().view(B, hw, ct)
+    print(f"fwd split-bf16 two GEMMs on [xh|xl]: us {T(two_gemms)}  max |d| vs fp32 {float((y.double() - ref).abs().max()):.2e}")
+except Exception as e:
+    print(f"fwd two GEMMs failed: {str(e)[:200]}")
+
 # ---- backward dx (B, C, hw) = dy + W^T dqkv^T
 g32 = lambda: torch.baddbmm(dy, w.t().unsqueeze(0).expand(B, -1, -1), dq.transpose(1, 2))
 print("dx fp32 baddbmm us:", T(g32))
@@ -83,3 +95,19 @@ for name, fn in cands.items():
     except Exception as e:
         print(f"dW {name} failed: {str(e)[:200]}")
 print("splits: x->planes3 via torch us:", T(lambda: torch.cat(list(split(xp)) + [xp.bfloat16()], dim=2)), " dq->D3 via torch us:", T(lambda: torch.cat(list(split(dq)) + [dq.bfloat16()], dim=2)))
+
+# ---- dW as ONE GEMM over 3M rows: X3' = [xh | xh | xl] and D3 = [dh | dl | dh] per pixel, viewed as (3M, C) / (3M, ct) row lists:
+# row pairs (dh, xh), (dl, xh), (dh, xl) -- the three products of the split, K = 3 B HW
+X3b = torch.cat([xh, xh, xl], dim=2).contiguous().view(3 * B * hw, C)
+D3r = D3.view(3 * B * hw, ct)
+for name, fn in (("mm(D3r^T, X3b) K = 3M", lambda: torch.mm(D3r.t(), X3b, out_dtype=torch.float32)),
+                 ("per image bmm + sum", lambda: torch.bmm(D3.view(B, 3 * hw, ct).transpose(1, 2), X3b.view(B, 3 * hw, C), out_dtype=torch.float32).sum(0)),
+                 ("(mm(X3b^T, D3r))^T", lambda: torch.mm(X3b.t(), D3r, out_dtype=torch.float32).t())):
+    try:
+        r = fn()
+        print(f"dW split-bf16 {name}: us {T(fn)}  max |d| {float((r.double() - refdw).abs().max()):.2e} (max |ref| {float(refdw.abs().max()):.1f})")
+    except Exception as e:
+        print(f"dW {name} failed: {str(e)[:200]}")
+W3b = torch.cat([wh, wl, wh], dim=1).contiguous()
+fnb = lambda: torch.mm(X3b.view(B * hw, 3 * C), W3b.t(), out_dtype=torch.float32).add_(bias)
+print(f"fwd split-bf16 on [xh|xh|xl] x [wh|wl|wh]: us {T(fnb)}  max |d| vs fp32 {float((fnb().view(B, hw, ct).double() - ref).abs().max()):.2e}")
