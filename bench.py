@@ -435,9 +435,12 @@ def capture_step_graph(step_fn):
 
 
 def launch_accounting(lib, wl, graph, steps=20):
-    """Where a step's wall time goes: the same step timed eagerly and as a hipGraph replay, and the sum of
-    its launches' OWN durations (HIP-event pair around every launch inside eager steps, ccnet_cca_profile_*) -- the
-    difference is GPU idle time between dependent launches (dispatch, host), not kernel time."""
+    """Where a step's wall time goes: the step timed eagerly and as a hipGraph replay with the shipped
+    options, and -- with every launch on ONE stream ("planes_overlap" 0: the backward's dv passes otherwise run on the library's
+    side stream next to dA / softmax-backward / dq | dk, and concurrent launches stretch each other) -- the step again and the
+    sum of its launches' OWN durations (HIP-event pair around every launch, ccnet_cca_profile_*).  single-stream step minus
+    that sum = GPU idle time between dependent launches (dispatch, host); single-stream step minus the shipped step = what
+    the overlap buys."""
     out = {}
     for _ in range(3):
         wl.step()
@@ -447,15 +450,21 @@ def launch_accounting(lib, wl, graph, steps=20):
         out["graph_ms_per_step"] = round(time_region(graph.replay, steps), 4)
     torch.cuda.synchronize()
     nrep = 5
-    rec = lib.profile_launches(lambda: [wl.step() for _ in range(nrep)])
+    prev = lib.ccnet_cca_set_option(b"planes_overlap", 0)
+    try:
+        for _ in range(3):
+            wl.step()
+        out["single_stream_eager_ms_per_step"] = round(time_region(wl.step, steps), 4)
+        rec = lib.profile_launches(lambda: [wl.step() for _ in range(nrep)])
+    finally:
+        lib.ccnet_cca_set_option(b"planes_overlap", prev)
     n = len(rec) // nrep
     ksum = sum(ms for _, ms in rec) / nrep
     out["launches_per_step"] = n
     out["gpu_kernel_sum_ms"] = round(ksum, 4)
-    out["idle_ms"] = {"eager": round(out["eager_ms_per_step"] - ksum, 4)}
-    if graph is not None:
-        out["idle_ms"]["graph"] = round(out["graph_ms_per_step"] - ksum, 4)
-    # launch i of a step, averaged over the profiled steps, in issue order
+    out["idle_ms"] = {"single_stream_eager": round(out["single_stream_eager_ms_per_step"] - ksum, 4)}
+    out["overlap_gain_ms"] = round(out["single_stream_eager_ms_per_step"] - out["eager_ms_per_step"], 4)
+    # launch i of a step, averaged over the profiled steps, in issue order (single stream: each launch alone on the GPU)
     out["launch_ms"] = [[rec[i][0].replace("cca::", ""), round(sum(rec[r * n + i][1] for r in range(nrep)) / nrep, 4)]
                         for i in range(n)]
     return out
@@ -845,6 +854,10 @@ def main(argv=None, workload_factory=None):
     ap.add_argument("--launch", default="graph", choices=("graph", "eager"),
                     help="graph (default): the step's launches are captured once into a hipGraph and the timed region replays "
                          "it (the task's 'capture launch-bound inner loops in hipGraphs'); eager: two C-ABI calls per step")
+    ap.add_argument("--overlap", default="auto", choices=("auto", "0", "1", "2"),
+                    help="the library's 'planes_overlap' option: auto (default, what ships) = the dv passes of the backward run on "
+                         "the library's side stream; 0 = every launch on one stream (per-launch rocprof durations then match "
+                         "the bench line's launch_ms)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo = host-logic tests on CPU with an injected workload (the product has no CPU path)")
     ap.add_argument("--workload-factory", default=None,
@@ -891,6 +904,7 @@ def main(argv=None, workload_factory=None):
             sys.exit("bench.py: --backend gloo needs --workload-factory (tests); the product path is HIP-only")
         from ccnet_amd import _lib
         lib = _lib.get_lib()
+        lib.ccnet_cca_set_option(b"planes_overlap", -1 if args.overlap == "auto" else int(args.overlap))
         use_planes = (not bf16 and args.family == "planes" and max(H, W) <= 132 and C % 8 == 0)
         cls = PixelMajorBF16Workload if bf16 else PlanesWorkload if use_planes else CoreWorkload
         wl = cls(lib, B, C, H, W, device, shard_seed(1234, rank))
@@ -959,6 +973,8 @@ def main(argv=None, workload_factory=None):
                                   + (", + all-reduce of the 7 parameter gradients per step)" if grads is not None else ")"),
                    "impl": impl},
         "launch": launch_mode,
+        "overlap": ("library default: the backward's dv passes on a side stream (event fork / join inside the C call, captured "
+                    "into the same graph)" if args.overlap == "auto" else f"planes_overlap={args.overlap}"),
         "algorithmic_bytes_per_step_per_gpu": nbytes,
         "frac_of_hbm_roofline": round(value / world / HBM_PEAK_GBS, 4),
         "frac_of_hbm_copy_ceiling": round(value / world / HBM_COPY_GBS, 4),

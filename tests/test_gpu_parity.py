@@ -835,6 +835,36 @@ def test_pixel_major_cores_are_bit_identical_run_to_run(lib, dev):
             assert all(torch.equal(a, b) for a, b in zip((wl.y, wl.dqkv, wl.dgamma, wl.A), ref)), i
 
 
+def test_side_stream_overlap_is_result_neutral_and_captures_into_one_graph(lib, dev):
+    """"planes_overlap": the dv passes run on the library's side stream (event fork / join).  Every option must give the bits of
+    the single-stream order, eagerly and as a captured hipGraph replay (the side stream joins the capture and comes back before it
+    ends), on the split-plane fp32 step and on the bf16 pixel-major step."""
+    import bench
+    try:
+        for wl in (bench.PlanesWorkload(lib, 2, 256, 97, 61, dev, 21), bench.PixelMajorBF16Workload(lib, 2, 256, 129, 65, dev, 22)):
+            lib.ccnet_cca_set_option(b"planes_overlap", 0)
+            wl.step()
+            torch.cuda.synchronize()
+            ref = [t.clone() for t in (wl.y, wl.dqkv, wl.dgamma, wl.A)]
+            for ov in (1, 2, -1):
+                lib.ccnet_cca_set_option(b"planes_overlap", ov)
+                for t in (wl.y, wl.dqkv):
+                    t.zero_()
+                wl.step()
+                torch.cuda.synchronize()
+                assert all(torch.equal(a, b) for a, b in zip((wl.y, wl.dqkv, wl.dgamma, wl.A), ref)), ("eager", ov)
+                g = bench.capture_step_graph(wl.step)
+                for _ in range(3):
+                    for t in (wl.y, wl.dqkv):
+                        t.zero_()
+                    g.replay()
+                    torch.cuda.synchronize()
+                    assert all(torch.equal(a, b) for a, b in zip((wl.y, wl.dqkv, wl.dgamma, wl.A), ref)), ("graph", ov)
+                del g
+    finally:
+        lib.ccnet_cca_set_option(b"planes_overlap", -1)
+
+
 def _random_pm_shapes(n, longest, align, seed):
     rng = np.random.default_rng(seed)
     shapes = []

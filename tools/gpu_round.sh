@@ -21,10 +21,12 @@ echo "== bench"; timeout 900 python bench.py --gpus 1 --steps 50 --warmup 10 > "
 echo "== rocprofv3 kernel stats"
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python "$R/bench.py" --steps 20 --warmup 5 --no-extras > "$OUT/prof_bench.json" 2> "$OUT/prof.err"; echo "rocprof rc=$?"
+# the same command with every launch on one stream: the per-kernel durations the bench line's launch_ms / roofline.launches quote
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_single" -- python "$R/bench.py" --steps 20 --warmup 5 --no-extras --overlap 0 > "$OUT/prof_single_bench.json" 2> "$OUT/prof_single.err"; echo "rocprof (single stream) rc=$?"
 cd "$R"
-find "$OUT/prof" -name "*kernel_stats*.csv" | head -3
+find "$OUT/prof" "$OUT/prof_single" -name "*kernel_stats*.csv" | head -3
 F=$(find "$OUT/prof" -name "*kernel_stats*.csv" | head -1)
 [ -n "$F" ] && head -30 "$F"
 # keep the merged-back payload small: drop the raw per-dispatch trace if it is huge
-find "$OUT/prof" -name "*kernel_trace*.csv" -size +20M -delete
+find "$OUT/prof" "$OUT/prof_single" -name "*kernel_trace*.csv" -size +20M -delete
 echo "== done"

@@ -36,24 +36,41 @@ if not lens:
 n = max(set(lens), key=lens.count)
 steps = [rows[a:a + n] for a, b in zip(starts, starts[1:]) if b - a == n]
 print(f"{len(rows)} cca launches, {len(steps)} complete steps of {n} launches; showing the last {min(nsteps, len(steps))}")
+
+
+def busy(st):
+    """time at least one launch of the step is running (launches of the library's side stream overlap the main chain)"""
+    total, cur_s, cur_e = 0, None, None
+    for s, e, _ in st:                      # sorted by start
+        if cur_e is None or s > cur_e:
+            total += (cur_e - cur_s) if cur_e is not None else 0
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    return total + ((cur_e - cur_s) if cur_e is not None else 0)
+
+
 tot = []
 for si, st in enumerate(steps):
-    t0, t1 = st[0][0], st[-1][1]
-    ksum = sum(e - s for s, e, _ in st)
-    tot.append(((t1 - t0) / 1e3, ksum / 1e3))
+    t0, t1 = st[0][0], max(e for _, e, _ in st)
+    tot.append(((t1 - t0) / 1e3, sum(e - s for s, e, _ in st) / 1e3, busy(st) / 1e3))
 for st in steps[-nsteps:]:
     t0 = st[0][0]
     prev_end = None
-    print(f"--- step: span {(st[-1][1] - t0) / 1e3:8.1f} us   kernel sum {sum(e - s for s, e, _ in st) / 1e3:8.1f} us")
+    print(f"--- step: span {(max(e for _, e, _ in st) - t0) / 1e3:8.1f} us   busy (>= 1 launch running) {busy(st) / 1e3:8.1f} us   "
+          f"sum of durations {sum(e - s for s, e, _ in st) / 1e3:8.1f} us")
     for s, e, name in st:
+        # gap = idle since every earlier launch ended; "ovl" = it started while an earlier launch was still running
         gap = (s - prev_end) / 1e3 if prev_end is not None else 0.0
-        print(f"  +{(s - t0) / 1e3:8.1f} us  dur {(e - s) / 1e3:7.1f} us  gap {gap:6.1f} us  {name[:96]}")
-        prev_end = e
+        tag = f"gap {gap:6.1f} us" if gap >= 0 else f"ovl {-gap:6.1f} us"
+        print(f"  +{(s - t0) / 1e3:8.1f} us  dur {(e - s) / 1e3:7.1f} us  {tag}  {name[:96]}")
+        prev_end = e if prev_end is None else max(prev_end, e)
 spans = sorted(t[0] for t in tot)
 sums = sorted(t[1] for t in tot)
+idle = sorted(t[0] - t[2] for t in tot)
 mid = len(tot) // 2
-print(f"=== over {len(tot)} steps: median span {spans[mid]:.1f} us, median kernel sum {sums[mid]:.1f} us, "
-      f"median idle inside a step {spans[mid] - sums[mid]:.1f} us")
+print(f"=== over {len(tot)} steps: median span {spans[mid]:.1f} us, median sum of launch durations {sums[mid]:.1f} us (concurrent "
+      f"launches count twice), median idle inside a step (no launch running) {idle[mid]:.1f} us")
 # step-to-step period (includes the host's gap between steps)
 per = sorted((b[0][0] - a[0][0]) / 1e3 for a, b in zip(steps, steps[1:]))
 if per:
