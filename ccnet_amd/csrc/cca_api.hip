@@ -801,13 +801,13 @@ int launch_gmap_dual_pm(const float *dE, const FT *k, const FT *q, FT *dq, FT *d
     const long pbs = (long)H * W * Cq;
     float *pq = partial, *pk = partial + (size_t)B * pbs;
     const GmapPlan gc = gmap_plan(B * W, Cq), gr = gmap_plan(B * H, Cq);
-    const cca::GmapJob<FT, float> jc{q, nullptr, pk, qbs, pbs, qps, Cq};
-    CCA_LAUNCH((cca::gmap_kernel<P, false, false, false, FT, float, false, true>), dim3((unsigned)gc.grid, 2), dim3(cca::GS_THREADS),
+    const cca::GmapJob<FT, float> jc{q, nullptr, pk, qbs, pbs, qps, Cq, gc.grid};
+    CCA_LAUNCH((cca::gmap_kernel<P, false, false, false, FT, float, false, true>), dim3(cca::gmap_dual_grid(gc.grid)), dim3(cca::GS_THREADS),
                stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
                0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
     if (int e = launch_status("gmap_dual_pm(column)")) return e;
-    const cca::GmapJob<FT, FT> jr{q, pk, dk, qbs, dkbs, qps, dkps};
-    CCA_LAUNCH((cca::gmap_kernel<P, true, false, true, FT, FT, false, true>), dim3((unsigned)gr.grid, 2), dim3(cca::GS_THREADS),
+    const cca::GmapJob<FT, FT> jr{q, pk, dk, qbs, dkbs, qps, dkps, gr.grid};
+    CCA_LAUNCH((cca::gmap_kernel<P, true, false, true, FT, FT, false, true>), dim3(cca::gmap_dual_grid(gr.grid)), dim3(cca::GS_THREADS),
                stream, dE, k, (const float *)pq, (const FT *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
                0L, 0, dqbs, dqps, gr.n_whole, gr.split, jr);
     return launch_status("gmap_dual_pm(row)");
@@ -1084,13 +1084,13 @@ int gmap_dual_f32(const float *dE, const float *k, const float *q, float *dq, fl
     const long pbs = (long)H * W * Cq;
     float *pq = partial, *pk = partial + (size_t)B * pbs;
     const GmapPlan gc = gmap_plan(B * W, Cq, 1), gr = gmap_plan(B * H, Cq, 1);
-    const cca::GmapJob<float, float> jc{q, nullptr, pk, qbs, pbs, qps, Cq};
-    CCA_LAUNCH((cca::gmap_kernel<132, false, false, false, float, float, false, true, 1>), dim3((unsigned)gc.grid, 2), dim3(cca::GS_THREADS),
+    const cca::GmapJob<float, float> jc{q, nullptr, pk, qbs, pbs, qps, Cq, gc.grid};
+    CCA_LAUNCH((cca::gmap_kernel<132, false, false, false, float, float, false, true, 1>), dim3(cca::gmap_dual_grid(gc.grid)), dim3(cca::GS_THREADS),
                stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
                0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
     if (int e = launch_status("gmap_dual_f32(column, 132)")) return e;
-    const cca::GmapJob<float, float> jr{q, pk, dk, qbs, dkbs, qps, dkps};
-    CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, float, float, false, true, 1>), dim3((unsigned)gr.grid, 2), dim3(cca::GS_THREADS),
+    const cca::GmapJob<float, float> jr{q, pk, dk, qbs, dkbs, qps, dkps, gr.grid};
+    CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, float, float, false, true, 1>), dim3(cca::gmap_dual_grid(gr.grid)), dim3(cca::GS_THREADS),
                stream, dE, k, (const float *)pq, (const float *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
                0L, 0, dqbs, dqps, gr.n_whole, gr.split, jr);
     return launch_status("gmap_dual_f32(row, 132)");
