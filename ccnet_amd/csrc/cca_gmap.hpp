@@ -198,7 +198,11 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
         F = j1.F; addend = j1.addend; out = j1.out; fbs = j1.fbs; fps = j1.fps; obs = j1.obs; ops = j1.ops;
     }
     constexpr int NT = (P + 15) / 16, TPW = (NT + GS_WAVES - 1) / GS_WAVES, NKS = P / 32;
-    constexpr int FSZ = PL ? 2 * TSP : GTile<FT>::size(P), OSZ = GTile<float>::size(P);
+    // pixel-major output image: one pixel = 64 channels + 4 dwords of pad, so that the 16 lanes of a ds_write_b128 pass
+    // (16 consecutive positions, the same 4 channels) fall into 16 different bank quads (PMC: 45 % conflict cycles in the dv
+    // row pass with the 4-pixel pieces of the feature-tile geometry, whose pad moved the bank once per 4 pixels)
+    constexpr int OPX = GM_CG + 4;
+    constexpr int FSZ = PL ? 2 * TSP : GTile<FT>::size(P), OSZ = P * OPX;
     constexpr int NPF = PL ? 2 * t16_pieces(P) : GTile<FT>::pieces(P);
     constexpr int SPX = OBF ? 8 : 4;                                  // pixels per store instruction
     constexpr int NSI = NCHW ? 1 : ((P + SPX - 1) / SPX + GS_WAVES - 1) / GS_WAVES;   // store instructions per wave and group (max)
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                             for (int q = 0; q < 4; ++q)
                                 CCA_LDS_ST(oimg + oimg_nchw_idx<P>(16 * nt + 4 * lg + q, i), alpha * acc[a][n][q] + addp[a][nt][q]);
                         } else {
-                            lds_store_x4(oimg + (i >> 2) * GM_PP + (i & 3) * GM_CG + 16 * nt + 4 * lg, alpha * acc[a][n]);
+                            lds_store_x4(oimg + i * OPX + 16 * nt + 4 * lg, alpha * acc[a][n]);
                         }
                     }
                 }
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
         for (int k = 0; k < NSI; ++k) {
             if (wv + GS_WAVES * k < nsi_total) {                         // wave-uniform: exactly `nstore` instructions
                 const int i = st_pos(k), c = cg * GM_CG + st_c;
-                const float *s = oimg + (i >> 2) * GM_PP + (i & 3) * GM_CG + st_c;
+                const float *s = oimg + i * OPX + st_c;
                 if (i < L && c < C) {
                     f32x4 u = lds_load_x4(s);
                     if (ADD) u += add0[k];
