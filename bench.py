@@ -321,7 +321,7 @@ class PlanesWorkload:
         B, C, H, W = self.shape
         L, cq, ct = self.lib, C // 8, self.ct
         L.check(L.ccnet_cca_split_planes_f32(self.qkv.data_ptr() + 8 * cq, self.vpl.data_ptr(), B, C, H, W, H * W * ct, ct,
-                                             H * W * 2 * C, 2 * C, 2, self.stream()), "split_planes")
+                                             H * W * 2 * C, 2 * C, 2, None, self.stream()), "split_planes")
 
     def forward(self):
         B, C, H, W = self.shape

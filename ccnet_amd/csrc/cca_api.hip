@@ -1106,7 +1106,7 @@ size_t ccnet_cca_planes_workspace_bytes(int B, int C, int Cq, int H, int W, int 
 }
 
 int ccnet_cca_split_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, int src_ps,
-                               long dst_bs, int dst_ps, int layout, ccnet_stream_t stream) {
+                               long dst_bs, int dst_ps, int layout, const float *bias, ccnet_stream_t stream) {
     if (int e = check_shape(B, C, H, W)) return e;
     if (!src || !dst) return fail(CCNET_E_NULLPTR, "split_planes: null tensor");
     cca::PlaneLayout pl;
@@ -1116,7 +1116,7 @@ int ccnet_cca_split_planes_f32(const float *src, uint16_t *dst, int B, int C, in
     const int hw = H * W;
     const long items = (long)hw * (C / 8);
     const unsigned gx = (unsigned)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
-    CCA_LAUNCH(cca::pm_split_kernel, dim3(gx, (unsigned)B), dim3(256), stream, src, (bf16p_t *)dst, C, hw, src_bs, src_ps, dst_bs, dst_ps, pl);
+    CCA_LAUNCH(cca::pm_split_kernel, dim3(gx, (unsigned)B), dim3(256), stream, src, (bf16p_t *)dst, C, hw, src_bs, src_ps, dst_bs, dst_ps, pl, bias);
     return launch_status("split_planes");
 }
 

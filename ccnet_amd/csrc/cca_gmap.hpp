@@ -739,9 +739,11 @@ __device__ __forceinline__ void planes_store8(const FBuf &Db, int off_bytes, con
 }
 
 // fp32 pixel-major (B, H*W, sps) channels [0, C) -> planes (B, H*W, 2, C) (pixel stride dps >= 2 C elements): the value
-// slice of the packed projection, split ONCE by its producer.  One thread = 8 channels of a pixel (32 B in, 16 + 16 B out).
+// slice of the packed projection, split ONCE by its producer (+ an optional per-channel bias: the projection's, so that the
+// GEMM's output needs no pass of its own for it).  One thread = 8 channels of a pixel (32 B in, 16 + 16 B out).
 __global__ __launch_bounds__(256) void pm_split_kernel(const float *__restrict__ src, bf16p_t *__restrict__ dst, int C, int HW,
-                                                       long sbs, int sps, long dbs, int dps, PlaneLayout pl) {
+                                                       long sbs, int sps, long dbs, int dps, PlaneLayout pl,
+                                                       const float *__restrict__ bias) {
     const int cpp = C >> 3;                                   // 8-channel chunks per pixel
     const int b = blockIdx.y;
     const FBuf Sb = make_fbuf(src + (size_t)b * sbs, ((size_t)(HW - 1) * sps + C) * sizeof(float));
@@ -749,7 +751,11 @@ __global__ __launch_bounds__(256) void pm_split_kernel(const float *__restrict__
     for (int e = blockIdx.x * 256 + threadIdx.x; e < HW * cpp; e += gridDim.x * 256) {
         const int px = e / cpp, c = 8 * (e - px * cpp);
         const f32x4 u = fbuf_load_x4(Sb, (px * sps + c) * 4, 0), v = fbuf_load_x4(Sb, (px * sps + c + 4) * 4, 0);
-        const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+        float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+        if (bias) {                                           // (the projection's bias, added where its output is split)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] += bias[c + k];
+        }
         planes_store8(Db, (px * dps + c) * 2, pl, x, true);
     }
 }

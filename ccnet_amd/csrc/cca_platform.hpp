@@ -236,10 +236,16 @@ inline Dev *dev_state() {
     }
     return &v;
 }
+// The record + wait pair of a fork (of a join) is issued under one lock: host threads driving different streams of one device
+// share the side stream and its two events, and a record of thread B between thread A's record and wait would make A's side
+// work wait for the wrong point.  (Sharing costs such callers parallelism, never ordering: the side stream then waits for
+// both callers, and a join waits for all side work enqueued so far.)
+inline std::mutex &pair_lock() { static std::mutex mu; return mu; }
 // nullptr when the side stream cannot be had (the caller then stays on its own stream)
 inline hipStream_t fork(hipStream_t main) {
     Dev *v = dev_state();
     if (!v) return nullptr;
+    std::lock_guard<std::mutex> lock(pair_lock());
     if (hipEventRecord(v->fork, main) != hipSuccess || hipStreamWaitEvent(v->s, v->fork, 0) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
@@ -248,7 +254,9 @@ inline hipStream_t fork(hipStream_t main) {
 }
 inline bool join(hipStream_t main) {
     Dev *v = dev_state();
-    return v && hipEventRecord(v->join, v->s) == hipSuccess && hipStreamWaitEvent(main, v->join, 0) == hipSuccess;
+    if (!v) return false;
+    std::lock_guard<std::mutex> lock(pair_lock());
+    return hipEventRecord(v->join, v->s) == hipSuccess && hipStreamWaitEvent(main, v->join, 0) == hipSuccess;
 }
 }  // namespace cca_side
 

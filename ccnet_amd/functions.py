@@ -503,7 +503,7 @@ class CrissCrossModuleFunction(torch.autograd.Function):
 PLANES_HL, PLANES_HLH, PLANES_HHL = 2, 3, 4          # include/ccnet_cca.h CCNET_PLANES_*
 
 
-def split_planes(t: torch.Tensor, c0: int, C: int, layout: int = PLANES_HL, dtype=torch.int16) -> torch.Tensor:
+def split_planes(t: torch.Tensor, c0: int, C: int, layout: int = PLANES_HL, dtype=torch.int16, bias=None) -> torch.Tensor:
     """Channels [c0, c0 + C) of the fp32 pixel-major tensor ``t`` (B, H, W, ps) as SPLIT PLANES (B, H, W, n, C):
     bf16 hi | lo halves of every value (include/ccnet_cca.h, "split-plane path"), produced once for all their consumers
     (``layout`` HLH / HHL: the three-plane rows of a K-concatenated split-bf16 GEMM; ``dtype`` bfloat16 for those)."""
@@ -513,7 +513,8 @@ def split_planes(t: torch.Tensor, c0: int, C: int, layout: int = PLANES_HL, dtyp
     lib = _lib.get_lib()
     with torch.cuda.device(t.device):
         lib.check(lib.ccnet_cca_split_planes_f32(t.data_ptr() + 4 * c0, out.data_ptr(), B, C, H, W, t.stride(0), t.stride(2),
-                                                 H * W * n * C, n * C, layout, _stream()), "split_planes")
+                                                 H * W * n * C, n * C, layout, None if bias is None else bias.data_ptr(),
+                                                 _stream()), "split_planes")
     return out
 
 
@@ -566,12 +567,14 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
         if split_gemm:
             x3 = nchw_to_planes(x, PLANES_HHL, torch.bfloat16)                              # (B, H, W, 3, C): xh | xh | xl
             wh, wl = _split_weight(w)
-            qkv = torch.mm(x3.view(B * hw, 3 * C), torch.cat([wh, wl, wh], 1).t(), out_dtype=torch.float32)
-            qkv = qkv.add_(b).view(B, hw, ct)
+            qkv = torch.mm(x3.view(B * hw, 3 * C), torch.cat([wh, wl, wh], 1).t(), out_dtype=torch.float32).view(B, hw, ct)
+            # the bias without a pass over the whole output: q | k in place (a fifth of it), v where its slice is split
+            qkv[..., :2 * cq].add_(b[:2 * cq])
+            vpl = split_planes(qkv.view(B, H, W, ct), 2 * cq, C, bias=b[2 * cq:].contiguous())
         else:
             xm = x.view(B, C, hw)
             qkv = torch.baddbmm(b.view(1, 1, -1), xm.transpose(1, 2), w.t().unsqueeze(0).expand(B, -1, -1))   # (B, HW, 2Cq + C)
-        vpl = split_planes(qkv.view(B, H, W, ct), 2 * cq, C)
+            vpl = split_planes(qkv.view(B, H, W, ct), 2 * cq, C)
         qk = qkv                                  # q | k are read in place (channel slices of the packed projection)
         lib = _lib.get_lib()
         y = torch.empty_like(x)

@@ -227,7 +227,8 @@ int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W);
  * kernels tuned for the headline geometry; 101 .. 132 -- the 129 x 129 map of BASELINE configs[4] in fp32 -- the same kernels
  * padded to 132 positions, the row passes with one workgroup per CU).
  *
- * ccnet_cca_split_planes_f32: fp32 pixel-major view (e.g. the value slice of the packed projection x^T W^T) -> planes.
+ * ccnet_cca_split_planes_f32: fp32 pixel-major view (e.g. the value slice of the packed projection x^T W^T) -> planes;
+ *   ``bias`` (C floats, or NULL) is added to every pixel before the split (the projection's bias, functions.py:35).
  * ccnet_cca_nchw_to_planes_f32: NCHW fp32 (B, C, H, W) -> planes.
  *   ``layout`` of both: CCNET_PLANES_HL = hi | lo as above (what the core consumes).  The THREE-plane rows are operands of
  *   K-concatenated split-bf16 GEMMs on a stock bf16 -> fp32 GEMM (the projections either side of the core, functions.py:29-35:
@@ -244,7 +245,7 @@ size_t ccnet_cca_planes_workspace_bytes(int B, int C, int Cq, int H, int W, int 
 #define CCNET_PLANES_HLH 3
 #define CCNET_PLANES_HHL 4
 int ccnet_cca_split_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, int src_ps,
-                               long dst_bs, int dst_ps, int layout, ccnet_stream_t stream);
+                               long dst_bs, int dst_ps, int layout, const float *bias, ccnet_stream_t stream);
 int ccnet_cca_nchw_to_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, long dst_bs,
                                  int dst_ps, int layout, ccnet_stream_t stream);
 int ccnet_cca_forward_planes_f32(const float *q, const float *k, const uint16_t *v_planes, const float *x, const float *gamma,

@@ -210,14 +210,14 @@ class EmuOps:
                                                            bs, ct, bs, ct, bs, ct, _p(ws), nbytes, None))
         return dqkv, dgamma
 
-    def split_planes(self, src_pm, C, c0=0, layout=2):
+    def split_planes(self, src_pm, C, c0=0, layout=2, bias=None):
         """src_pm: float32 (B, H, W, ps) pixel-major; channels [c0, c0 + C) -> planes uint16 (B, H, W, n, C)
         (layout = CCNET_PLANES_HL 2: hi | lo; HLH 3: hi | lo | hi; HHL 4: hi | hi | lo)."""
         B, H, W, ps = src_pm.shape
         n = 2 if layout == 2 else 3
         dst = np.full((B, H, W, n, C), 0xFFFF, np.uint16)
         self.lib.check(self.lib.ccnet_cca_split_planes_f32(src_pm.ctypes.data + 4 * c0, _p(dst), B, C, H, W, H * W * ps, ps,
-                                                           H * W * n * C, n * C, layout, None))
+                                                           H * W * n * C, n * C, layout, None if bias is None else _p(bias), None))
         return dst
 
     def nchw_to_planes(self, src, layout=2):

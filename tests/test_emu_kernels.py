@@ -584,6 +584,12 @@ def test_split_plane_producers_are_exact_hi_lo_splits(ops):
         assert np.array_equal(ops.split_planes(wide, C, c0=16, layout=layout), want3)
     with pytest.raises(RuntimeError):
         ops.split_planes(wide, C, c0=16, layout=5)
+    # with a per-channel bias (the projection's): the split of x + b, rounded once in fp32 like an elementwise add
+    bias = rng.standard_normal(C, dtype=np.float32)
+    xb = _pm(x) + bias
+    hb = _bf16_bits_rne(xb)
+    wantb = np.stack([hb, _bf16_bits_rne(xb - _bf16_to_f32(hb))], axis=3)
+    assert np.array_equal(ops.split_planes(wide, C, c0=16, bias=bias), wantb)
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 96, 17, 20), (1, 64, 9, 1), (1, 160, 33, 18), (1, 64, 2, 99), (1, 64, 100, 3),
