@@ -25,6 +25,8 @@ CCNET_IMPL_MFMA = 2
 CCNET_PRECISION_F32 = 0
 CCNET_PRECISION_BF16X3 = 1
 CCNET_PRECISION_DEFAULT = 2
+CCNET_WS_SOFTMAX_BACKWARD, CCNET_WS_FORWARD, CCNET_WS_BACKWARD = 0, 1, 2
+CCNET_WS_PM_FORWARD, CCNET_WS_PM_BACKWARD, CCNET_WS_PLANES_FORWARD, CCNET_WS_PLANES_BACKWARD = 3, 4, 5, 6
 
 _P = c_void_p  # every tensor argument is a raw device pointer
 
@@ -33,35 +35,26 @@ _PROTOTYPES = {
     "ccnet_cca_version": (c_int, []),
     "ccnet_cca_arch": (c_char_p, []),
     "ccnet_cca_last_error_string": (c_char_p, []),
-    "ccnet_cca_set_impl": (c_int, [c_int]),
-    "ccnet_cca_get_impl": (c_int, []),
-    "ccnet_cca_set_branch_mask": (c_int, [c_int]),
-    "ccnet_cca_set_precision": (c_int, [c_int]),
-    "ccnet_cca_get_precision": (c_int, []),
+    "ccnet_cca_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "ccnet_ca_forward_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ccnet_ca_backward_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ccnet_ca_softmax_forward_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
-    "ccnet_ca_softmax_backward_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ccnet_ca_softmax_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, _P]),
     "ccnet_ca_map_forward_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ccnet_ca_map_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ccnet_cca_forward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "ccnet_cca_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t,
                                        c_int, c_int, c_int, c_int, c_int, _P]),
-    "ccnet_cca_forward_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "ccnet_cca_backward_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "ccnet_cca_forward_ws_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
                                          c_long, c_long, c_long, _P, c_size_t, _P]),
     "ccnet_cca_attention_strided_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_long, c_long, _P]),
     "ccnet_cca_backward_strided_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t,
                                                c_int, c_int, c_int, c_int, c_int,
                                                c_long, c_long, c_long, c_long, c_long, c_long, _P]),
-    "ccnet_cca_pm_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "ccnet_cca_forward_pm_bf16": (c_int, [_P] * 7 + [c_int] * 5 + [c_long, c_int] * 5 + [_P, c_size_t, _P]),
     "ccnet_cca_backward_pm_bf16": (c_int, [_P] * 11 + [c_int] * 5 + [c_long, c_int] * 7 + [_P, c_size_t, _P]),
     "ccnet_cca_forward_pm_f32": (c_int, [_P] * 7 + [c_int] * 5 + [c_long, c_int] * 5 + [_P, c_size_t, _P]),
     "ccnet_cca_backward_pm_f32": (c_int, [_P] * 11 + [c_int] * 5 + [c_long, c_int] * 7 + [_P, c_size_t, _P]),
-    "ccnet_cca_planes_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "ccnet_cca_split_planes_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_int, _P, _P]),
     "ccnet_cca_nchw_to_planes_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_long, c_long, c_int, c_int, _P]),
     "ccnet_cca_forward_planes_f32": (c_int, [_P] * 7 + [c_int] * 5 + [c_long, c_int] * 3 + [_P, c_size_t, _P]),
@@ -69,6 +62,7 @@ _PROTOTYPES = {
     "ccnet_cca_shape_uses_mfma": (c_int, [c_int, c_int, c_int, c_int]),
     "ccnet_cca_mfma_selftest": (c_int, [_P, _P]),
     "ccnet_cca_set_option": (c_int, [c_char_p, c_int]),
+    "ccnet_cca_get_option": (c_int, [c_char_p]),
     "ccnet_cca_profile_begin": (c_int, [c_int]),
     "ccnet_cca_profile_end": (c_int, [_P, _P, c_int, c_int]),
 }
@@ -100,6 +94,37 @@ class CcaLibrary:
             fn.restype = res
             fn.argtypes = args
             setattr(self, name, fn)
+
+    # ---- named forms of the two generic entry points (options by name, workspace sizes by entry code) ----
+    def ccnet_cca_set_impl(self, impl: int) -> int:
+        return self.ccnet_cca_set_option(b"impl", impl)
+
+    def ccnet_cca_get_impl(self) -> int:
+        return self.ccnet_cca_get_option(b"impl")
+
+    def ccnet_cca_set_precision(self, precision: int) -> int:
+        return self.ccnet_cca_set_option(b"precision", precision)
+
+    def ccnet_cca_get_precision(self) -> int:
+        return self.ccnet_cca_get_option(b"precision")
+
+    def ccnet_cca_set_branch_mask(self, mask: int) -> int:
+        return self.ccnet_cca_set_option(b"branch_mask", mask)
+
+    def ccnet_ca_softmax_backward_workspace_bytes(self, B, H, W) -> int:
+        return self.ccnet_cca_workspace_bytes(CCNET_WS_SOFTMAX_BACKWARD, B, 0, 0, H, W)
+
+    def ccnet_cca_forward_workspace_bytes(self, B, C, Cq, H, W) -> int:
+        return self.ccnet_cca_workspace_bytes(CCNET_WS_FORWARD, B, C, Cq, H, W)
+
+    def ccnet_cca_backward_workspace_bytes(self, B, C, Cq, H, W) -> int:
+        return self.ccnet_cca_workspace_bytes(CCNET_WS_BACKWARD, B, C, Cq, H, W)
+
+    def ccnet_cca_pm_workspace_bytes(self, B, C, Cq, H, W, backward) -> int:
+        return self.ccnet_cca_workspace_bytes(CCNET_WS_PM_BACKWARD if backward else CCNET_WS_PM_FORWARD, B, C, Cq, H, W)
+
+    def ccnet_cca_planes_workspace_bytes(self, B, C, Cq, H, W, backward) -> int:
+        return self.ccnet_cca_workspace_bytes(CCNET_WS_PLANES_BACKWARD if backward else CCNET_WS_PLANES_FORWARD, B, C, Cq, H, W)
 
     def last_error(self) -> str:
         return self.ccnet_cca_last_error_string().decode()

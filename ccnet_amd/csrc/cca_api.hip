@@ -83,7 +83,7 @@ int check_shape(int B, int C, int H, int W) {
 int require_both_branches(const char *what) {
     if (g_branch_mask.load() != CCNET_BRANCH_BOTH) {
         static thread_local std::string msg;
-        msg = std::string(what) + ": a profiling branch mask is set (ccnet_cca_set_branch_mask); restore 3 first";
+        msg = std::string(what) + ": a profiling branch mask is set (option branch_mask); restore 3 first";
         return fail(CCNET_E_BADFLAGS, msg.c_str());
     }
     return 0;
@@ -532,12 +532,12 @@ extern "C" {
 int ccnet_cca_version(void) { return CCNET_CCA_VERSION; }
 const char *ccnet_cca_arch(void) { return "gfx950"; }
 const char *ccnet_cca_last_error_string(void) { return g_last_error.c_str(); }
-int ccnet_cca_set_impl(int impl) {
+static int set_impl(int impl) {
     if (impl == CCNET_IMPL_AUTO || impl == CCNET_IMPL_DIRECT || impl == CCNET_IMPL_MFMA) return g_impl.exchange(impl);
     return g_impl.load();
 }
-int ccnet_cca_get_impl(void) { return g_impl.load(); }
-int ccnet_cca_set_precision(int precision) {
+static int get_impl(void) { return g_impl.load(); }
+static int set_precision(int precision) {
     const int mb = g_map_bf16.load(), wb = g_weight_bf16.load();
     const int prev = mb == 2 ? CCNET_PRECISION_BF16X3 : (mb == 1 || wb ? CCNET_PRECISION_DEFAULT : CCNET_PRECISION_F32);
     if (precision == CCNET_PRECISION_F32)     { g_map_bf16.store(0); g_weight_bf16.store(0); }
@@ -545,11 +545,11 @@ int ccnet_cca_set_precision(int precision) {
     if (precision == CCNET_PRECISION_BF16X3)  { g_map_bf16.store(2); g_weight_bf16.store(1); }
     return prev;
 }
-int ccnet_cca_get_precision(void) {
+static int get_precision(void) {
     const int mb = g_map_bf16.load(), wb = g_weight_bf16.load();
     return mb == 2 ? CCNET_PRECISION_BF16X3 : (mb == 1 || wb ? CCNET_PRECISION_DEFAULT : CCNET_PRECISION_F32);
 }
-int ccnet_cca_set_branch_mask(int mask) {
+static int set_branch_mask(int mask) {
     if (mask >= 1 && mask <= 3) return g_branch_mask.exchange(mask);
     return g_branch_mask.load();
 }
@@ -579,7 +579,7 @@ int ccnet_ca_backward_f32(const float *dE, const float *q, const float *k, float
     return ca_backward_impl(dE, q, k, dq, dk, B, Cq, H, W, stream, d, d, d, d);
 }
 
-size_t ccnet_ca_softmax_backward_workspace_bytes(int B, int H, int W) {
+static size_t ws_softmax_backward_bytes(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const size_t npix = (size_t)B * H * W;
     return ((npix + cca::SM_WAVES - 1) / cca::SM_WAVES) * sizeof(float);
@@ -621,16 +621,16 @@ int ccnet_ca_softmax_backward_f32(const float *A, const float *dA, const float *
     return softmax_backward_impl(A, dA, gamma, dE, dgamma, workspace, workspace_bytes, B, H, W, stream, KSplit());
 }
 
-size_t ccnet_cca_forward_workspace_bytes(int B, int C, int Cq, int H, int W) {
+static size_t ws_forward_bytes(int B, int C, int Cq, int H, int W) {
     (void)C;
     if (B <= 0 || Cq <= 0 || H <= 0 || W <= 0) return 0;
     return ksplit_bytes(B, Cq, H, W);
 }
 
-size_t ccnet_cca_backward_workspace_bytes(int B, int C, int Cq, int H, int W) {
+static size_t ws_backward_bytes(int B, int C, int Cq, int H, int W) {
     (void)Cq;
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
-    return align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W)) + ksplit_bytes(B, C, H, W);
+    return align256(ws_softmax_backward_bytes(B, H, W)) + ksplit_bytes(B, C, H, W);
 }
 
 int ccnet_ca_map_forward_f32(const float *A, const float *v, const float *x, const float *gamma, float *out,
@@ -725,7 +725,7 @@ int ccnet_cca_backward_strided_f32(const float *dy, const float *q, const float 
     if (int e = check_stride(dk_bs, Cq, H, W, "cca_backward(dk)")) return e;
     if (int e = check_stride(dv_bs, C, H, W, "cca_backward(dv)")) return e;
     // workspace = [softmax-backward partial sums | pad to 256 B | K-split slabs of dA (small batches, optional)]
-    const size_t part = align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W));
+    const size_t part = align256(ws_softmax_backward_bytes(B, H, W));
     KSplit ks;
     if (workspace && workspace_bytes > part)
         ks = ksplit_plan(B, C, H, W, static_cast<char *>(workspace) + part, workspace_bytes - part);
@@ -858,7 +858,7 @@ size_t pm_workspace_bytes(int B, int C, int Cq, int H, int W, int backward) {
     // column partials of dq and dk side by side (a region of their own: those launches may run next to the dv passes)
     const size_t px = (size_t)B * H * W * sizeof(float);
     if (!backward) return px * C;
-    return align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W)) + align256(px * C) + px * 2 * Cq;
+    return align256(ws_softmax_backward_bytes(B, H, W)) + align256(px * C) + px * 2 * Cq;
 }
 float *partial_qk_of(float *partial, int B, int C, int H, int W) {
     return reinterpret_cast<float *>(reinterpret_cast<char *>(partial) + align256((size_t)B * H * W * C * sizeof(float)));
@@ -916,7 +916,7 @@ int cca_backward_pm(const char *name, const FT *dy, const FT *q, const FT *k, co
     if (int e = check_pm_view<FT>("cca_backward_pm: dv view", dv_bs, dv_ps, C, H, W)) return e;
     if (!workspace || workspace_bytes < pm_workspace_bytes(B, C, Cq, H, W, 1))
         return fail(CCNET_E_WORKSPACE, "cca_backward_pm: workspace missing or too small");
-    const size_t sm = align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W));
+    const size_t sm = align256(ws_softmax_backward_bytes(B, H, W));
     float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + sm);
     // t = un-scaled dA (the adjoint of the aggregation, functions.py:46-47), dv = gamma * A^T-weighted dy
     // dv (two C-sized, HBM-bound passes) is independent of the chain dA -> dE -> dq | dk: it runs on the side stream
@@ -936,7 +936,7 @@ int cca_backward_pm(const char *name, const FT *dy, const FT *q, const FT *k, co
 }  // namespace
 }  // extern "C++"
 
-size_t ccnet_cca_pm_workspace_bytes(int B, int C, int Cq, int H, int W, int backward) {
+static size_t ws_pm_bytes(int B, int C, int Cq, int H, int W, int backward) {
     return pm_workspace_bytes(B, C, Cq, H, W, backward);
 }
 
@@ -1099,10 +1099,23 @@ size_t planes_bytes(int B, int C, int H, int W) { return (size_t)B * H * W * 2 *
 }  // namespace
 }  // extern "C++"
 
-size_t ccnet_cca_planes_workspace_bytes(int B, int C, int Cq, int H, int W, int backward) {
+static size_t ws_planes_bytes(int B, int C, int Cq, int H, int W, int backward) {
     const size_t base = pm_workspace_bytes(B, C, Cq, H, W, backward);
     if (!base) return 0;
     return align256(base) + (backward ? planes_bytes(B, C, H, W) : 0);                       /* + dy as planes */
+}
+
+size_t ccnet_cca_workspace_bytes(int entry, int B, int C, int Cq, int H, int W) {
+    switch (entry) {
+    case CCNET_WS_SOFTMAX_BACKWARD: return ws_softmax_backward_bytes(B, H, W);
+    case CCNET_WS_FORWARD: return ws_forward_bytes(B, C, Cq, H, W);
+    case CCNET_WS_BACKWARD: return ws_backward_bytes(B, C, Cq, H, W);
+    case CCNET_WS_PM_FORWARD: return ws_pm_bytes(B, C, Cq, H, W, 0);
+    case CCNET_WS_PM_BACKWARD: return ws_pm_bytes(B, C, Cq, H, W, 1);
+    case CCNET_WS_PLANES_FORWARD: return ws_planes_bytes(B, C, Cq, H, W, 0);
+    case CCNET_WS_PLANES_BACKWARD: return ws_planes_bytes(B, C, Cq, H, W, 1);
+    }
+    return 0;
 }
 
 int ccnet_cca_split_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, int src_ps,
@@ -1145,7 +1158,7 @@ int ccnet_cca_forward_planes_f32(const float *q, const float *k, const uint16_t 
     if (int e = check_pm_view<float>("cca_forward_planes: k view", k_bs, k_ps, Cq, H, W)) return e;
     if (int e = check_planes_view("cca_forward_planes: v planes view", v_bs, v_ps, C, H, W)) return e;
     if ((double)C * H * W >= 536870912.0) return fail(CCNET_E_BADSHAPE, "cca_forward_planes: image exceeds 2^29 elements");
-    if (!workspace || workspace_bytes < ccnet_cca_planes_workspace_bytes(B, C, Cq, H, W, 0))
+    if (!workspace || workspace_bytes < ws_planes_bytes(B, C, Cq, H, W, 0))
         return fail(CCNET_E_WORKSPACE, "cca_forward_planes: workspace missing or too small");
     if (int e = gweight_energies_f32(q, k, A, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
     if (int e = softmax_forward(A, A, B, H, W, stream)) return e;
@@ -1169,9 +1182,9 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
     if (int e = check_pm_view<float>("cca_backward_planes: dq view", dq_bs, dq_ps, Cq, H, W)) return e;
     if (int e = check_pm_view<float>("cca_backward_planes: dk view", dk_bs, dk_ps, Cq, H, W)) return e;
     if (int e = check_pm_view<float>("cca_backward_planes: dv view", dv_bs, dv_ps, C, H, W)) return e;
-    if (!workspace || workspace_bytes < ccnet_cca_planes_workspace_bytes(B, C, Cq, H, W, 1))
+    if (!workspace || workspace_bytes < ws_planes_bytes(B, C, Cq, H, W, 1))
         return fail(CCNET_E_WORKSPACE, "cca_backward_planes: workspace missing or too small");
-    const size_t sm = align256(ccnet_ca_softmax_backward_workspace_bytes(B, H, W));
+    const size_t sm = align256(ws_softmax_backward_bytes(B, H, W));
     const size_t base = align256(pm_workspace_bytes(B, C, Cq, H, W, 1));
     float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + sm);
     uint16_t *dy_pl = reinterpret_cast<uint16_t *>(static_cast<char *>(workspace) + base);
@@ -1213,10 +1226,25 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
 
 int ccnet_cca_set_option(const char *name, int value) {
     if (!name) return fail(CCNET_E_NULLPTR, "set_option: null name");
+    if (std::string(name) == "impl") return set_impl(value);
+    if (std::string(name) == "precision") return set_precision(value);
+    if (std::string(name) == "branch_mask") return set_branch_mask(value);
     if (std::string(name) == "planes_ring") return g_planes_ring.exchange(value);
     if (std::string(name) == "planes_stream") return g_planes_stream.exchange(value);
     if (std::string(name) == "planes_overlap") return g_planes_overlap.exchange(value);
     return fail(CCNET_E_BADFLAGS, "set_option: unknown option");
+}
+
+int ccnet_cca_get_option(const char *name) {
+    if (!name) return fail(CCNET_E_NULLPTR, "get_option: null name");
+    const std::string n(name);
+    if (n == "impl") return get_impl();
+    if (n == "precision") return get_precision();
+    if (n == "branch_mask") return g_branch_mask.load();
+    if (n == "planes_ring") return g_planes_ring.load();
+    if (n == "planes_stream") return g_planes_stream.load();
+    if (n == "planes_overlap") return g_planes_overlap.load();
+    return fail(CCNET_E_BADFLAGS, "get_option: unknown option");
 }
 
 /* ---- launch profiler: per-launch HIP-event durations inside a step (see cca_platform.hpp, cca_prof) ---- */

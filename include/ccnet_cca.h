@@ -20,7 +20,7 @@
  *   - launches go to ``stream`` (a hipStream_t; NULL = the legacy default stream); no call
  *     synchronises.  The compute entry points hold no per-call state and may be called concurrently
  *     from several host threads / streams; the only process-wide state are the three MODE words behind
- *     ccnet_cca_set_impl / _set_precision / _set_branch_mask (atomics; defaults need no call).  A setter
+ *     the options "impl", "precision", "branch_mask" of ccnet_cca_set_option (atomics; defaults need no call).  A setter
  *     racing with a call in flight affects that call or the next one, never part of one.  The fused
  *     ccnet_cca_forward / backward entry points refuse to run under a profiling branch mask.
  *   - return value: 0 on success; a positive hipError_t if a launch failed; a negative
@@ -60,7 +60,7 @@ extern "C" {
  * to an fmaf chain).  The PIXEL-MAJOR and SPLIT-PLANE entry points (*_pm_*, *_planes_*) are not governed by this knob:
  * they compute the energies in exact fp32 and EVERY other contraction (dq / dk included) as split-bf16 x3 -- callers that
  * pin CCNET_PRECISION_F32 or CCNET_IMPL_DIRECT for validation must call the strip / direct entry points; the Python module
- * reads the two knobs (ccnet_cca_get_precision / ccnet_cca_get_impl) and routes accordingly.
+ * reads the two knobs (ccnet_cca_get_option) and routes accordingly.
  * The three C-sized contractions of the strip family may split
  * every fp32 operand into bf16 hi + lo and evaluate the products on the bf16 matrix pipe with fp32 accumulation
  * (relative error ~2^-17 per product; measured max-abs error at (8,512,97,97): 2e-4 on dq/dk, 3e-5 on y/dv,
@@ -85,11 +85,18 @@ typedef void *ccnet_stream_t;          /* hipStream_t */
 int         ccnet_cca_version(void);
 const char *ccnet_cca_arch(void);                  /* "gfx950" */
 const char *ccnet_cca_last_error_string(void);
-int         ccnet_cca_set_impl(int impl);          /* returns the previous setting */
-int         ccnet_cca_get_impl(void);
-int         ccnet_cca_set_branch_mask(int mask);   /* returns the previous mask */
-int         ccnet_cca_set_precision(int precision);/* returns the previous setting */
-int         ccnet_cca_get_precision(void);
+/* The MODE words above are options "impl", "precision" and "branch_mask" of ccnet_cca_set_option / ccnet_cca_get_option
+ * (declared with the other options below): set returns the previous value, an invalid value leaves the word unchanged. */
+
+/* Scratch sizes of the entry points that take a ``workspace`` (bytes; 0 = none needed).  ``entry``: */
+#define CCNET_WS_SOFTMAX_BACKWARD 0    /* ccnet_ca_softmax_backward_f32 with dgamma (C, Cq ignored) */
+#define CCNET_WS_FORWARD          1    /* ccnet_cca_forward_ws_f32 */
+#define CCNET_WS_BACKWARD         2    /* ccnet_cca_backward_f32 / _backward_strided_f32 */
+#define CCNET_WS_PM_FORWARD       3    /* ccnet_cca_forward_pm_{bf16,f32} */
+#define CCNET_WS_PM_BACKWARD      4    /* ccnet_cca_backward_pm_{bf16,f32} */
+#define CCNET_WS_PLANES_FORWARD   5    /* ccnet_cca_forward_planes_f32 */
+#define CCNET_WS_PLANES_BACKWARD  6    /* ccnet_cca_backward_planes_f32 */
+size_t      ccnet_cca_workspace_bytes(int entry, int B, int C, int Cq, int H, int W);
 
 /* Affinity: replaces functions.py:30-34 (layout shuffles), :38 (bmm + INF), :39 (bmm), :40 (cat
  * [+ Softmax when CCNET_CA_SOFTMAX]).  out (B,H,W,H+W). */
@@ -108,8 +115,7 @@ int ccnet_ca_softmax_forward_f32(const float *energy, float *out,
 /* Adjoint of the softmax: dE = g * A * (dA - sum_s A dA) with g = *gamma (1 if gamma == NULL);
  * if dgamma != NULL also writes dgamma[0] = sum A*dA (= sum dy*(out_H+out_W), the gradient of
  * functions.py:49's gamma when dA is the un-scaled map adjoint).  dE may alias dA.
- * workspace: ccnet_ca_softmax_backward_workspace_bytes() bytes when dgamma != NULL. */
-size_t ccnet_ca_softmax_backward_workspace_bytes(int B, int H, int W);
+ * workspace: ccnet_cca_workspace_bytes(CCNET_WS_SOFTMAX_BACKWARD, ...) bytes when dgamma != NULL. */
 int ccnet_ca_softmax_backward_f32(const float *A, const float *dA, const float *gamma, float *dE,
                                   float *dgamma, void *workspace, size_t workspace_bytes,
                                   int B, int H, int W, ccnet_stream_t stream);
@@ -132,10 +138,8 @@ int ccnet_ca_map_backward_f32(const float *dout, const float *A, const float *v,
  * behind the affinity (forward) and behind dA (backward) are split into channel ranges whose partial attention-shaped
  * results live in the workspace and are added, in a fixed order, by the softmax kernels.  With a NULL / smaller
  * workspace the same results are computed unsplit (backward: at least
- * ccnet_ca_softmax_backward_workspace_bytes() is always required; the backward size includes it).  At batch sizes
+ * CCNET_WS_SOFTMAX_BACKWARD is always required; the backward size includes it).  At batch sizes
  * that fill the chip the forward size is 0 and the backward size is just the softmax part. */
-size_t ccnet_cca_forward_workspace_bytes(int B, int C, int Cq, int H, int W);
-size_t ccnet_cca_backward_workspace_bytes(int B, int C, int Cq, int H, int W);
 
 /* The strided forward (see "strided forms" above), with the optional workspace described above (NULL / 0: unsplit). */
 int ccnet_cca_forward_ws_f32(const float *q, const float *k, const float *v, const float *x, const float *gamma,
@@ -183,8 +187,8 @@ int ccnet_cca_backward_strided_f32(const float *dy, const float *q, const float 
  * of the bf16 features are exact on the matrix pipe; outputs are rounded to nearest even once, on store.
  * Constraints: max(H, W) <= 132, C % 8 == 0, Cq % 8 == 0, every bs / ps a multiple of 8, pointers 16-byte aligned.
  * y = gamma * (column + row aggregation) + x       (functions.py:46-49)
- * ``workspace``: ccnet_cca_pm_workspace_bytes(..., backward) bytes (fp32 column partials; + softmax partials). */
-size_t ccnet_cca_pm_workspace_bytes(int B, int C, int Cq, int H, int W, int backward);      /* (bf16 and fp32 views alike) */
+ * ``workspace``: ccnet_cca_workspace_bytes(CCNET_WS_PM_FORWARD / _BACKWARD, ...) bytes (fp32 column partials; + softmax
+ * partials; bf16 and fp32 views alike). */
 int ccnet_cca_forward_pm_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v, const uint16_t *x,
                               const float *gamma, uint16_t *y, float *A, int B, int C, int Cq, int H, int W,
                               long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long x_bs, int x_ps,
@@ -237,10 +241,9 @@ int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W);
  *   products as well (the weight gradient as one GEMM over 3 B H W rows).
  * ccnet_cca_forward_planes_f32 / _backward_planes_f32: functions.py:38-49 and its autograd with q, k fp32 pixel-major
  *   views (exact fp32 energies), v as planes, the module's x / y / dy NCHW fp32, dq | dk | dv fp32 pixel-major views,
- *   A / scratch (B,H,W,H+W) fp32 as everywhere.  Workspace: ccnet_cca_planes_workspace_bytes (backward: holds the fp32
+ *   A / scratch (B,H,W,H+W) fp32 as everywhere.  Workspace: CCNET_WS_PLANES_FORWARD / _BACKWARD (backward: holds the fp32
  *   column partial and dy as planes).  Arithmetic: energies exact fp32; every other contraction split-bf16 x3 with fp32
  *   accumulation (the lo x lo term, 2^-18 relative, is dropped) -- the CCNET_PRECISION_* knob does not apply here. */
-size_t ccnet_cca_planes_workspace_bytes(int B, int C, int Cq, int H, int W, int backward);
 #define CCNET_PLANES_HL 2
 #define CCNET_PLANES_HLH 3
 #define CCNET_PLANES_HHL 4
@@ -258,7 +261,9 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
                                   long v_bs, int v_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
                                   void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
 
-/* Development / A-B switches by name (returns the previous value, < 0 for an unknown name); defaults are what ships:
+/* Options by name (set returns the previous value, < 0 for an unknown name); defaults are what ships:
+ *   "impl" CCNET_IMPL_*, "precision" CCNET_PRECISION_*, "branch_mask" CCNET_BRANCH_* (see above);
+ * development / A-B switches:
  *   "planes_ring"  which kernels run the split-plane passes that have a pixel-major output:
  *                  2 (default) gmap3_kernel -- stores straight from the accumulators; column passes with two ring slots and
  *                    three workgroups per CU, row passes with three ring slots and two workgroups per CU;
@@ -273,6 +278,7 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
  *                    dq | dk; 1 next to softmax-backward and dq | dk only; 0 everything on ``stream``; -1 (default) what
  *                    measured best per family (2 on split planes, 1 on the bf16 / fp32 pixel-major entries). */
 int ccnet_cca_set_option(const char *name, int value);
+int ccnet_cca_get_option(const char *name);            /* current value; < 0 (CCNET_E_*) for an unknown name */
 
 /* Launch profiler (a measurement aid, off by default).  Between ``begin`` and ``end`` every kernel launch the library
  * issues is bracketed by a HIP-event pair on its stream; ``end`` disarms, waits for the recorded launches and returns
