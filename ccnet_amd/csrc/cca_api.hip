@@ -989,12 +989,15 @@ int check_planes_view(const char *what, long bs, int ps, int C, int H, int W, in
     if ((double)H * W * ps >= 1073741824.0) return fail(CCNET_E_BADSHAPE, what);            /* 2-byte elements, 31-bit offsets */
     return 0;
 }
-int check_planes_problem(const char *what, int B, int C, int Cq, int H, int W) {
+// ``long_rows``: the forward also takes ROW strips of 133 .. 528 positions (columns <= 132) as 2 .. 4 blocks (cca::long_block)
+int check_planes_problem(const char *what, int B, int C, int Cq, int H, int W, bool long_rows = false) {
     if (int e = check_shape(B, C, H, W)) return e;
     if (int e = check_shape(B, Cq, H, W)) return e;
-    if ((H > W ? H : W) > 132 || C % 8 || Cq % 4) return fail(CCNET_E_BADSHAPE, what);
+    if (H > 132 || W > (long_rows ? 4 * 132 : 132) || C % 8 || Cq % 4) return fail(CCNET_E_BADSHAPE, what);
+    if (W > 132 && Cq > cca::GM_CG) return fail(CCNET_E_BADSHAPE, what);       /* (the blocked energies kernel: one 64-channel chunk) */
     return 0;
 }
+inline int long_blocks(int L) { return (L + 131) / 132; }
 // CCNET_PLANES_* -> where the halves go inside a pixel's row (false: unknown layout)
 bool plane_layout(int layout, int C, cca::PlaneLayout *pl) {
     if (layout == CCNET_PLANES_HL) *pl = cca::PlaneLayout{C, 0, 2 * C};
@@ -1060,9 +1063,36 @@ int launch_gmap_planes_p(const float *T, const bf16p_t *F, const float *resid, c
                gr.n_whole, gr.split, cca::GmapJob<bf16p_t, float>{});
     return launch_status("gmap_planes(row)");
 }
+// forward aggregation with LONG rows (133 .. 528 positions, columns <= 132): the column pass as ever (its strips are columns);
+// the row pass as nb launches, one per KEY block: partial += gamma * A[:, key block] . v[key block] in place, the last one adds
+// the residual and writes y (NCHW).  A workgroup owns one QUERY block of a row strip.
+int launch_gmap_planes_long_rows(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
+                                 int B, int C, int H, int W, long fbs, int fps, long rbs, long obs, ccnet_stream_t stream) {
+    if (int e = launch_gmap3_planes<132, false>(T, F, gamma, out, partial, B, C, H, W, fbs, fps, 0L, 0, false, stream)) return e;
+    const int nb = long_blocks(W);
+    const long pbs = (long)H * W * C;
+    const GmapPlan gr = gmap_plan(B * H * nb, C, 1);
+    for (int j = 0; j < nb; ++j) {
+        cca::GmapJob<bf16p_t, float> job{};
+        job.nb = nb;
+        job.jblk = j;
+        if (j + 1 < nb)
+            CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, bf16p_t, float, false, false, 1, true>), dim3((unsigned)gr.grid),
+                       dim3(cca::GS_THREADS), stream, T, F, (const float *)partial, (const float *)nullptr, gamma, partial, C, H, W,
+                       fbs, fps, pbs, C, 0L, 0, pbs, C, gr.n_whole, gr.split, job);
+        else
+            CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, bf16p_t, float, true, false, 1, true>), dim3((unsigned)gr.grid),
+                       dim3(cca::GS_THREADS), stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C,
+                       rbs, 0, obs, 0, gr.n_whole, gr.split, job);
+        if (int e = launch_status("gmap_planes(long rows)")) return e;
+    }
+    return 0;
+}
 template <bool TRANS, bool NCHW>
 int launch_gmap_planes(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
                        int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
+    if constexpr (!TRANS && NCHW)
+        if (W > 132) return launch_gmap_planes_long_rows(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, obs, stream);
     if ((H > W ? H : W) <= 100)
         return launch_gmap_planes_p<100, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
     return launch_gmap_planes_p<132, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
@@ -1072,6 +1102,12 @@ int launch_gmap_planes(const float *T, const bf16p_t *F, const float *resid, con
 int gweight_energies_f32(const float *q, const float *k, float *A, int B, int Cq, int H, int W, long qbs, int qps, long kbs, int kps,
                          ccnet_stream_t stream) {
     if ((H > W ? H : W) <= 100) return gweight_pm<true, float>(q, k, A, B, Cq, H, W, qbs, qps, kbs, kps, stream);
+    if (W > 132) {          // long rows: nb x nb blocks per row strip, whole column strips
+        const int nb = long_blocks(W);
+        const dim3 grid((unsigned)(B * (W + H * nb * nb))), block(cca::GM_THREADS);
+        CCA_LAUNCH((cca::gweight_kernel<132, true, float, true, true>), grid, block, stream, q, k, A, Cq, H, W, qbs, qps, kbs, kps, nb);
+        return launch_status("gweight_energies(long rows)");
+    }
     const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
     if (Cq <= cca::GM_CG) CCA_LAUNCH((cca::gweight_kernel<132, true, float, true>), grid, block, stream, q, k, A, Cq, H, W, qbs, qps, kbs, kps);
     else                  CCA_LAUNCH((cca::gweight_kernel<132, true, float, false>), grid, block, stream, q, k, A, Cq, H, W, qbs, qps, kbs, kps);
@@ -1153,7 +1189,8 @@ int ccnet_cca_forward_planes_f32(const float *q, const float *k, const uint16_t 
                                  void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
     if (int e = require_both_branches("cca_forward_planes_f32")) return e;
     if (!q || !k || !v_planes || !x || !gamma || !y || !A) return fail(CCNET_E_NULLPTR, "cca_forward_planes: null tensor");
-    if (int e = check_planes_problem("cca_forward_planes: strips <= 132, C % 8 == 0, Cq % 4 == 0", B, C, Cq, H, W)) return e;
+    if (int e = check_planes_problem("cca_forward_planes: columns <= 132, rows <= 528 (> 132: C/8 <= 64), C % 8 == 0, Cq % 4 == 0",
+                                     B, C, Cq, H, W, true)) return e;
     if (int e = check_pm_view<float>("cca_forward_planes: q view", q_bs, q_ps, Cq, H, W)) return e;
     if (int e = check_pm_view<float>("cca_forward_planes: k view", k_bs, k_ps, Cq, H, W)) return e;
     if (int e = check_planes_view("cca_forward_planes: v planes view", v_bs, v_ps, C, H, W)) return e;

@@ -174,12 +174,17 @@ struct GmapJob {
     long fbs, obs;
     int fps, ops;
     int nwg;
+    int nb, jblk;     // LONG (strips of 133 .. 4 x 132 positions): blocks per strip, the key block of this launch
 };
+// LONG strips: a strip of L > P positions is cut into nb blocks of ``long_block(L, nb)`` positions (the last one shorter).  A
+// workgroup then owns the QUERY block I of a strip and contracts over the KEY block J: out_I (+)= F_J . A_{I,J}^T; the key blocks
+// are separate launches chained through the addend (the partial is updated in place), the last one runs the epilogue.
+__host__ __device__ inline int long_block(int L, int nb) { return (((L + nb - 1) / nb) + 3) & ~3; }
 inline unsigned gmap_dual_grid(int nwg) { return 16u * (unsigned)((nwg + 7) / 8); }
 
 // WPC: workgroups per CU the LDS budget is checked for (2 everywhere except the 132-position kernels on fp32 / split-plane
 // features, whose two feature tiles + output image take 104 KB: one workgroup per CU)
-template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT, bool NCHW = false, bool DUAL = false, int WPC = 2>
+template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT, bool NCHW = false, bool DUAL = false, int WPC = 2, bool LONG = false>
 __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__restrict__ T, const FT *__restrict__ F,
                                                               const float *__restrict__ addend,
                                                               const OT *__restrict__ resid,
@@ -210,6 +215,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     constexpr int CPI = P <= 128 ? 2 : 1, LPC = kWave / CPI;          // NCHW: channels per store instruction, lanes per channel (4 positions each)
     constexpr int NSX = GM_CG / CPI / GS_WAVES;                       // NCHW: store instructions per wave and group
     static_assert(!NCHW || (ROW && ADD && !OBF && !TRANS && !DUAL), "gmap: the NCHW epilogue belongs to the final fp32 row pass");
+    static_assert(!LONG || (ROW && ADD && !TRANS && !DUAL), "gmap: blocked long strips exist for the forward row passes");
     static_assert(!PL || !OBF, "gmap: split-plane features produce fp32 outputs");
     static_assert(P % 4 == 0 && (2 * FSZ + OIMG) * 4 * WPC <= 163840, "gmap: LDS of WPC workgroups per CU");
     __shared__ __attribute__((aligned(16))) float lds[2 * FSZ + OIMG];
@@ -227,11 +233,20 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
         cg0 = part * ncg / split;
         cg1 = (part + 1) * ncg / split;
     }
+    // LONG: id = (strip, query block); this launch contracts over key block j1.jblk
+    const int qblk = LONG ? id % j1.nb : 0;
+    if (LONG) id /= j1.nb;
     const int b = id / G, g = id - b * G;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
     const int ln = lane & 15, lg = lane >> 4;
     const int pix0 = ROW ? g * W : g, pstep = ROW ? 1 : W;                             // pixel(i) = pix0 + i * pstep
     const int a_off = ROW ? H : 0;
+    // query side (attention rows, outputs, addend, residual): positions i0 .. i0 + Lm; key side (attention columns, features):
+    // j0 .. j0 + Lk.  Whole strips: both are the strip.
+    const int lb = LONG ? long_block(L, j1.nb) : 0;
+    const int i0 = LONG ? qblk * lb : 0, j0 = LONG ? j1.jblk * lb : 0;
+    const int Lm = LONG ? (L - i0 < lb ? L - i0 : lb) : L, Lk = LONG ? (L - j0 < lb ? L - j0 : lb) : L;
+    const int pixM = pix0 + i0 * pstep, pixK = pix0 + j0 * pstep, aK = a_off + j0;
 
     const FBuf Tb = make_fbuf(T + (size_t)b * HW * S, (size_t)HW * S * sizeof(float));
     const FBuf Fb = make_fbuf(reinterpret_cast<const float *>(F + (size_t)b * fbs), ((size_t)(HW - 1) * fps + (PL ? 2 : 1) * C) * sizeof(FT));
@@ -241,16 +256,16 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                               !resid ? 4 : NCHW ? (size_t)C * HW * sizeof(OT) : ((size_t)(HW - 1) * rps + C) * sizeof(OT));
     const FBuf Db = make_fbuf(ADD ? addend + (size_t)b * abs_ : T, ADD ? ((size_t)(HW - 1) * aps + C) * sizeof(float) : 4);
     const float alpha = gamma ? gamma[0] : 1.f;
-    const BandK kp = band_ksteps(L);
+    const BandK kp = band_ksteps(Lk);
 
     auto issue_feat = [&](int cg) {
         for (int it = wv; it < NPF; it += GS_WAVES) {
             if constexpr (PL) {
                 const int plane = it >= NPF / 2;
-                t16_dma_piece(Fb, FB + ((cg - cg0) & 1) * FSZ + plane * TSP, it - plane * (NPF / 2), lane, pix0, pstep, L, fps,
+                t16_dma_piece(Fb, FB + ((cg - cg0) & 1) * FSZ + plane * TSP, it - plane * (NPF / 2), lane, pixK, pstep, Lk, fps,
                               cg * GM_CG, C, plane ? C : 0);
             } else {
-                gtile_dma_piece<FT>(Fb, FB + ((cg - cg0) & 1) * FSZ, it, lane, pix0, pstep, L, fps, cg * GM_CG, C);
+                gtile_dma_piece<FT>(Fb, FB + ((cg - cg0) & 1) * FSZ, it, lane, pixK, pstep, Lk, fps, cg * GM_CG, C);
             }
         }
     };
@@ -266,14 +281,14 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             float x[8];
-            if (ks < kp.nbf && 16 * t < L) {                          // wave-uniform
+            if (ks < kp.nbf && 16 * t < Lm) {                         // wave-uniform
                 const int k0 = 32 * ks + 8 * lg;
                 if (!trans) {
-                    const int base = ((pix0 + m * pstep) * S + a_off + k0) * 4;
-                    const f32x4 u = fbuf_load_x4(Tb, (m < L && k0 < L) ? base : kOobOffset, 0);
-                    const f32x4 v = fbuf_load_x4(Tb, (m < L && k0 + 4 < L) ? base + 16 : kOobOffset, 0);
+                    const int base = ((pixM + m * pstep) * S + aK + k0) * 4;
+                    const f32x4 u = fbuf_load_x4(Tb, (m < Lm && k0 < Lk) ? base : kOobOffset, 0);
+                    const f32x4 v = fbuf_load_x4(Tb, (m < Lm && k0 + 4 < Lk) ? base + 16 : kOobOffset, 0);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { x[e] = k0 + e < L ? u[e] : 0.f; x[4 + e] = k0 + 4 + e < L ? v[e] : 0.f; }
+                    for (int e = 0; e < 4; ++e) { x[e] = k0 + e < Lk ? u[e] : 0.f; x[4 + e] = k0 + 4 + e < Lk ? v[e] : 0.f; }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
@@ -288,12 +303,12 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
             al[a][ks] = sp.lo;
         }
         const int kt = 32 * kp.nbf + lg;
-        at[a] = fbuf_load(Tb, (kp.tail && m < L && kt < L) ? (trans ? ((pix0 + kt * pstep) * S + a_off + m) * 4
-                                                                     : ((pix0 + m * pstep) * S + a_off + kt) * 4) : kOobOffset, 0);
+        at[a] = fbuf_load(Tb, (kp.tail && m < Lm && kt < Lk) ? (trans ? ((pix0 + kt * pstep) * S + a_off + m) * 4
+                                                                       : ((pixM + m * pstep) * S + aK + kt) * 4) : kOobOffset, 0);
     }
 
     // this lane's slice of store instruction k of its wave: pixel position and first channel (within the group)
-    const int nsi_total = (L + SPX - 1) / SPX;
+    const int nsi_total = (Lm + SPX - 1) / SPX;
     const int nstore = (nsi_total - wv + GS_WAVES - 1) / GS_WAVES;          // store instructions this wave issues per group
     auto st_pos = [&](int k) { return SPX * (wv + GS_WAVES * k) + (OBF ? lane >> 3 : lane >> 4); };
     const int st_c = OBF ? 8 * (lane & 7) : 4 * (lane & 15);
@@ -317,21 +332,21 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     const int c = cg * GM_CG + 16 * nt + 4 * lg;
-                    addp[a][nt] = fbuf_load_x4(Db, (i < L && c < C) ? ((pix0 + i) * aps + c) * 4 : kOobOffset, 0);
+                    addp[a][nt] = fbuf_load_x4(Db, (i < Lm && c < C) ? ((pixM + i) * aps + c) * 4 : kOobOffset, 0);
                 }
             }
 #pragma unroll
             for (int k = 0; k < NSX; ++k) {                 // residual in the store layout: 4 positions of channel c
                 const int c = cg * GM_CG + CPI * (wv + GS_WAVES * k) + (lane / LPC), w4 = lane & (LPC - 1);
-                const int w0 = (4 * w4 + 3 < L || L < 4) ? 4 * w4 : L - 4;      // the last granule is shifted back to end at L
-                resx[k] = fbuf_load_x4(Rb, (resid && 4 * w4 < L && c < C) ? (c * HW + pix0 + w0) * 4 : kOobOffset, 0);
+                const int w0 = (4 * w4 + 3 < Lm || Lm < 4) ? 4 * w4 : Lm - 4;      // the last granule is shifted back to end at Lm
+                resx[k] = fbuf_load_x4(Rb, (resid && 4 * w4 < Lm && c < C) ? (c * HW + pixM + w0) * 4 : kOobOffset, 0);
             }
         }
 #pragma unroll
         for (int k = 0; k < (NCHW ? 0 : NSI); ++k) {
             const int i = st_pos(k), c = cg * GM_CG + st_c;
-            const bool ok = i < L && c < C;
-            const int pix = pix0 + i * pstep;
+            const bool ok = i < Lm && c < C;
+            const int pix = pixM + i * pstep;
             if (ADD) {
                 add0[k] = fbuf_load_x4(Db, ok ? (pix * aps + c) * 4 : kOobOffset, 0);
                 if (OBF) add1[k] = fbuf_load_x4(Db, ok ? (pix * aps + c + 4) * 4 : kOobOffset, 0);
@@ -375,7 +390,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                         }
 #pragma unroll
                         for (int a = 0; a < TPW; ++a) {
-                            if ((wv + GS_WAVES * a) * 16 < L) {
+                            if ((wv + GS_WAVES * a) * 16 < Lm) {
                                 acc[a][n] = mfma_bf16_16x16x32(fb.hi, ah[a][ks], acc[a][n]);
                                 if (!BF) acc[a][n] = mfma_bf16_16x16x32(fb.lo, ah[a][ks], acc[a][n]);
                                 acc[a][n] = mfma_bf16_16x16x32(fb.hi, al[a][ks], acc[a][n]);
@@ -396,14 +411,14 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                     else              fbv = CCA_LDS_LD(img + gtile_f32_idx(pos, 16 * nt + ln));
 #pragma unroll
                     for (int a = 0; a < TPW; ++a)
-                        if ((wv + GS_WAVES * a) * 16 < L) acc[a][n] = mfma_16x16x4(fbv, at[a], acc[a][n]);
+                        if ((wv + GS_WAVES * a) * 16 < Lm) acc[a][n] = mfma_16x16x4(fbv, at[a], acc[a][n]);
                 }
                 mfma_f32_result_fence();
             }
 #pragma unroll
             for (int a = 0; a < TPW; ++a) {
                 const int i = 16 * (wv + GS_WAVES * a) + ln;
-                if (i < L) {
+                if (i < Lm) {
 #pragma unroll
                     for (int n = 0; n < NTH; ++n) {
                         const int nt = nh * NTH + n;
@@ -422,11 +437,11 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
         if constexpr (NCHW) {
             // runs of W floats per channel: CPI channels x LPC lanes (4 positions each) per instruction (2 x 32 up to 128
             // positions, 1 x 64 beyond).  Store instructions this wave issues in this group (for the next group's counted
-            // barrier): one 16-byte store per valid channel set (rows shorter than 4: L single stores)
+            // barrier): one 16-byte store per valid channel set (rows shorter than 4: Lm single stores)
             {
                 const int crem = C - cg * GM_CG, first = CPI * wv;
                 const int nk = crem <= first ? 0 : (crem - first + CPI * GS_WAVES - 1) / (CPI * GS_WAVES);
-                nstore_nchw = (nk < NSX ? nk : NSX) * (L >= 4 ? 1 : L);
+                nstore_nchw = (nk < NSX ? nk : NSX) * (Lm >= 4 ? 1 : Lm);
             }
             const int crem = C - cg * GM_CG;
 #pragma unroll
@@ -435,25 +450,25 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                 // counted barrier may only count instructions that really go to memory
                 if (CPI * (wv + GS_WAVES * k) < crem) {
                     const int ch = CPI * (wv + GS_WAVES * k) + (lane / LPC), c = cg * GM_CG + ch, w4 = lane & (LPC - 1);
-                    const bool whole = 4 * w4 + 3 < L;
-                    if (L >= 4) {
-                        // a row of L floats = whole 4-float granules + one granule shifted back to end at L (it rewrites up to
+                    const bool whole = 4 * w4 + 3 < Lm;
+                    if (Lm >= 4) {
+                        // a row of Lm floats = whole 4-float granules + one granule shifted back to end at Lm (it rewrites up to
                         // 3 floats of its neighbour with the same values): 16-byte stores only, one instruction per channel pair
-                        const int w0 = whole ? 4 * w4 : L - 4;
+                        const int w0 = whole ? 4 * w4 : Lm - 4;
                         f32x4 u;
                         if (whole) {
                             u = lds_load_x4(oimg + oimg_nchw_idx<P>(ch, 4 * w4));
                         } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) u[e] = CCA_LDS_LD(oimg + oimg_nchw_idx<P>(ch, (4 * w4 < L ? w0 : 0) + e));
+                            for (int e = 0; e < 4; ++e) u[e] = CCA_LDS_LD(oimg + oimg_nchw_idx<P>(ch, (4 * w4 < Lm ? w0 : 0) + e));
                         }
-                        if (4 * w4 < L && c < C) fbuf_store_x4(Ob, u + resx[k], (c * HW + pix0 + w0) * 4, 0);
+                        if (4 * w4 < Lm && c < C) fbuf_store_x4(Ob, u + resx[k], (c * HW + pixM + w0) * 4, 0);
                     } else {
 #pragma unroll
                         for (int e = 0; e < 3; ++e) {
-                            if (e < L) {
+                            if (e < Lm) {
                                 if (w4 == 0 && c < C)
-                                    fbuf_store(Ob, CCA_LDS_LD(oimg + oimg_nchw_idx<P>(ch, e)) + resx[k][e], (c * HW + pix0 + e) * 4, 0);
+                                    fbuf_store(Ob, CCA_LDS_LD(oimg + oimg_nchw_idx<P>(ch, e)) + resx[k][e], (c * HW + pixM + e) * 4, 0);
                             }
                         }
                     }
@@ -467,7 +482,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
             if (wv + GS_WAVES * k < nsi_total) {                         // wave-uniform: exactly `nstore` instructions
                 const int i = st_pos(k), c = cg * GM_CG + st_c;
                 const float *s = oimg + i * OPX + st_c;
-                if (i < L && c < C) {
+                if (i < Lm && c < C) {
                     f32x4 u = lds_load_x4(s);
                     if (ADD) u += add0[k];
                     if constexpr (OBF) {
@@ -480,10 +495,10 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                         }
                         const f32x4 packed = __builtin_bit_cast(f32x4, u32x4{cvt_pk_bf16(u[0], u[1]), cvt_pk_bf16(u[2], u[3]),
                                                                              cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])});
-                        fbuf_store_x4(Ob, packed, ((pix0 + i * pstep) * ops + c) * 2, 0);
+                        fbuf_store_x4(Ob, packed, ((pixM + i * pstep) * ops + c) * 2, 0);
                     } else {
                         u += __builtin_bit_cast(f32x4, res[k]);          // (+ the fp32 residual; zeros when there is none)
-                        fbuf_store_x4(Ob, u, ((pix0 + i * pstep) * ops + c) * 4, 0);
+                        fbuf_store_x4(Ob, u, ((pixM + i * pstep) * ops + c) * 4, 0);
                     }
                 }
             }
@@ -798,10 +813,12 @@ __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float *__rest
 // ---------------------------------------------------------------------------------------------------------------
 // SINGLE: the contraction is one 64-channel chunk (the energies, K = C/8 <= 64): no double buffering, half the LDS, and
 // two (fp32) or more workgroups per CU overlap their latency chains.
-template <int P, bool MASK, typename FT, bool SINGLE>
+// LONG (row strips of 133 .. 4 x 132 positions, ``nb`` blocks each -- see long_block): a workgroup computes the block
+// T[query block I][key block J] of a row strip from the X tile of block I and the Y tile of block J; column strips (<= P) stay whole.
+template <int P, bool MASK, typename FT, bool SINGLE, bool LONG = false>
 __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(const FT *__restrict__ X, const FT *__restrict__ Y,
                                                                               float *__restrict__ T, int Cx, int H, int W,
-                                                                              long xbs, int xps, long ybs, int yps) {
+                                                                              long xbs, int xps, long ybs, int yps, int nb = 1) {
     constexpr bool BF = GTile<FT>::BF;
     constexpr bool PL = std::is_same<FT, bf16p_t>::value;     // split planes: an operand tile = hi image | lo image (bf16 tile geometry)
     static_assert(!(PL && MASK), "gweight: the energies are computed from fp32 q, k (exact products)");
@@ -822,14 +839,21 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
     CCA_LDS_REGISTER(lds);
     const int HW = H * W, S = H + W;
     const int id = xcd_logical_id(blockIdx.x, gridDim.x);
-    const int per_image = W + H;                              // W column strips, then H row strips
+    const int nbb = LONG ? nb * nb : 1;
+    const int per_image = W + H * nbb;                        // W column strips, then H row strips (LONG: nb x nb blocks each)
     const int b = id / per_image, r = id - b * per_image;
     const bool row = r >= W;
-    const int g = row ? r - W : r;
-    const int L = row ? W : H;
+    const int blk = (LONG && row) ? (r - W) % nbb : 0;
+    const int g = row ? (r - W) / nbb : r;
+    const int Ls = row ? W : H;                               // the strip; this workgroup's query / key ranges:
+    const int lb = (LONG && row) ? long_block(Ls, nb) : 0;
+    const int i0 = (LONG && row) ? (blk / nb) * lb : 0, j0 = (LONG && row) ? (blk % nb) * lb : 0;
+    const int L = (LONG && row) ? (Ls - i0 < lb ? Ls - i0 : lb) : Ls;      // query positions (rows of T)
+    const int Lk = (LONG && row) ? (Ls - j0 < lb ? Ls - j0 : lb) : Ls;     // key positions (slots)
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
     const int ln = lane & 15, lg = lane >> 4;
-    const int pix0 = row ? g * W : g, pstep = row ? 1 : W, a_off = row ? H : 0;
+    const int pstep = row ? 1 : W;
+    const int pix0 = (row ? g * W : g) + i0 * pstep, pixY = (row ? g * W : g) + j0 * pstep, a_off = (row ? H : 0) + j0;
     const FBuf Xb = make_fbuf(reinterpret_cast<const float *>(X + (size_t)b * xbs), ((size_t)(HW - 1) * xps + (PL ? 2 : 1) * Cx) * sizeof(FT));
     const FBuf Yb = make_fbuf(reinterpret_cast<const float *>(Y + (size_t)b * ybs), ((size_t)(HW - 1) * yps + (PL ? 2 : 1) * Cx) * sizeof(FT));
     const int nch = (Cx + GM_CG - 1) / GM_CG;                 // (SINGLE: the host launches this form only when nch == 1)
@@ -839,11 +863,11 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
         for (int it = wv; it < 2 * NPF; it += GM_WAVES) {
             if constexpr (PL) {
                 const int op = it >= NPF, r = it - op * NPF, plane = r >= NPB;
-                t16_dma_piece<false>(op ? Yb : Xb, (op ? yb : xb) + plane * TSB, r - plane * NPB, lane, pix0, pstep, L,
-                              op ? yps : xps, ch * GM_CG, Cx, plane ? Cx : 0);
+                t16_dma_piece<false>(op ? Yb : Xb, (op ? yb : xb) + plane * TSB, r - plane * NPB, lane, op ? pixY : pix0, pstep,
+                              op ? Lk : L, op ? yps : xps, ch * GM_CG, Cx, plane ? Cx : 0);
             } else {
                 if (it < NPF) gtile_dma_piece<FT>(Xb, xb, it, lane, pix0, pstep, L, xps, ch * GM_CG, Cx);
-                else          gtile_dma_piece<FT>(Yb, yb, it - NPF, lane, pix0, pstep, L, yps, ch * GM_CG, Cx);
+                else          gtile_dma_piece<FT>(Yb, yb, it - NPF, lane, pixY, pstep, Lk, yps, ch * GM_CG, Cx);
             }
         }
     };
@@ -885,7 +909,7 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    if (t * 16 < L) {
+                    if (t * 16 < Lk) {
                         const int px = 16 * t + ln;
                         const float bv = CCA_LDS_LD(yb + gtile_f32_idx(px < NPF * 4 ? px : 0, 4 * ks + lg));
 #pragma unroll
@@ -924,7 +948,7 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                if (t * 16 < L) {
+                if (t * 16 < Lk) {
                     const u32x4 bh = frag(yh, 16 * t + ln, kk);
                     u32x4 bl = bh;
                     if (!BF) bl = frag(yl, 16 * t + ln, kk);
@@ -951,7 +975,7 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int i = 16 * (wv + GM_WAVES * a) + 4 * lg + q, j = 16 * t + ln;
-                if (i < L && j < L) {
+                if (i < L && j < Lk) {
                     float val = acc[a][t][q];
                     if (MASK && !row && i == j) val = -INFINITY;            // functions.py:11-12 (column self slot)
                     Tg[(size_t)(pix0 + i * pstep) * S + a_off + j] = val;

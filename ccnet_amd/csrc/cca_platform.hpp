@@ -216,13 +216,16 @@ struct Dev {
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
-inline Dev *dev_state() {
+// ``may_create`` false: hand out the device's side stream only if it exists already (a stream must not be created while the
+// caller's stream is being captured: stream / event creation is not a capturable operation and may invalidate the capture)
+inline Dev *dev_state(bool may_create = true) {
     static Dev devs[64];
     static std::mutex mu;
     const int d = [] { int x = 0; return hipGetDevice(&x) == hipSuccess && x >= 0 && x < 64 ? x : -1; }();
     if (d < 0) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
     Dev &v = devs[d];
+    if (!v.s && !may_create) return nullptr;
     if (!v.s) {
         hipStream_t s = nullptr;
         hipEvent_t f = nullptr, j = nullptr;
@@ -243,7 +246,9 @@ inline Dev *dev_state() {
 inline std::mutex &pair_lock() { static std::mutex mu; return mu; }
 // nullptr when the side stream cannot be had (the caller then stays on its own stream)
 inline hipStream_t fork(hipStream_t main) {
-    Dev *v = dev_state();
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(main, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    Dev *v = dev_state(cap == hipStreamCaptureStatusNone);      // first use inside a capture: stay on the caller's stream
     if (!v) return nullptr;
     std::lock_guard<std::mutex> lock(pair_lock());
     if (hipEventRecord(v->fork, main) != hipSuccess || hipStreamWaitEvent(v->s, v->fork, 0) != hipSuccess) {

@@ -627,6 +627,29 @@ def test_split_plane_core_matches_the_fp32_pixel_major_core_and_the_oracle(ops, 
     assert np.array_equal(y, y3)                                                    # run-to-run bit identity
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 3, 133), (2, 64, 5, 140), (1, 128, 2, 257), (1, 64, 4, 264), (1, 64, 2, 270), (1, 64, 132, 133)])
+def test_split_plane_forward_with_long_rows_matches_the_oracle(ops, shape):
+    """ccnet_cca_forward_planes_f32 with ROW strips of 133 .. 528 positions (the 129 x 257 map of the reference's whole-image
+    evaluation, evaluate.py:102-143): a row strip is cut into blocks of <= 132 positions (cca::long_block); the energies kernel
+    computes one (query block, key block) tile pair per workgroup, the row pass of the aggregation runs once per KEY block with
+    the partial updated in place.  y and A against the oracle at the fp32 bar; masked self slots; run-to-run bit identity;
+    the backward entry refuses such shapes (training crops are 97 x 97: networks/ccnet.py, train.py)."""
+    B, C, H, W = shape
+    cq = C // 8
+    c = rand_case(*shape, seed=71)
+    qkv = np.ascontiguousarray(np.concatenate([_pm(c["q"]), _pm(c["k"]), _pm(c["v"])], axis=3))
+    vpl = ops.split_planes(qkv, C, c0=2 * cq)
+    y, A = ops.cca_forward_planes(qkv, vpl, c["x"], c["gamma"], cq)
+    assert np.all(np.isfinite(y)) and np.all(A[:, np.arange(H), :, np.arange(H)] == 0)
+    yo, Ao = O.cca_core_forward(T(c["q"]), T(c["k"]), T(c["v"]), T(c["x"]), T(c["gamma"]))
+    assert maxerr(A, Ao.numpy()) < 2e-6
+    assert maxerr(y, yo.numpy()) < 2e-4 * max(1.0, float(yo.abs().max()))
+    y2, A2 = ops.cca_forward_planes(qkv, vpl, c["x"], c["gamma"], cq)
+    assert np.array_equal(y, y2) and np.array_equal(A, A2)
+    with pytest.raises(RuntimeError):
+        ops.cca_backward_planes(c["dy"], qkv, vpl, A, c["gamma"], cq)
+
+
 @pytest.mark.parametrize("shape", [(2, 128, 5, 6), (1, 192, 17, 20), (1, 64, 3, 97)])
 def test_streaming_dA_kernel_walks_many_strips_per_workgroup(ops, shape):
     """gweight_stream_kernel (persistent dA contraction of the split-plane backward): with the workgroup count capped at 3 every

@@ -503,6 +503,34 @@ def test_split_plane_module_node_matches_the_oracle_and_the_other_nodes(lib, dev
     assert abs(float(a[2]["gamma"]) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
 
 
+@pytest.mark.parametrize("shape", [(1, 512, 129, 257), (2, 256, 97, 193), (1, 64, 132, 400)])
+def test_inference_with_long_rows_runs_the_plane_kernels_and_matches_the_oracle(lib, dev, shape):
+    """evaluate.py:102-143,246: whole-image inference puts a 129 x 257 map through the module under torch.no_grad().  The forward of
+    the split-plane path takes such rows in blocks of <= 132 positions; y against the oracle at the north_star bar (projections
+    at their default initialisation), against the NCHW strip / windowed kernels, and with autograd on the module still takes the
+    strip node (no blocked backward)."""
+    from ccnet_amd import CrissCrossAttention
+    B, C, H, W = shape
+    torch.manual_seed(11)
+    m = CrissCrossAttention(C).to(dev).eval()
+    with torch.no_grad():
+        m.gamma.fill_(0.5)
+    x = torch.randn(B, C, H, W, device=dev)
+    assert m.route(x) == "f32-strips-node"
+    with torch.no_grad():
+        assert m.route(x) == "f32-planes"
+        y = m(x)
+        m.split_planes = False
+        assert m.route(x) != "f32-planes"
+        ys = m(x)
+        f = lambda t: t.detach().float().cpu()                              # noqa: E731
+        qo, ko, vo = (f(c(x)) for c in (m.query_conv, m.key_conv, m.value_conv))
+    yo, _ = O.cca_core_forward(qo, ko, vo, f(x), torch.tensor([0.5]))
+    print("long-row inference", shape, "y vs oracle", f"{err(y, yo):.1e}", "vs strip kernels", f"{err(y, ys):.1e}")
+    assert err(y, yo) < TOL and err(y, ys) < 2e-4
+    assert y.is_contiguous() and bool(torch.isfinite(y).all())
+
+
 def test_split_plane_core_at_the_headline_shape_against_the_oracle(lib, dev):
     """(8,512,97,97) fp32 -- BASELINE.json configs[1] -- through the split-plane C ABI (unscaled N(0,1) q, k: the
     peaky-softmax worst case): y, dq, dk, dv vs the CPU oracle image by image at the north_star bar; run-to-run bit
