@@ -228,6 +228,33 @@ def test_measured_traffic_is_keyed_to_the_kernel_sources(tmp_path, monkeypatch):
     assert bench.measured_traffic(None, "missing.json") is None
 
 
+def test_options_and_workspace_sizes_are_host_logic_behind_two_entry_points(device_lib_path):
+    """The process-wide options live behind ccnet_cca_set_option / _get_option by name and every workspace size behind
+    ccnet_cca_workspace_bytes(entry, ...) (29 exported symbols).  Pure host logic: no kernel is launched."""
+    from ccnet_amd import _lib
+    lib = _lib.get_lib()
+    assert len(_lib.declared_symbols()) <= 30
+    for name, default in ((b"impl", _lib.CCNET_IMPL_AUTO), (b"precision", _lib.CCNET_PRECISION_DEFAULT), (b"branch_mask", 3),
+                          (b"planes_ring", 2), (b"planes_stream", 1), (b"planes_overlap", -1)):
+        assert lib.ccnet_cca_get_option(name) == default, name
+    assert lib.ccnet_cca_set_option(b"planes_overlap", 0) == -1 and lib.ccnet_cca_get_option(b"planes_overlap") == 0
+    assert lib.ccnet_cca_set_option(b"planes_overlap", -1) == 0
+    assert lib.ccnet_cca_set_option(b"impl", 99) == _lib.CCNET_IMPL_AUTO and lib.ccnet_cca_get_impl() == _lib.CCNET_IMPL_AUTO   # invalid: unchanged
+    assert lib.ccnet_cca_set_option(b"no_such_option", 1) < 0 and lib.ccnet_cca_get_option(b"no_such_option") < 0
+    assert b"unknown option" in lib.ccnet_cca_last_error_string()
+    B, C, Cq, H, W = 8, 512, 64, 97, 97
+    px = B * H * W * 4
+    sm = lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
+    assert sm > 0 and lib.ccnet_cca_workspace_bytes(_lib.CCNET_WS_SOFTMAX_BACKWARD, B, 0, 0, H, W) == sm
+    assert lib.ccnet_cca_pm_workspace_bytes(B, C, Cq, H, W, 0) == px * C                       # the column partial
+    pmb = lib.ccnet_cca_pm_workspace_bytes(B, C, Cq, H, W, 1)
+    assert pmb >= sm + px * C + px * 2 * Cq                                                     # + softmax slabs + the dq | dk partials
+    plb = lib.ccnet_cca_planes_workspace_bytes(B, C, Cq, H, W, 1)
+    assert plb >= pmb + B * H * W * 2 * C * 2                                                   # + dy as planes
+    assert lib.ccnet_cca_planes_workspace_bytes(B, C, Cq, H, W, 0) == px * C
+    assert lib.ccnet_cca_workspace_bytes(99, B, C, Cq, H, W) == 0 and lib.ccnet_cca_workspace_bytes(_lib.CCNET_WS_PM_FORWARD, 0, C, Cq, H, W) == 0
+
+
 def test_module_routing_table(device_lib_path):
     """``CrissCrossAttention.forward`` is ONE routing table.  ``route`` is a pure function of the input's
     dtype / layout / shape, the module's flags and the two process-wide knobs; enumerate it (no kernel is launched: the
