@@ -827,10 +827,13 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
     // split planes: T16 tile geometry (unpadded 1 KiB pieces, cca_gmap's plane tiles) so that THREE stages of X hi | X lo |
     // Y hi | Y lo fit the 160 KB (159,744 B at P = 100): two stages in flight while one is multiplied (with two stages the
     // launch ran at 4.2 TB/s, bound by the one stage a CU had in flight: profiles/r03e_bench.json)
-    constexpr int TSB = PL ? t16_size(P) : GTile<bf16_t>::size(P);   // dwords per bf16 image
-    constexpr int NPB = PL ? t16_pieces(P) : GTile<bf16_t>::pieces(P);
+    // bf16 features use the same unpadded row-read T16 geometry (the padded 8-pixel pieces it had put positions p and p + 8 two
+    // bank quads apart: 48 % LDS conflict cycles in the configs[4] dA / energies launches, profiles/r03v_bf16_config5_pmc_summary.json)
+    constexpr bool T16 = PL || BF;
+    constexpr int TSB = T16 ? t16_size(P) : GTile<bf16_t>::size(P);   // dwords per bf16 image
+    constexpr int NPB = T16 ? t16_pieces(P) : GTile<bf16_t>::pieces(P);
     constexpr int NT = (P + 15) / 16, NTR = (NT + GM_WAVES - 1) / GM_WAVES;
-    constexpr int TSZ = PL ? 2 * TSB : GTile<FT>::size(P), NPF = PL ? 2 * NPB : GTile<FT>::pieces(P);
+    constexpr int TSZ = PL ? 2 * TSB : BF ? TSB : GTile<FT>::size(P), NPF = PL ? 2 * NPB : BF ? NPB : GTile<FT>::pieces(P);
     constexpr int NBUF = SINGLE ? 1 : (PL && 3 * 2 * 2 * TSB * 4 <= 163840) ? 3 : 2;
     constexpr int D = NBUF > 1 ? NBUF - 1 : 1;                        // fills run D stages ahead
     constexpr int LDS = 2 * NBUF * TSZ + (PRESPLIT ? 4 * TSB : 0);
@@ -865,6 +868,10 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
                 const int op = it >= NPF, r = it - op * NPF, plane = r >= NPB;
                 t16_dma_piece<false>(op ? Yb : Xb, (op ? yb : xb) + plane * TSB, r - plane * NPB, lane, op ? pixY : pix0, pstep,
                               op ? Lk : L, op ? yps : xps, ch * GM_CG, Cx, plane ? Cx : 0);
+            } else if constexpr (BF) {
+                const int op = it >= NPF;
+                t16_dma_piece<false>(op ? Yb : Xb, op ? yb : xb, it - op * NPF, lane, op ? pixY : pix0, pstep, op ? Lk : L,
+                                     op ? yps : xps, ch * GM_CG, Cx, 0);
             } else {
                 if (it < NPF) gtile_dma_piece<FT>(Xb, xb, it, lane, pix0, pstep, L, xps, ch * GM_CG, Cx);
                 else          gtile_dma_piece<FT>(Yb, yb, it - NPF, lane, pixY, pstep, Lk, yps, ch * GM_CG, Cx);
@@ -881,7 +888,7 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
     auto frag = [&](const float *tile, int pixel_, int kk) {
         const int pixel = pixel_ < 8 * NPB ? pixel_ : 0;                            // (tile rows beyond the strip: results unused)
         const int chunk = 4 * kk + lg;
-        if constexpr (PL) return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(tile) + t16_byte<false>(pixel, 8 * chunk));
+        if constexpr (T16) return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(tile) + t16_byte<false>(pixel, 8 * chunk));
         const int off = (pixel >> 3) * GM_PB + (pixel & 7) * 32 + ((chunk ^ (pixel & 7)) << 2);
         return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint32_t *>(tile) + off);
     };
