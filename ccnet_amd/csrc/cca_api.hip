@@ -1063,12 +1063,15 @@ int launch_gmap_planes_p(const float *T, const bf16p_t *F, const float *resid, c
                gr.n_whole, gr.split, cca::GmapJob<bf16p_t, float>{});
     return launch_status("gmap_planes(row)");
 }
-// forward aggregation with LONG rows (133 .. 528 positions, columns <= 132): the column pass as ever (its strips are columns);
-// the row pass as nb launches, one per KEY block: partial += gamma * A[:, key block] . v[key block] in place, the last one adds
-// the residual and writes y (NCHW).  A workgroup owns one QUERY block of a row strip.
+// aggregation (or its dv adjoint, TRANS) with LONG rows (133 .. 528 positions, columns <= 132): the column pass as ever (its
+// strips are columns); the row pass as nb launches, one per block of the CONTRACTED positions: partial += gamma * (attention
+// block) . (feature block) in place, the last one writes the output (NCHW: + the residual).  A workgroup owns one OUTPUT block of
+// a row strip.
+template <bool TRANS, bool NCHW>
 int launch_gmap_planes_long_rows(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
-                                 int B, int C, int H, int W, long fbs, int fps, long rbs, long obs, ccnet_stream_t stream) {
-    if (int e = launch_gmap3_planes<132, false>(T, F, gamma, out, partial, B, C, H, W, fbs, fps, 0L, 0, false, stream)) return e;
+                                 int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops,
+                                 ccnet_stream_t stream) {
+    if (int e = launch_gmap3_planes<132, TRANS>(T, F, gamma, out, partial, B, C, H, W, fbs, fps, 0L, 0, false, stream)) return e;
     const int nb = long_blocks(W);
     const long pbs = (long)H * W * C;
     const GmapPlan gr = gmap_plan(B * H * nb, C, 1);
@@ -1077,13 +1080,13 @@ int launch_gmap_planes_long_rows(const float *T, const bf16p_t *F, const float *
         job.nb = nb;
         job.jblk = j;
         if (j + 1 < nb)
-            CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, bf16p_t, float, false, false, 1, true>), dim3((unsigned)gr.grid),
+            CCA_LAUNCH((cca::gmap_kernel<132, true, TRANS, true, bf16p_t, float, false, false, 1, true>), dim3((unsigned)gr.grid),
                        dim3(cca::GS_THREADS), stream, T, F, (const float *)partial, (const float *)nullptr, gamma, partial, C, H, W,
                        fbs, fps, pbs, C, 0L, 0, pbs, C, gr.n_whole, gr.split, job);
         else
-            CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, bf16p_t, float, true, false, 1, true>), dim3((unsigned)gr.grid),
+            CCA_LAUNCH((cca::gmap_kernel<132, true, TRANS, true, bf16p_t, float, NCHW, false, 1, true>), dim3((unsigned)gr.grid),
                        dim3(cca::GS_THREADS), stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C,
-                       rbs, 0, obs, 0, gr.n_whole, gr.split, job);
+                       rbs, rps, obs, ops, gr.n_whole, gr.split, job);
         if (int e = launch_status("gmap_planes(long rows)")) return e;
     }
     return 0;
@@ -1091,8 +1094,8 @@ int launch_gmap_planes_long_rows(const float *T, const bf16p_t *F, const float *
 template <bool TRANS, bool NCHW>
 int launch_gmap_planes(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
                        int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
-    if constexpr (!TRANS && NCHW)
-        if (W > 132) return launch_gmap_planes_long_rows(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, obs, stream);
+    if (W > 132)
+        return launch_gmap_planes_long_rows<TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
     if ((H > W ? H : W) <= 100)
         return launch_gmap_planes_p<100, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
     return launch_gmap_planes_p<132, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
@@ -1125,6 +1128,19 @@ int gmap_dual_f32(const float *dE, const float *k, const float *q, float *dq, fl
                stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
                0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
     if (int e = launch_status("gmap_dual_f32(column, 132)")) return e;
+    if (W > 132) {          // long rows: one launch per block of the contracted positions, the partials updated in place
+        const int nb = long_blocks(W);
+        const GmapPlan gl = gmap_plan(B * H * nb, Cq, 1);
+        for (int j = 0; j < nb; ++j) {
+            const bool last = j + 1 == nb;
+            const cca::GmapJob<float, float> jl{q, pk, last ? dk : pk, qbs, last ? dkbs : pbs, qps, last ? dkps : Cq, gl.grid, nb, j};
+            CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, float, float, false, true, 1, true>), dim3(cca::gmap_dual_grid(gl.grid)),
+                       dim3(cca::GS_THREADS), stream, dE, k, (const float *)pq, (const float *)nullptr, (const float *)nullptr,
+                       last ? dq : pq, Cq, H, W, kbs, kps, pbs, Cq, 0L, 0, last ? dqbs : pbs, last ? dqps : Cq, gl.n_whole, gl.split, jl);
+            if (int e = launch_status("gmap_dual_f32(long rows)")) return e;
+        }
+        return 0;
+    }
     const cca::GmapJob<float, float> jr{q, pk, dk, qbs, dkbs, qps, dkps, gr.grid};
     CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, float, float, false, true, 1>), dim3(cca::gmap_dual_grid(gr.grid)), dim3(cca::GS_THREADS),
                stream, dE, k, (const float *)pq, (const float *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
@@ -1212,7 +1228,8 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
     if (int e = require_both_branches("cca_backward_planes_f32")) return e;
     if (!dy || !q || !k || !v_planes || !A || !gamma || !dq || !dk || !dv || !dgamma || !scratch)
         return fail(CCNET_E_NULLPTR, "cca_backward_planes: null tensor");
-    if (int e = check_planes_problem("cca_backward_planes: strips <= 132, C % 8 == 0, Cq % 4 == 0", B, C, Cq, H, W)) return e;
+    if (int e = check_planes_problem("cca_backward_planes: columns <= 132, rows <= 528 (> 132: C/8 <= 64), C % 8 == 0, Cq % 4 == 0",
+                                     B, C, Cq, H, W, true)) return e;
     if (int e = check_pm_view<float>("cca_backward_planes: q view", q_bs, q_ps, Cq, H, W)) return e;
     if (int e = check_pm_view<float>("cca_backward_planes: k view", k_bs, k_ps, Cq, H, W)) return e;
     if (int e = check_planes_view("cca_backward_planes: v planes view", v_bs, v_ps, C, H, W)) return e;
@@ -1236,7 +1253,13 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
     if (overlap == 2) sf.fork();
     // t = un-scaled dA (the adjoint of the aggregation, functions.py:46-47), dv = gamma * A^T-weighted dy
     int e = 0;
-    if ((H > W ? H : W) > 100) {
+    if (W > 132) {           // long rows: nb x nb (query block, key block) tiles per row strip
+        const int nb = long_blocks(W);
+        const dim3 grid((unsigned)(B * (W + H * nb * nb))), block(cca::GM_THREADS);
+        CCA_LAUNCH((cca::gweight_kernel<132, false, bf16p_t, false, true>), grid, block, stream, dyp, vp, scratch, C, H, W, dbs, 2 * C,
+                   v_bs, v_ps, nb);
+        e = launch_status("gweight_planes(dA, long rows)");
+    } else if ((H > W ? H : W) > 100) {
         const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
         CCA_LAUNCH((cca::gweight_kernel<132, false, bf16p_t, false>), grid, block, stream, dyp, vp, scratch, C, H, W, dbs, 2 * C, v_bs, v_ps);
         e = launch_status("gweight_planes(dA, 132)");

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     constexpr int CPI = P <= 128 ? 2 : 1, LPC = kWave / CPI;          // NCHW: channels per store instruction, lanes per channel (4 positions each)
     constexpr int NSX = GM_CG / CPI / GS_WAVES;                       // NCHW: store instructions per wave and group
     static_assert(!NCHW || (ROW && ADD && !OBF && !TRANS && !DUAL), "gmap: the NCHW epilogue belongs to the final fp32 row pass");
-    static_assert(!LONG || (ROW && ADD && !TRANS && !DUAL), "gmap: blocked long strips exist for the forward row passes");
+    static_assert(!LONG || (ROW && ADD), "gmap: blocked long strips exist for the row passes (their addend chains the key blocks)");
     static_assert(!PL || !OBF, "gmap: split-plane features produce fp32 outputs");
     static_assert(P % 4 == 0 && (2 * FSZ + OIMG) * 4 * WPC <= 163840, "gmap: LDS of WPC workgroups per CU");
     __shared__ __attribute__((aligned(16))) float lds[2 * FSZ + OIMG];
@@ -246,7 +246,8 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     const int lb = LONG ? long_block(L, j1.nb) : 0;
     const int i0 = LONG ? qblk * lb : 0, j0 = LONG ? j1.jblk * lb : 0;
     const int Lm = LONG ? (L - i0 < lb ? L - i0 : lb) : L, Lk = LONG ? (L - j0 < lb ? L - j0 : lb) : L;
-    const int pixM = pix0 + i0 * pstep, pixK = pix0 + j0 * pstep, aK = a_off + j0;
+    // (the attention block P_g[m][k] is T[pixel(query)][slot(key)]: non-transposed the queries are the M side, transposed the K side)
+    const int pixM = pix0 + i0 * pstep, pixK = pix0 + j0 * pstep, aK = a_off + j0, aM = a_off + i0;
 
     const FBuf Tb = make_fbuf(T + (size_t)b * HW * S, (size_t)HW * S * sizeof(float));
     const FBuf Fb = make_fbuf(reinterpret_cast<const float *>(F + (size_t)b * fbs), ((size_t)(HW - 1) * fps + (PL ? 2 : 1) * C) * sizeof(FT));
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        x[e] = fbuf_load(Tb, (m < L && k0 + e < L) ? ((pix0 + (k0 + e) * pstep) * S + a_off + m) * 4 : kOobOffset, 0);
+                        x[e] = fbuf_load(Tb, (m < Lm && k0 + e < Lk) ? ((pixK + (k0 + e) * pstep) * S + aM + m) * 4 : kOobOffset, 0);
                 }
             } else {
 #pragma unroll
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
             al[a][ks] = sp.lo;
         }
         const int kt = 32 * kp.nbf + lg;
-        at[a] = fbuf_load(Tb, (kp.tail && m < Lm && kt < Lk) ? (trans ? ((pix0 + kt * pstep) * S + a_off + m) * 4
+        at[a] = fbuf_load(Tb, (kp.tail && m < Lm && kt < Lk) ? (trans ? ((pixK + kt * pstep) * S + aM + m) * 4
                                                                        : ((pixM + m * pstep) * S + aK + kt) * 4) : kOobOffset, 0);
     }
 

@@ -536,15 +536,15 @@ def _split_weight(w: torch.Tensor):
     return hi, (w - hi.float()).to(torch.bfloat16)
 
 
-def planes_cover(B, C, Cq, H, W, forward_only=False):
-    """geometry of the split-plane kernels (csrc/cca_gmap.hpp, bf16p_t).  ``forward_only`` (inference, torch.no_grad()): rows of up
-    to 4 x 132 positions run as blocks -- the 129 x 257 feature map of the reference's whole-image evaluation
-    (evaluate.py:102-143, 246) -- as long as the columns fit 132 and C/8 <= 64."""
+def planes_cover(B, C, Cq, H, W):
+    """geometry of the split-plane kernels (csrc/cca_gmap.hpp, bf16p_t): strips up to 132 positions, and -- as long as the
+    columns fit 132 and C/8 <= 64 -- ROWS of up to 4 x 132 positions, which run as blocks (the 129 x 257 feature map of the
+    reference's whole-image evaluation, evaluate.py:102-143, 246)."""
     if C % 8 or Cq % 4 or H * W * (C + 2 * Cq) >= 2 ** 29:
         return False
     if max(H, W) <= 132:
         return True
-    return bool(forward_only) and H <= 132 and W <= 4 * 132 and Cq <= 64
+    return H <= 132 and W <= 4 * 132 and Cq <= 64
 
 
 class CrissCrossPlanesModuleFunction(torch.autograd.Function):
@@ -718,8 +718,7 @@ class CrissCrossAttention(nn.Module):
             cl = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
             if fast_ok and cl and self.pixel_major_for_channels_last and pm_covers(torch.float32, B, C, cq, H, W):
                 return "f32-channels-last"
-            if (fast_ok and not cl and self.fuse_module_backward and self.split_planes
-                    and planes_cover(B, C, cq, H, W, forward_only=not torch.is_grad_enabled())):
+            if fast_ok and not cl and self.fuse_module_backward and self.split_planes and planes_cover(B, C, cq, H, W):
                 return "f32-planes"
             if self.fuse_projections and self.fuse_module_backward:
                 return "f32-strips-node"

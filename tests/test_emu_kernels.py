@@ -628,12 +628,12 @@ def test_split_plane_core_matches_the_fp32_pixel_major_core_and_the_oracle(ops, 
 
 
 @pytest.mark.parametrize("shape", [(1, 64, 3, 133), (2, 64, 5, 140), (1, 128, 2, 257), (1, 64, 4, 264), (1, 64, 2, 270), (1, 64, 132, 133)])
-def test_split_plane_forward_with_long_rows_matches_the_oracle(ops, shape):
+def test_split_plane_core_with_long_rows_matches_the_oracle(ops, shape):
     """ccnet_cca_forward_planes_f32 with ROW strips of 133 .. 528 positions (the 129 x 257 map of the reference's whole-image
     evaluation, evaluate.py:102-143): a row strip is cut into blocks of <= 132 positions (cca::long_block); the energies kernel
     computes one (query block, key block) tile pair per workgroup, the row pass of the aggregation runs once per KEY block with
-    the partial updated in place.  y and A against the oracle at the fp32 bar; masked self slots; run-to-run bit identity;
-    the backward entry refuses such shapes (training crops are 97 x 97: networks/ccnet.py, train.py)."""
+    the partial updated in place.  y, A and (the backward runs the same blocks) dq / dk / dv / dgamma against the oracle at the
+    fp32 bar; masked self slots; run-to-run bit identity."""
     B, C, H, W = shape
     cq = C // 8
     c = rand_case(*shape, seed=71)
@@ -646,8 +646,15 @@ def test_split_plane_forward_with_long_rows_matches_the_oracle(ops, shape):
     assert maxerr(y, yo.numpy()) < 2e-4 * max(1.0, float(yo.abs().max()))
     y2, A2 = ops.cca_forward_planes(qkv, vpl, c["x"], c["gamma"], cq)
     assert np.array_equal(y, y2) and np.array_equal(A, A2)
-    with pytest.raises(RuntimeError):
-        ops.cca_backward_planes(c["dy"], qkv, vpl, A, c["gamma"], cq)
+    # the backward in the same blocks: dA tiles per (query block, key block), dv / dq | dk row passes once per contracted block
+    nchw = lambda a: np.transpose(a, (0, 3, 1, 2))                                 # noqa: E731
+    dqkv, dg = ops.cca_backward_planes(c["dy"], qkv, vpl, A, c["gamma"], cq)
+    go = O.cca_core_backward(T(c["dy"]), T(c["q"]), T(c["k"]), T(c["v"]), Ao, T(c["gamma"]))
+    for name, got in (("dq", dqkv[..., :cq]), ("dk", dqkv[..., cq:2 * cq]), ("dv", dqkv[..., 2 * cq:])):
+        assert maxerr(nchw(got), go[name].numpy()) < 5e-4 * max(1.0, float(go[name].abs().max())), name
+    assert abs(float(dg[0]) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
+    dqkv2, _ = ops.cca_backward_planes(c["dy"], qkv, vpl, A, c["gamma"], cq)
+    assert np.array_equal(dqkv, dqkv2)
 
 
 @pytest.mark.parametrize("shape", [(2, 128, 5, 6), (1, 192, 17, 20), (1, 64, 3, 97)])

@@ -504,31 +504,42 @@ def test_split_plane_module_node_matches_the_oracle_and_the_other_nodes(lib, dev
 
 
 @pytest.mark.parametrize("shape", [(1, 512, 129, 257), (2, 256, 97, 193), (1, 64, 132, 400)])
-def test_inference_with_long_rows_runs_the_plane_kernels_and_matches_the_oracle(lib, dev, shape):
-    """evaluate.py:102-143,246: whole-image inference puts a 129 x 257 map through the module under torch.no_grad().  The forward of
-    the split-plane path takes such rows in blocks of <= 132 positions; y against the oracle at the north_star bar (projections
-    at their default initialisation), against the NCHW strip / windowed kernels, and with autograd on the module still takes the
-    strip node (no blocked backward)."""
+def test_long_rows_run_the_plane_kernels_and_match_the_oracle(lib, dev, shape):
+    """evaluate.py:102-143,246: whole-image inference puts a 129 x 257 map through the module.  The split-plane path takes such
+    rows in blocks of <= 132 positions, forward and backward: y (no_grad and with autograd) against the oracle at the north_star
+    bar (projections at their default initialisation) and against the NCHW strip / windowed kernels; dx and the seven parameter
+    gradients against the strip node."""
     from ccnet_amd import CrissCrossAttention
     B, C, H, W = shape
     torch.manual_seed(11)
-    m = CrissCrossAttention(C).to(dev).eval()
+    m = CrissCrossAttention(C).to(dev)
     with torch.no_grad():
         m.gamma.fill_(0.5)
     x = torch.randn(B, C, H, W, device=dev)
-    assert m.route(x) == "f32-strips-node"
+    dy = torch.randn(B, C, H, W, device=dev)
+    outs = {}
+    for planes in (True, False):
+        m.split_planes = planes
+        assert (m.route(x) == "f32-planes") == planes
+        m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        y = m(xi)
+        y.backward(dy)
+        with torch.no_grad():
+            assert torch.equal(m(x), y.detach())                             # inference = the same forward
+        outs[planes] = (y.detach(), xi.grad, {n: p.grad.clone() for n, p in m.named_parameters()})
     with torch.no_grad():
-        assert m.route(x) == "f32-planes"
-        y = m(x)
-        m.split_planes = False
-        assert m.route(x) != "f32-planes"
-        ys = m(x)
         f = lambda t: t.detach().float().cpu()                              # noqa: E731
         qo, ko, vo = (f(c(x)) for c in (m.query_conv, m.key_conv, m.value_conv))
     yo, _ = O.cca_core_forward(qo, ko, vo, f(x), torch.tensor([0.5]))
-    print("long-row inference", shape, "y vs oracle", f"{err(y, yo):.1e}", "vs strip kernels", f"{err(y, ys):.1e}")
-    assert err(y, yo) < TOL and err(y, ys) < 2e-4
-    assert y.is_contiguous() and bool(torch.isfinite(y).all())
+    a, b = outs[True], outs[False]
+    rel = {n: err(g, b[2][n]) / max(1.0, float(g.abs().max())) for n, g in a[2].items()}
+    print("long rows", shape, "y vs oracle", f"{err(a[0], yo):.1e}", "vs strip kernels", f"{err(a[0], b[0]):.1e}", "dx",
+          f"{err(a[1], b[1]) / max(1.0, float(b[1].abs().max())):.1e}", {n: f"{e:.1e}" for n, e in rel.items()})
+    assert err(a[0], yo) < TOL and err(a[0], b[0]) < 2e-4
+    assert err(a[1], b[1]) < 5e-4 * max(1.0, float(b[1].abs().max()))
+    for n, e in rel.items():
+        assert e < 3e-3, n
 
 
 def test_split_plane_core_at_the_headline_shape_against_the_oracle(lib, dev):

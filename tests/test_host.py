@@ -269,15 +269,16 @@ def test_module_routing_table(device_lib_path):
         ("f32 NCHW 97x97 B=8", lambda: m.route(nchw(8, 97, 97))): "f32-planes",
         ("f32 NCHW 97x97 B=1", lambda: m.route(nchw(1, 97, 97))): "f32-planes",
         ("f32 NCHW 129x129 (plane kernels padded to 132 positions)", lambda: m.route(nchw(2, 129, 129))): "f32-planes",
-        ("f32 NCHW 129x257 with autograd (beyond the plane kernels' backward)", lambda: m.route(nchw(2, 129, 257))): "f32-strips-node",
+        ("f32 NCHW 129x257 (rows in blocks of <= 132 positions)", lambda: m.route(nchw(2, 129, 257))): "f32-planes",
+        ("f32 NCHW 97x193", lambda: m.route(nchw(1, 97, 193))): "f32-planes",
         ("f32 NCHW 161x321 (columns beyond 132)", lambda: m.route(nchw(1, 161, 321))): "f32-strips-node",
+        ("f32 NCHW 129x600 (rows beyond 4 blocks)", lambda: m.route(nchw(1, 129, 600))): "f32-strips-node",
         ("f32 channels_last", lambda: m.route(cl(2, 33, 18))): "f32-channels-last",
     }
     for (what, fn), want in table.items():
         assert fn() == want, what
-    with torch.no_grad():       # inference (evaluate.py:246): the forward takes rows of up to 4 x 132 positions in blocks
-        assert m.route(nchw(1, 129, 257)) == "f32-planes" and m.route(nchw(1, 97, 193)) == "f32-planes"
-        assert m.route(nchw(1, 161, 321)) == "f32-strips-node" and m.route(nchw(1, 129, 600)) == "f32-strips-node"
+    with torch.no_grad():       # inference (evaluate.py:246) takes the same routes
+        assert m.route(nchw(1, 129, 257)) == "f32-planes" and m.route(nchw(1, 161, 321)) == "f32-strips-node"
     m.to(torch.bfloat16)
     assert m.route(cl(2, 129, 129, torch.bfloat16)) == "bf16-pixel-major"
     assert m.route(nchw(1, 330, 9, torch.bfloat16)) == "packed-strips"           # any-shape fp32 kernels through fp32 copies
