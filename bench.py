@@ -470,6 +470,29 @@ def launch_accounting(lib, wl, graph, steps=20):
     return out
 
 
+def gpu_state_under_load(step, device_index=0, replays=1500):
+    """Clocks and power of the GPU WHILE the step is running (rocm-smi sampled against a queue of asynchronously enqueued
+    steps): boxes of the pool differ by up to 12 % on this workload with identical streaming-kernel times -- the slow ones run
+    every latency- / matrix-bound launch 10-35 % slower (profiles/r04b_*) -- and the shader clock under load is the first thing
+    to look at.  None when rocm-smi is not there."""
+    import re
+    try:
+        for _ in range(replays):
+            step()
+        p = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower", "--showperflevel", "--json"],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20)
+        busy = not torch.cuda.current_stream().query()          # (the queue must still be running when the sample returns)
+        torch.cuda.synchronize()
+        card = next(iter(json.loads(p.stdout).values()))
+        num = lambda k: (lambda m: float(m.group(1)) if m else None)(re.search(r"([0-9.]+)", str(card.get(k, ""))))   # noqa: E731
+        return {"sclk_mhz": num("sclk clock speed:"), "mclk_mhz": num("mclk clock speed:"), "fclk_mhz": num("fclk clock speed:"),
+                "socket_power_w": num("Current Socket Graphics Package Power (W)"), "perf_level": card.get("Performance Level"),
+                "sampled_while_busy": bool(busy)}
+    except Exception as e:          # the metric does not depend on it
+        torch.cuda.synchronize()
+        return {"error": str(e)[:120]}
+
+
 def planes_launch_bytes(B, C, H, W):
     """Algorithmic (compulsory) bytes of every launch of one split-plane step, in issue order: what the launch must read and
     write once, from the tensor sizes of SURVEY 8(d) (feature C-sized 4*P*C, Cq-sized 4*P*Cq, attention-shaped 4*P*S)."""
@@ -1004,6 +1027,7 @@ def main(argv=None, workload_factory=None):
         bwd_ms = time_region(wl.backward, 10)
         out["fwd_ms"], out["bwd_ms"] = round(fwd_ms, 4), round(bwd_ms, 4)
         out.update(launch_accounting(lib, wl, graph))
+        out["gpu_state_under_load"] = gpu_state_under_load(step, local)
         if isinstance(wl, PlanesWorkload):
             out["roofline"] = planes_roofline(lib, wl, ms, out.get("launch_ms", []))
             out["producer_split_ms"] = round(time_region(wl.split, 20), 4)
