@@ -1067,24 +1067,26 @@ int launch_gmap_planes_p(const float *T, const bf16p_t *F, const float *resid, c
 // strips are columns); the row pass as nb launches, one per block of the CONTRACTED positions: partial += gamma * (attention
 // block) . (feature block) in place, the last one writes the output (NCHW: + the residual).  A workgroup owns one OUTPUT block of
 // a row strip.
-template <bool TRANS, bool NCHW>
-int launch_gmap_planes_long_rows(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
-                                 int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops,
-                                 ccnet_stream_t stream) {
-    if (int e = launch_gmap3_planes<132, TRANS>(T, F, gamma, out, partial, B, C, H, W, fbs, fps, 0L, 0, false, stream)) return e;
-    const int nb = long_blocks(W);
+// P = 100 with blocks of <= 100 positions where four of them cover the row (W <= 400): the 100-position kernels keep their
+// attention fragments in 96 registers and run two workgroups per CU; at 132 positions they take 192 and run one (1 wave per SIMD)
+template <int P, bool TRANS, bool NCHW>
+int launch_gmap_planes_long_rows_p(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
+                                   int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops,
+                                   ccnet_stream_t stream) {
+    constexpr int WPC = P > 100 ? 1 : 2;
+    const int nb = (W + P - 1) / P;
     const long pbs = (long)H * W * C;
-    const GmapPlan gr = gmap_plan(B * H * nb, C, 1);
+    const GmapPlan gr = gmap_plan(B * H * nb, C, WPC);
     for (int j = 0; j < nb; ++j) {
         cca::GmapJob<bf16p_t, float> job{};
         job.nb = nb;
         job.jblk = j;
         if (j + 1 < nb)
-            CCA_LAUNCH((cca::gmap_kernel<132, true, TRANS, true, bf16p_t, float, false, false, 1, true>), dim3((unsigned)gr.grid),
+            CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, bf16p_t, float, false, false, WPC, true>), dim3((unsigned)gr.grid),
                        dim3(cca::GS_THREADS), stream, T, F, (const float *)partial, (const float *)nullptr, gamma, partial, C, H, W,
                        fbs, fps, pbs, C, 0L, 0, pbs, C, gr.n_whole, gr.split, job);
         else
-            CCA_LAUNCH((cca::gmap_kernel<132, true, TRANS, true, bf16p_t, float, NCHW, false, 1, true>), dim3((unsigned)gr.grid),
+            CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, bf16p_t, float, NCHW, false, WPC, true>), dim3((unsigned)gr.grid),
                        dim3(cca::GS_THREADS), stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C,
                        rbs, rps, obs, ops, gr.n_whole, gr.split, job);
         if (int e = launch_status("gmap_planes(long rows)")) return e;
@@ -1092,8 +1094,19 @@ int launch_gmap_planes_long_rows(const float *T, const bf16p_t *F, const float *
     return 0;
 }
 template <bool TRANS, bool NCHW>
+int launch_gmap_planes_long_rows(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
+                                 int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops,
+                                 ccnet_stream_t stream) {
+    if (int e = launch_gmap3_planes<132, TRANS>(T, F, gamma, out, partial, B, C, H, W, fbs, fps, 0L, 0, false, stream)) return e;
+    if (W <= 400)
+        return launch_gmap_planes_long_rows_p<100, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+    return launch_gmap_planes_long_rows_p<132, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+}
+template <bool TRANS, bool NCHW>
 int launch_gmap_planes(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
                        int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
+    // (rows of 101 .. 132 positions stay whole on the 132-position kernels: as two blocks on the 100-position ones the extra pass
+    // over the partial costs more than the second workgroup per CU returns -- (16,512,129,129) 3.55 -> 3.70 ms, profiles/r04f_planes_129.txt)
     if (W > 132)
         return launch_gmap_planes_long_rows<TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
     if ((H > W ? H : W) <= 100)
@@ -1129,14 +1142,20 @@ int gmap_dual_f32(const float *dE, const float *k, const float *q, float *dq, fl
                0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
     if (int e = launch_status("gmap_dual_f32(column, 132)")) return e;
     if (W > 132) {          // long rows: one launch per block of the contracted positions, the partials updated in place
-        const int nb = long_blocks(W);
-        const GmapPlan gl = gmap_plan(B * H * nb, Cq, 1);
+        const bool p100 = W <= 400;          // (blocks of <= 100 positions on the two-workgroups-per-CU kernels, see launch_gmap_planes_long_rows)
+        const int nb = p100 ? (W + 99) / 100 : long_blocks(W);
+        const GmapPlan gl = gmap_plan(B * H * nb, Cq, p100 ? 2 : 1);
         for (int j = 0; j < nb; ++j) {
             const bool last = j + 1 == nb;
             const cca::GmapJob<float, float> jl{q, pk, last ? dk : pk, qbs, last ? dkbs : pbs, qps, last ? dkps : Cq, gl.grid, nb, j};
-            CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, float, float, false, true, 1, true>), dim3(cca::gmap_dual_grid(gl.grid)),
-                       dim3(cca::GS_THREADS), stream, dE, k, (const float *)pq, (const float *)nullptr, (const float *)nullptr,
-                       last ? dq : pq, Cq, H, W, kbs, kps, pbs, Cq, 0L, 0, last ? dqbs : pbs, last ? dqps : Cq, gl.n_whole, gl.split, jl);
+            if (p100)
+                CCA_LAUNCH((cca::gmap_kernel<100, true, false, true, float, float, false, true, 2, true>), dim3(cca::gmap_dual_grid(gl.grid)),
+                           dim3(cca::GS_THREADS), stream, dE, k, (const float *)pq, (const float *)nullptr, (const float *)nullptr,
+                           last ? dq : pq, Cq, H, W, kbs, kps, pbs, Cq, 0L, 0, last ? dqbs : pbs, last ? dqps : Cq, gl.n_whole, gl.split, jl);
+            else
+                CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, float, float, false, true, 1, true>), dim3(cca::gmap_dual_grid(gl.grid)),
+                           dim3(cca::GS_THREADS), stream, dE, k, (const float *)pq, (const float *)nullptr, (const float *)nullptr,
+                           last ? dq : pq, Cq, H, W, kbs, kps, pbs, Cq, 0L, 0, last ? dqbs : pbs, last ? dqps : Cq, gl.n_whole, gl.split, jl);
             if (int e = launch_status("gmap_dual_f32(long rows)")) return e;
         }
         return 0;

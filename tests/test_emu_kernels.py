@@ -627,7 +627,8 @@ def test_split_plane_core_matches_the_fp32_pixel_major_core_and_the_oracle(ops, 
     assert np.array_equal(y, y3)                                                    # run-to-run bit identity
 
 
-@pytest.mark.parametrize("shape", [(1, 64, 3, 133), (2, 64, 5, 140), (1, 128, 2, 257), (1, 64, 4, 264), (1, 64, 2, 270), (1, 64, 132, 133)])
+@pytest.mark.parametrize("shape", [(1, 64, 3, 133), (2, 64, 5, 140), (1, 128, 2, 257), (1, 64, 4, 264), (1, 64, 2, 299), (1, 64, 132, 133),
+                                   (1, 64, 2, 404), (1, 64, 1, 528)])      # rows > 400: blocks of <= 132 on the 132-position kernels
 def test_split_plane_core_with_long_rows_matches_the_oracle(ops, shape):
     """ccnet_cca_forward_planes_f32 with ROW strips of 133 .. 528 positions (the 129 x 257 map of the reference's whole-image
     evaluation, evaluate.py:102-143): a row strip is cut into blocks of <= 132 positions (cca::long_block); the energies kernel
