@@ -672,9 +672,10 @@ class CrissCrossAttention(nn.Module):
     #: pixel-major / split-plane routes are skipped while it is set.  Under torch.no_grad() / eval nothing is kept either way.
     recompute_attention = False
 
-    #: fp32 NCHW inputs (no autocast, strips <= 132): the SPLIT-PLANE node (``CrissCrossPlanesModuleFunction``: q | k | v out
-    #: of one GEMM pixel-major, v and dy pre-split into bf16 hi | lo planes, x / y / dy NCHW).  Measured on MI355X, core
-    #: fwd+bwd at (8,512,97,97): 0.83 ms vs 0.87 ms on the NCHW strips of the same box (profiles/r03d_family_compare.txt).
+    #: fp32 NCHW inputs (no autocast; columns <= 132, rows <= 528 positions -- see ``planes_cover``): the SPLIT-PLANE node
+    #: (``CrissCrossPlanesModuleFunction``: q | k | v out of one GEMM pixel-major, v and dy pre-split into bf16 hi | lo planes,
+    #: x / y / dy NCHW).  Measured on MI355X, core fwd+bwd at (8,512,97,97): 0.75-0.78 ms vs 0.88-0.90 ms on the NCHW strips of
+    #: the same boxes (profiles/r03q_bench.json, r03z_bench.json); whole-image inference (1,512,129,257): 0.475 vs 1.18 ms.
     split_planes = True
     #: the split-plane node also runs its three projection GEMMs split-bf16 x3 (one bf16 -> fp32 GEMM each on three-plane
     #: operands, fp32 accumulate, ~1e-5 relative): fwd 496 -> 278, dx 488 -> 265, dW 508 -> 325 us at (8,512,97,97)
@@ -703,7 +704,7 @@ class CrissCrossAttention(nn.Module):
     def route(self, x):
         """Which implementation ``forward`` runs for this input (a key of ``ROUTES``).  The pixel-major and split-plane
         routes always compute split-bf16 x3 (exact fp32 energies): they are skipped while the process-wide knobs pin exact
-        fp32 arithmetic (``ccnet_cca_set_precision(CCNET_PRECISION_F32)``) or the any-shape kernels (``CCNET_IMPL_DIRECT``),
+        fp32 arithmetic (option ``"precision"`` = CCNET_PRECISION_F32) or the any-shape kernels (``"impl"`` = CCNET_IMPL_DIRECT),
         while ``recompute_attention`` is set (they keep the attention tensor) and while ``fuse_projections`` is off."""
         B, C, H, W = x.shape
         cq = self.query_conv.out_channels
