@@ -18,7 +18,8 @@
  *     (key/value at (h,j)).
  *   - outputs are fully overwritten; nothing relies on pre-zeroed buffers.
  *   - launches go to ``stream`` (a hipStream_t; NULL = the legacy default stream); no call
- *     synchronises.  The compute entry points hold no per-call state and may be called concurrently
+ *     synchronises (the pixel-major / split-plane backwards fork part of their launches onto a library-owned side stream
+ *     and join it again before they return: see "planes_overlap").  The compute entry points hold no per-call state and may be called concurrently
  *     from several host threads / streams; the only process-wide state are the three MODE words behind
  *     the options "impl", "precision", "branch_mask" of ccnet_cca_set_option (atomics; defaults need no call).  A setter
  *     racing with a call in flight affects that call or the next one, never part of one.  The fused
