@@ -696,6 +696,7 @@ class CrissCrossAttention(nn.Module):
         "bf16-pixel-major": "one x^T W^T projection + pixel-major bf16 MFMA kernels (BASELINE configs[4])",
         "f32-channels-last": "one x^T W^T projection + pixel-major fp32 kernels, channels_last in / out",
         "f32-planes": "one autograd node: projection GEMM, v / dy as bf16 hi | lo planes, NCHW x / y / dy",
+        "f32-planes-transposed": "the same node on the spatially transposed input (maps taller than 132 whose width fits 132)",
         "f32-strips-node": "one autograd node on the NCHW strip kernels (honours recompute_attention)",
         "packed-strips": "stacked conv2d + NCHW strip kernels through channel-slice strides (any float dtype, autocast)",
         "separate-strips": "three convolutions + NCHW strip / windowed / any-shape kernels (functions.py:29-35 as written)",
@@ -721,6 +722,11 @@ class CrissCrossAttention(nn.Module):
                 return "f32-channels-last"
             if fast_ok and not cl and self.fuse_module_backward and self.split_planes and planes_cover(B, C, cq, H, W):
                 return "f32-planes"
+            # the op commutes with the spatial transposition (a pixel attends its column and its row, itself once: which of
+            # the two branches carries the masked self slot does not change the softmax), so a TALL map whose width fits the
+            # column kernels runs as its transpose: two transposing copies each way instead of the windowed strip kernels
+            if fast_ok and not cl and self.fuse_module_backward and self.split_planes and planes_cover(B, C, cq, W, H):
+                return "f32-planes-transposed"
             if self.fuse_projections and self.fuse_module_backward:
                 return "f32-strips-node"
         if self.fuse_projections and self._fusable():
@@ -747,8 +753,11 @@ class CrissCrossAttention(nn.Module):
             xp = x.permute(0, 2, 3, 1)
             qkv = torch.nn.functional.linear(xp, self._stacked_weight().flatten(1), self._stacked_bias())
             return CrissCrossPMFunction.apply(qkv, xp, self.gamma, cq).permute(0, 3, 1, 2)
-        if r == "f32-planes":
+        if r in ("f32-planes", "f32-planes-transposed"):
             split_gemm = self.split_bf16_projections and x.shape[0] * x.shape[2] * x.shape[3] >= self.split_bf16_min_pixels
+            if r == "f32-planes-transposed":
+                xt = x.transpose(2, 3).contiguous()
+                return CrissCrossPlanesModuleFunction.apply(xt, *params, self.gamma, split_gemm).transpose(2, 3).contiguous()
             return CrissCrossPlanesModuleFunction.apply(x, *params, self.gamma, split_gemm)
         if r == "f32-strips-node":
             return CrissCrossModuleFunction.apply(x, *params, self.gamma, self.recompute_attention)

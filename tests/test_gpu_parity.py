@@ -542,6 +542,39 @@ def test_long_rows_run_the_plane_kernels_and_match_the_oracle(lib, dev, shape):
         assert e < 3e-3, n
 
 
+def test_tall_maps_run_as_their_transpose(lib, dev):
+    """A map taller than 132 whose width fits the column kernels takes the split-plane node on its spatial transpose (the op
+    commutes with it: each pixel attends its row and its column, itself once).  y, dx and the parameter gradients against the NCHW
+    strip / windowed kernels on the untransposed map, y against the oracle."""
+    from ccnet_amd import CrissCrossAttention
+    B, C, H, W = 1, 128, 200, 60
+    torch.manual_seed(13)
+    m = CrissCrossAttention(C).to(dev)
+    with torch.no_grad():
+        m.gamma.fill_(0.5)
+    x = torch.randn(B, C, H, W, device=dev)
+    dy = torch.randn(B, C, H, W, device=dev)
+    outs = {}
+    for planes in (True, False):
+        m.split_planes = planes
+        assert (m.route(x) == "f32-planes-transposed") == planes
+        m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        y = m(xi)
+        y.backward(dy)
+        outs[planes] = (y.detach(), xi.grad, {n: p.grad.clone() for n, p in m.named_parameters()})
+    with torch.no_grad():
+        f = lambda t: t.detach().float().cpu()                              # noqa: E731
+        qo, ko, vo = (f(c(x)) for c in (m.query_conv, m.key_conv, m.value_conv))
+    yo, _ = O.cca_core_forward(qo, ko, vo, f(x), torch.tensor([0.5]))
+    a, b = outs[True], outs[False]
+    assert a[0].is_contiguous() and a[0].shape == x.shape
+    assert err(a[0], yo) < TOL and err(a[0], b[0]) < 2e-4
+    assert err(a[1], b[1]) < 5e-4 * max(1.0, float(b[1].abs().max()))
+    for n, g in a[2].items():
+        assert err(g, b[2][n]) < 3e-3 * max(1.0, float(g.abs().max())), n
+
+
 def test_split_plane_core_at_the_headline_shape_against_the_oracle(lib, dev):
     """(8,512,97,97) fp32 -- BASELINE.json configs[1] -- through the split-plane C ABI (unscaled N(0,1) q, k: the
     peaky-softmax worst case): y, dq, dk, dv vs the CPU oracle image by image at the north_star bar; run-to-run bit

@@ -272,6 +272,7 @@ def test_module_routing_table(device_lib_path):
         ("f32 NCHW 129x257 (rows in blocks of <= 132 positions)", lambda: m.route(nchw(2, 129, 257))): "f32-planes",
         ("f32 NCHW 97x193", lambda: m.route(nchw(1, 97, 193))): "f32-planes",
         ("f32 NCHW 161x321 (columns beyond 132)", lambda: m.route(nchw(1, 161, 321))): "f32-strips-node",
+        ("f32 NCHW 257x129 (tall: runs as its transpose)", lambda: m.route(nchw(1, 257, 129))): "f32-planes-transposed",
         ("f32 NCHW 129x600 (rows beyond 4 blocks)", lambda: m.route(nchw(1, 129, 600))): "f32-strips-node",
         ("f32 channels_last", lambda: m.route(cl(2, 33, 18))): "f32-channels-last",
     }
