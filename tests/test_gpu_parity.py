@@ -542,6 +542,38 @@ def test_long_rows_run_the_plane_kernels_and_match_the_oracle(lib, dev, shape):
         assert e < 3e-3, n
 
 
+def test_long_rows_at_random_geometries_match_the_strip_kernels(lib, dev):
+    """Block boundaries of the long-row path at arbitrary geometry: rows of 133 .. 528 positions (2 .. 4 blocks of <= 100 or <= 132,
+    ragged last block), columns 1 .. 132, channel counts that leave a partial 64-channel group, batches 1 .. 3 -- y, dx and the value
+    projection's weight gradient against the NCHW strip / windowed / any-shape kernels on the same module."""
+    from ccnet_amd import CrissCrossAttention
+    rng = np.random.default_rng(77)
+    shapes = [(1, 32, 1, 133), (2, 96, 7, 401), (1, 64, 132, 528), (3, 32, 2, 300), (1, 160, 33, 134)]
+    for _ in range(7):
+        shapes.append((int(rng.integers(1, 3)), 32 * int(rng.integers(1, 6)), int(rng.integers(1, 40)), int(rng.integers(133, 529))))
+    for B, C, H, W in shapes:
+        torch.manual_seed(B * 1000 + H * 7 + W)
+        m = CrissCrossAttention(C).to(dev)
+        with torch.no_grad():
+            m.gamma.fill_(0.7)
+        x = torch.randn(B, C, H, W, device=dev)
+        dy = torch.randn(B, C, H, W, device=dev)
+        outs = {}
+        for planes in (True, False):
+            m.split_planes = planes
+            assert (m.route(x) == "f32-planes") == planes, (B, C, H, W)
+            m.zero_grad(set_to_none=True)
+            xi = x.clone().requires_grad_(True)
+            y = m(xi)
+            y.backward(dy)
+            outs[planes] = (y.detach(), xi.grad, m.value_conv.weight.grad.clone(), m.key_conv.weight.grad.clone())
+        a, b = outs[True], outs[False]
+        assert bool(torch.isfinite(a[0]).all()), (B, C, H, W)
+        assert err(a[0], b[0]) < 2e-4, (B, C, H, W)
+        for i in (1, 2, 3):
+            assert err(a[i], b[i]) < 1e-3 * max(1.0, float(b[i].abs().max())), (B, C, H, W, i)
+
+
 def test_tall_maps_run_as_their_transpose(lib, dev):
     """A map taller than 132 whose width fits the column kernels takes the split-plane node on its spatial transpose (the op
     commutes with it: each pixel attends its row and its column, itself once).  y, dx and the parameter gradients against the NCHW
