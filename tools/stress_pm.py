@@ -14,7 +14,9 @@ cases = [("bf16 (16,512,129,129)", bench.PixelMajorBF16Workload(lib, 16, 512, 12
          ("bf16 (2,512,97,97)", bench.PixelMajorBF16Workload(lib, 2, 512, 97, 97, dev, 8)),
          ("f32 planes (8,512,97,97)", bench.PlanesWorkload(lib, 8, 512, 97, 97, dev, 9)),
          ("f32 planes (1,512,97,97)", bench.PlanesWorkload(lib, 1, 512, 97, 97, dev, 10)),
-         ("f32 planes (3,256,100,61)", bench.PlanesWorkload(lib, 3, 256, 100, 61, dev, 11))]
+         ("f32 planes (3,256,100,61)", bench.PlanesWorkload(lib, 3, 256, 100, 61, dev, 11)),
+         ("f32 planes, long rows (2,512,129,257)", bench.PlanesWorkload(lib, 2, 512, 129, 257, dev, 12)),       # blocks of <= 100
+         ("f32 planes, long rows (1,128,60,500)", bench.PlanesWorkload(lib, 1, 128, 60, 500, dev, 13))]          # blocks of <= 132
 for name, wl in cases:
     outs = lambda: (wl.y, wl.dqkv, wl.dgamma, wl.A)          # noqa: E731
     wl.step(); torch.cuda.synchronize()
