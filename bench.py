@@ -250,7 +250,8 @@ class PixelMajorBF16Workload:
         self.x, self.dy = rnd(B, H, W, C), rnd(B, H, W, C)
         self.gamma = torch.full((1,), 0.5, device=device)
         self.y, self.dqkv = torch.empty_like(self.x), torch.empty_like(self.qkv)
-        self.A = torch.empty(B, H, W, H + W, device=device)
+        self.A = torch.empty(B, H, W, H + W, device=device)          # two-stage softmax: un-normalised exponentials ...
+        self.stats = torch.empty(B, H, W, 4, device=device)          # ... and the per-pixel branch statistics
         self.scratch = torch.empty_like(self.A)
         self.dgamma = torch.empty(1, device=device)
         self.fws_bytes = lib.ccnet_cca_pm_workspace_bytes(B, C, Cq, H, W, 0)
@@ -265,7 +266,8 @@ class PixelMajorBF16Workload:
         L, cq, ct, p = self.lib, C // 8, self.ct, self.qkv.data_ptr()
         bs = H * W * ct
         L.check(L.ccnet_cca_forward_pm_bf16(p, p + 2 * cq, p + 4 * cq, self.x.data_ptr(), self.gamma.data_ptr(),
-                                            self.y.data_ptr(), self.A.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct, bs, ct,
+                                            self.y.data_ptr(), self.A.data_ptr(), self.stats.data_ptr(), B, C, cq, H, W,
+                                            bs, ct, bs, ct, bs, ct,
                                             H * W * C, C, H * W * C, C, self.ws.data_ptr(), self.fws_bytes, self.stream()),
                 "cca_forward_pm_bf16")
 
@@ -273,7 +275,7 @@ class PixelMajorBF16Workload:
         B, C, H, W = self.shape
         L, cq, ct, p, g = self.lib, C // 8, self.ct, self.qkv.data_ptr(), self.dqkv.data_ptr()
         bs = H * W * ct
-        L.check(L.ccnet_cca_backward_pm_bf16(self.dy.data_ptr(), p, p + 2 * cq, p + 4 * cq, self.A.data_ptr(),
+        L.check(L.ccnet_cca_backward_pm_bf16(self.dy.data_ptr(), p, p + 2 * cq, p + 4 * cq, self.A.data_ptr(), self.stats.data_ptr(),
                                              self.gamma.data_ptr(), g, g + 2 * cq, g + 4 * cq, self.dgamma.data_ptr(),
                                              self.scratch.data_ptr(), B, C, cq, H, W, H * W * C, C, bs, ct, bs, ct, bs, ct,
                                              bs, ct, bs, ct, bs, ct, self.ws.data_ptr(), self.ws_bytes, self.stream()),
@@ -283,12 +285,17 @@ class PixelMajorBF16Workload:
         self.forward()
         self.backward()
 
+    def attention(self):
+        from ccnet_amd.functions import attention_from_parts
+        return attention_from_parts(self.A, self.stats)
+
 
 class PlanesWorkload:
-    """The fp32 core on the SPLIT-PLANE path (include/ccnet_cca.h): q | k fp32 pixel-major slices of the packed projection,
-    v as bf16 hi | lo planes (split once by its producer, ccnet_cca_split_planes_f32 -- outside the core step, like the
-    projection itself; ``producer_split_ms`` times it), x / y / dy NCHW, dy split inside the timed step, dq | dk | dv fp32
-    pixel-major."""
+    """The fp32 core on the SPLIT-PLANE path (include/ccnet_cca.h): the step's inputs are what the reference's op gets --
+    q | k | v fp32 (pixel-major channel slices of the packed projection, functions.py:29-37), x / dy NCHW fp32 -- and EVERY pass
+    the op needs is inside the step (round 3 split v outside it): the forward entry point turns the fp32 value slice
+    into bf16 hi | lo planes itself (side stream, next to the affinity launch), the backward does the same for dy.  Outputs:
+    y NCHW, dq | dk | dv fp32 pixel-major, dgamma."""
 
     def __init__(self, lib, B, C, H, W, device, seed):
         self.lib, self.shape = lib, (B, C, H, W)
@@ -300,15 +307,14 @@ class PlanesWorkload:
         self.x, self.dy = rnd(B, C, H, W), rnd(B, C, H, W)
         self.gamma = torch.full((1,), 0.5, device=device)
         self.y, self.dqkv = torch.empty_like(self.x), torch.empty_like(self.qkv)
-        self.A = torch.empty(B, H, W, H + W, device=device)
+        self.A = torch.empty(B, H, W, H + W, device=device)          # two-stage softmax: un-normalised exponentials ...
+        self.stats = torch.empty(B, H, W, 4, device=device)          # ... and the per-pixel branch statistics
         self.scratch = torch.empty_like(self.A)
         self.dgamma = torch.empty(1, device=device)
-        self.vpl = torch.empty(B, H, W, 2, C, dtype=torch.int16, device=device)
+        self.vpl = torch.empty(B, H, W, 2, C, dtype=torch.int16, device=device)     # written by the forward, read by the backward
         self.fws_bytes = lib.ccnet_cca_planes_workspace_bytes(B, C, Cq, H, W, 0)
         self.ws_bytes = lib.ccnet_cca_planes_workspace_bytes(B, C, Cq, H, W, 1)
         self.ws = torch.empty(max(self.fws_bytes, self.ws_bytes) // 4 + 64, device=device)
-        self.split()
-        torch.cuda.synchronize()
 
     def stream(self):
         return torch.cuda.current_stream().cuda_stream
@@ -317,7 +323,12 @@ class PlanesWorkload:
         self.forward()
         self.backward()
 
+    def attention(self):
+        from ccnet_amd.functions import attention_from_parts
+        return attention_from_parts(self.A, self.stats)
+
     def split(self):
+        """the v -> planes pass alone (what the forward runs on its side stream), for ``producer_split_ms``"""
         B, C, H, W = self.shape
         L, cq, ct = self.lib, C // 8, self.ct
         L.check(L.ccnet_cca_split_planes_f32(self.qkv.data_ptr() + 8 * cq, self.vpl.data_ptr(), B, C, H, W, H * W * ct, ct,
@@ -327,9 +338,10 @@ class PlanesWorkload:
         B, C, H, W = self.shape
         L, cq, ct, p = self.lib, C // 8, self.ct, self.qkv.data_ptr()
         bs = H * W * ct
-        L.check(L.ccnet_cca_forward_planes_f32(p, p + 4 * cq, self.vpl.data_ptr(), self.x.data_ptr(), self.gamma.data_ptr(),
-                                               self.y.data_ptr(), self.A.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct,
-                                               H * W * 2 * C, 2 * C, self.ws.data_ptr(), self.fws_bytes, self.stream()),
+        L.check(L.ccnet_cca_forward_planes_f32(p, p + 4 * cq, p + 8 * cq, None, self.vpl.data_ptr(), self.x.data_ptr(),
+                                               self.gamma.data_ptr(), self.y.data_ptr(), self.A.data_ptr(), self.stats.data_ptr(),
+                                               B, C, cq, H, W, bs, ct, bs, ct, bs, ct, H * W * 2 * C, 2 * C,
+                                               self.ws.data_ptr(), self.fws_bytes, self.stream()),
                 "cca_forward_planes")
 
     def backward(self):
@@ -337,9 +349,10 @@ class PlanesWorkload:
         L, cq, ct, p, g = self.lib, C // 8, self.ct, self.qkv.data_ptr(), self.dqkv.data_ptr()
         bs = H * W * ct
         L.check(L.ccnet_cca_backward_planes_f32(self.dy.data_ptr(), p, p + 4 * cq, self.vpl.data_ptr(), self.A.data_ptr(),
-                                                self.gamma.data_ptr(), g, g + 4 * cq, g + 8 * cq, self.dgamma.data_ptr(),
-                                                self.scratch.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct, H * W * 2 * C, 2 * C,
-                                                bs, ct, bs, ct, bs, ct, self.ws.data_ptr(), self.ws_bytes, self.stream()),
+                                                self.stats.data_ptr(), self.gamma.data_ptr(), g, g + 4 * cq, g + 8 * cq,
+                                                self.dgamma.data_ptr(), self.scratch.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct,
+                                                H * W * 2 * C, 2 * C, bs, ct, bs, ct, bs, ct, self.ws.data_ptr(), self.ws_bytes,
+                                                self.stream()),
                 "cca_backward_planes")
 
 
@@ -450,14 +463,14 @@ def launch_accounting(lib, wl, graph, steps=20):
         out["graph_ms_per_step"] = round(time_region(graph.replay, steps), 4)
     torch.cuda.synchronize()
     nrep = 5
-    prev = lib.ccnet_cca_set_option(b"planes_overlap", 0)
+    prev = lib.set_option("planes_overlap", 0)
     try:
         for _ in range(3):
             wl.step()
         out["single_stream_eager_ms_per_step"] = round(time_region(wl.step, steps), 4)
         rec = lib.profile_launches(lambda: [wl.step() for _ in range(nrep)])
     finally:
-        lib.ccnet_cca_set_option(b"planes_overlap", prev)
+        lib.set_option("planes_overlap", prev)
     n = len(rec) // nrep
     ksum = sum(ms for _, ms in rec) / nrep
     out["launches_per_step"] = n
@@ -498,19 +511,21 @@ def planes_launch_bytes(B, C, H, W):
     write once, from the tensor sizes of SURVEY 8(d) (feature C-sized 4*P*C, Cq-sized 4*P*Cq, attention-shaped 4*P*S)."""
     P, S, Cq = B * H * W, H + W, C // 8
     fc, fq, att = 4 * P * C, 4 * P * Cq, 4 * P * S
+    # (label, algorithmic bytes, regex of the launch's kernel name as rocprofv3 spells it: the key of the PMC traffic summary --
+    #  the launch profiler only knows the SOURCE spelling of the launch, template parameters by name; VERDICT r3 weak #2)
     return [
-        ("energies q.k (both branches)", 2 * fq + att),
-        ("softmax", 2 * att),
-        ("aggregation, column pass (v, A/2 -> partial)", 2 * fc + att // 2),
-        ("aggregation, row pass (v, A/2, partial, x -> y NCHW)", 4 * fc + att // 2),
-        ("dy NCHW -> planes", 2 * fc),
-        ("dA = dy.v (both branches)", 2 * fc + att),
-        ("dv, column pass (dy, A/2 -> partial)", 2 * fc + att // 2),
-        ("dv, row pass (dy, A/2, partial -> dv)", 3 * fc + att // 2),
-        ("softmax backward", 3 * att),
-        ("dgamma reduction", 0),
-        ("dq | dk, column pass", att // 2 + 4 * fq),
-        ("dq | dk, row pass", att // 2 + 6 * fq),
+        ("v fp32 -> planes (side stream, next to the energies)", 2 * fc, r"pm_split_kernel"),
+        ("energies q.k + per-branch softmax statistics (both branches)", 2 * fq + att, r"gweight_kernel<\d+, true, float"),
+        ("aggregation, column pass (v, A/2 -> partial)", 2 * fc + att // 2, r"gmap3_kernel<\d+, false, false, false"),
+        ("aggregation, row pass (v, A/2, partial, x -> y NCHW)", 4 * fc + att // 2,
+         r"gmap_kernel<\d+, true, false, true, cca::bf16p_t, float, true"),
+        ("dy NCHW -> planes", 2 * fc, r"nchw_to_planes_kernel"),
+        ("dA = dy.v (both branches)", 2 * fc + att, r"gweight_stream_kernel|gweight_kernel<\d+, false, cca::bf16p_t"),
+        ("dv, column pass (dy, A/2 -> partial)", 2 * fc + att // 2, r"gmap3_kernel<\d+, false, true, false"),
+        ("dv, row pass (dy, A/2, partial -> dv)", 3 * fc + att // 2, r"gmap_kernel<\d+, true, true, true, cca::bf16p_t"),
+        ("softmax backward + dgamma partials", 3 * att, r"softmax_bwd_kernel"),
+        ("dq | dk, column pass (+ dgamma reduction)", att // 2 + 4 * fq, r"gmap_kernel<\d+, false, false, false, float, float, false, true"),
+        ("dq | dk, row pass", att // 2 + 6 * fq, r"gmap_kernel<\d+, true, false, true, float, float, false, true"),
     ]
 
 
@@ -525,9 +540,16 @@ def planes_roofline(lib, wl, step_ms, launch_ms):
            "level": "op (one core fwd+bwd)", "algorithmic_bytes": nbytes, "step_ms": round(step_ms, 4),
            "traffic": (traffic or {}).get("_step_total_bytes")}
     table = planes_launch_bytes(B, C, H, W)
+
+    def pmc_bytes(pattern):
+        import re
+        hits = [v for k, v in (traffic or {}).items() if not k.startswith("_") and re.search(pattern, k)]
+        return hits[0] if len(hits) == 1 else None
+
     if len(launch_ms) == len(table):
-        rows = [{"launch": what, "kernel": name, "ms": ms, "bytes": nb} for (what, nb), (name, ms) in zip(table, launch_ms)]
-        obj["launches"] = [{"launch": r["launch"], "ms": r["ms"], "algorithmic_bytes": r["bytes"],
+        rows = [{"launch": what, "kernel": name, "ms": ms, "bytes": nb, "traffic": pmc_bytes(pat)}
+                for (what, nb, pat), (name, ms) in zip(table, launch_ms)]
+        obj["launches"] = [{"launch": r["launch"], "ms": r["ms"], "algorithmic_bytes": r["bytes"], "traffic": r["traffic"],
                             "achieved_gbs": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1) if r["ms"] > 0 else None} for r in rows]
         dom = max(rows, key=lambda r: r["ms"])
         obj["dominant_kernel"] = {"kernel": dom["kernel"], "launch": dom["launch"], "kernel_ms": round(dom["ms"], 4),
@@ -535,7 +557,7 @@ def planes_roofline(lib, wl, step_ms, launch_ms):
                                   "achieved_gbs": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
                                   "frac": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                   "how": "HIP-event pair around the launch inside eager steps (ccnet_cca_profile_*)",
-                                  "traffic": (traffic or {}).get(dom["kernel"])}
+                                  "traffic": dom["traffic"]}
     return obj
 
 
@@ -927,7 +949,7 @@ def main(argv=None, workload_factory=None):
             sys.exit("bench.py: --backend gloo needs --workload-factory (tests); the product path is HIP-only")
         from ccnet_amd import _lib
         lib = _lib.get_lib()
-        lib.ccnet_cca_set_option(b"planes_overlap", -1 if args.overlap == "auto" else int(args.overlap))
+        lib.set_option("planes_overlap", -1 if args.overlap == "auto" else int(args.overlap))
         use_planes = (not bf16 and args.family == "planes" and max(H, W) <= 132 and C % 8 == 0)
         cls = PixelMajorBF16Workload if bf16 else PlanesWorkload if use_planes else CoreWorkload
         wl = cls(lib, B, C, H, W, device, shard_seed(1234, rank))
@@ -977,7 +999,7 @@ def main(argv=None, workload_factory=None):
     value = aggregate_value(nbytes, args.steps, world, secs)
     ms = secs / args.steps * 1e3
     impl = "injected" if lib is None else ("pixel-major bf16 mfma" if bf16 else
-                                           "split-plane mfma (v, dy pre-split into bf16 hi|lo planes)" if isinstance(wl, PlanesWorkload) else
+                                           "split-plane mfma (v, dy split into bf16 hi|lo planes INSIDE the step)" if isinstance(wl, PlanesWorkload) else
                                            "mfma-strip" if lib.ccnet_cca_shape_uses_mfma(B, C, H, W) else "direct")
     out = {
         "metric": metric_label(C, H, W),
@@ -989,8 +1011,9 @@ def main(argv=None, workload_factory=None):
                                 if bf16 else
                                 f"BASELINE.json configs[1]: single-op CrissCrossAttention core fwd+bwd, "
                                 f"({B},{C},{H},{W}) fp32 per GPU, R=1"
-                                + ("; q | k fp32 pixel-major slices of the packed projection, v pre-split into bf16 hi|lo planes by "
-                                   "its producer, x / y / dy NCHW fp32, dq | dk | dv fp32 pixel-major" if isinstance(wl, PlanesWorkload) else "")),
+                                + ("; inputs q | k | v fp32 (pixel-major channel slices of the packed projection), x / dy NCHW fp32; "
+                                   "outputs y NCHW, dq | dk | dv fp32 pixel-major; every pass of the op is inside the timed step"
+                                   if isinstance(wl, PlanesWorkload) else "")),
                    "per_gpu_batch": B, "global_batch": B * world, "shape": [B, C, H, W],
                    "parallelism": f"batch-sharded x{world} (no data-path collective"
                                   + (", + all-reduce of the 7 parameter gradients per step)" if grads is not None else ")"),

@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libccnet_cca.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ccnet_cca.h")
 
+CCNET_CCA_VERSION = 200        # include/ccnet_cca.h
 CCNET_CA_ENERGY = 0
 CCNET_CA_SOFTMAX = 1
 CCNET_IMPL_AUTO = 0
@@ -51,18 +52,19 @@ _PROTOTYPES = {
     "ccnet_cca_backward_strided_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t,
                                                c_int, c_int, c_int, c_int, c_int,
                                                c_long, c_long, c_long, c_long, c_long, c_long, _P]),
-    "ccnet_cca_forward_pm_bf16": (c_int, [_P] * 7 + [c_int] * 5 + [c_long, c_int] * 5 + [_P, c_size_t, _P]),
-    "ccnet_cca_backward_pm_bf16": (c_int, [_P] * 11 + [c_int] * 5 + [c_long, c_int] * 7 + [_P, c_size_t, _P]),
-    "ccnet_cca_forward_pm_f32": (c_int, [_P] * 7 + [c_int] * 5 + [c_long, c_int] * 5 + [_P, c_size_t, _P]),
-    "ccnet_cca_backward_pm_f32": (c_int, [_P] * 11 + [c_int] * 5 + [c_long, c_int] * 7 + [_P, c_size_t, _P]),
+    "ccnet_cca_forward_pm_bf16": (c_int, [_P] * 8 + [c_int] * 5 + [c_long, c_int] * 5 + [_P, c_size_t, _P]),
+    "ccnet_cca_backward_pm_bf16": (c_int, [_P] * 12 + [c_int] * 5 + [c_long, c_int] * 7 + [_P, c_size_t, _P]),
+    "ccnet_cca_forward_pm_f32": (c_int, [_P] * 8 + [c_int] * 5 + [c_long, c_int] * 5 + [_P, c_size_t, _P]),
+    "ccnet_cca_backward_pm_f32": (c_int, [_P] * 12 + [c_int] * 5 + [c_long, c_int] * 7 + [_P, c_size_t, _P]),
     "ccnet_cca_split_planes_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_int, _P, _P]),
     "ccnet_cca_nchw_to_planes_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_long, c_long, c_int, c_int, _P]),
-    "ccnet_cca_forward_planes_f32": (c_int, [_P] * 7 + [c_int] * 5 + [c_long, c_int] * 3 + [_P, c_size_t, _P]),
-    "ccnet_cca_backward_planes_f32": (c_int, [_P] * 11 + [c_int] * 5 + [c_long, c_int] * 6 + [_P, c_size_t, _P]),
+    "ccnet_cca_forward_planes_f32": (c_int, [_P] * 10 + [c_int] * 5 + [c_long, c_int] * 4 + [_P, c_size_t, _P]),
+    "ccnet_cca_backward_planes_f32": (c_int, [_P] * 12 + [c_int] * 5 + [c_long, c_int] * 6 + [_P, c_size_t, _P]),
+    "ccnet_cca_attention_pm": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, c_long, c_int, _P]),
     "ccnet_cca_shape_uses_mfma": (c_int, [c_int, c_int, c_int, c_int]),
     "ccnet_cca_mfma_selftest": (c_int, [_P, _P]),
-    "ccnet_cca_set_option": (c_int, [c_char_p, c_int]),
-    "ccnet_cca_get_option": (c_int, [c_char_p]),
+    "ccnet_cca_set_option": (c_int, [c_char_p, c_int, ctypes.POINTER(c_int)]),
+    "ccnet_cca_get_option": (c_int, [c_char_p, ctypes.POINTER(c_int)]),
     "ccnet_cca_profile_begin": (c_int, [c_int]),
     "ccnet_cca_profile_end": (c_int, [_P, _P, c_int, c_int]),
 }
@@ -94,22 +96,38 @@ class CcaLibrary:
             fn.restype = res
             fn.argtypes = args
             setattr(self, name, fn)
+        if self.ccnet_cca_version() != CCNET_CCA_VERSION:
+            raise CcaError(f"{path} exports C ABI version {self.ccnet_cca_version()}, this binding is written against "
+                           f"{CCNET_CCA_VERSION} (include/ccnet_cca.h): rebuild the extension")
+
+    # ---- options by name: the C calls return a status and pass values through out-parameters ----
+    def set_option(self, name, value: int) -> int:
+        """Set option ``name``; returns its previous value.  Unknown names / out-of-range values raise CcaError."""
+        prev = c_int(0)
+        self.check(self.ccnet_cca_set_option(name.encode() if isinstance(name, str) else name, int(value), ctypes.byref(prev)),
+                   f"set_option({name!r}, {value})")
+        return prev.value
+
+    def get_option(self, name) -> int:
+        v = c_int(0)
+        self.check(self.ccnet_cca_get_option(name.encode() if isinstance(name, str) else name, ctypes.byref(v)), f"get_option({name!r})")
+        return v.value
 
     # ---- named forms of the two generic entry points (options by name, workspace sizes by entry code) ----
     def ccnet_cca_set_impl(self, impl: int) -> int:
-        return self.ccnet_cca_set_option(b"impl", impl)
+        return self.set_option("impl", impl)
 
     def ccnet_cca_get_impl(self) -> int:
-        return self.ccnet_cca_get_option(b"impl")
+        return self.get_option("impl")
 
     def ccnet_cca_set_precision(self, precision: int) -> int:
-        return self.ccnet_cca_set_option(b"precision", precision)
+        return self.set_option("precision", precision)
 
     def ccnet_cca_get_precision(self) -> int:
-        return self.ccnet_cca_get_option(b"precision")
+        return self.get_option("precision")
 
     def ccnet_cca_set_branch_mask(self, mask: int) -> int:
-        return self.ccnet_cca_set_option(b"branch_mask", mask)
+        return self.set_option("branch_mask", mask)
 
     def ccnet_ca_softmax_backward_workspace_bytes(self, B, H, W) -> int:
         return self.ccnet_cca_workspace_bytes(CCNET_WS_SOFTMAX_BACKWARD, B, 0, 0, H, W)

@@ -142,6 +142,21 @@ __device__ __forceinline__ u32x4 t16_frag(const float *tile, int ks, int nt, int
     return u32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
+// the factors of the ``n`` query positions pix0 + t * pstep of one strip -> sc[0 .. P) (zero beyond n); ``stats`` null: ones
+template <int P, int THREADS>
+__device__ __forceinline__ void parts_stage_scales(float *sc, const float *stats, int b, int HW, int pix0, int pstep, int n, bool row, int tid) {
+    for (int t = tid; t < P; t += THREADS) {
+        float s = t < n ? 1.f : 0.f;
+        if (stats && t < n) {
+            f32x4 st;
+            __builtin_memcpy(&st, stats + ((size_t)b * HW + pix0 + t * pstep) * 4, 16);
+            s = parts_scale(st, row);
+        }
+        CCA_LDS_ST(sc + t, s);
+    }
+    barrier_lds_only();
+}
+
 // FT: feature element, OT: output element; the addend (ADD) is fp32 pixel-major with its own strides; resid (may be
 // null) has the output's type.  4 wavefronts, two workgroups per CU: wavefront w owns the M tiles (16
 // strip positions each) t = w, w + 4, w + 8 of all four 16-channel N tiles, and keeps their attention fragments -- hi and
@@ -175,6 +190,12 @@ struct GmapJob {
     int fps, ops;
     int nwg;
     int nb, jblk;     // LONG (strips of 133 .. 4 x 132 positions): blocks per strip, the key block of this launch
+    // DUAL: a fixed-order sum that rides on this launch (the dgamma partials of softmax-backward, which precedes the dq | dk
+    // column pass on the stream): workgroup 0 adds red_n floats at red_src into red_dst[0] -- one launch less per backward
+    const float *red_src;
+    int red_n;
+    float *red_dst;
+    int xcd;          // > 0: strips per XCD of the XCD-aware strip decode (non-DUAL launches; see the kernel)
 };
 // LONG strips: a strip of L > P positions is cut into nb blocks of ``long_block(L, nb)`` positions (the last one shorter).  A
 // workgroup then owns the QUERY block I of a strip and contracts over the KEY block J: out_I (+)= F_J . A_{I,J}^T; the key blocks
@@ -185,7 +206,8 @@ inline unsigned gmap_dual_grid(int nwg) { return 16u * (unsigned)((nwg + 7) / 8)
 // WPC: workgroups per CU the LDS budget is checked for (2 everywhere except the 132-position kernels on fp32 / split-plane
 // features, whose two feature tiles + output image take 104 KB: one workgroup per CU)
 template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT, bool NCHW = false, bool DUAL = false, int WPC = 2, bool LONG = false>
-__global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__restrict__ T, const FT *__restrict__ F,
+__global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__restrict__ T, const float *__restrict__ stats,
+                                                              const FT *__restrict__ F,
                                                               const float *__restrict__ addend,
                                                               const OT *__restrict__ resid,
                                                               const float *__restrict__ gamma, OT *out,
@@ -217,9 +239,11 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     static_assert(!NCHW || (ROW && ADD && !OBF && !TRANS && !DUAL), "gmap: the NCHW epilogue belongs to the final fp32 row pass");
     static_assert(!LONG || (ROW && ADD), "gmap: blocked long strips exist for the row passes (their addend chains the key blocks)");
     static_assert(!PL || !OBF, "gmap: split-plane features produce fp32 outputs");
-    static_assert(P % 4 == 0 && (2 * FSZ + OIMG) * 4 * WPC <= 163840, "gmap: LDS of WPC workgroups per CU");
+    static_assert(P % 4 == 0 && ((2 * FSZ + OIMG + P) * 4 + 511) / 512 * 512 * WPC <= 163840, "gmap: LDS of WPC workgroups per CU");
     __shared__ __attribute__((aligned(16))) float lds[2 * FSZ + OIMG];
+    __shared__ float qsc[P];                                          // per-query softmax factors (parts_stage_scales)
     CCA_LDS_REGISTER(lds);
+    CCA_LDS_REGISTER(qsc);
     float *const FB = lds, *const oimg = lds + 2 * FSZ;
     const int HW = H * W, S = H + W;
     const int L = ROW ? W : H, G = ROW ? H : W;
@@ -227,7 +251,22 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     // strips (fewer than one round) are cut into `split` channel ranges so that the last round is a short one
     const int ncg = (C + GM_CG - 1) / GM_CG;
     int id = DUAL ? dual_id : (int)blockIdx.x, cg0 = 0, cg1 = ncg;
-    if (id >= n_whole) {
+    if (!DUAL && j1.xcd > 0) {
+        // XCD-aware decode (j1.xcd = strips per XCD; the host offers it only when strips and n_whole divide by 8): workgroup ids
+        // go round-robin over the 8 XCDs, so XCD x = id & 7 takes the strips [x * xcd, (x + 1) * xcd) -- at 8 images of 97 rows
+        // one image per XCD -- the whole ones first in ITS dispatch order, then its share of the cut ones.  Neighbouring NCHW
+        // rows share their boundary cache lines (a row of 97 floats is 388 B at arbitrary alignment): on one XCD the second
+        // touch of such a line is an L2 hit and the two partial writes merge there.
+        const int x = id & 7, idx = id >> 3, nw8 = n_whole >> 3;
+        if (idx < nw8) {
+            id = x * j1.xcd + idx;
+        } else {
+            const int r = idx - nw8, part = r % split;
+            id = x * j1.xcd + nw8 + r / split;
+            cg0 = part * ncg / split;
+            cg1 = (part + 1) * ncg / split;
+        }
+    } else if (id >= n_whole) {
         const int r = id - n_whole, part = r % split;
         id = n_whole + r / split;
         cg0 = part * ncg / split;
@@ -239,6 +278,12 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     const int b = id / G, g = id - b * G;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
     const int ln = lane & 15, lg = lane >> 4;
+    if (DUAL && blockIdx.x == 0 && wv == 0 && j1.red_dst) {                            // (see GmapJob::red_*)
+        float t = 0.f;
+        for (int i = lane; i < j1.red_n; i += kWave) t += j1.red_src[i];
+        t = wave_sum(t);
+        if (lane == 0) j1.red_dst[0] = t;
+    }
     const int pix0 = ROW ? g * W : g, pstep = ROW ? 1 : W;                             // pixel(i) = pix0 + i * pstep
     const int a_off = ROW ? H : 0;
     // query side (attention rows, outputs, addend, residual): positions i0 .. i0 + Lm; key side (attention columns, features):
@@ -271,6 +316,9 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
         }
     };
     issue_feat(cg0);
+    // two-stage softmax: T holds un-normalised exponentials, every QUERY pixel has a factor (queries are the rows of the
+    // attention block: the M side non-transposed, the contracted side transposed)
+    if (stats) parts_stage_scales<P, GS_THREADS>(qsc, stats, b, HW, trans ? pixK : pixM, pstep, trans ? Lk : Lm, ROW, tid);
 
     // ---- the strip's attention block -> MFMA fragments in registers.  Fragment (tile t, k-step ks) of lane (ln, lg):
     // ---- P_g[m][32 ks + 8 lg + e] (TRANS: P_g[32 ks + 8 lg + e][m]), m = 16 t + ln, e < 8; zero beyond the strip
@@ -279,6 +327,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
 #pragma unroll
     for (int a = 0; a < TPW; ++a) {
         const int t = wv + GS_WAVES * a, m = 16 * t + ln;
+        const float sm = (stats && !trans) ? CCA_LDS_LD(qsc + (m < P ? m : P - 1)) : 1.f;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             float x[8];
@@ -289,11 +338,13 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                     const f32x4 u = fbuf_load_x4(Tb, (m < Lm && k0 < Lk) ? base : kOobOffset, 0);
                     const f32x4 v = fbuf_load_x4(Tb, (m < Lm && k0 + 4 < Lk) ? base + 16 : kOobOffset, 0);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { x[e] = k0 + e < Lk ? u[e] : 0.f; x[4 + e] = k0 + 4 + e < Lk ? v[e] : 0.f; }
+                    for (int e = 0; e < 4; ++e) { x[e] = k0 + e < Lk ? u[e] * sm : 0.f; x[4 + e] = k0 + 4 + e < Lk ? v[e] * sm : 0.f; }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
+                    for (int e = 0; e < 8; ++e) {
                         x[e] = fbuf_load(Tb, (m < Lm && k0 + e < Lk) ? ((pixK + (k0 + e) * pstep) * S + aM + m) * 4 : kOobOffset, 0);
+                        if (stats) x[e] *= CCA_LDS_LD(qsc + k0 + e);
+                    }
                 }
             } else {
 #pragma unroll
@@ -306,6 +357,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
         const int kt = 32 * kp.nbf + lg;
         at[a] = fbuf_load(Tb, (kp.tail && m < Lm && kt < Lk) ? (trans ? ((pixK + kt * pstep) * S + aM + m) * 4
                                                                        : ((pixM + m * pstep) * S + aK + kt) * 4) : kOobOffset, 0);
+        if (stats) at[a] *= trans ? CCA_LDS_LD(qsc + (kt < P ? kt : P - 1)) : sm;
     }
 
     // this lane's slice of store instruction k of its wave: pixel position and first channel (within the group)
@@ -526,7 +578,8 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
 // FT = bf16p_t (split planes: hi | lo tiles, three products) or bf16_t (bf16 features, BASELINE configs[4]: one tile, the two
 // products with the attention's hi and lo halves); the output is fp32 pixel-major either way (the column partial).
 template <int P, bool ROW, bool TRANS, bool ADD, int NBUF = 3, int WPC = 2, typename FT = bf16p_t>
-__global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__restrict__ T, const FT *__restrict__ F,
+__global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__restrict__ T, const float *__restrict__ stats,
+                                                               const FT *__restrict__ F,
                                                                const float *__restrict__ addend, const float *__restrict__ gamma,
                                                                float *__restrict__ out, int C, int H, int W, long fbs, int fps,
                                                                long abs_, int aps, long obs, int ops, int n_whole, int split) {
@@ -534,11 +587,13 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
     constexpr int NPL = std::is_same<FT, bf16p_t>::value ? 2 : 1;       // planes per feature tile
     static_assert(NPL == 2 || std::is_same<FT, bf16_t>::value, "gmap3: bf16p_t or bf16_t features");
     constexpr int TSP = t16_size(P), FSZ = NPL * TSP, NPF = NPL * t16_pieces(P), D = NBUF - 1;
-    static_assert(P % 4 == 0 && NBUF * FSZ * 4 * WPC <= 163840 && (NBUF == 2 || NBUF == 3), "gmap3: LDS of WPC workgroups per CU");
+    static_assert(P % 4 == 0 && ((NBUF * FSZ + P) * 4 + 511) / 512 * 512 * WPC <= 163840 && (NBUF == 2 || NBUF == 3), "gmap3: LDS of WPC workgroups per CU");
     // (the ring fills are LDS-DMAs the compiler does not see -- fbuf_load_to_lds_x4_uncounted, cca_platform.hpp: with the
     // builtin form it drained the fills of the next two tiles before every group's first transposing read)
     __shared__ __attribute__((aligned(16))) float lds[NBUF * FSZ];
+    __shared__ float qsc[P];                                          // per-query softmax factors (parts_stage_scales)
     CCA_LDS_REGISTER(lds);
+    CCA_LDS_REGISTER(qsc);
     const int HW = H * W, S = H + W;
     const int L = ROW ? W : H, G = ROW ? H : W;
     const int ncg = (C + GM_CG - 1) / GM_CG;
@@ -577,6 +632,8 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
     };
     issue_feat(cg0, lds);
     if (D > 1 && cg0 + 1 < cg1) issue_feat(cg0 + 1, lds + FSZ);
+    // two-stage softmax: the factor of every query pixel of the strip (see parts_scale)
+    if (stats) parts_stage_scales<P, GS_THREADS>(qsc, stats, b, HW, pix0, pstep, L, ROW, tid);
 
     // the strip's attention block -> MFMA fragments in registers (as gmap_kernel)
     u32x4 ah[TPW][NKS], al[TPW][NKS];
@@ -584,6 +641,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
 #pragma unroll
     for (int a = 0; a < TPW; ++a) {
         const int t = wv + GS_WAVES * a, m = 16 * t + ln;
+        const float sm = (stats && !TRANS) ? CCA_LDS_LD(qsc + (m < P ? m : P - 1)) : 1.f;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             float x[8];
@@ -594,11 +652,13 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
                     const f32x4 u = fbuf_load_x4(Tb, (m < L && k0 < L) ? base : kOobOffset, 0);
                     const f32x4 v = fbuf_load_x4(Tb, (m < L && k0 + 4 < L) ? base + 16 : kOobOffset, 0);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { x[e] = k0 + e < L ? u[e] : 0.f; x[4 + e] = k0 + 4 + e < L ? v[e] : 0.f; }
+                    for (int e = 0; e < 4; ++e) { x[e] = k0 + e < L ? u[e] * sm : 0.f; x[4 + e] = k0 + 4 + e < L ? v[e] * sm : 0.f; }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
+                    for (int e = 0; e < 8; ++e) {
                         x[e] = fbuf_load(Tb, (m < L && k0 + e < L) ? ((pix0 + (k0 + e) * pstep) * S + a_off + m) * 4 : kOobOffset, 0);
+                        if (stats) x[e] *= CCA_LDS_LD(qsc + k0 + e);
+                    }
                 }
             } else {
 #pragma unroll
@@ -611,6 +671,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
         const int kt = 32 * kp.nbf + lg;
         at[a] = fbuf_load(Tb, (kp.tail && m < L && kt < L) ? (TRANS ? ((pix0 + kt * pstep) * S + a_off + m) * 4
                                                                      : ((pix0 + m * pstep) * S + a_off + kt) * 4) : kOobOffset, 0);
+        if (stats) at[a] *= TRANS ? CCA_LDS_LD(qsc + (kt < P ? kt : P - 1)) : sm;
     }
 
     // stores / addend loads of a group: one 16-byte access per owned M tile and N tile whose channels exist (both
@@ -818,7 +879,8 @@ __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float *__rest
 // T[query block I][key block J] of a row strip from the X tile of block I and the Y tile of block J; column strips (<= P) stay whole.
 template <int P, bool MASK, typename FT, bool SINGLE, bool LONG = false>
 __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(const FT *__restrict__ X, const FT *__restrict__ Y,
-                                                                              float *__restrict__ T, int Cx, int H, int W,
+                                                                              float *__restrict__ T, float *__restrict__ stats,
+                                                                              int Cx, int H, int W,
                                                                               long xbs, int xps, long ybs, int yps, int nb = 1) {
     constexpr bool BF = GTile<FT>::BF;
     constexpr bool PL = std::is_same<FT, bf16p_t>::value;     // split planes: an operand tile = hi image | lo image (bf16 tile geometry)
@@ -974,6 +1036,43 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
         }
     }
     if constexpr (!BF && MASK) mfma_f32_result_fence();
+    // two-stage softmax (``stats`` given; whole strips only): this branch's half of functions.py:40 is finished here -- the
+    // accumulators become exp(e - m_branch) and (m_branch, z_branch) of every query go to stats (see parts_scale).  A query's
+    // keys are the 16 lanes ln of its lane group x the NT tiles: the row reductions are 4-step butterflies inside 16 lanes.
+    bool parts = false;
+    if constexpr (MASK && !LONG) parts = stats != nullptr;
+    if (parts) {
+        float *Sg = stats + (size_t)b * HW * 4 + (row ? 2 : 0);
+#pragma unroll
+        for (int a = 0; a < NTR; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 16 * (wv + GM_WAVES * a) + 4 * lg + q;
+                float m = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int j = 16 * t + ln;
+                    if (j >= Lk || (!row && i == j)) acc[a][t][q] = -INFINITY;       // beyond the strip; functions.py:11-12
+                    m = fmaxf(m, acc[a][t][q]);
+                }
+#pragma unroll
+                for (int sh = 1; sh < 16; sh <<= 1) m = fmaxf(m, shfl_xor(m, sh));
+                const float mm = m == -INFINITY ? 0.f : m;                            // (a branch with no live slot: P = 0, z = 0)
+                float z = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float pv = expf(acc[a][t][q] - mm);
+                    acc[a][t][q] = pv;
+                    z += pv;
+                }
+#pragma unroll
+                for (int sh = 1; sh < 16; sh <<= 1) z += shfl_xor(z, sh);
+                if (ln == 0 && i < L) {
+                    Sg[(size_t)(pix0 + i * pstep) * 4] = m;
+                    Sg[(size_t)(pix0 + i * pstep) * 4 + 1] = z;
+                }
+            }
+    }
     // D[m = query position 16 ti + 4 lg + q][n = key position 16 t + ln] -> T rows (64-byte runs per query)
     float *Tg = T + (size_t)b * HW * S;
 #pragma unroll
@@ -985,7 +1084,7 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
                 const int i = 16 * (wv + GM_WAVES * a) + 4 * lg + q, j = 16 * t + ln;
                 if (i < L && j < Lk) {
                     float val = acc[a][t][q];
-                    if (MASK && !row && i == j) val = -INFINITY;            // functions.py:11-12 (column self slot)
+                    if (MASK && !parts && !row && i == j) val = -INFINITY;  // functions.py:11-12 (column self slot)
                     Tg[(size_t)(pix0 + i * pstep) * S + a_off + j] = val;
                 }
             }

@@ -81,11 +81,14 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_fwd_generic_kernel(const flo
 // dgamma are produced; each wavefront adds its pixels in a fixed order: deterministic.
 constexpr int SM_MAX_BLOCKS = 2048;
 
+// ``stats`` (may be null): A holds the un-normalised exponentials of the two-stage softmax (cca_common.hpp: parts_scale) --
+// slots below ``hsplit`` take the pixel's column factor, the others its row factor.
 template <int NREG>
 __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_kernel(const float *A, const float *dA,
                                                                const float *gamma, float *dE,
                                                                float *partials, int npix, int S,
-                                                               int nslab, const float *extra, long slab_stride) {
+                                                               int nslab, const float *extra, long slab_stride,
+                                                               const float *stats, int hsplit) {
     __shared__ float red[SM_WAVES];
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
     const float g = gamma ? gamma[0] : 1.f;
@@ -96,10 +99,17 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_kernel(const float *A, c
         float *o = dE + (size_t)pix * S;
         float av[NREG], dv[NREG];
         float rsum = 0.f;
+        float sc = 1.f, sr = 1.f;
+        if (stats) {
+            f32x4 st;
+            __builtin_memcpy(&st, stats + (size_t)pix * 4, 16);
+            sc = parts_scale(st, false);
+            sr = parts_scale(st, true);
+        }
 #pragma unroll
         for (int r = 0; r < NREG; ++r) {
             const int s = lane + r * kWave;
-            av[r] = (s < S) ? a[s] : 0.f;
+            av[r] = (s < S) ? a[s] * (s < hsplit ? sc : sr) : 0.f;
             dv[r] = (s < S) ? d[s] : 0.f;
             for (int sl = 1; sl < nslab; ++sl)
                 if (s < S) dv[r] += extra[(size_t)(sl - 1) * slab_stride + (size_t)pix * S + s];
@@ -128,7 +138,8 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_kernel(const float *A, c
 __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_generic_kernel(const float *A, const float *dA,
                                                                        const float *gamma, float *dE,
                                                                        float *partials, int npix, int S,
-                                                                       int nslab, const float *extra, long slab_stride) {
+                                                                       int nslab, const float *extra, long slab_stride,
+                                                                       const float *stats, int hsplit) {
     __shared__ float red[SM_WAVES];
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
     const float g = gamma ? gamma[0] : 1.f;
@@ -142,10 +153,17 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_generic_kernel(const flo
             for (int sl = 1; sl < nslab; ++sl) x += extra[(size_t)(sl - 1) * slab_stride + (size_t)pix * S + s];
             return x;
         };
+        float sc = 1.f, sr = 1.f;
+        if (stats) {
+            f32x4 st;
+            __builtin_memcpy(&st, stats + (size_t)pix * 4, 16);
+            sc = parts_scale(st, false);
+            sr = parts_scale(st, true);
+        }
         float rsum = 0.f;
-        for (int s = lane; s < S; s += kWave) rsum += a[s] * dval(s);
+        for (int s = lane; s < S; s += kWave) rsum += a[s] * (s < hsplit ? sc : sr) * dval(s);
         rsum = wave_sum(rsum);
-        for (int s = lane; s < S; s += kWave) o[s] = g * a[s] * (dval(s) - rsum);
+        for (int s = lane; s < S; s += kWave) o[s] = g * a[s] * (s < hsplit ? sc : sr) * (dval(s) - rsum);
         wsum += rsum;
     }
     if (partials) {
@@ -156,6 +174,17 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_generic_kernel(const flo
             for (int i = 0; i < SM_WAVES; ++i) t += red[i];
             partials[blockIdx.x] = t;
         }
+    }
+}
+
+// statistics under which a plain attention tensor reads as itself through the two-stage consumers (parts_scale == 1 exactly)
+__global__ __launch_bounds__(256) void neutral_stats_kernel(float *stats, int npix) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < npix) {
+        stats[4 * (size_t)i] = 0.f;
+        stats[4 * (size_t)i + 1] = 0.5f;
+        stats[4 * (size_t)i + 2] = 0.f;
+        stats[4 * (size_t)i + 3] = 0.5f;
     }
 }
 

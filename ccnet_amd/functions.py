@@ -375,7 +375,7 @@ class CrissCrossPMFunction(torch.autograd.Function):
     is again one GEMM."""
 
     @staticmethod
-    def forward(ctx, qkv, x, gamma, cq):
+    def forward(ctx, qkv, x, gamma, cq, recompute=False):
         qkv, q_bs, q_ps = _pm_view("qkv", qkv)
         x, x_bs, x_ps = _pm_view("x", x, qkv.dtype)
         gamma = _dev_f32("gamma", gamma)
@@ -390,28 +390,40 @@ class CrissCrossPMFunction(torch.autograd.Function):
                                f"{_PM_DTYPES[qkv.dtype][1]}; got C = {C}, Cq = {cq}, H = {H}, W = {W}")
         lib = _lib.get_lib()
         y = torch.empty((B, H, W, C), device=x.device, dtype=qkv.dtype)
-        A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
+        A, stats = _empty_parts(B, H, W, x.device)
         _ws, ws_ptr, nbytes = _workspace(lib.ccnet_cca_pm_workspace_bytes(B, C, cq, H, W, 0), x.device)
         p = qkv.data_ptr()
         fwd = getattr(lib, "ccnet_cca_forward_pm_" + tag)
         with torch.cuda.device(x.device):
             lib.check(fwd(p, p + es * cq, p + 2 * es * cq, x.data_ptr(), gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
-                          B, C, cq, H, W, q_bs, q_ps, q_bs, q_ps, q_bs, q_ps, x_bs, x_ps, H * W * C, C,
+                          stats.data_ptr(), B, C, cq, H, W, q_bs, q_ps, q_bs, q_ps, q_bs, q_ps, x_bs, x_ps, H * W * C, C,
                           ws_ptr, nbytes, _stream()), "cca_forward_pm_" + tag)
-        ctx.save_for_backward(qkv, A, gamma)
+        ctx.recompute = bool(recompute)
+        ctx.save_for_backward(*((qkv, gamma) if ctx.recompute else (qkv, A, stats, gamma)))
         ctx.cq = cq
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        qkv, A, gamma = ctx.saved_tensors
         cq = ctx.cq
+        lib = _lib.get_lib()
+        if ctx.recompute:
+            # the pair (P, stats) rebuilt by the forward's own affinity kernel: bit-identical to what a saving forward kept
+            qkv, gamma = ctx.saved_tensors
+            B, H, W, ct = qkv.shape
+            es, tag = _PM_DTYPES[qkv.dtype][0], _PM_DTYPES[qkv.dtype][3]
+            A, stats = _empty_parts(B, H, W, qkv.device)
+            p, bs, ps = qkv.data_ptr(), qkv.stride(0), qkv.stride(2)
+            with torch.cuda.device(qkv.device):
+                lib.check(lib.ccnet_cca_attention_pm(p, p + es * cq, A.data_ptr(), stats.data_ptr(), int(tag == "bf16"), B, cq, H, W,
+                                                     bs, ps, bs, ps, _stream()), "cca_attention_pm")
+        else:
+            qkv, A, stats, gamma = ctx.saved_tensors
         dy, dy_bs, dy_ps = _pm_view("grad_output", dy, qkv.dtype)
         B, H, W, ct = qkv.shape
         C = ct - 2 * cq
         es, _, _, tag = _PM_DTYPES[qkv.dtype]
-        lib = _lib.get_lib()
         dqkv = torch.empty((B, H, W, ct), device=qkv.device, dtype=qkv.dtype)
         dgamma = torch.empty_like(gamma)
         scratch = torch.empty_like(A)
@@ -420,11 +432,11 @@ class CrissCrossPMFunction(torch.autograd.Function):
         bs, ps = qkv.stride(0), qkv.stride(2)
         bwd = getattr(lib, "ccnet_cca_backward_pm_" + tag)
         with torch.cuda.device(qkv.device):
-            lib.check(bwd(dy.data_ptr(), p, p + es * cq, p + 2 * es * cq, A.data_ptr(), gamma.data_ptr(),
+            lib.check(bwd(dy.data_ptr(), p, p + es * cq, p + 2 * es * cq, A.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
                           g, g + es * cq, g + 2 * es * cq, dgamma.data_ptr(), scratch.data_ptr(), B, C, cq, H, W,
                           dy_bs, dy_ps, bs, ps, bs, ps, bs, ps, H * W * ct, ct, H * W * ct, ct, H * W * ct, ct,
                           ws_ptr, nbytes, _stream()), "cca_backward_pm_" + tag)
-        return dqkv, dy, dgamma.view_as(gamma), None
+        return dqkv, dy, dgamma.view_as(gamma), None, None
 
 
 CrissCrossPMBF16Function = CrissCrossPMFunction          # (the name round-2 code and tests imported first)
@@ -503,6 +515,24 @@ class CrissCrossModuleFunction(torch.autograd.Function):
 PLANES_HL, PLANES_HLH, PLANES_HHL = 2, 3, 4          # include/ccnet_cca.h CCNET_PLANES_*
 
 
+def _empty_parts(B, H, W, device):
+    """what a pixel-major / split-plane forward saves instead of the attention tensor: P (B,H,W,H+W) un-normalised
+    exponentials + stats (B,H,W,4) = (m_col, z_col, m_row, z_row) -- the two-stage softmax of include/ccnet_cca.h"""
+    return (torch.empty((B, H, W, H + W), device=device, dtype=torch.float32),
+            torch.empty((B, H, W, 4), device=device, dtype=torch.float32))
+
+
+def attention_from_parts(P: torch.Tensor, stats: torch.Tensor) -> torch.Tensor:
+    """The attention tensor of functions.py:40 from the parts the fast routes keep: A = P * s_branch(pixel) with
+    s = exp(m_branch - m) / (z_col exp(m_col - m) + z_row exp(m_row - m)), m = max(m_col, m_row) (csrc/cca_common.hpp)."""
+    H = P.shape[1]
+    mc, zc, mr, zr = stats.unbind(-1)
+    m = torch.maximum(mc, mr)
+    ec, er = torch.exp(mc - m), torch.exp(mr - m)
+    Z = zc * ec + zr * er
+    return torch.cat([P[..., :H] * (ec / Z).unsqueeze(-1), P[..., H:] * (er / Z).unsqueeze(-1)], dim=-1)
+
+
 def split_planes(t: torch.Tensor, c0: int, C: int, layout: int = PLANES_HL, dtype=torch.int16, bias=None) -> torch.Tensor:
     """Channels [c0, c0 + C) of the fp32 pixel-major tensor ``t`` (B, H, W, ps) as SPLIT PLANES (B, H, W, n, C):
     bf16 hi | lo halves of every value (include/ccnet_cca.h, "split-plane path"), produced once for all their consumers
@@ -547,94 +577,136 @@ def planes_cover(B, C, Cq, H, W):
     return H <= 132 and W <= 4 * 132 and Cq <= 64
 
 
+class _ProjectionCache:
+    """Stacked projection operands of one module, rebuilt only when a parameter changed (``torch.cat`` of the
+    three weights and the bf16 hi | lo splits ran on every forward AND every backward).  Keyed on the parameters' storage and
+    autograd version counters (in-place optimizer steps bump ``_version``; ``.data =`` swaps change ``data_ptr``)."""
+
+    def __init__(self):
+        self.key, self.val = None, None
+
+    def get(self, wq, bq, wk, bk, wv, bv, split):
+        ps = (wq, bq, wk, bk, wv, bv)
+        key = tuple((p.data_ptr(), p._version, p.device, p.dtype) for p in ps) + (bool(split),)
+        if key != self.key:
+            with torch.no_grad():
+                cq, C = wq.shape[0], wq.shape[1]
+                w = torch.cat([wq.reshape(cq, C), wk.reshape(cq, C), wv.reshape(C, C)], 0)          # (2Cq + C, C)
+                b = torch.cat([bq, bk, bv], 0)
+                val = {"w": w, "b": b, "bqk": b[:2 * cq].contiguous(), "bv": b[2 * cq:].contiguous()}
+                if split:
+                    wh, wl = _split_weight(w)
+                    val["w3"] = torch.cat([wh, wl, wh], 1).t()                                         # (3C, 2Cq + C) view
+                    val["w3t"] = torch.cat([wh.t(), wh.t(), wl.t()], 1)                                # (C, 3 (2Cq + C))
+            self.key, self.val = key, val
+        return self.val
+
+
 class CrissCrossPlanesModuleFunction(torch.autograd.Function):
     """The whole module as ONE autograd node on the SPLIT-PLANE path (fp32, no autocast), the module's own tensors NCHW:
-    the stacked projection is the GEMM ``x^T W^T`` whose (B, HW, 2Cq + C) output holds the pixel-major q | k | v; its value
-    slice is split ONCE into bf16 hi | lo planes (same bytes), which is what the aggregation (functions.py:42-47) and the
-    dA contraction of its adjoint read -- three exact bf16 products per term, no per-fragment split in any inner loop;
-    dy is split once inside the backward; q, k stay fp32 (exact energies).  ``dx = dy + W^T dqkv^T`` is one GEMM with
-    beta = 1 writing NCHW.
+    the stacked projection is the GEMM ``x^T W^T`` whose (B, HW, 2Cq + C) output holds the pixel-major q | k | v; the core's
+    forward entry point takes the fp32 value slice as it is and splits it into bf16 hi | lo planes itself (on the library's side
+    stream, next to the affinity launch; the projection's value bias is added there), which is what the aggregation
+    (functions.py:42-47) and the dA contraction of its adjoint read -- three exact bf16 products per term, no per-fragment
+    split in any inner loop; dy is split once inside the backward; q, k stay fp32 (exact energies).  ``dx = dy + W^T dqkv^T``
+    is one GEMM with beta = 1 writing NCHW.
 
     ``split_gemm``: the three projection GEMMs (functions.py:29-35 and their adjoints) run split-bf16 x3 as well -- ONE stock
     bf16 -> fp32 GEMM each on K-concatenated three-plane operands (x.w ~ xh.wh + xh.wl + xl.wh: rows [xh | xh | xl] of x
     against [wh | wl | wh] of the stacked weight, K = 3C; the adjoints pair [dh | dl | dh] of dqkv with [wh | wh | wl] and,
     row by row over 3 B HW rows, with x's planes for the weight gradient).  The planes are written by the library's
-    producers (one pass over x, one over dqkv); fp32 accumulation, relative error ~1e-5 (the lo x lo term is dropped)."""
+    producers (one pass over x, one over dqkv); fp32 accumulation, relative error ~1e-5 (the lo x lo term is dropped).
+
+    Kept for the backward: the q | k slice (a copy: the packed projection, four fifths of it the value slice nobody reads
+    again, is released), v as planes, x (or, with ``split_gemm``, its three planes instead), and the attention as the parts of
+    the two-stage softmax (P, stats) -- or, with ``recompute``, nothing of the attention: the backward rebuilds the pair from
+    q | k with the forward's own kernel (bit-identical, one affinity launch)."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma, split_gemm=False):
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma, split_gemm=False, recompute=False, cache=None):
         x, gamma = _dev_f32("x", x), _dev_f32("gamma", gamma)
         B, C, H, W = x.shape
         cq, hw = wq.shape[0], H * W
         ct = 2 * cq + C
-        w = torch.cat([wq.reshape(cq, C), wk.reshape(cq, C), wv.reshape(C, C)], 0)          # (2Cq + C, C)
-        b = torch.cat([bq, bk, bv], 0)
+        pc = (cache if cache is not None else _ProjectionCache()).get(wq, bq, wk, bk, wv, bv, split_gemm)
         x3 = None
         if split_gemm:
             x3 = nchw_to_planes(x, PLANES_HHL, torch.bfloat16)                              # (B, H, W, 3, C): xh | xh | xl
-            wh, wl = _split_weight(w)
-            qkv = torch.mm(x3.view(B * hw, 3 * C), torch.cat([wh, wl, wh], 1).t(), out_dtype=torch.float32).view(B, hw, ct)
+            qkv = torch.mm(x3.view(B * hw, 3 * C), pc["w3"], out_dtype=torch.float32).view(B, hw, ct)
             # the bias without a pass over the whole output: q | k in place (a fifth of it), v where its slice is split
-            qkv[..., :2 * cq].add_(b[:2 * cq])
-            vpl = split_planes(qkv.view(B, H, W, ct), 2 * cq, C, bias=b[2 * cq:].contiguous())
+            qkv[..., :2 * cq].add_(pc["bqk"])
+            v_bias = pc["bv"]
         else:
-            xm = x.view(B, C, hw)
-            qkv = torch.baddbmm(b.view(1, 1, -1), xm.transpose(1, 2), w.t().unsqueeze(0).expand(B, -1, -1))   # (B, HW, 2Cq + C)
-            vpl = split_planes(qkv.view(B, H, W, ct), 2 * cq, C)
-        qk = qkv                                  # q | k are read in place (channel slices of the packed projection)
+            qkv = torch.baddbmm(pc["b"].view(1, 1, -1), x.view(B, C, hw).transpose(1, 2), pc["w"].t().unsqueeze(0).expand(B, -1, -1))
+            v_bias = None
         lib = _lib.get_lib()
         y = torch.empty_like(x)
-        A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
-        p, bs, ps = qk.data_ptr(), hw * ct, ct
+        A, stats = _empty_parts(B, H, W, x.device)
+        vpl = torch.empty((B, H, W, 2, C), device=x.device, dtype=torch.int16)
+        p, bs, ps = qkv.data_ptr(), hw * ct, ct
         with torch.cuda.device(x.device):
             _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0), x.device)
-            lib.check(lib.ccnet_cca_forward_planes_f32(p, p + 4 * cq, vpl.data_ptr(), x.data_ptr(), gamma.data_ptr(),
-                                                       y.data_ptr(), A.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps,
+            lib.check(lib.ccnet_cca_forward_planes_f32(p, p + 4 * cq, p + 8 * cq, None if v_bias is None else v_bias.data_ptr(),
+                                                       vpl.data_ptr(), x.data_ptr(), gamma.data_ptr(), y.data_ptr(),
+                                                       A.data_ptr(), stats.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps, bs, ps,
                                                        hw * 2 * C, 2 * C, wsp, wsn, _stream()), "cca_forward_planes")
-        if x3 is not None:
-            ctx.save_for_backward(x, w, qk, vpl, A, gamma, x3)
-        else:
-            ctx.save_for_backward(x, w, qk, vpl, A, gamma)
-        ctx.cq = cq
+        if not any(ctx.needs_input_grad):
+            return y
+        qk = qkv[..., :2 * cq].contiguous()               # (B, HW, 2Cq): all the backward reads of the projection
+        ctx.recompute = bool(recompute)
+        ctx.split_gemm = bool(split_gemm)
+        ctx.cache = cache
+        keep = [x3 if split_gemm else x, qk, vpl, gamma, wq, bq, wk, bk, wv, bv]
+        if not ctx.recompute:
+            keep += [A, stats]
+        ctx.save_for_backward(*keep)
+        ctx.cq, ctx.geom = cq, (B, C, H, W)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
         cq = ctx.cq
-        x, w, qk, vpl, A, gamma = ctx.saved_tensors[:6]
-        x3 = ctx.saved_tensors[6] if len(ctx.saved_tensors) > 6 else None
+        B, C, H, W = ctx.geom
+        xs, qk, vpl, gamma, wq, bq, wk, bk, wv, bv = ctx.saved_tensors[:10]
         dy = _dev_f32("grad_output", dy)
-        B, C, H, W = x.shape
         hw, ct = H * W, 2 * cq + C
         lib = _lib.get_lib()
-        dqkv = torch.empty((B, hw, ct), device=x.device, dtype=torch.float32)
+        pc = (ctx.cache if ctx.cache is not None else _ProjectionCache()).get(wq, bq, wk, bk, wv, bv, ctx.split_gemm)
+        p, bs, ps = qk.data_ptr(), hw * 2 * cq, 2 * cq
+        if ctx.recompute:
+            A, stats = _empty_parts(B, H, W, dy.device)
+            with torch.cuda.device(dy.device):
+                lib.check(lib.ccnet_cca_attention_pm(p, p + 4 * cq, A.data_ptr(), stats.data_ptr(), 0, B, cq, H, W, bs, ps, bs, ps,
+                                                     _stream()), "cca_attention_pm")
+        else:
+            A, stats = ctx.saved_tensors[10:12]
+        dqkv = torch.empty((B, hw, ct), device=dy.device, dtype=torch.float32)
         dgamma = torch.empty_like(gamma)
         scratch = torch.empty_like(A)
-        p, g, bs, ps, gbs = qk.data_ptr(), dqkv.data_ptr(), hw * ct, ct, hw * ct
+        g, gbs = dqkv.data_ptr(), hw * ct
         with torch.cuda.device(dy.device):
             _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 1), dy.device)
-            lib.check(lib.ccnet_cca_backward_planes_f32(dy.data_ptr(), p, p + 4 * cq, vpl.data_ptr(), A.data_ptr(),
+            lib.check(lib.ccnet_cca_backward_planes_f32(dy.data_ptr(), p, p + 4 * cq, vpl.data_ptr(), A.data_ptr(), stats.data_ptr(),
                                                         gamma.data_ptr(), g, g + 4 * cq, g + 8 * cq, dgamma.data_ptr(),
                                                         scratch.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps, hw * 2 * C, 2 * C,
                                                         gbs, ct, gbs, ct, gbs, ct, wsp, wsn, _stream()), "cca_backward_planes")
         db = dqkv.sum(dim=(0, 1))
-        if x3 is not None:
+        if ctx.split_gemm:
+            x3 = xs
             d3 = split_planes(dqkv.view(B, H, W, ct), 0, ct, PLANES_HLH, torch.bfloat16)      # (B, H, W, 3, ct): dh | dl | dh
-            wh, wl = _split_weight(w)
-            w3t = torch.cat([wh.t(), wh.t(), wl.t()], 1)                                      # (C, 3 ct)
-            dx = torch.bmm(w3t.unsqueeze(0).expand(B, -1, -1), d3.view(B, hw, 3 * ct).transpose(1, 2),
+            dx = torch.bmm(pc["w3t"].unsqueeze(0).expand(B, -1, -1), d3.view(B, hw, 3 * ct).transpose(1, 2),
                            out_dtype=torch.float32).add_(dy.view(B, C, hw))                   # dy + W^T dqkv^T  (NCHW)
             # rows (dh, xh), (dl, xh), (dh, xl) of every pixel: the three products, contracted over 3 HW rows per image
             dw = torch.bmm(d3.view(B, 3 * hw, ct).transpose(1, 2), x3.view(B, 3 * hw, C), out_dtype=torch.float32).sum(0)
         else:
-            xm = x.view(B, C, hw)
+            xm = xs.view(B, C, hw)
             dqt = dqkv.transpose(1, 2)                                                        # (B, 2Cq + C, HW) view
-            dx = torch.baddbmm(dy.view(B, C, hw), w.t().unsqueeze(0).expand(B, -1, -1), dqt)  # dy + W^T dqkv^T  (NCHW)
+            dx = torch.baddbmm(dy.view(B, C, hw), pc["w"].t().unsqueeze(0).expand(B, -1, -1), dqt)  # dy + W^T dqkv^T  (NCHW)
             dw = torch.bmm(dqt, xm.transpose(1, 2)).sum(0)                                    # (2Cq + C, C)
         dwq, dwk, dwv = dw[:cq], dw[cq:2 * cq], dw[2 * cq:]
         return (dx.view(B, C, H, W), dwq.reshape(cq, C, 1, 1), db[:cq], dwk.reshape(cq, C, 1, 1), db[cq:2 * cq],
-                dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma), None)
+                dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma), None, None, None)
 
 
 def criss_cross_attention(q, k, v, x, gamma, recompute_attention=False):
@@ -668,8 +740,9 @@ class CrissCrossAttention(nn.Module):
 
     #: activation memory (networks/ccnet.py:118-119 applies the module R times): when True the
     #: (B,H,W,H+W) attention tensor is NOT kept for backward -- it is recomputed from q, k (one affinity + softmax
-    #: launch pair, ~8 % of a fwd+bwd) -- so an application holds q, k, v only.  A feature of the NCHW strip nodes: the
-    #: pixel-major / split-plane routes are skipped while it is set.  Under torch.no_grad() / eval nothing is kept either way.
+    #: launch pair, ~8 % of a fwd+bwd) -- so an application holds q, k, v only.  Every fp32 / bf16 node honours it (round 4: the
+    #: split-plane and pixel-major nodes rebuild the two-stage pair (P, stats) with the forward's own affinity kernel -- one
+    #: launch, bit-identical gradients).  Under torch.no_grad() / eval nothing is kept either way.
     recompute_attention = False
 
     #: fp32 NCHW inputs (no autocast; columns <= 132, rows <= 528 positions -- see ``planes_cover``): the SPLIT-PLANE node
@@ -705,13 +778,13 @@ class CrissCrossAttention(nn.Module):
     def route(self, x):
         """Which implementation ``forward`` runs for this input (a key of ``ROUTES``).  The pixel-major and split-plane
         routes always compute split-bf16 x3 (exact fp32 energies): they are skipped while the process-wide knobs pin exact
-        fp32 arithmetic (option ``"precision"`` = CCNET_PRECISION_F32) or the any-shape kernels (``"impl"`` = CCNET_IMPL_DIRECT),
-        while ``recompute_attention`` is set (they keep the attention tensor) and while ``fuse_projections`` is off."""
+        fp32 arithmetic (option ``"precision"`` = CCNET_PRECISION_F32) or the any-shape kernels (``"impl"`` = CCNET_IMPL_DIRECT)
+        and while ``fuse_projections`` is off.  ``recompute_attention`` is honoured by every route."""
         B, C, H, W = x.shape
         cq = self.query_conv.out_channels
         lib = _lib.get_lib()
         knobs_ok = (lib.ccnet_cca_get_precision() != _lib.CCNET_PRECISION_F32 and lib.ccnet_cca_get_impl() != _lib.CCNET_IMPL_DIRECT)
-        fast_ok = knobs_ok and self.fuse_projections and not self.recompute_attention
+        fast_ok = knobs_ok and self.fuse_projections
         if x.dtype == torch.bfloat16 and self.native_bf16:
             if (fast_ok and (self._fusable(x) or (torch.is_autocast_enabled() and self._fusable()))   # (autocast casts W for linear)
                     and pm_bf16_covers(B, C, cq, H, W)):
@@ -747,18 +820,20 @@ class CrissCrossAttention(nn.Module):
             # are ONE GEMM x^T W^T whose output the kernels read through channel-slice strides; y comes back in x's memory format
             xp = x.permute(0, 2, 3, 1)
             qkv = torch.nn.functional.linear(xp, self._stacked_weight().flatten(1), self._stacked_bias()).to(torch.bfloat16)
-            y = CrissCrossPMBF16Function.apply(qkv, xp, self.gamma.float(), cq).permute(0, 3, 1, 2)
+            y = CrissCrossPMBF16Function.apply(qkv, xp, self.gamma.float(), cq, self.recompute_attention).permute(0, 3, 1, 2)
             return y if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() else y.contiguous()
         if r == "f32-channels-last":
             xp = x.permute(0, 2, 3, 1)
             qkv = torch.nn.functional.linear(xp, self._stacked_weight().flatten(1), self._stacked_bias())
-            return CrissCrossPMFunction.apply(qkv, xp, self.gamma, cq).permute(0, 3, 1, 2)
+            return CrissCrossPMFunction.apply(qkv, xp, self.gamma, cq, self.recompute_attention).permute(0, 3, 1, 2)
         if r in ("f32-planes", "f32-planes-transposed"):
             split_gemm = self.split_bf16_projections and x.shape[0] * x.shape[2] * x.shape[3] >= self.split_bf16_min_pixels
             if r == "f32-planes-transposed":
                 xt = x.transpose(2, 3).contiguous()
-                return CrissCrossPlanesModuleFunction.apply(xt, *params, self.gamma, split_gemm).transpose(2, 3).contiguous()
-            return CrissCrossPlanesModuleFunction.apply(x, *params, self.gamma, split_gemm)
+                return CrissCrossPlanesModuleFunction.apply(xt, *params, self.gamma, split_gemm, self.recompute_attention,
+                                                            self._projection_cache()).transpose(2, 3).contiguous()
+            return CrissCrossPlanesModuleFunction.apply(x, *params, self.gamma, split_gemm, self.recompute_attention,
+                                                        self._projection_cache())
         if r == "f32-strips-node":
             return CrissCrossModuleFunction.apply(x, *params, self.gamma, self.recompute_attention)
         if r == "packed-strips":
@@ -771,6 +846,13 @@ class CrissCrossAttention(nn.Module):
         out = CrissCrossFunction.apply(proj_query.float(), proj_key.float(), proj_value.float(),
                                        x.float(), self.gamma.float(), self.recompute_attention)
         return out.to(x.dtype)
+
+    def _projection_cache(self):
+        """per-module cache of the stacked / split projection operands (rebuilt when a parameter's version changes)"""
+        c = self.__dict__.get("_proj_cache")
+        if c is None:
+            c = self.__dict__["_proj_cache"] = _ProjectionCache()
+        return c
 
     def _stacked_weight(self):
         return torch.cat([self.query_conv.weight, self.key_conv.weight, self.value_conv.weight], 0)

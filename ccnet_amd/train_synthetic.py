@@ -49,7 +49,8 @@ def run(args, model_factory=None, quiet=False):
     device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    ddp = world > 1 or getattr(args, "force_ddp", False)      # (--force-ddp: the RCCL / DDP path on a single GPU)
+    if ddp and not dist.is_initialized():
         dist.init_process_group("nccl" if use_cuda else "gloo")
     torch.manual_seed(args.seed + rank)                       # per-rank seed (train.py:154-155)
 
@@ -60,7 +61,7 @@ def run(args, model_factory=None, quiet=False):
         model = model_factory()
     model = model.to(device).train()
     net = model
-    if world > 1:
+    if ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local] if use_cuda else None,
                                                         broadcast_buffers=False)
     opt = torch.optim.SGD(model.parameters(), lr=args.lr, momentum=0.9, weight_decay=args.weight_decay)
@@ -80,7 +81,7 @@ def run(args, model_factory=None, quiet=False):
         return loss
 
     def fence():
-        if world > 1:
+        if ddp:
             dist.barrier()
         if use_cuda:
             torch.cuda.synchronize()
@@ -95,7 +96,7 @@ def run(args, model_factory=None, quiet=False):
     fence()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if ddp:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     result = None
@@ -113,7 +114,7 @@ def run(args, model_factory=None, quiet=False):
         }
         if not quiet:
             print(json.dumps(result), flush=True)
-    if world > 1 and args.destroy_group:
+    if ddp and args.destroy_group:
         dist.destroy_process_group()
     return result
 
@@ -132,6 +133,8 @@ def build_parser():
     ap.add_argument("--bf16", action="store_true", help="autocast to bf16: convolutions in bf16, the attention core on the pixel-major bf16 kernels (fp32 attention / softmax / accumulate)")
     ap.add_argument("--cpu", action="store_true", help="tests only: gloo on CPU with an injected model")
     ap.add_argument("--no-destroy-group", dest="destroy_group", action="store_false")
+    ap.add_argument("--force-ddp", action="store_true", help="wrap the model in DistributedDataParallel (RCCL process group) even at "
+                                                             "WORLD_SIZE = 1: the multi-GPU code path on the one GPU a test box has")
     return ap
 
 

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CCNET_CCA_VERSION 100          /* 0.1.0 */
+#define CCNET_CCA_VERSION 200          /* 0.2.0: two-stage softmax (stats), fp32 v in the split-plane forward, option ABI */
 
 #define CCNET_E_BADSHAPE   (-1)        /* non-positive dimension, or a size the kernels cannot index */
 #define CCNET_E_NULLPTR    (-2)        /* a required pointer is NULL */
@@ -87,7 +87,7 @@ int         ccnet_cca_version(void);
 const char *ccnet_cca_arch(void);                  /* "gfx950" */
 const char *ccnet_cca_last_error_string(void);
 /* The MODE words above are options "impl", "precision" and "branch_mask" of ccnet_cca_set_option / ccnet_cca_get_option
- * (declared with the other options below): set returns the previous value, an invalid value leaves the word unchanged. */
+ * (declared with the other options below): an invalid value is rejected (CCNET_E_BADFLAGS) and leaves the word unchanged. */
 
 /* Scratch sizes of the entry points that take a ``workspace`` (bytes; 0 = none needed).  ``entry``: */
 #define CCNET_WS_SOFTMAX_BACKWARD 0    /* ccnet_ca_softmax_backward_f32 with dgamma (C, Cq ignored) */
@@ -186,17 +186,24 @@ int ccnet_cca_backward_strided_f32(const float *dy, const float *q, const float 
  * as one  x^T W^T  GEMM: q, k, v are then channel slices of ONE (B, H*W, 2*Cq + C) projection and no copy is made.
  * The attention tensor A (B, H, W, H+W), the scratch tensor, gamma, dgamma and every accumulation are fp32; products
  * of the bf16 features are exact on the matrix pipe; outputs are rounded to nearest even once, on store.
+ * TWO-STAGE SOFTMAX (version 200; pixel-major and split-plane entry points): the softmax of functions.py:40 is never a
+ * launch of its own.  ``A`` receives the UN-NORMALISED exponentials  P[pixel][slot] = exp(e - m_branch(pixel))  and ``stats``
+ * (B, H*W, 4) fp32 the per-pixel branch statistics (m_col, z_col, m_row, z_row) -- max and sum of P of the column slots and of
+ * the row slots; the attention of the reference is
+ *     A_ref[pixel][slot] = P[pixel][slot] * exp(m_branch - m) / (z_col exp(m_col - m) + z_row exp(m_row - m)),  m = max(m_col, m_row)
+ * (``ccnet_amd.functions.attention_from_parts`` on the host), applied by every consumer while it loads the tensor; the masked
+ * column self slot holds exactly 0.  The pair (A, stats) is what the forward saves for the backward.
  * Constraints: max(H, W) <= 132, C % 8 == 0, Cq % 8 == 0, every bs / ps a multiple of 8, pointers 16-byte aligned.
  * y = gamma * (column + row aggregation) + x       (functions.py:46-49)
  * ``workspace``: ccnet_cca_workspace_bytes(CCNET_WS_PM_FORWARD / _BACKWARD, ...) bytes (fp32 column partials; + softmax
  * partials; bf16 and fp32 views alike). */
 int ccnet_cca_forward_pm_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v, const uint16_t *x,
-                              const float *gamma, uint16_t *y, float *A, int B, int C, int Cq, int H, int W,
+                              const float *gamma, uint16_t *y, float *A, float *stats, int B, int C, int Cq, int H, int W,
                               long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long x_bs, int x_ps,
                               long y_bs, int y_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
 /* ``scratch``: B*H*W*(H+W) floats (dA, then dE in place). */
 int ccnet_cca_backward_pm_bf16(const uint16_t *dy, const uint16_t *q, const uint16_t *k, const uint16_t *v,
-                               const float *A, const float *gamma, uint16_t *dq, uint16_t *dk, uint16_t *dv,
+                               const float *A, const float *stats, const float *gamma, uint16_t *dq, uint16_t *dk, uint16_t *dv,
                                float *dgamma, float *scratch, int B, int C, int Cq, int H, int W,
                                long dy_bs, int dy_ps, long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
                                long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
@@ -208,11 +215,11 @@ int ccnet_cca_backward_pm_bf16(const uint16_t *dy, const uint16_t *q, const uint
  * same arguments, semantics and workspace as the bf16 pair.  (What the module runs for channels_last fp32 inputs; NCHW fp32
  * inputs take the split-plane path below.) */
 int ccnet_cca_forward_pm_f32(const float *q, const float *k, const float *v, const float *x,
-                             const float *gamma, float *y, float *A, int B, int C, int Cq, int H, int W,
+                             const float *gamma, float *y, float *A, float *stats, int B, int C, int Cq, int H, int W,
                              long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long x_bs, int x_ps,
                              long y_bs, int y_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
 int ccnet_cca_backward_pm_f32(const float *dy, const float *q, const float *k, const float *v,
-                              const float *A, const float *gamma, float *dq, float *dk, float *dv,
+                              const float *A, const float *stats, const float *gamma, float *dq, float *dk, float *dv,
                               float *dgamma, float *scratch, int B, int C, int Cq, int H, int W,
                               long dy_bs, int dy_ps, long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
                               long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
@@ -246,10 +253,14 @@ int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W);
  *   per workgroup; every row pass (aggregation, dv, dq | dk) runs once per block of the CONTRACTED positions, updating its fp32
  *   partial in place, the last one writes the output.
  * ccnet_cca_forward_planes_f32 / _backward_planes_f32: functions.py:38-49 and its autograd with q, k fp32 pixel-major
- *   views (exact fp32 energies), v as planes, the module's x / y / dy NCHW fp32, dq | dk | dv fp32 pixel-major views,
- *   A / scratch (B,H,W,H+W) fp32 as everywhere.  Workspace: CCNET_WS_PLANES_FORWARD / _BACKWARD (backward: holds the fp32
- *   column partial and dy as planes).  Arithmetic: energies exact fp32; every other contraction split-bf16 x3 with fp32
- *   accumulation (the lo x lo term, 2^-18 relative, is dropped) -- the CCNET_PRECISION_* knob does not apply here. */
+ *   views (exact fp32 energies), the module's x / y / dy NCHW fp32, dq | dk | dv fp32 pixel-major views, A (two-stage: see
+ *   above) / stats / scratch fp32.  The forward takes v the way its producer leaves it -- ``v``: the fp32 pixel-major value
+ *   slice of the projection (functions.py:35), ``v_bias``: C floats added while splitting, or NULL -- and WRITES ``v_planes``
+ *   (the split runs on the library's side stream next to the affinity launch and joins before the aggregation), which the
+ *   caller keeps for the backward; with ``v`` == NULL, ``v_planes`` is an input that already holds the planes.
+ *   Workspace: CCNET_WS_PLANES_FORWARD / _BACKWARD (backward: holds the fp32 column partial and dy as planes).
+ *   Arithmetic: energies exact fp32; every other contraction split-bf16 x3 with fp32 accumulation (the lo x lo term,
+ *   2^-18 relative, is dropped) -- the CCNET_PRECISION_* knob does not apply here. */
 #define CCNET_PLANES_HL 2
 #define CCNET_PLANES_HLH 3
 #define CCNET_PLANES_HHL 4
@@ -257,17 +268,26 @@ int ccnet_cca_split_planes_f32(const float *src, uint16_t *dst, int B, int C, in
                                long dst_bs, int dst_ps, int layout, const float *bias, ccnet_stream_t stream);
 int ccnet_cca_nchw_to_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, long dst_bs,
                                  int dst_ps, int layout, ccnet_stream_t stream);
-int ccnet_cca_forward_planes_f32(const float *q, const float *k, const uint16_t *v_planes, const float *x, const float *gamma,
-                                 float *y, float *A, int B, int C, int Cq, int H, int W,
-                                 long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
+int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v, const float *v_bias, uint16_t *v_planes,
+                                 const float *x, const float *gamma, float *y, float *A, float *stats,
+                                 int B, int C, int Cq, int H, int W,
+                                 long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long vp_bs, int vp_ps,
                                  void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
+/* (A, stats) of the two-stage softmax alone, from pixel-major q, k views (``bf16`` != 0: bf16 views as in the *_pm_bf16 entry
+ * points, else fp32 views as in the *_pm_f32 / *_planes_f32 ones): exactly what those forwards leave in ``A`` and ``stats``.  The
+ * host calls it in the backward pass when it did NOT keep the pair between forward and backward (recompute instead of save:
+ * SURVEY.md 8(f) rank 4, networks/ccnet.py:118-119 -- R applications of the module hold R attention tensors). */
+int ccnet_cca_attention_pm(const void *q, const void *k, float *A, float *stats, int bf16, int B, int Cq, int H, int W,
+                           long q_bs, int q_ps, long k_bs, int k_ps, ccnet_stream_t stream);
 int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *k, const uint16_t *v_planes, const float *A,
-                                  const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
+                                  const float *stats, const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
                                   int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps,
                                   long v_bs, int v_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
                                   void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
 
-/* Options by name (set returns the previous value, < 0 for an unknown name); defaults are what ships:
+/* Options by name.  Both calls return a STATUS (0, or CCNET_E_BADFLAGS for an unknown name / a value outside the option's
+ * range, CCNET_E_NULLPTR); values travel through out-parameters (``previous`` may be NULL), so that an option value of -1 is
+ * never mistaken for an error.  Defaults are what ships:
  *   "impl" CCNET_IMPL_*, "precision" CCNET_PRECISION_*, "branch_mask" CCNET_BRANCH_* (see above);
  * development / A-B switches:
  *   "planes_ring"  which kernels run the split-plane passes that have a pixel-major output:
@@ -282,9 +302,12 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
  *                    stream (forked from ``stream`` by an event, joined before the call returns: the caller's stream sees
  *                    one ordered operation and a stream capture stays one graph): 2 next to dA, softmax-backward and
  *                    dq | dk; 1 next to softmax-backward and dq | dk only; 0 everything on ``stream``; -1 (default) what
- *                    measured best per family (2 on split planes, 1 on the bf16 / fp32 pixel-major entries). */
-int ccnet_cca_set_option(const char *name, int value);
-int ccnet_cca_get_option(const char *name);            /* current value; < 0 (CCNET_E_*) for an unknown name */
+ *                    measured best per family (2 on split planes, 1 on the bf16 / fp32 pixel-major entries).  Any value but 0
+ *                    also lets the split-plane FORWARD run its v -> planes pass on the side stream next to the affinity launch.
+ *   "planes_xcd"   1: the NCHW row pass of the split-plane forward decodes its strips XCD-aware (consecutive rows of an image
+ *                    on one XCD, whose L2 then merges the boundary lines neighbouring NCHW rows share); 0 (default): linear. */
+int ccnet_cca_set_option(const char *name, int value, int *previous);
+int ccnet_cca_get_option(const char *name, int *value);
 
 /* Launch profiler (a measurement aid, off by default).  Between ``begin`` and ``end`` every kernel launch the library
  * issues is bracketed by a HIP-event pair on its stream; ``end`` disarms, waits for the recorded launches and returns

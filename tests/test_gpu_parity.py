@@ -501,6 +501,54 @@ def test_split_plane_module_node_matches_the_oracle_and_the_other_nodes(lib, dev
           f"{abs(float(a[2]['gamma']) - float(go['dgamma'])):.1e}")
     assert err(a[0], yo) < TOL
     assert abs(float(a[2]["gamma"]) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
+    # dx and ALL SEVEN parameter gradients of both plane nodes against the ORACLE (the whole module,
+    # projections included, restated on the CPU), not only against the sibling strip node -- at (2,512,97,97) the call has
+    # 18,818 pixels per image x 2 and the default module runs split-bf16 projection GEMMs (every golden fixture is smaller).
+    # Bars: 3x the worst value measured on MI355X (printed), relative to max(1, |g|max).
+    params = {n: f(p_) for n, p_ in m.state_dict().items()}
+    yr, dxr, gr = O.cca_module_forward_backward(f(x), params, f(dy))
+    bars = {"y": 1e-3, "dx": 5e-4, "gamma": 1e-3, "weight": 3e-3, "bias": 3e-3}
+    for variant in ("planes", "planes+split-gemm"):
+        a = outs[variant]
+        rel = {"y": err(a[0], yr) / max(1.0, float(yr.abs().max())), "dx": err(a[1], dxr) / max(1.0, float(dxr.abs().max()))}
+        for n, g in a[2].items():
+            rel[n] = err(g, gr[n].reshape(g.shape)) / max(1.0, float(gr[n].abs().max()))
+        print(f"split-plane node ({variant}) vs the ORACLE module", shape, {n: f"{e:.1e}" for n, e in rel.items()})
+        for n, e in rel.items():
+            assert e < bars[n.split(".")[-1]], (variant, n, e)
+
+
+def test_split_plane_core_logit_scale_sweep_at_the_headline_geometry(lib, dev):
+    """where does the default arithmetic (split-bf16 x3 everywhere but the energies) leave the 1e-3 bar?
+    q, k ~ N(0, s^2) at C/8 = 64 channels give logits of standard deviation 8 s^2: s = 1 is already a peaky softmax, trained
+    CCNet logits are not bounded by it.  One image of (.,512,97,97) through the split-plane C ABI per scale; max-abs error of
+    dq / dk / dv / y against the fp64-accumulating oracle, and the same error relative to the gradient's own magnitude (the
+    quantity a split-bf16 product actually bounds: 2^-17 per operand)."""
+    import bench
+    B, C, H, W = 1, 512, 97, 97
+    cq = C // 8
+    nchw = lambda t: t.permute(0, 3, 1, 2).contiguous().cpu()               # noqa: E731
+    rows = {}
+    for s in (1.0, 1.5, 2.0, 3.0):
+        wl = bench.PlanesWorkload(lib, B, C, H, W, dev, 99)
+        wl.qkv[..., :2 * cq] *= s
+        wl.step()
+        torch.cuda.synchronize()
+        q, k, v = nchw(wl.qkv[..., :cq]), nchw(wl.qkv[..., cq:2 * cq]), nchw(wl.qkv[..., 2 * cq:])
+        yo, Ao = O.cca_core_forward(q, k, v, wl.x.cpu(), torch.tensor([0.5]))
+        go = O.cca_core_backward(wl.dy.cpu(), q, k, v, Ao, torch.tensor([0.5]))
+        got = {"y": wl.y, "dq": nchw(wl.dqkv[..., :cq]), "dk": nchw(wl.dqkv[..., cq:2 * cq]), "dv": nchw(wl.dqkv[..., 2 * cq:])}
+        ref = {"y": yo, "dq": go["dq"], "dk": go["dk"], "dv": go["dv"]}
+        rows[s] = {n: (err(got[n], ref[n]), err(got[n], ref[n]) / float(ref[n].abs().max())) for n in got}
+        assert err(wl.attention(), Ao) < TIGHT
+        del wl
+    for s, r in rows.items():
+        print(f"logit-scale sweep: q, k x {s}: max-abs (relative to |ref|max)", {n: f"{a:.1e} ({b:.1e})" for n, (a, b) in r.items()})
+    # the absolute north_star bar holds at the reference's own initialisation scale and one step beyond; everywhere the error
+    # stays a fixed fraction of the gradient's magnitude (that is what the arithmetic bounds) -- include/ccnet_cca.h states it
+    for s in (1.0, 1.5):
+        assert all(a < TOL for a, _ in rows[s].values()), (s, rows[s])
+    assert all(b < 1e-4 for r in rows.values() for _, b in r.values()), rows
 
 
 @pytest.mark.parametrize("shape", [(1, 512, 129, 257), (2, 256, 97, 193), (1, 64, 132, 400)])
@@ -631,7 +679,7 @@ def test_split_plane_core_at_the_headline_shape_against_the_oracle(lib, dev):
         sl = slice(i, i + 1)
         yo, Ao = O.cca_core_forward(q[sl], k[sl], v[sl], wl.x[sl].cpu(), torch.tensor([0.5]))
         go = O.cca_core_backward(wl.dy[sl].cpu(), q[sl], k[sl], v[sl], Ao, torch.tensor([0.5]))
-        e = {"y": err(wl.y[sl], yo), "A": err(wl.A[sl], Ao), "dq": err(nchw(wl.dqkv[sl][..., :cq]), go["dq"]),
+        e = {"y": err(wl.y[sl], yo), "A": err(wl.attention()[sl], Ao), "dq": err(nchw(wl.dqkv[sl][..., :cq]), go["dq"]),
              "dk": err(nchw(wl.dqkv[sl][..., cq:2 * cq]), go["dk"]), "dv": err(nchw(wl.dqkv[sl][..., 2 * cq:]), go["dv"])}
         for n, val in e.items():
             worst[n] = max(worst.get(n, 0.0), val)
@@ -838,38 +886,51 @@ def test_split_bf16_precision_option(lib, dev):
 @pytest.mark.gpu
 def test_recompute_attention_matches_saved_attention_and_keeps_less(lib, dev):
     """SURVEY 8(f) rank 4 / networks/ccnet.py:118-119: with ``recompute_attention`` the module keeps q, k, v only and
-    rebuilds A in backward -- same kernels, so every gradient is bit-identical; the autograd graph holds no
-    (B,H,W,H+W) tensor; under no_grad nothing is kept at all."""
+    rebuilds the attention in backward -- same kernels, so every gradient is bit-identical; the autograd graph holds no
+    (B,H,W,H+W) tensor; under no_grad nothing is kept at all.  EVERY route honours the flag: the
+    split-plane node and the pixel-major bf16 / fp32 nodes rebuild the two-stage pair (P, stats) with the forward's own
+    affinity kernel, the NCHW strip nodes their attention tensor."""
     from ccnet_amd import CrissCrossAttention
     lib.ccnet_cca_set_impl(0)
     torch.manual_seed(4)
     B, C, H, W = 2, 64, 33, 40
     x = torch.randn(B, C, H, W, device=dev)
     dy = torch.randn(B, C, H, W, device=dev)
-    res = {}
-    for fused in (True, False):
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)           # noqa: E731
+    setups = {          # name -> (module tweaks, input transform, expected route)
+        "f32-planes": ({}, lambda t: t, "f32-planes"),
+        "f32-channels-last": ({}, cl, "f32-channels-last"),
+        "bf16-pixel-major": ({"bf16": True}, lambda t: cl(t.to(torch.bfloat16)), "bf16-pixel-major"),
+        "f32-strips-node": ({"split_planes": False}, lambda t: t, "f32-strips-node"),
+        "packed-strips": ({"split_planes": False, "fuse_module_backward": False}, lambda t: t, "packed-strips"),
+    }
+    for name, (tweaks, tf, route) in setups.items():
+        res = {}
         for rec in (False, True):
             torch.manual_seed(7)
             m = CrissCrossAttention(C).to(dev)
-            m.fuse_module_backward = fused
+            if tweaks.get("bf16"):
+                m = m.to(torch.bfloat16)
+            for attr, val in tweaks.items():
+                if attr != "bf16":
+                    setattr(m, attr, val)
             m.recompute_attention = rec
-            m.split_planes = False   # (recompute is a feature of the NCHW strip nodes; keep both runs on them)
             with torch.no_grad():
                 m.gamma.fill_(0.5)
-            xd = x.clone().requires_grad_(True)
+            xd = tf(x.clone()).requires_grad_(True)
+            assert m.route(xd) == route, (name, m.route(xd))
             kept = []
             with torch.autograd.graph.saved_tensors_hooks(lambda t: (kept.append(tuple(t.shape)), t)[1], lambda t: t):
                 y = m(m(xd))                      # R = 2, shared weights
-            y.backward(dy)
-            res[(fused, rec)] = [y.detach(), xd.grad] + [p.grad for p in m.parameters()]
+            y.backward(tf(dy).to(y.dtype))
+            res[rec] = [y.detach(), xd.grad] + [p.grad for p in m.parameters()]
             has_attention = (B, H, W, H + W) in kept
-            assert has_attention == (not rec), (fused, rec, kept)
-    for fused in (True, False):
-        a, b = res[(fused, False)], res[(fused, True)]
-        assert torch.equal(a[0], b[0])                       # y: the same forward
+            assert has_attention == (not rec), (name, rec, kept)
+        a, b = res[False], res[True]
+        assert torch.equal(a[0], b[0]), name                 # y: the same forward
         for u, v in zip(a[1:], b[1:]):                       # gradients pass through hipBLASLt reductions (not run-to-run
-            rel = float((u - v).norm() / v.norm().clamp_min(1e-20))   # bit-stable); the attention they use is identical
-            assert rel < 1e-4, rel
+            rel = float((u.float() - v.float()).norm() / v.float().norm().clamp_min(1e-20))   # bit-stable); the attention is identical
+            assert rel < (1e-2 if tweaks.get("bf16") else 1e-4), (name, rel)
     m.eval()
     with torch.no_grad():
         y = m(x)
@@ -946,12 +1007,12 @@ def test_side_stream_overlap_is_result_neutral_and_captures_into_one_graph(lib, 
     import bench
     try:
         for wl in (bench.PlanesWorkload(lib, 2, 256, 97, 61, dev, 21), bench.PixelMajorBF16Workload(lib, 2, 256, 129, 65, dev, 22)):
-            lib.ccnet_cca_set_option(b"planes_overlap", 0)
+            lib.set_option("planes_overlap", 0)
             wl.step()
             torch.cuda.synchronize()
             ref = [t.clone() for t in (wl.y, wl.dqkv, wl.dgamma, wl.A)]
             for ov in (1, 2, -1):
-                lib.ccnet_cca_set_option(b"planes_overlap", ov)
+                lib.set_option("planes_overlap", ov)
                 for t in (wl.y, wl.dqkv):
                     t.zero_()
                 wl.step()
@@ -966,7 +1027,7 @@ def test_side_stream_overlap_is_result_neutral_and_captures_into_one_graph(lib, 
                     assert all(torch.equal(a, b) for a, b in zip((wl.y, wl.dqkv, wl.dgamma, wl.A), ref)), ("graph", ov)
                 del g
     finally:
-        lib.ccnet_cca_set_option(b"planes_overlap", -1)
+        lib.set_option("planes_overlap", -1)
 
 
 def _random_pm_shapes(n, longest, align, seed):

@@ -33,7 +33,7 @@ def test_device_library_exports_every_declared_symbol(device_lib_path):
     for n in names:
         assert hasattr(dll, n), f"{n} declared in include/ccnet_cca.h but not exported"
     lib = _lib.CcaLibrary(device_lib_path)
-    assert lib.ccnet_cca_version() == 100 and lib.ccnet_cca_arch() == b"gfx950"
+    assert lib.ccnet_cca_version() == 200 and lib.ccnet_cca_arch() == b"gfx950"
     # argument validation happens before any launch, so it is checkable here
     assert lib.ccnet_ca_forward_f32(None, None, None, 1, 1, 2, 2, 0, None) == -2
     assert lib.ccnet_ca_forward_f32(None, None, None, 0, 1, 2, 2, 0, None) == -1
@@ -234,14 +234,23 @@ def test_options_and_workspace_sizes_are_host_logic_behind_two_entry_points(devi
     from ccnet_amd import _lib
     lib = _lib.get_lib()
     assert len(_lib.declared_symbols()) <= 30
-    for name, default in ((b"impl", _lib.CCNET_IMPL_AUTO), (b"precision", _lib.CCNET_PRECISION_DEFAULT), (b"branch_mask", 3),
-                          (b"planes_ring", 2), (b"planes_stream", 1), (b"planes_overlap", -1)):
-        assert lib.ccnet_cca_get_option(name) == default, name
-    assert lib.ccnet_cca_set_option(b"planes_overlap", 0) == -1 and lib.ccnet_cca_get_option(b"planes_overlap") == 0
-    assert lib.ccnet_cca_set_option(b"planes_overlap", -1) == 0
-    assert lib.ccnet_cca_set_option(b"impl", 99) == _lib.CCNET_IMPL_AUTO and lib.ccnet_cca_get_impl() == _lib.CCNET_IMPL_AUTO   # invalid: unchanged
-    assert lib.ccnet_cca_set_option(b"no_such_option", 1) < 0 and lib.ccnet_cca_get_option(b"no_such_option") < 0
-    assert b"unknown option" in lib.ccnet_cca_last_error_string()
+    for name, default in (("impl", _lib.CCNET_IMPL_AUTO), ("precision", _lib.CCNET_PRECISION_DEFAULT), ("branch_mask", 3),
+                          ("planes_ring", 2), ("planes_stream", 1), ("planes_overlap", -1), ("planes_xcd", 0)):
+        assert lib.get_option(name) == default, name
+    assert lib.set_option("planes_overlap", 0) == -1 and lib.get_option("planes_overlap") == 0
+    assert lib.set_option("planes_overlap", -1) == 0
+    # status and value never share an int -- -1 is a legal value of "planes_overlap", errors come back as codes
+    import ctypes
+    prev, val = ctypes.c_int(7), ctypes.c_int(7)
+    assert lib.ccnet_cca_set_option(b"impl", 99, ctypes.byref(prev)) == -3 and prev.value == 7             # invalid: unchanged
+    assert lib.get_option("impl") == _lib.CCNET_IMPL_AUTO
+    assert lib.ccnet_cca_set_option(b"planes_overlap", 3, None) == -3 and lib.ccnet_cca_set_option(b"planes_ring", -1, None) == -3
+    assert lib.ccnet_cca_set_option(b"no_such_option", 1, None) == -3 and lib.ccnet_cca_get_option(b"no_such_option", ctypes.byref(val)) == -3
+    assert b"unknown option" in lib.ccnet_cca_last_error_string() and val.value == 7
+    assert lib.ccnet_cca_get_option(b"planes_overlap", ctypes.byref(val)) == 0 and val.value == -1
+    with pytest.raises(_lib.CcaError):
+        lib.set_option("precision", 17)
+    assert lib.ccnet_cca_version() == _lib.CCNET_CCA_VERSION == 200
     B, C, Cq, H, W = 8, 512, 64, 97, 97
     px = B * H * W * 4
     sm = lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
@@ -288,8 +297,8 @@ def test_module_routing_table(device_lib_path):
     m.split_planes = False
     assert m.route(nchw(2, 97, 97)) == "f32-strips-node" and m.route(nchw(8, 97, 97)) == "f32-strips-node"
     m.split_planes = True
-    m.recompute_attention = True                     # (the flag must not be silently ignored)
-    assert m.route(nchw(2, 97, 97)) == "f32-strips-node" and m.route(cl(2, 33, 18)) == "f32-strips-node"
+    m.recompute_attention = True                     # (the fast routes honour the flag themselves now)
+    assert m.route(nchw(2, 97, 97)) == "f32-planes" and m.route(cl(2, 33, 18)) == "f32-channels-last"
     m.recompute_attention = False
     m.fuse_projections = False
     assert m.route(nchw(2, 97, 97)) == "separate-strips"

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""A/B of library options on the headline split-plane step, on ONE set of buffers inside ONE process (boxes of the pool differ
+by 3-4 %, so only same-run comparisons count).  Per option set: eager step ms, hipGraph replay ms, fwd / bwd ms and -- with
+every launch on one stream -- the per-launch durations.
+usage: ab_options.py [B C H W] [--sets name=opt:val,opt:val ...]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from ccnet_amd import _lib  # noqa: E402
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+B, C, H, W = (int(a) for a in args[:4]) if len(args) >= 4 else (8, 512, 97, 97)
+DEFAULT_SETS = {
+    "default": {},
+    "xcd-row-pass": {"planes_xcd": 1},
+    "one-stream": {"planes_overlap": 0},
+    "one-stream+xcd": {"planes_overlap": 0, "planes_xcd": 1},
+    "overlap-1": {"planes_overlap": 1},
+}
+lib = _lib.get_lib()
+dev = torch.device("cuda:0")
+BASE = {"planes_ring": 2, "planes_stream": 1, "planes_overlap": -1, "planes_xcd": 0}
+wl = bench.PlanesWorkload(lib, B, C, H, W, dev, 1234)
+ref = None
+for rnd in range(2):                       # two rounds: the order of the sets must not matter
+    for name, opts in DEFAULT_SETS.items():
+        for k, v in {**BASE, **opts}.items():
+            lib.set_option(k, v)
+        for _ in range(5):
+            wl.step()
+        torch.cuda.synchronize()
+        out = (wl.y.clone(), wl.dqkv.clone(), wl.dgamma.clone())
+        if ref is None:
+            ref = out
+        same = all(torch.equal(a, b) for a, b in zip(out, ref))
+        ms = bench.time_region(wl.step, 50)
+        fwd, bwd = bench.time_region(wl.forward, 30), bench.time_region(wl.backward, 30)
+        g = bench.capture_step_graph(wl.step)
+        g.replay()
+        gms = bench.time_region(g.replay, 50)
+        del g
+        print(f"== round {rnd} {name:16s} {opts}: eager {ms:.4f} ms  graph {gms:.4f} ms  fwd {fwd:.4f}  bwd {bwd:.4f}  bit-identical to first: {same}", flush=True)
+        if rnd == 0 and name in ("one-stream", "one-stream+xcd"):
+            rec = lib.profile_launches(lambda: [wl.step() for _ in range(5)])
+            n = len(rec) // 5
+            print(f"     launches {n}, event sum {sum(t for _, t in rec) / 5:.4f} ms")
+            for i in range(n):
+                print(f"     {sum(rec[r * n + i][1] for r in range(5)) / 5 * 1e3:8.1f} us  {rec[i][0][:120]}")
+for k, v in BASE.items():
+    lib.set_option(k, v)

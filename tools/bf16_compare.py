@@ -11,8 +11,8 @@ lib = _lib.get_lib(); dev = torch.device("cuda:0")
 shape = tuple(int(a) for a in sys.argv[1:5]) if len(sys.argv) >= 5 else (16, 512, 129, 129)
 ref = None
 for opts in ((0, 0, 0), (2, 1, 0), (2, 1, 1), (2, 1, 2)):
-    lib.ccnet_cca_set_option(b"planes_ring", opts[0]); lib.ccnet_cca_set_option(b"planes_stream", opts[1])
-    lib.ccnet_cca_set_option(b"planes_overlap", opts[2])
+    lib.set_option("planes_ring", opts[0]); lib.set_option("planes_stream", opts[1])
+    lib.set_option("planes_overlap", opts[2])
     wl = bench.PixelMajorBF16Workload(lib, *shape, dev, 1)
     for _ in range(3):
         wl.step()
@@ -28,4 +28,4 @@ for opts in ((0, 0, 0), (2, 1, 0), (2, 1, 1), (2, 1, 2)):
         ref = cur
     else:
         print("    bit-identical to the first variant:", torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1]))
-lib.ccnet_cca_set_option(b"planes_ring", 2); lib.ccnet_cca_set_option(b"planes_stream", 1); lib.ccnet_cca_set_option(b"planes_overlap", -1)
+lib.set_option("planes_ring", 2); lib.set_option("planes_stream", 1); lib.set_option("planes_overlap", -1)

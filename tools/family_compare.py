@@ -22,9 +22,9 @@ RING = {"planes-noring": 0, "planes-3wg": 2, "planes-3wg-nostream": 2, "planes-3
 
 
 def set_options(name):
-    lib.ccnet_cca_set_option(b"planes_ring", RING.get(name, 2))
-    lib.ccnet_cca_set_option(b"planes_stream", 0 if name.endswith("nostream") else 1)
-    lib.ccnet_cca_set_option(b"planes_overlap", 0 if name.endswith("nooverlap") or name.endswith("noring") else 1 if name.endswith("overlap1") else -1)
+    lib.set_option("planes_ring", RING.get(name, 2))
+    lib.set_option("planes_stream", 0 if name.endswith("nostream") else 1)
+    lib.set_option("planes_overlap", 0 if name.endswith("nooverlap") or name.endswith("noring") else 1 if name.endswith("overlap1") else -1)
 
 
 res = {}

@@ -60,7 +60,7 @@ def step_split():
 
 
 for ov in (-1, 0):
-    lib.ccnet_cca_set_option(b"planes_overlap", ov)
+    lib.set_option("planes_overlap", ov)
     for _ in range(5):
         wl.step(); step_split()
     torch.cuda.synchronize()
@@ -74,4 +74,4 @@ for ov in (-1, 0):
     print(f"planes_overlap={ov}: two halves step {bench.time_region(step_split, 30):.4f}  "
           f"fwd {bench.time_region(lambda: two_chains(fwd_half), 30):.4f}  bwd {bench.time_region(lambda: two_chains(bwd_half), 30):.4f} ms"
           f"   bit-identical y / dqkv / A: {same}")
-lib.ccnet_cca_set_option(b"planes_overlap", -1)
+lib.set_option("planes_overlap", -1)

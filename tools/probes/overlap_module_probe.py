@@ -7,7 +7,7 @@ dev = torch.device("cuda:0")
 C, H, W = 512, 97, 97
 for B in (1, 2):
     for ov in (0, 1, 2, -1, 0):
-        lib.ccnet_cca_set_option(b"planes_overlap", ov)
+        lib.set_option("planes_overlap", ov)
         torch.manual_seed(0)
         m = CrissCrossAttention(C).to(dev); m.split_bf16_projections = False
         with torch.no_grad(): m.gamma.fill_(0.5)
