@@ -251,7 +251,7 @@ class PixelMajorBF16Workload:
         self.gamma = torch.full((1,), 0.5, device=device)
         self.y, self.dqkv = torch.empty_like(self.x), torch.empty_like(self.qkv)
         self.A = torch.empty(B, H, W, H + W, device=device)          # two-stage softmax: un-normalised exponentials ...
-        self.stats = torch.empty(B, H, W, 4, device=device)          # ... and the per-pixel branch statistics
+        self.stats = torch.empty(B, H, W, 2, device=device)          # ... and the per-pixel factors (s_col, s_row)
         self.scratch = torch.empty_like(self.A)
         self.dgamma = torch.empty(1, device=device)
         self.fws_bytes = lib.ccnet_cca_pm_workspace_bytes(B, C, Cq, H, W, 0)
@@ -308,7 +308,7 @@ class PlanesWorkload:
         self.gamma = torch.full((1,), 0.5, device=device)
         self.y, self.dqkv = torch.empty_like(self.x), torch.empty_like(self.qkv)
         self.A = torch.empty(B, H, W, H + W, device=device)          # two-stage softmax: un-normalised exponentials ...
-        self.stats = torch.empty(B, H, W, 4, device=device)          # ... and the per-pixel branch statistics
+        self.stats = torch.empty(B, H, W, 2, device=device)          # ... and the per-pixel factors (s_col, s_row)
         self.scratch = torch.empty_like(self.A)
         self.dgamma = torch.empty(1, device=device)
         self.vpl = torch.empty(B, H, W, 2, C, dtype=torch.int16, device=device)     # written by the forward, read by the backward
@@ -520,12 +520,13 @@ def planes_launch_bytes(B, C, H, W):
         ("aggregation, row pass (v, A/2, partial, x -> y NCHW)", 4 * fc + att // 2,
          r"gmap_kernel<\d+, true, false, true, cca::bf16p_t, float, true"),
         ("dy NCHW -> planes", 2 * fc, r"nchw_to_planes_kernel"),
-        ("dA = dy.v (both branches)", 2 * fc + att, r"gweight_stream_kernel|gweight_kernel<\d+, false, cca::bf16p_t"),
+        ("dA = dy.v (both branches) + the branch dots sum_j P t", 2 * fc + 2 * att, r"gweight_stream_kernel|gweight_kernel<\d+, false, cca::bf16p_t"),
         ("dv, column pass (dy, A/2 -> partial)", 2 * fc + att // 2, r"gmap3_kernel<\d+, false, true, false"),
         ("dv, row pass (dy, A/2, partial -> dv)", 3 * fc + att // 2, r"gmap_kernel<\d+, true, true, true, cca::bf16p_t"),
-        ("softmax backward + dgamma partials", 3 * att, r"softmax_bwd_kernel"),
-        ("dq | dk, column pass (+ dgamma reduction)", att // 2 + 4 * fq, r"gmap_kernel<\d+, false, false, false, float, float, false, true"),
-        ("dq | dk, row pass", att // 2 + 6 * fq, r"gmap_kernel<\d+, true, false, true, float, float, false, true"),
+        ("softmax backward, folded: per-pixel (g, D) + dgamma partials", 4 * P * 10, r"parts_backward_finalize_kernel"),
+        ("dq | dk, column pass (dE formed from t, P on the way; + dgamma reduction)", att + 4 * fq,
+         r"gmap_kernel<\d+, false, false, false, float, float, false, true"),
+        ("dq | dk, row pass (dE formed from t, P on the way)", att + 6 * fq, r"gmap_kernel<\d+, true, false, true, float, float, false, true"),
     ]
 
 

@@ -77,10 +77,19 @@ __device__ __forceinline__ float wave_max(float v) {
 // to two roundings.  The masked column self slot holds exp(-inf) = 0 exactly.  A tensor whose statistics are the
 // neutral (0, 0.5, 0, 0.5) is a plain attention tensor (s = 1 exactly): what the blocked long-row forward writes.
 // ---------------------------------------------------------------------------------------------------------------
+// both factors of a pixel: ONE exponential (the branch that holds the joint maximum has exp(0) = 1) and one division
+__device__ __forceinline__ void parts_scales(const f32x4 st, float &s_col, float &s_row) {
+    const float d = st[0] - st[2];                                    // m_col - m_row  (-inf: a column branch with no live slot)
+    const float e = expf(-fabsf(d));
+    const float ec = d >= 0.f ? 1.f : e, er = d >= 0.f ? e : 1.f;
+    const float inv = 1.f / (st[1] * ec + st[3] * er);
+    s_col = ec * inv;
+    s_row = er * inv;
+}
 __device__ __forceinline__ float parts_scale(const f32x4 st, bool row) {
-    const float m = fmaxf(st[0], st[2]);
-    const float ec = expf(st[0] - m), er = expf(st[2] - m);          // (one of them is exp(0) = 1; exp(-inf) = 0)
-    return (row ? er : ec) / (st[1] * ec + st[3] * er);
+    float sc, sr;
+    parts_scales(st, sc, sr);
+    return row ? sr : sc;
 }
 
 // Split-bf16: x = hi + lo + O(2^-17 |x|) with hi = bf16_rne(x), lo = bf16_rne(x - hi).  A product a*b is then

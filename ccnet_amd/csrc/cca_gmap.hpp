@@ -142,19 +142,42 @@ __device__ __forceinline__ u32x4 t16_frag(const float *tile, int ks, int nt, int
     return u32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
-// the factors of the ``n`` query positions pix0 + t * pstep of one strip -> sc[0 .. P) (zero beyond n); ``stats`` null: ones
-template <int P, int THREADS>
-__device__ __forceinline__ void parts_stage_scales(float *sc, const float *stats, int b, int HW, int pix0, int pstep, int n, bool row, int tid) {
-    for (int t = tid; t < P; t += THREADS) {
-        float s = t < n ? 1.f : 0.f;
-        if (stats && t < n) {
-            f32x4 st;
-            __builtin_memcpy(&st, stats + ((size_t)b * HW + pix0 + t * pstep) * 4, 16);
-            s = parts_scale(st, row);
-        }
-        CCA_LDS_ST(sc + t, s);
+// What a consumer of the two-stage softmax's tensor gets (all null: T is a plain tensor -- dA, dE, a classic attention):
+//   raw     (B, H*W, 4) branch statistics straight from the affinity kernel (m_col, z_col, m_row, z_row); only the FIRST
+//           consumer of a forward reads them -- the column pass of the aggregation, which visits every pixel exactly once --
+//   out     (B, H*W, 2) and writes the FINAL factors (s_col, s_row) of its pixels there (what the forward saves);
+//   scales  (B, H*W, 2) final factors, read by every later consumer.
+// Non-transposed passes (queries = the M side) never touch the attention fragments: out = s_i * sum_j P[i][j] F[j], the factor
+// joins gamma in the epilogue, its load is needed only there.  Transposed passes (queries = the contracted side) multiply
+// P[i][j] by s_i while they build their fragments: eight more 4-byte loads next to the eight of the values, no staging.
+// FOLDED SOFTMAX BACKWARD (the dq | dk launches; ``pexp`` given): T is the un-scaled map adjoint t = dA, ``pexp`` the forward's
+// un-normalised exponentials and ``fin`` (B, H*W, 2 branches, 2) = (g_b, D) per pixel and branch with g_b = gamma * s_branch and
+// D = sum_s A dA -- the softmax adjoint  dE[i][j] = g_i * P[i][j] * (t[i][j] - D_i)  is formed while the fragments are built
+// (non-transposed: P (t - D_i) in the fragments, g_i in the epilogue; transposed: the whole product per contracted position),
+// so neither dE nor a softmax-backward launch exists.
+struct PartsArgs {
+    const float *scales;
+    const float *raw;
+    float *out;
+    const float *pexp;
+    const float *fin;
+};
+__device__ __forceinline__ bool parts_any(const PartsArgs &pa) { return pa.scales != nullptr || pa.raw != nullptr; }
+// buffer view of one image's final factors (transposed passes: branch-free loads, out-of-range lanes read 0)
+__device__ __forceinline__ FBuf parts_scales_buf(const PartsArgs &pa, size_t img_pix0, int HW, const float *any_valid) {
+    return make_fbuf(pa.scales ? pa.scales + img_pix0 * 2 : any_valid, pa.scales ? (size_t)HW * 8 : 4);
+}
+// factor of query pixel ``pix`` (image-relative) for the branch, non-transposed passes; ``write``: this lane stores the pixel's final pair
+__device__ __forceinline__ float parts_query_scale(const PartsArgs &pa, size_t img_pix0, int pix, bool ok, bool row, bool write) {
+    if (pa.raw) {                                   // (wave-uniform)
+        f32x4 st = f32x4{0.f, 1.f, 0.f, 1.f};
+        if (ok) __builtin_memcpy(&st, pa.raw + (img_pix0 + pix) * 4, 16);
+        float sc, sr;
+        parts_scales(st, sc, sr);
+        if (ok && write && pa.out) { pa.out[(img_pix0 + pix) * 2] = sc; pa.out[(img_pix0 + pix) * 2 + 1] = sr; }
+        return ok ? (row ? sr : sc) : 0.f;
     }
-    barrier_lds_only();
+    return ok ? pa.scales[(img_pix0 + pix) * 2 + (row ? 1 : 0)] : 0.f;
 }
 
 // FT: feature element, OT: output element; the addend (ADD) is fp32 pixel-major with its own strides; resid (may be
@@ -206,7 +229,7 @@ inline unsigned gmap_dual_grid(int nwg) { return 16u * (unsigned)((nwg + 7) / 8)
 // WPC: workgroups per CU the LDS budget is checked for (2 everywhere except the 132-position kernels on fp32 / split-plane
 // features, whose two feature tiles + output image take 104 KB: one workgroup per CU)
 template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT, bool NCHW = false, bool DUAL = false, int WPC = 2, bool LONG = false>
-__global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__restrict__ T, const float *__restrict__ stats,
+__global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__restrict__ T, const PartsArgs pa,
                                                               const FT *__restrict__ F,
                                                               const float *__restrict__ addend,
                                                               const OT *__restrict__ resid,
@@ -239,11 +262,9 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     static_assert(!NCHW || (ROW && ADD && !OBF && !TRANS && !DUAL), "gmap: the NCHW epilogue belongs to the final fp32 row pass");
     static_assert(!LONG || (ROW && ADD), "gmap: blocked long strips exist for the row passes (their addend chains the key blocks)");
     static_assert(!PL || !OBF, "gmap: split-plane features produce fp32 outputs");
-    static_assert(P % 4 == 0 && ((2 * FSZ + OIMG + P) * 4 + 511) / 512 * 512 * WPC <= 163840, "gmap: LDS of WPC workgroups per CU");
+    static_assert(P % 4 == 0 && (2 * FSZ + OIMG) * 4 * WPC <= 163840, "gmap: LDS of WPC workgroups per CU");
     __shared__ __attribute__((aligned(16))) float lds[2 * FSZ + OIMG];
-    __shared__ float qsc[P];                                          // per-query softmax factors (parts_stage_scales)
     CCA_LDS_REGISTER(lds);
-    CCA_LDS_REGISTER(qsc);
     float *const FB = lds, *const oimg = lds + 2 * FSZ;
     const int HW = H * W, S = H + W;
     const int L = ROW ? W : H, G = ROW ? H : W;
@@ -316,9 +337,14 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
         }
     };
     issue_feat(cg0);
-    // two-stage softmax: T holds un-normalised exponentials, every QUERY pixel has a factor (queries are the rows of the
-    // attention block: the M side non-transposed, the contracted side transposed)
-    if (stats) parts_stage_scales<P, GS_THREADS>(qsc, stats, b, HW, trans ? pixK : pixM, pstep, trans ? Lk : Lm, ROW, tid);
+    const bool parts = parts_any(pa);               // two-stage softmax: T holds un-normalised exponentials (see PartsArgs)
+    const bool defly = pa.pexp != nullptr;          // folded softmax backward: dE is formed here from t, P and (g, D)
+    const size_t img_pix0 = (size_t)b * HW;
+    const FBuf Sb = parts_scales_buf(pa, img_pix0, HW, T);
+    const FBuf Pb = make_fbuf(defly ? pa.pexp + (size_t)b * HW * S : T, defly ? (size_t)HW * S * sizeof(float) : 4);
+    const FBuf Gb = make_fbuf(defly ? pa.fin + img_pix0 * 4 : T, defly ? (size_t)HW * 16 : 4);
+    const int gbr = ROW ? 8 : 0;                     // byte offset of this branch's (g, D) pair inside a pixel's 16 bytes
+    float qs[TPW];                                   // non-transposed: the factor of this lane's query row of each owned tile
 
     // ---- the strip's attention block -> MFMA fragments in registers.  Fragment (tile t, k-step ks) of lane (ln, lg):
     // ---- P_g[m][32 ks + 8 lg + e] (TRANS: P_g[32 ks + 8 lg + e][m]), m = 16 t + ln, e < 8; zero beyond the strip
@@ -327,7 +353,14 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
 #pragma unroll
     for (int a = 0; a < TPW; ++a) {
         const int t = wv + GS_WAVES * a, m = 16 * t + ln;
-        const float sm = (stats && !trans) ? CCA_LDS_LD(qsc + (m < P ? m : P - 1)) : 1.f;
+        qs[a] = 1.f;
+        if (parts && !trans) qs[a] = parts_query_scale(pa, img_pix0, pixM + m * pstep, m < Lm, ROW, lg == 0);
+        float Dm = 0.f;
+        if (defly && !trans) {                              // this lane's query row: g_i joins the epilogue, D_i the fragments
+            const f32x2 gd = fbuf_load_x2(Gb, m < Lm ? (pixM + m * pstep) * 16 + gbr : kOobOffset, 0);
+            qs[a] = gd[0];
+            Dm = gd[1];
+        }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             float x[8];
@@ -338,12 +371,38 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                     const f32x4 u = fbuf_load_x4(Tb, (m < Lm && k0 < Lk) ? base : kOobOffset, 0);
                     const f32x4 v = fbuf_load_x4(Tb, (m < Lm && k0 + 4 < Lk) ? base + 16 : kOobOffset, 0);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { x[e] = k0 + e < Lk ? u[e] * sm : 0.f; x[4 + e] = k0 + 4 + e < Lk ? v[e] * sm : 0.f; }
+                    for (int e = 0; e < 4; ++e) { x[e] = k0 + e < Lk ? u[e] : 0.f; x[4 + e] = k0 + 4 + e < Lk ? v[e] : 0.f; }
+                    if (defly) {
+                        const f32x4 pu = fbuf_load_x4(Pb, (m < Lm && k0 < Lk) ? base : kOobOffset, 0);
+                        const f32x4 pv = fbuf_load_x4(Pb, (m < Lm && k0 + 4 < Lk) ? base + 16 : kOobOffset, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            x[e] = k0 + e < Lk ? pu[e] * (x[e] - Dm) : 0.f;
+                            x[4 + e] = k0 + 4 + e < Lk ? pv[e] * (x[4 + e] - Dm) : 0.f;
+                        }
+                    }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
+                    for (int e = 0; e < 8; ++e)
                         x[e] = fbuf_load(Tb, (m < Lm && k0 + e < Lk) ? ((pixK + (k0 + e) * pstep) * S + aM + m) * 4 : kOobOffset, 0);
-                        if (stats) x[e] *= CCA_LDS_LD(qsc + k0 + e);
+                    if (defly) {            // (all value loads issued first, branch-free)
+                        float pe[8];
+                        f32x2 gd[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            pe[e] = fbuf_load(Pb, (m < Lm && k0 + e < Lk) ? ((pixK + (k0 + e) * pstep) * S + aM + m) * 4 : kOobOffset, 0);
+                            gd[e] = fbuf_load_x2(Gb, k0 + e < Lk ? (pixK + (k0 + e) * pstep) * 16 + gbr : kOobOffset, 0);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = pe[e] * (x[e] - gd[e][1]) * gd[e][0];
+                    }
+                    if (parts) {            // (all eight value loads are issued: now a factor per contracted position)
+                        float sq[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            sq[e] = fbuf_load(Sb, k0 + e < Lk ? ((pixK + (k0 + e) * pstep) * 2 + (ROW ? 1 : 0)) * 4 : kOobOffset, 0);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] *= sq[e];
                     }
                 }
             } else {
@@ -357,7 +416,17 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
         const int kt = 32 * kp.nbf + lg;
         at[a] = fbuf_load(Tb, (kp.tail && m < Lm && kt < Lk) ? (trans ? ((pixK + kt * pstep) * S + aM + m) * 4
                                                                        : ((pixM + m * pstep) * S + aK + kt) * 4) : kOobOffset, 0);
-        if (stats) at[a] *= trans ? CCA_LDS_LD(qsc + (kt < P ? kt : P - 1)) : sm;
+        if (parts && trans) at[a] *= fbuf_load(Sb, (kp.tail && kt < Lk) ? ((pixK + kt * pstep) * 2 + (ROW ? 1 : 0)) * 4 : kOobOffset, 0);
+        if (defly) {
+            const bool okt = kp.tail && m < Lm && kt < Lk;
+            const float pt = fbuf_load(Pb, okt ? (trans ? ((pixK + kt * pstep) * S + aM + m) * 4 : ((pixM + m * pstep) * S + aK + kt) * 4) : kOobOffset, 0);
+            if (trans) {
+                const f32x2 gd = fbuf_load_x2(Gb, okt ? (pixK + kt * pstep) * 16 + gbr : kOobOffset, 0);
+                at[a] = pt * (at[a] - gd[1]) * gd[0];
+            } else {
+                at[a] = pt * (at[a] - Dm);
+            }
+        }
     }
 
     // this lane's slice of store instruction k of its wave: pixel position and first channel (within the group)
@@ -478,9 +547,9 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                         if constexpr (NCHW) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
-                                CCA_LDS_ST(oimg + oimg_nchw_idx<P>(16 * nt + 4 * lg + q, i), alpha * acc[a][n][q] + addp[a][nt][q]);
+                                CCA_LDS_ST(oimg + oimg_nchw_idx<P>(16 * nt + 4 * lg + q, i), alpha * qs[a] * acc[a][n][q] + addp[a][nt][q]);
                         } else {
-                            lds_store_x4(oimg + i * OPX + 16 * nt + 4 * lg, alpha * acc[a][n]);
+                            lds_store_x4(oimg + i * OPX + 16 * nt + 4 * lg, (alpha * qs[a]) * acc[a][n]);
                         }
                     }
                 }
@@ -578,7 +647,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
 // FT = bf16p_t (split planes: hi | lo tiles, three products) or bf16_t (bf16 features, BASELINE configs[4]: one tile, the two
 // products with the attention's hi and lo halves); the output is fp32 pixel-major either way (the column partial).
 template <int P, bool ROW, bool TRANS, bool ADD, int NBUF = 3, int WPC = 2, typename FT = bf16p_t>
-__global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__restrict__ T, const float *__restrict__ stats,
+__global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__restrict__ T, const PartsArgs pa,
                                                                const FT *__restrict__ F,
                                                                const float *__restrict__ addend, const float *__restrict__ gamma,
                                                                float *__restrict__ out, int C, int H, int W, long fbs, int fps,
@@ -587,13 +656,11 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
     constexpr int NPL = std::is_same<FT, bf16p_t>::value ? 2 : 1;       // planes per feature tile
     static_assert(NPL == 2 || std::is_same<FT, bf16_t>::value, "gmap3: bf16p_t or bf16_t features");
     constexpr int TSP = t16_size(P), FSZ = NPL * TSP, NPF = NPL * t16_pieces(P), D = NBUF - 1;
-    static_assert(P % 4 == 0 && ((NBUF * FSZ + P) * 4 + 511) / 512 * 512 * WPC <= 163840 && (NBUF == 2 || NBUF == 3), "gmap3: LDS of WPC workgroups per CU");
+    static_assert(P % 4 == 0 && NBUF * FSZ * 4 * WPC <= 163840 && (NBUF == 2 || NBUF == 3), "gmap3: LDS of WPC workgroups per CU");
     // (the ring fills are LDS-DMAs the compiler does not see -- fbuf_load_to_lds_x4_uncounted, cca_platform.hpp: with the
     // builtin form it drained the fills of the next two tiles before every group's first transposing read)
     __shared__ __attribute__((aligned(16))) float lds[NBUF * FSZ];
-    __shared__ float qsc[P];                                          // per-query softmax factors (parts_stage_scales)
     CCA_LDS_REGISTER(lds);
-    CCA_LDS_REGISTER(qsc);
     const int HW = H * W, S = H + W;
     const int L = ROW ? W : H, G = ROW ? H : W;
     const int ncg = (C + GM_CG - 1) / GM_CG;
@@ -632,8 +699,10 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
     };
     issue_feat(cg0, lds);
     if (D > 1 && cg0 + 1 < cg1) issue_feat(cg0 + 1, lds + FSZ);
-    // two-stage softmax: the factor of every query pixel of the strip (see parts_scale)
-    if (stats) parts_stage_scales<P, GS_THREADS>(qsc, stats, b, HW, pix0, pstep, L, ROW, tid);
+    const bool parts = parts_any(pa);               // two-stage softmax: T holds un-normalised exponentials (see PartsArgs)
+    const size_t img_pix0 = (size_t)b * HW;
+    const FBuf Sb = parts_scales_buf(pa, img_pix0, HW, T);
+    float qs[TPW];                                   // non-transposed: the factor of this lane's query row of each owned tile
 
     // the strip's attention block -> MFMA fragments in registers (as gmap_kernel)
     u32x4 ah[TPW][NKS], al[TPW][NKS];
@@ -641,7 +710,8 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
 #pragma unroll
     for (int a = 0; a < TPW; ++a) {
         const int t = wv + GS_WAVES * a, m = 16 * t + ln;
-        const float sm = (stats && !TRANS) ? CCA_LDS_LD(qsc + (m < P ? m : P - 1)) : 1.f;
+        qs[a] = 1.f;
+        if (parts && !TRANS) qs[a] = parts_query_scale(pa, img_pix0, pix0 + m * pstep, m < L, ROW, lg == 0);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             float x[8];
@@ -652,12 +722,18 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
                     const f32x4 u = fbuf_load_x4(Tb, (m < L && k0 < L) ? base : kOobOffset, 0);
                     const f32x4 v = fbuf_load_x4(Tb, (m < L && k0 + 4 < L) ? base + 16 : kOobOffset, 0);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { x[e] = k0 + e < L ? u[e] * sm : 0.f; x[4 + e] = k0 + 4 + e < L ? v[e] * sm : 0.f; }
+                    for (int e = 0; e < 4; ++e) { x[e] = k0 + e < L ? u[e] : 0.f; x[4 + e] = k0 + 4 + e < L ? v[e] : 0.f; }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
+                    for (int e = 0; e < 8; ++e)
                         x[e] = fbuf_load(Tb, (m < L && k0 + e < L) ? ((pix0 + (k0 + e) * pstep) * S + a_off + m) * 4 : kOobOffset, 0);
-                        if (stats) x[e] *= CCA_LDS_LD(qsc + k0 + e);
+                    if (parts) {            // (all eight value loads are issued: now a factor per contracted position)
+                        float sq[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            sq[e] = fbuf_load(Sb, k0 + e < L ? ((pix0 + (k0 + e) * pstep) * 2 + (ROW ? 1 : 0)) * 4 : kOobOffset, 0);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] *= sq[e];
                     }
                 }
             } else {
@@ -671,7 +747,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
         const int kt = 32 * kp.nbf + lg;
         at[a] = fbuf_load(Tb, (kp.tail && m < L && kt < L) ? (TRANS ? ((pix0 + kt * pstep) * S + a_off + m) * 4
                                                                      : ((pix0 + m * pstep) * S + a_off + kt) * 4) : kOobOffset, 0);
-        if (stats) at[a] *= TRANS ? CCA_LDS_LD(qsc + (kt < P ? kt : P - 1)) : sm;
+        if (parts && TRANS) at[a] *= fbuf_load(Sb, (kp.tail && kt < L) ? ((pix0 + kt * pstep) * 2 + (ROW ? 1 : 0)) * 4 : kOobOffset, 0);
     }
 
     // stores / addend loads of a group: one 16-byte access per owned M tile and N tile whose channels exist (both
@@ -761,7 +837,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
                 for (int nt = 0; nt < 4; ++nt) {
                     const int c = cg * GM_CG + 16 * nt + 4 * lg;
                     if (cg * GM_CG + 16 * nt < C) {
-                        f32x4 u = alpha * acc[a][nt];
+                        f32x4 u = (alpha * qs[a]) * acc[a][nt];
                         if constexpr (ADD) u += addp[SL][a][nt];
                         fbuf_store_x4(Ob, u, (i < L && c < C) ? ((pix0 + i * pstep) * ops + c) * 4 : kOobOffset, 0);
                     }
@@ -880,6 +956,7 @@ __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float *__rest
 template <int P, bool MASK, typename FT, bool SINGLE, bool LONG = false>
 __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(const FT *__restrict__ X, const FT *__restrict__ Y,
                                                                               float *__restrict__ T, float *__restrict__ stats,
+                                                                              const float *__restrict__ Pexp, float *__restrict__ ddot,
                                                                               int Cx, int H, int W,
                                                                               long xbs, int xps, long ybs, int yps, int nb = 1) {
     constexpr bool BF = GTile<FT>::BF;
@@ -1061,7 +1138,7 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
                 float z = 0.f;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const float pv = expf(acc[a][t][q] - mm);
+                    const float pv = fast_expf(acc[a][t][q] - mm);
                     acc[a][t][q] = pv;
                     z += pv;
                 }
@@ -1072,6 +1149,28 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
                     Sg[(size_t)(pix0 + i * pstep) * 4 + 1] = z;
                 }
             }
+    }
+    // folded softmax backward (dA launches, whole strips; see gweight_stream_kernel): ddot[pixel(i)][branch] = sum_j Pexp[i][j] T[i][j]
+    if constexpr (!MASK && !LONG) {
+        if (Pexp) {
+            const float *Pg = Pexp + (size_t)b * HW * S;
+            float *Dg = ddot + (size_t)b * HW * 2 + (row ? 1 : 0);
+#pragma unroll
+            for (int a = 0; a < NTR; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 16 * (wv + GM_WAVES * a) + 4 * lg + q;
+                    float d = 0.f;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int j = 16 * t + ln;
+                        if (i < L && j < Lk) d += Pg[(size_t)(pix0 + i * pstep) * S + a_off + j] * acc[a][t][q];
+                    }
+#pragma unroll
+                    for (int sh = 1; sh < 16; sh <<= 1) d += shfl_xor(d, sh);
+                    if (ln == 0 && i < L) Dg[(size_t)(pix0 + i * pstep) * 2] = d;
+                }
+        }
     }
     // D[m = query position 16 ti + 4 lg + q][n = key position 16 t + ln] -> T rows (64-byte runs per query)
     float *Tg = T + (size_t)b * HW * S;
@@ -1106,7 +1205,8 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
 // bf16 / P = 100 instantiation came out with 256 VGPRs and 13 spilled)
 template <int P, typename FT = bf16p_t>
 __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT *__restrict__ X, const FT *__restrict__ Y,
-                                                                        float *__restrict__ T, int Cx, int B, int H, int W,
+                                                                        float *__restrict__ T, const float *__restrict__ Pexp,
+                                                                        float *__restrict__ ddot, int Cx, int B, int H, int W,
                                                                         long xbs, int xps, long ybs, int yps) {
     constexpr int NPL = std::is_same<FT, bf16p_t>::value ? 2 : 1;        // planes per operand
     static_assert(NPL == 2 || std::is_same<FT, bf16_t>::value, "gweight_stream: bf16p_t or bf16_t operands");
@@ -1158,8 +1258,25 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
             for (int q = 0; q < 4; ++q) rows += 16 * (wv + GM_WAVES * a) + q < L ? 1 : 0;
         return rows * ((L + 15) / 16);
     };
+    // FOLDED SOFTMAX BACKWARD (Pexp given): a strip's epilogue also forms, per query i of the strip,
+    //     ddot[pixel(i)][branch] = sum_j Pexp[i][j] * T[i][j]          (the branch's share of sum_s A dA, up to the factor s_i)
+    // from the accumulators and the un-normalised exponentials of the block (one 4-byte load per accumulator value, issued at
+    // the top of the strip's LAST stage so that they land behind its MFMAs).  Those loads are ordinary loads the compiler waits
+    // for with vmcnt(0) -- which would also drain any ring fill issued after them -- so a last stage issues its ring fill AFTER
+    // the epilogue instead of before the MFMAs: the ring runs one stage shallower for one stage per strip.
+    const bool dots = Pexp != nullptr;
+    auto nrowstores = [&](int L) {                                          // ddot stores of a strip: one per (owned tile row, q) in range
+        int rows = 0;
+#pragma unroll
+        for (int a = 0; a < NTR; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rows += 16 * (wv + GM_WAVES * a) + q < L ? 1 : 0;
+        return rows;
+    };
     auto stores_after = [&](int m) {                                        // stores issued at the end of iteration m
-        return (m >= 0 && m % nch == nch - 1) ? nstores(strip_of(m).L) : 0;
+        if (m < 0 || m % nch != nch - 1) return 0;
+        const int L = strip_of(m).L;
+        return nstores(L) + (dots ? nrowstores(L) : 0);
     };
     auto frag = [&](const float *tile, int pixel_, int kk) {               // 8 consecutive channels of one position: 16 bytes
         const int pixel = pixel_ < 8 * NPB ? pixel_ : 0;
@@ -1180,12 +1297,14 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
         if (n == 0) {
             barrier_dma_keep<0>();
         } else {
-            int keep = 0;
+            // (with dots a last stage issues stores(m) BEFORE fill(m + D): the stores of iteration n - D are then older than fill(n))
+            int keep = dots ? 0 : stores_after(n - D);
 #pragma unroll
-            for (int d = 1; d <= D; ++d) keep += stores_after(n - d) + (d < D && n + d < total ? npw : 0);
+            for (int d = 1; d < D; ++d) keep += stores_after(n - d) + (n + d < total ? npw : 0);
             barrier_dma_keep_n(keep);
         }
-        if (n + D < total) issue(n + D);
+        const bool last = ch == nch - 1;
+        if (!(dots && last) && n + D < total) issue(n + D);
         if (ch == 0) {
             cur = strip_of(n);
 #pragma unroll
@@ -1194,6 +1313,19 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
                 for (int t = 0; t < NT; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         const int L = cur.L;
+        float pv[NTR][4][NT];
+        if (dots && last) {
+            const FBuf Pb = make_fbuf(Pexp + (size_t)cur.b * HW * S, (size_t)HW * S * sizeof(float));
+#pragma unroll
+            for (int a = 0; a < NTR; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int i = 16 * (wv + GM_WAVES * a) + 4 * lg + q, j = 16 * t + ln;
+                        pv[a][q][t] = fbuf_load(Pb, (i < L && j < L) ? ((cur.pix0 + i * cur.pstep) * S + cur.a_off + j) * 4 : kOobOffset, 0);
+                    }
+        }
         const float *xh = lds + (n % NBUF) * STG, *xl = xh + (NPL - 1) * TSB, *yh = xh + NPL * TSB, *yl = yh + (NPL - 1) * TSB;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {                                    // two k-steps of 32 channels
@@ -1221,7 +1353,24 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
                 }
             }
         }
-        if (ch == nch - 1) {
+        if (last) {
+            if (dots) {
+                const FBuf Db = make_fbuf(ddot + (size_t)cur.b * HW * 2, (size_t)HW * 2 * sizeof(float));
+#pragma unroll
+                for (int a = 0; a < NTR; ++a)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float d = 0.f;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) d += pv[a][q][t] * acc[a][t][q];      // (beyond the strip: 0 * 0)
+#pragma unroll
+                        for (int sh = 1; sh < 16; sh <<= 1) d += shfl_xor(d, sh);
+                        if (16 * (wv + GM_WAVES * a) + q < L) {             // (wave-uniform: lane (ln, lg) = (0, 0) is in range)
+                            const int i = 16 * (wv + GM_WAVES * a) + 4 * lg + q;
+                            fbuf_store(Db, d, (ln == 0 && i < L) ? ((cur.pix0 + i * cur.pstep) * 2 + (cur.a_off ? 1 : 0)) * 4 : kOobOffset, 0);
+                        }
+                    }
+            }
             // D[m = query position 16 ti + 4 lg + q][n = key position 16 t + ln] -> T rows (64-byte runs per query)
             const FBuf Tb = make_fbuf(T + (size_t)cur.b * HW * S, (size_t)HW * S * sizeof(float));
 #pragma unroll
@@ -1238,6 +1387,7 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
                         }
                     }
                 }
+            if (dots && n + D < total) issue(n + D);                        // (the delayed ring fill of this stage)
         }
     }
 }

@@ -81,8 +81,8 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_fwd_generic_kernel(const flo
 // dgamma are produced; each wavefront adds its pixels in a fixed order: deterministic.
 constexpr int SM_MAX_BLOCKS = 2048;
 
-// ``stats`` (may be null): A holds the un-normalised exponentials of the two-stage softmax (cca_common.hpp: parts_scale) --
-// slots below ``hsplit`` take the pixel's column factor, the others its row factor.
+// ``stats`` (may be null): A holds the un-normalised exponentials of the two-stage softmax (cca_common.hpp) and stats the final
+// per-pixel factors (s_col, s_row): slots below ``hsplit`` take the pixel's column factor, the others its row factor.
 template <int NREG>
 __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_kernel(const float *A, const float *dA,
                                                                const float *gamma, float *dE,
@@ -101,10 +101,8 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_kernel(const float *A, c
         float rsum = 0.f;
         float sc = 1.f, sr = 1.f;
         if (stats) {
-            f32x4 st;
-            __builtin_memcpy(&st, stats + (size_t)pix * 4, 16);
-            sc = parts_scale(st, false);
-            sr = parts_scale(st, true);
+            sc = stats[(size_t)pix * 2];
+            sr = stats[(size_t)pix * 2 + 1];
         }
 #pragma unroll
         for (int r = 0; r < NREG; ++r) {
@@ -155,10 +153,8 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_generic_kernel(const flo
         };
         float sc = 1.f, sr = 1.f;
         if (stats) {
-            f32x4 st;
-            __builtin_memcpy(&st, stats + (size_t)pix * 4, 16);
-            sc = parts_scale(st, false);
-            sr = parts_scale(st, true);
+            sc = stats[(size_t)pix * 2];
+            sr = stats[(size_t)pix * 2 + 1];
         }
         float rsum = 0.f;
         for (int s = lane; s < S; s += kWave) rsum += a[s] * (s < hsplit ? sc : sr) * dval(s);
@@ -177,15 +173,54 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_generic_kernel(const flo
     }
 }
 
-// statistics under which a plain attention tensor reads as itself through the two-stage consumers (parts_scale == 1 exactly)
-__global__ __launch_bounds__(256) void neutral_stats_kernel(float *stats, int npix) {
+// factors under which a plain attention tensor reads as itself through the two-stage consumers
+__global__ __launch_bounds__(256) void neutral_scales_kernel(float *scales, int npix) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < npix) {
-        stats[4 * (size_t)i] = 0.f;
-        stats[4 * (size_t)i + 1] = 0.5f;
-        stats[4 * (size_t)i + 2] = 0.f;
-        stats[4 * (size_t)i + 3] = 0.5f;
+        scales[2 * (size_t)i] = 1.f;
+        scales[2 * (size_t)i + 1] = 1.f;
     }
+}
+
+// raw branch statistics (m_col, z_col, m_row, z_row) -> final factors (s_col, s_row): what the forward's first consumer writes
+// on its way; a launch of its own only where the pair is rebuilt without a consumer (ccnet_cca_attention_pm)
+__global__ __launch_bounds__(256) void parts_finalize_kernel(const float *raw, float *scales, int npix) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < npix) {
+        f32x4 st;
+        __builtin_memcpy(&st, raw + 4 * (size_t)i, 16);
+        float sc, sr;
+        parts_scales(st, sc, sr);
+        scales[2 * (size_t)i] = sc;
+        scales[2 * (size_t)i + 1] = sr;
+    }
+}
+
+// FOLDED SOFTMAX BACKWARD, the per-pixel step between the dA launch and the dq | dk launches: the branch dots the dA kernels
+// left in ``ddot`` (B H W, 2) and the forward's factors ``scales`` (B H W, 2) give
+//     D = s_col * ddot_col + s_row * ddot_row  (= sum_s A dA),   fin[pixel][branch] = (gamma * s_branch, D)
+// and the workgroup's share of dgamma = sum_pixels D goes to partials[blockIdx.x] (summed in a fixed order by the dq | dk column
+// launch, GmapJob::red_*).  One thread per pixel.
+constexpr int FIN_BLOCK = 256;
+__global__ __launch_bounds__(FIN_BLOCK) void parts_backward_finalize_kernel(const float *scales, const float *ddot, const float *gamma,
+                                                                            float *fin, float *partials, int npix) {
+    __shared__ float red[FIN_BLOCK];
+    const int i = blockIdx.x * FIN_BLOCK + threadIdx.x;
+    const float g = gamma ? gamma[0] : 1.f;
+    float D = 0.f;
+    if (i < npix) {
+        const float sc = scales[2 * (size_t)i], sr = scales[2 * (size_t)i + 1];
+        D = sc * ddot[2 * (size_t)i] + sr * ddot[2 * (size_t)i + 1];
+        f32x4 o = f32x4{g * sc, D, g * sr, D};
+        __builtin_memcpy(fin + 4 * (size_t)i, &o, 16);
+    }
+    red[threadIdx.x] = D;
+    __syncthreads();
+    for (int s = FIN_BLOCK / 2; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && partials) partials[blockIdx.x] = red[0];
 }
 
 // fixed-order reduction of the per-workgroup partial sums -> out[0]  (single workgroup)

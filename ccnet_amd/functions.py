@@ -413,11 +413,8 @@ class CrissCrossPMFunction(torch.autograd.Function):
             qkv, gamma = ctx.saved_tensors
             B, H, W, ct = qkv.shape
             es, tag = _PM_DTYPES[qkv.dtype][0], _PM_DTYPES[qkv.dtype][3]
-            A, stats = _empty_parts(B, H, W, qkv.device)
-            p, bs, ps = qkv.data_ptr(), qkv.stride(0), qkv.stride(2)
-            with torch.cuda.device(qkv.device):
-                lib.check(lib.ccnet_cca_attention_pm(p, p + es * cq, A.data_ptr(), stats.data_ptr(), int(tag == "bf16"), B, cq, H, W,
-                                                     bs, ps, bs, ps, _stream()), "cca_attention_pm")
+            p = qkv.data_ptr()
+            A, stats = _attention_pm(lib, p, p + es * cq, tag == "bf16", B, cq, H, W, qkv.stride(0), qkv.stride(2), qkv.device)
         else:
             qkv, A, stats, gamma = ctx.saved_tensors
         dy, dy_bs, dy_ps = _pm_view("grad_output", dy, qkv.dtype)
@@ -517,20 +514,26 @@ PLANES_HL, PLANES_HLH, PLANES_HHL = 2, 3, 4          # include/ccnet_cca.h CCNET
 
 def _empty_parts(B, H, W, device):
     """what a pixel-major / split-plane forward saves instead of the attention tensor: P (B,H,W,H+W) un-normalised
-    exponentials + stats (B,H,W,4) = (m_col, z_col, m_row, z_row) -- the two-stage softmax of include/ccnet_cca.h"""
+    exponentials + stats (B,H,W,2) = the per-pixel factors (s_col, s_row) -- the two-stage softmax of include/ccnet_cca.h"""
     return (torch.empty((B, H, W, H + W), device=device, dtype=torch.float32),
-            torch.empty((B, H, W, 4), device=device, dtype=torch.float32))
+            torch.empty((B, H, W, 2), device=device, dtype=torch.float32))
 
 
 def attention_from_parts(P: torch.Tensor, stats: torch.Tensor) -> torch.Tensor:
-    """The attention tensor of functions.py:40 from the parts the fast routes keep: A = P * s_branch(pixel) with
-    s = exp(m_branch - m) / (z_col exp(m_col - m) + z_row exp(m_row - m)), m = max(m_col, m_row) (csrc/cca_common.hpp)."""
+    """The attention tensor of functions.py:40 from the pair the fast routes keep: A[pixel][slot] = P[pixel][slot] * s_col(pixel)
+    for the H column slots, * s_row(pixel) for the W row slots (include/ccnet_cca.h, "two-stage softmax")."""
     H = P.shape[1]
-    mc, zc, mr, zr = stats.unbind(-1)
-    m = torch.maximum(mc, mr)
-    ec, er = torch.exp(mc - m), torch.exp(mr - m)
-    Z = zc * ec + zr * er
-    return torch.cat([P[..., :H] * (ec / Z).unsqueeze(-1), P[..., H:] * (er / Z).unsqueeze(-1)], dim=-1)
+    return torch.cat([P[..., :H] * stats[..., 0:1], P[..., H:] * stats[..., 1:2]], dim=-1)
+
+
+def _attention_pm(lib, qptr, kptr, bf16, B, cq, H, W, bs, ps, device):
+    """(P, stats) rebuilt from q, k (recompute instead of save): ccnet_cca_attention_pm + its small workspace"""
+    A, stats = _empty_parts(B, H, W, device)
+    with torch.cuda.device(device):
+        _ws, wsp, wsn = _workspace(lib.ccnet_cca_workspace_bytes(_lib.CCNET_WS_ATTENTION_PM, B, 0, 0, H, W), device)
+        lib.check(lib.ccnet_cca_attention_pm(qptr, kptr, A.data_ptr(), stats.data_ptr(), int(bf16), B, cq, H, W, bs, ps, bs, ps,
+                                             wsp, wsn, _stream()), "cca_attention_pm")
+    return A, stats
 
 
 def split_planes(t: torch.Tensor, c0: int, C: int, layout: int = PLANES_HL, dtype=torch.int16, bias=None) -> torch.Tensor:
@@ -675,10 +678,7 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
         pc = (ctx.cache if ctx.cache is not None else _ProjectionCache()).get(wq, bq, wk, bk, wv, bv, ctx.split_gemm)
         p, bs, ps = qk.data_ptr(), hw * 2 * cq, 2 * cq
         if ctx.recompute:
-            A, stats = _empty_parts(B, H, W, dy.device)
-            with torch.cuda.device(dy.device):
-                lib.check(lib.ccnet_cca_attention_pm(p, p + 4 * cq, A.data_ptr(), stats.data_ptr(), 0, B, cq, H, W, bs, ps, bs, ps,
-                                                     _stream()), "cca_attention_pm")
+            A, stats = _attention_pm(lib, p, p + 4 * cq, False, B, cq, H, W, bs, ps, dy.device)
         else:
             A, stats = ctx.saved_tensors[10:12]
         dqkv = torch.empty((B, hw, ct), device=dy.device, dtype=torch.float32)

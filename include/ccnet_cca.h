@@ -97,6 +97,7 @@ const char *ccnet_cca_last_error_string(void);
 #define CCNET_WS_PM_BACKWARD      4    /* ccnet_cca_backward_pm_{bf16,f32} */
 #define CCNET_WS_PLANES_FORWARD   5    /* ccnet_cca_forward_planes_f32 */
 #define CCNET_WS_PLANES_BACKWARD  6    /* ccnet_cca_backward_planes_f32 */
+#define CCNET_WS_ATTENTION_PM     7    /* ccnet_cca_attention_pm (C, Cq ignored) */
 size_t      ccnet_cca_workspace_bytes(int entry, int B, int C, int Cq, int H, int W);
 
 /* Affinity: replaces functions.py:30-34 (layout shuffles), :38 (bmm + INF), :39 (bmm), :40 (cat
@@ -187,16 +188,19 @@ int ccnet_cca_backward_strided_f32(const float *dy, const float *q, const float 
  * The attention tensor A (B, H, W, H+W), the scratch tensor, gamma, dgamma and every accumulation are fp32; products
  * of the bf16 features are exact on the matrix pipe; outputs are rounded to nearest even once, on store.
  * TWO-STAGE SOFTMAX (version 200; pixel-major and split-plane entry points): the softmax of functions.py:40 is never a
- * launch of its own.  ``A`` receives the UN-NORMALISED exponentials  P[pixel][slot] = exp(e - m_branch(pixel))  and ``stats``
- * (B, H*W, 4) fp32 the per-pixel branch statistics (m_col, z_col, m_row, z_row) -- max and sum of P of the column slots and of
- * the row slots; the attention of the reference is
- *     A_ref[pixel][slot] = P[pixel][slot] * exp(m_branch - m) / (z_col exp(m_col - m) + z_row exp(m_row - m)),  m = max(m_col, m_row)
- * (``ccnet_amd.functions.attention_from_parts`` on the host), applied by every consumer while it loads the tensor; the masked
- * column self slot holds exactly 0.  The pair (A, stats) is what the forward saves for the backward.
+ * launch of its own.  The affinity kernel finishes each branch of a pixel where it is computed (a column strip, a row strip):
+ * ``A`` receives the UN-NORMALISED exponentials  P[pixel][slot] = exp(e - m_branch(pixel))  and a workspace the branch
+ * statistics (m, z = sum of P); the first consumer (the column pass of the aggregation) turns them into the per-pixel factors
+ *     s_branch = exp(m_branch - m) / (z_col exp(m_col - m) + z_row exp(m_row - m)),   m = max(m_col, m_row)
+ * which land in ``stats`` (B, H*W, 2) fp32 = (s_col, s_row).  The attention of the reference is
+ *     A_ref[pixel][slot] = P[pixel][slot] * s_branch(pixel)          (``ccnet_amd.functions.attention_from_parts`` on the host);
+ * every consumer applies the factor on its way (non-transposed passes in their epilogue, transposed ones while they build
+ * their fragments); the masked column self slot holds exactly 0.  The pair (A, stats) is what the forward saves for the
+ * backward.  Maps with rows beyond 132 positions keep the classic form: A = the attention, stats = (1, 1).
  * Constraints: max(H, W) <= 132, C % 8 == 0, Cq % 8 == 0, every bs / ps a multiple of 8, pointers 16-byte aligned.
  * y = gamma * (column + row aggregation) + x       (functions.py:46-49)
- * ``workspace``: ccnet_cca_workspace_bytes(CCNET_WS_PM_FORWARD / _BACKWARD, ...) bytes (fp32 column partials; + softmax
- * partials; bf16 and fp32 views alike). */
+ * ``workspace``: ccnet_cca_workspace_bytes(CCNET_WS_PM_FORWARD / _BACKWARD, ...) bytes (forward: fp32 column partials + the
+ * raw branch statistics; backward: + softmax partials; bf16 and fp32 views alike). */
 int ccnet_cca_forward_pm_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v, const uint16_t *x,
                               const float *gamma, uint16_t *y, float *A, float *stats, int B, int C, int Cq, int H, int W,
                               long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long x_bs, int x_ps,
@@ -278,7 +282,7 @@ int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v,
  * host calls it in the backward pass when it did NOT keep the pair between forward and backward (recompute instead of save:
  * SURVEY.md 8(f) rank 4, networks/ccnet.py:118-119 -- R applications of the module hold R attention tensors). */
 int ccnet_cca_attention_pm(const void *q, const void *k, float *A, float *stats, int bf16, int B, int Cq, int H, int W,
-                           long q_bs, int q_ps, long k_bs, int k_ps, ccnet_stream_t stream);
+                           long q_bs, int q_ps, long k_bs, int k_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
 int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *k, const uint16_t *v_planes, const float *A,
                                   const float *stats, const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
                                   int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps,

@@ -43,17 +43,12 @@ def _p(a):
 
 
 def attention_from_parts(P, stats):
-    """The attention of functions.py:40 out of the two-stage softmax's parts (include/ccnet_cca.h, version 200): P (B, H, W, H+W)
-    un-normalised exponentials, stats (B, H, W, 4) = (m_col, z_col, m_row, z_row); fp32 arithmetic like the kernels' consumers."""
+    """The attention of functions.py:40 out of the two-stage softmax's pair (include/ccnet_cca.h, version 200): P (B, H, W, H+W)
+    un-normalised exponentials, stats (B, H, W, 2) = the per-pixel factors (s_col, s_row)."""
     H = P.shape[1]
-    mc, zc, mr, zr = (stats[..., i].astype(np.float32) for i in range(4))
-    m = np.maximum(mc, mr)
-    with np.errstate(invalid="ignore"):
-        ec, er = np.exp(mc - m, dtype=np.float32), np.exp(mr - m, dtype=np.float32)
-    Z = zc * ec + zr * er
     A = np.empty_like(P)
-    A[..., :H] = P[..., :H] * (ec / Z)[..., None]
-    A[..., H:] = P[..., H:] * (er / Z)[..., None]
+    A[..., :H] = P[..., :H] * stats[..., 0:1]
+    A[..., H:] = P[..., H:] * stats[..., 1:2]
     return A
 
 
@@ -76,9 +71,7 @@ def _parts_of(A):
     if isinstance(A, PartsArray) and A.P is not None:
         return A.P, A.stats
     A = np.ascontiguousarray(A, np.float32)
-    stats = np.empty(A.shape[:3] + (4,), np.float32)
-    stats[...] = (0.0, 0.5, 0.0, 0.5)
-    return A, stats
+    return A, np.ones(A.shape[:3] + (2,), np.float32)
 
 
 class EmuOps:
@@ -219,7 +212,7 @@ class EmuOps:
         C = ct - 2 * cq
         y = np.zeros((B, H, W, C), qkv.dtype)
         A = np.full((B, H, W, H + W), np.nan, np.float32)
-        stats = np.full((B, H, W, 4), np.nan, np.float32)
+        stats = np.full((B, H, W, 2), np.nan, np.float32)
         f32 = qkv.dtype == np.float32
         es = 4 if f32 else 2
         fwd = self.lib.ccnet_cca_forward_pm_f32 if f32 else self.lib.ccnet_cca_forward_pm_bf16
@@ -276,7 +269,7 @@ class EmuOps:
         C = v_planes.shape[4]
         y = np.full((B, C, H, W), np.nan, np.float32)
         A = np.full((B, H, W, H + W), np.nan, np.float32)
-        stats = np.full((B, H, W, 4), np.nan, np.float32)
+        stats = np.full((B, H, W, 2), np.nan, np.float32)
         nbytes = self.lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0)
         ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
         base, bs = qkv.ctypes.data, H * W * ct

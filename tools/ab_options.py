@@ -16,14 +16,15 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 B, C, H, W = (int(a) for a in args[:4]) if len(args) >= 4 else (8, 512, 97, 97)
 DEFAULT_SETS = {
     "default": {},
-    "xcd-row-pass": {"planes_xcd": 1},
+    "no-xcd": {"planes_xcd": 0},
     "one-stream": {"planes_overlap": 0},
-    "one-stream+xcd": {"planes_overlap": 0, "planes_xcd": 1},
-    "overlap-1": {"planes_overlap": 1},
+    "split-main": {"planes_split": 0},
+    "split-after": {"planes_split": 2},
+    "split-after-capped": {"planes_split": 3},
 }
 lib = _lib.get_lib()
 dev = torch.device("cuda:0")
-BASE = {"planes_ring": 2, "planes_stream": 1, "planes_overlap": -1, "planes_xcd": 0}
+BASE = {"planes_ring": 2, "planes_stream": 1, "planes_overlap": -1, "planes_xcd": 1, "planes_split": 1}
 wl = bench.PlanesWorkload(lib, B, C, H, W, dev, 1234)
 ref = None
 for rnd in range(2):                       # two rounds: the order of the sets must not matter
@@ -44,7 +45,7 @@ for rnd in range(2):                       # two rounds: the order of the sets m
         gms = bench.time_region(g.replay, 50)
         del g
         print(f"== round {rnd} {name:16s} {opts}: eager {ms:.4f} ms  graph {gms:.4f} ms  fwd {fwd:.4f}  bwd {bwd:.4f}  bit-identical to first: {same}", flush=True)
-        if rnd == 0 and name in ("one-stream", "one-stream+xcd"):
+        if rnd == 0 and name in ("one-stream",):
             rec = lib.profile_launches(lambda: [wl.step() for _ in range(5)])
             n = len(rec) // 5
             print(f"     launches {n}, event sum {sum(t for _, t in rec) / 5:.4f} ms")
