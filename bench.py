@@ -250,8 +250,7 @@ class PixelMajorBF16Workload:
         self.x, self.dy = rnd(B, H, W, C), rnd(B, H, W, C)
         self.gamma = torch.full((1,), 0.5, device=device)
         self.y, self.dqkv = torch.empty_like(self.x), torch.empty_like(self.qkv)
-        self.A = torch.empty(B, H, W, H + W, device=device)          # two-stage softmax: un-normalised exponentials ...
-        self.stats = torch.empty(B, H, W, 2, device=device)          # ... and the per-pixel factors (s_col, s_row)
+        self.A = torch.empty(B, H, W, H + W, device=device)
         self.scratch = torch.empty_like(self.A)
         self.dgamma = torch.empty(1, device=device)
         self.fws_bytes = lib.ccnet_cca_pm_workspace_bytes(B, C, Cq, H, W, 0)
@@ -266,8 +265,7 @@ class PixelMajorBF16Workload:
         L, cq, ct, p = self.lib, C // 8, self.ct, self.qkv.data_ptr()
         bs = H * W * ct
         L.check(L.ccnet_cca_forward_pm_bf16(p, p + 2 * cq, p + 4 * cq, self.x.data_ptr(), self.gamma.data_ptr(),
-                                            self.y.data_ptr(), self.A.data_ptr(), self.stats.data_ptr(), B, C, cq, H, W,
-                                            bs, ct, bs, ct, bs, ct,
+                                            self.y.data_ptr(), self.A.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct, bs, ct,
                                             H * W * C, C, H * W * C, C, self.ws.data_ptr(), self.fws_bytes, self.stream()),
                 "cca_forward_pm_bf16")
 
@@ -275,7 +273,7 @@ class PixelMajorBF16Workload:
         B, C, H, W = self.shape
         L, cq, ct, p, g = self.lib, C // 8, self.ct, self.qkv.data_ptr(), self.dqkv.data_ptr()
         bs = H * W * ct
-        L.check(L.ccnet_cca_backward_pm_bf16(self.dy.data_ptr(), p, p + 2 * cq, p + 4 * cq, self.A.data_ptr(), self.stats.data_ptr(),
+        L.check(L.ccnet_cca_backward_pm_bf16(self.dy.data_ptr(), p, p + 2 * cq, p + 4 * cq, self.A.data_ptr(),
                                              self.gamma.data_ptr(), g, g + 2 * cq, g + 4 * cq, self.dgamma.data_ptr(),
                                              self.scratch.data_ptr(), B, C, cq, H, W, H * W * C, C, bs, ct, bs, ct, bs, ct,
                                              bs, ct, bs, ct, bs, ct, self.ws.data_ptr(), self.ws_bytes, self.stream()),
@@ -285,16 +283,12 @@ class PixelMajorBF16Workload:
         self.forward()
         self.backward()
 
-    def attention(self):
-        from ccnet_amd.functions import attention_from_parts
-        return attention_from_parts(self.A, self.stats)
-
 
 class PlanesWorkload:
     """The fp32 core on the SPLIT-PLANE path (include/ccnet_cca.h): the step's inputs are what the reference's op gets --
     q | k | v fp32 (pixel-major channel slices of the packed projection, functions.py:29-37), x / dy NCHW fp32 -- and EVERY pass
     the op needs is inside the step (round 3 split v outside it): the forward entry point turns the fp32 value slice
-    into bf16 hi | lo planes itself (side stream, next to the affinity launch), the backward does the same for dy.  Outputs:
+    into bf16 hi | lo planes itself (its first launch), the backward does the same for dy.  Outputs:
     y NCHW, dq | dk | dv fp32 pixel-major, dgamma."""
 
     def __init__(self, lib, B, C, H, W, device, seed):
@@ -307,8 +301,7 @@ class PlanesWorkload:
         self.x, self.dy = rnd(B, C, H, W), rnd(B, C, H, W)
         self.gamma = torch.full((1,), 0.5, device=device)
         self.y, self.dqkv = torch.empty_like(self.x), torch.empty_like(self.qkv)
-        self.A = torch.empty(B, H, W, H + W, device=device)          # two-stage softmax: un-normalised exponentials ...
-        self.stats = torch.empty(B, H, W, 2, device=device)          # ... and the per-pixel factors (s_col, s_row)
+        self.A = torch.empty(B, H, W, H + W, device=device)
         self.scratch = torch.empty_like(self.A)
         self.dgamma = torch.empty(1, device=device)
         self.vpl = torch.empty(B, H, W, 2, C, dtype=torch.int16, device=device)     # written by the forward, read by the backward
@@ -323,10 +316,6 @@ class PlanesWorkload:
         self.forward()
         self.backward()
 
-    def attention(self):
-        from ccnet_amd.functions import attention_from_parts
-        return attention_from_parts(self.A, self.stats)
-
     def split(self):
         """the v -> planes pass alone (what the forward runs on its side stream), for ``producer_split_ms``"""
         B, C, H, W = self.shape
@@ -339,7 +328,7 @@ class PlanesWorkload:
         L, cq, ct, p = self.lib, C // 8, self.ct, self.qkv.data_ptr()
         bs = H * W * ct
         L.check(L.ccnet_cca_forward_planes_f32(p, p + 4 * cq, p + 8 * cq, None, self.vpl.data_ptr(), self.x.data_ptr(),
-                                               self.gamma.data_ptr(), self.y.data_ptr(), self.A.data_ptr(), self.stats.data_ptr(),
+                                               self.gamma.data_ptr(), self.y.data_ptr(), self.A.data_ptr(),
                                                B, C, cq, H, W, bs, ct, bs, ct, bs, ct, H * W * 2 * C, 2 * C,
                                                self.ws.data_ptr(), self.fws_bytes, self.stream()),
                 "cca_forward_planes")
@@ -349,7 +338,7 @@ class PlanesWorkload:
         L, cq, ct, p, g = self.lib, C // 8, self.ct, self.qkv.data_ptr(), self.dqkv.data_ptr()
         bs = H * W * ct
         L.check(L.ccnet_cca_backward_planes_f32(self.dy.data_ptr(), p, p + 4 * cq, self.vpl.data_ptr(), self.A.data_ptr(),
-                                                self.stats.data_ptr(), self.gamma.data_ptr(), g, g + 4 * cq, g + 8 * cq,
+                                                self.gamma.data_ptr(), g, g + 4 * cq, g + 8 * cq,
                                                 self.dgamma.data_ptr(), self.scratch.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct,
                                                 H * W * 2 * C, 2 * C, bs, ct, bs, ct, bs, ct, self.ws.data_ptr(), self.ws_bytes,
                                                 self.stream()),
@@ -514,19 +503,19 @@ def planes_launch_bytes(B, C, H, W):
     # (label, algorithmic bytes, regex of the launch's kernel name as rocprofv3 spells it: the key of the PMC traffic summary --
     #  the launch profiler only knows the SOURCE spelling of the launch, template parameters by name)
     return [
-        ("v fp32 -> planes (side stream, next to the energies)", 2 * fc, r"pm_split_kernel"),
-        ("energies q.k + per-branch softmax statistics (both branches)", 2 * fq + att, r"gweight_kernel<\d+, true, float"),
+        ("v fp32 -> planes", 2 * fc, r"pm_split_kernel"),
+        ("energies q.k (both branches)", 2 * fq + att, r"gweight_kernel<\d+, true, float"),
+        ("softmax", 2 * att, r"softmax_fwd_kernel"),
         ("aggregation, column pass (v, A/2 -> partial)", 2 * fc + att // 2, r"gmap3_kernel<\d+, false, false, false"),
         ("aggregation, row pass (v, A/2, partial, x -> y NCHW)", 4 * fc + att // 2,
          r"gmap_kernel<\d+, true, false, true, cca::bf16p_t, float, true"),
         ("dy NCHW -> planes", 2 * fc, r"nchw_to_planes_kernel"),
-        ("dA = dy.v (both branches) + the branch dots sum_j P t", 2 * fc + 2 * att, r"gweight_stream_kernel|gweight_kernel<\d+, false, cca::bf16p_t"),
+        ("dA = dy.v (both branches)", 2 * fc + att, r"gweight_stream_kernel|gweight_kernel<\d+, false, cca::bf16p_t"),
         ("dv, column pass (dy, A/2 -> partial)", 2 * fc + att // 2, r"gmap3_kernel<\d+, false, true, false"),
         ("dv, row pass (dy, A/2, partial -> dv)", 3 * fc + att // 2, r"gmap_kernel<\d+, true, true, true, cca::bf16p_t"),
-        ("softmax backward, folded: per-pixel (g, D) + dgamma partials", 4 * P * 10, r"parts_backward_finalize_kernel"),
-        ("dq | dk, column pass (dE formed from t, P on the way; + dgamma reduction)", att + 4 * fq,
-         r"gmap_kernel<\d+, false, false, false, float, float, false, true"),
-        ("dq | dk, row pass (dE formed from t, P on the way)", att + 6 * fq, r"gmap_kernel<\d+, true, false, true, float, float, false, true"),
+        ("softmax backward + dgamma partials", 3 * att, r"softmax_bwd_kernel"),
+        ("dq | dk, column pass (+ dgamma reduction)", att // 2 + 4 * fq, r"gmap_kernel<\d+, false, false, false, float, float, false, true"),
+        ("dq | dk, row pass", att // 2 + 6 * fq, r"gmap_kernel<\d+, true, false, true, float, float, false, true"),
     ]
 
 

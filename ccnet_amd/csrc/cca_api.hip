@@ -48,11 +48,9 @@ std::atomic<int> g_planes_stream{1};
 // per family: 2 on split planes (0.821 -> 0.776 -> 0.760 ms at the headline shape), 1 on the bf16 / fp32 pixel-major entries
 // (configs[4] bf16: 1.917 -> 1.903, but 1.959 with 2: its one-workgroup-per-strip dA shares the CUs badly)
 std::atomic<int> g_planes_overlap{-1};
-// "planes_xcd" 1: the final NCHW row pass of the split-plane forward decodes its strips from an XCD-aware id (consecutive rows of
-// an image on ONE XCD): the 388-byte NCHW rows of x / y share every boundary line with their neighbour row
+// "planes_xcd" 1 (default): the final NCHW row pass of the split-plane forward decodes its strips from an XCD-aware id (consecutive
+// rows of an image on ONE XCD): the 388-byte NCHW rows of x / y share every boundary line with their neighbour row
 std::atomic<int> g_planes_xcd{1};
-// "planes_split": how the split-plane forward runs its v -> planes pass (see ccnet_cca_forward_planes_f32)
-std::atomic<int> g_planes_split{1};
 
 int fail(int code, const char *what) {
     char buf[256];
@@ -587,22 +585,15 @@ int ccnet_ca_backward_f32(const float *dE, const float *q, const float *k, float
 static size_t ws_softmax_backward_bytes(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const size_t npix = (size_t)B * H * W;
-    // dgamma partials (one per softmax-backward workgroup, or per finalize workgroup of the folded form) | the folded form's
-    // branch dots (npix x 2) | its per-pixel (g, D) pairs (npix x 4)
-    return (((npix + cca::SM_WAVES - 1) / cca::SM_WAVES) * sizeof(float) + 255) / 256 * 256 + npix * 6 * sizeof(float);
-}
-static float *fold_ddot_of(void *workspace, int B, int H, int W) {
-    const size_t npix = (size_t)B * H * W;
-    return reinterpret_cast<float *>(static_cast<char *>(workspace) + (((npix + cca::SM_WAVES - 1) / cca::SM_WAVES) * sizeof(float) + 255) / 256 * 256);
+    return ((npix + cca::SM_WAVES - 1) / cca::SM_WAVES) * sizeof(float);
 }
 
 namespace {
-// ``stats``: A is the un-normalised half of a two-stage softmax; stats = its final per-pixel factors (s_col, s_row).  ``defer_reduce`` (may be null): do NOT launch
-// the fixed-order reduction of the dgamma partials -- *defer_reduce receives their count and the caller folds the reduction
-// into a later launch of the same stream (the dq | dk column pass, GmapJob::red_*).
+// ``defer_reduce`` (may be null): do NOT launch the fixed-order reduction of the dgamma partials -- *defer_reduce receives their
+// count and the caller folds the reduction into a later launch of the same stream (the dq | dk column pass, GmapJob::red_*).
 int softmax_backward_impl(const float *A, const float *dA, const float *gamma, float *dE, float *dgamma,
                           void *workspace, size_t workspace_bytes, int B, int H, int W, ccnet_stream_t stream,
-                          const KSplit &ks, const float *stats = nullptr, int *defer_reduce = nullptr) {
+                          const KSplit &ks, int *defer_reduce = nullptr) {
     if (int e = check_shape(B, 1, H, W)) return e;
     if (!A || !dA || !dE) return fail(CCNET_E_NULLPTR, "softmax_backward: null tensor");
     const int npix = B * H * W, S = H + W;
@@ -616,9 +607,9 @@ int softmax_backward_impl(const float *A, const float *dA, const float *gamma, f
     }
     const dim3 grid(nblocks), block(cca::SM_BLOCK);
     const float *extra = ks.extra;
-    if (S <= 256)      CCA_LAUNCH((cca::softmax_bwd_kernel<4>), grid, block, stream, A, dA, gamma, dE, partials, npix, S, ks.n, extra, ks.stride, stats, H);
-    else if (S <= 512) CCA_LAUNCH((cca::softmax_bwd_kernel<8>), grid, block, stream, A, dA, gamma, dE, partials, npix, S, ks.n, extra, ks.stride, stats, H);
-    else               CCA_LAUNCH(cca::softmax_bwd_generic_kernel, grid, block, stream, A, dA, gamma, dE, partials, npix, S, ks.n, extra, ks.stride, stats, H);
+    if (S <= 256)      CCA_LAUNCH((cca::softmax_bwd_kernel<4>), grid, block, stream, A, dA, gamma, dE, partials, npix, S, ks.n, extra, ks.stride);
+    else if (S <= 512) CCA_LAUNCH((cca::softmax_bwd_kernel<8>), grid, block, stream, A, dA, gamma, dE, partials, npix, S, ks.n, extra, ks.stride);
+    else               CCA_LAUNCH(cca::softmax_bwd_generic_kernel, grid, block, stream, A, dA, gamma, dE, partials, npix, S, ks.n, extra, ks.stride);
     if (int e = launch_status("softmax_bwd")) return e;
     if (dgamma && defer_reduce) {
         *defer_reduce = nblocks;
@@ -773,33 +764,12 @@ template <typename FT> struct PmTraits;
 template <> struct PmTraits<bf16_t> { static constexpr int kAlign = 8, kMaxStrip = 132; };
 template <> struct PmTraits<float>  { static constexpr int kAlign = 4, kMaxStrip = 100; };
 
-// Two-stage softmax plumbing (cca_gmap.hpp: PartsArgs).  The host hands a launch PAIR one PartsArgs: {scales, raw, out} with
-// ``raw`` set for the forward's aggregation (its column pass finalises the statistics into ``out`` = the saved factors, its row
-// pass reads them from there), {scales, null, null} for every backward consumer, all null for plain tensors.
-cca::PartsArgs col_parts(const cca::PartsArgs &p) { return p.raw ? cca::PartsArgs{nullptr, p.raw, p.out} : cca::PartsArgs{p.scales, nullptr, nullptr}; }
-cca::PartsArgs row_parts(const cca::PartsArgs &p) { return cca::PartsArgs{p.raw ? p.out : p.scales, nullptr, nullptr}; }
-size_t parts_raw_bytes(int B, int H, int W) { return (size_t)B * H * W * 4 * sizeof(float); }
-
 // a fixed-order sum of ``n`` floats at ``src`` into ``dst[0]`` that rides on another launch (GmapJob::red_*)
 struct DeferredSum {
     const float *src = nullptr;
     int n = 0;
     float *dst = nullptr;
 };
-
-// FOLDED SOFTMAX BACKWARD (whole strips): the dA launch leaves the branch dots in the workspace (fold_ddot_of), this tiny launch
-// turns them into the per-pixel (g, D) pairs the dq | dk launches consume and into dgamma partials; returns the PartsArgs of
-// those launches and the deferred sum.
-int fold_finalize(const float *A, const float *scales, const float *gamma, float *dgamma, void *workspace, int B, int H, int W,
-                  ccnet_stream_t stream, cca::PartsArgs *de, DeferredSum *red) {
-    const int npix = B * H * W, nblocks = (npix + cca::FIN_BLOCK - 1) / cca::FIN_BLOCK;
-    float *ddot = fold_ddot_of(workspace, B, H, W), *fin = ddot + (size_t)npix * 2, *partials = static_cast<float *>(workspace);
-    CCA_LAUNCH(cca::parts_backward_finalize_kernel, dim3((unsigned)nblocks), dim3(cca::FIN_BLOCK), stream, scales, (const float *)ddot, gamma,
-               fin, partials, npix);
-    *de = cca::PartsArgs{nullptr, nullptr, nullptr, A, fin};
-    *red = DeferredSum{partials, nblocks, dgamma};
-    return launch_status("parts_backward_finalize");
-}
 
 template <typename FT>
 int check_pm_view(const char *what, long bs, int ps, int C, int H, int W) {
@@ -811,75 +781,76 @@ int check_pm_view(const char *what, long bs, int ps, int C, int H, int W) {
 // out = FT(alpha * contraction + resid): column strips into the fp32 partial, row strips add it and round once.
 // NCHW (fp32, TRANS = false): resid / out are NCHW tensors with batch strides rbs / obs (rps / ops unused).
 template <int P, bool TRANS, typename FT, bool NCHW = false>
-int launch_gmap_pm(const float *T, cca::PartsArgs stats, const FT *F, const FT *resid, const float *gamma, FT *out, float *partial, int B, int C,
+int launch_gmap_pm(const float *T, const FT *F, const FT *resid, const float *gamma, FT *out, float *partial, int B, int C,
                    int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
     const long pbs = (long)H * W * C;
     const GmapPlan gc = gmap_plan(B * W, C), gr = gmap_plan(B * H, C);
     if (std::is_same<FT, bf16_t>::value && g_planes_ring.load() != 0) {
         // bf16 features: the column pass on the ring kernel (three feature tiles, stores from the accumulators)
         if constexpr (std::is_same<FT, bf16_t>::value)
-            CCA_LAUNCH((cca::gmap3_kernel<P, false, TRANS, false, 3, 2, bf16_t>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS), stream, T, col_parts(stats), F, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0, pbs, C, gc.n_whole, gc.split);
+            CCA_LAUNCH((cca::gmap3_kernel<P, false, TRANS, false, 3, 2, bf16_t>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS), stream,
+                       T, F, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0, pbs, C, gc.n_whole, gc.split);
     } else {
         CCA_LAUNCH((cca::gmap_kernel<P, false, TRANS, false, FT, float>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS),
-                   stream, T, col_parts(stats), F, (const float *)nullptr, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0,
+                   stream, T, F, (const float *)nullptr, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0,
                    0L, 0, pbs, C, gc.n_whole, gc.split, cca::GmapJob<FT, float>{});
     }
     if (int e = launch_status("gmap_pm(column)")) return e;
     CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, FT, FT, NCHW>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS),
-               stream, T, row_parts(stats), F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C, rbs, rps, obs, ops,
+               stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C, rbs, rps, obs, ops,
                gr.n_whole, gr.split, cca::GmapJob<FT, FT>{});
     return launch_status("gmap_pm(row)");
 }
 template <bool TRANS, typename FT>
-int gmap_pm(const float *T, cca::PartsArgs stats, const FT *F, const FT *resid, const float *gamma, FT *out, float *partial,
+int gmap_pm(const float *T, const FT *F, const FT *resid, const float *gamma, FT *out, float *partial,
             int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
     if ((H > W ? H : W) <= 100)
-        return launch_gmap_pm<100, TRANS, FT>(T, stats, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+        return launch_gmap_pm<100, TRANS, FT>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
     if constexpr (PmTraits<FT>::kMaxStrip >= 132)
-        return launch_gmap_pm<132, TRANS, FT>(T, stats, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+        return launch_gmap_pm<132, TRANS, FT>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
     return fail(CCNET_E_BADSHAPE, "gmap_pm: strip too long for this element type");
 }
 // dq (features k) and dk (features q) from the same dE: one launch per branch, blockIdx.y picks the job
 template <int P, typename FT>
 int launch_gmap_dual_pm(const float *dE, const FT *k, const FT *q, FT *dq, FT *dk, float *partial, int B, int Cq, int H, int W,
                         long kbs, int kps, long qbs, int qps, long dqbs, int dqps, long dkbs, int dkps, ccnet_stream_t stream,
-                        const DeferredSum &red, const cca::PartsArgs &de) {
+                        const DeferredSum &red) {
     const long pbs = (long)H * W * Cq;
     float *pq = partial, *pk = partial + (size_t)B * pbs;
     const GmapPlan gc = gmap_plan(B * W, Cq), gr = gmap_plan(B * H, Cq);
     cca::GmapJob<FT, float> jc{q, nullptr, pk, qbs, pbs, qps, Cq, gc.grid};
     jc.red_src = red.src; jc.red_n = red.n; jc.red_dst = red.dst;
     CCA_LAUNCH((cca::gmap_kernel<P, false, false, false, FT, float, false, true>), dim3(cca::gmap_dual_grid(gc.grid)), dim3(cca::GS_THREADS),
-               stream, dE, de, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
+               stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
                0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
     if (int e = launch_status("gmap_dual_pm(column)")) return e;
     const cca::GmapJob<FT, FT> jr{q, pk, dk, qbs, dkbs, qps, dkps, gr.grid};
     CCA_LAUNCH((cca::gmap_kernel<P, true, false, true, FT, FT, false, true>), dim3(cca::gmap_dual_grid(gr.grid)), dim3(cca::GS_THREADS),
-               stream, dE, de, k, (const float *)pq, (const FT *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
+               stream, dE, k, (const float *)pq, (const FT *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
                0L, 0, dqbs, dqps, gr.n_whole, gr.split, jr);
     return launch_status("gmap_dual_pm(row)");
 }
 template <typename FT>
 int gmap_dual_pm(const float *dE, const FT *k, const FT *q, FT *dq, FT *dk, float *partial, int B, int Cq, int H, int W,
                  long kbs, int kps, long qbs, int qps, long dqbs, int dqps, long dkbs, int dkps, ccnet_stream_t stream,
-                 const DeferredSum &red = DeferredSum(), const cca::PartsArgs &de = cca::PartsArgs{}) {
+                 const DeferredSum &red = DeferredSum()) {
     if ((H > W ? H : W) <= 100)
-        return launch_gmap_dual_pm<100, FT>(dE, k, q, dq, dk, partial, B, Cq, H, W, kbs, kps, qbs, qps, dqbs, dqps, dkbs, dkps, stream, red, de);
+        return launch_gmap_dual_pm<100, FT>(dE, k, q, dq, dk, partial, B, Cq, H, W, kbs, kps, qbs, qps, dqbs, dqps, dkbs, dkps, stream, red);
     if constexpr (PmTraits<FT>::kMaxStrip >= 132)
-        return launch_gmap_dual_pm<132, FT>(dE, k, q, dq, dk, partial, B, Cq, H, W, kbs, kps, qbs, qps, dqbs, dqps, dkbs, dkps, stream, red, de);
+        return launch_gmap_dual_pm<132, FT>(dE, k, q, dq, dk, partial, B, Cq, H, W, kbs, kps, qbs, qps, dqbs, dqps, dkbs, dkps, stream, red);
     return fail(CCNET_E_BADSHAPE, "gmap_dual_pm: strip too long for this element type");
 }
 template <bool MASK, typename FT>
-int gweight_pm(const FT *X, const FT *Y, float *T, float *stats, int B, int Cx, int H, int W, long xbs, int xps, long ybs, int yps,
-               ccnet_stream_t stream, const float *Pexp = nullptr, float *ddot = nullptr) {
+int gweight_pm(const FT *X, const FT *Y, float *T, int B, int Cx, int H, int W, long xbs, int xps, long ybs, int yps,
+               ccnet_stream_t stream) {
     // (bf16 dA stays on gweight_kernel: the persistent gweight_stream_kernel<132, bf16_t> measured 350 us against 301 us at
     // configs[4] -- profiles/r03j_bf16_compare.txt -- wavefront 0 owns two of the nine tile rows and every barrier waits for it)
     const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
     const bool single = Cx <= cca::GM_CG;           // one chunk: the single-buffered form (more workgroups per CU)
 #define CCA_GWEIGHT(P_)                                                                                                   \
     do {                                                                                                                  \
-        if (single) CCA_LAUNCH((cca::gweight_kernel<P_, MASK, FT, true>), grid, block, stream, X, Y, T, stats, Pexp, ddot, Cx, H, W, xbs, xps, ybs, yps); \
-        else        CCA_LAUNCH((cca::gweight_kernel<P_, MASK, FT, false>), grid, block, stream, X, Y, T, stats, Pexp, ddot, Cx, H, W, xbs, xps, ybs, yps); \
+        if (single) CCA_LAUNCH((cca::gweight_kernel<P_, MASK, FT, true>), grid, block, stream, X, Y, T, Cx, H, W, xbs, xps, ybs, yps); \
+        else        CCA_LAUNCH((cca::gweight_kernel<P_, MASK, FT, false>), grid, block, stream, X, Y, T, Cx, H, W, xbs, xps, ybs, yps); \
     } while (0)
     if ((H > W ? H : W) <= 100) {
         CCA_GWEIGHT(100);
@@ -905,11 +876,8 @@ size_t pm_workspace_bytes(int B, int C, int Cq, int H, int W, int backward) {
     // forward: the column partial of the aggregation.  backward: softmax-backward's slabs | the column partial of dv | the
     // column partials of dq and dk side by side (a region of their own: those launches may run next to the dv passes)
     const size_t px = (size_t)B * H * W * sizeof(float);
-    if (!backward) return align256(px * C) + parts_raw_bytes(B, H, W);      // + the affinity kernel's raw branch statistics
+    if (!backward) return px * C;
     return align256(ws_softmax_backward_bytes(B, H, W)) + align256(px * C) + px * 2 * Cq;
-}
-float *parts_raw_of(void *forward_workspace, int B, int C, int H, int W) {
-    return reinterpret_cast<float *>(static_cast<char *>(forward_workspace) + align256((size_t)B * H * W * C * sizeof(float)));
 }
 float *partial_qk_of(float *partial, int B, int C, int H, int W) {
     return reinterpret_cast<float *>(reinterpret_cast<char *>(partial) + align256((size_t)B * H * W * C * sizeof(float)));
@@ -931,10 +899,10 @@ struct SideFork {
 
 template <typename FT>
 int cca_forward_pm(const char *name, const FT *q, const FT *k, const FT *v, const FT *x, const float *gamma, FT *y, float *A,
-                   float *stats, int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
+                   int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
                    long x_bs, int x_ps, long y_bs, int y_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
     if (int e = require_both_branches(name)) return e;
-    if (!q || !k || !v || !x || !gamma || !y || !A || !stats) return fail(CCNET_E_NULLPTR, "cca_forward_pm: null tensor");
+    if (!q || !k || !v || !x || !gamma || !y || !A) return fail(CCNET_E_NULLPTR, "cca_forward_pm: null tensor");
     if (int e = check_pm_problem<FT>("cca_forward_pm: strip length / channel divisibility (see ccnet_cca.h)", B, C, Cq, H, W)) return e;
     if (int e = check_pm_view<FT>("cca_forward_pm: q view", q_bs, q_ps, Cq, H, W)) return e;
     if (int e = check_pm_view<FT>("cca_forward_pm: k view", k_bs, k_ps, Cq, H, W)) return e;
@@ -943,22 +911,19 @@ int cca_forward_pm(const char *name, const FT *q, const FT *k, const FT *v, cons
     if (int e = check_pm_view<FT>("cca_forward_pm: y view", y_bs, y_ps, C, H, W)) return e;
     if (!workspace || workspace_bytes < pm_workspace_bytes(B, C, Cq, H, W, 0))
         return fail(CCNET_E_WORKSPACE, "cca_forward_pm: workspace missing or too small");
-    // two-stage softmax: the affinity kernel leaves exp(e - m_branch) in A and the branch statistics in stats; the
-    // aggregation passes normalise while they load their fragments (cca_common.hpp: parts_scale) -- no softmax launch
-    float *raw = parts_raw_of(workspace, B, C, H, W);
-    if (int e = gweight_pm<true, FT>(q, k, A, raw, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
-    return gmap_pm<false, FT>(A, cca::PartsArgs{nullptr, raw, stats}, v, x, gamma, y, (float *)workspace, B, C, H, W, v_bs, v_ps, x_bs, x_ps,
-                              y_bs, y_ps, stream);
+    if (int e = gweight_pm<true, FT>(q, k, A, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
+    if (int e = softmax_forward(A, A, B, H, W, stream)) return e;
+    return gmap_pm<false, FT>(A, v, x, gamma, y, (float *)workspace, B, C, H, W, v_bs, v_ps, x_bs, x_ps, y_bs, y_ps, stream);
 }
 
 template <typename FT>
-int cca_backward_pm(const char *name, const FT *dy, const FT *q, const FT *k, const FT *v, const float *A, const float *stats,
-                    const float *gamma, FT *dq, FT *dk, FT *dv, float *dgamma, float *scratch, int B, int C, int Cq, int H, int W,
+int cca_backward_pm(const char *name, const FT *dy, const FT *q, const FT *k, const FT *v, const float *A, const float *gamma,
+                    FT *dq, FT *dk, FT *dv, float *dgamma, float *scratch, int B, int C, int Cq, int H, int W,
                     long dy_bs, int dy_ps, long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
                     long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
                     void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
     if (int e = require_both_branches(name)) return e;
-    if (!dy || !q || !k || !v || !A || !stats || !gamma || !dq || !dk || !dv || !dgamma || !scratch)
+    if (!dy || !q || !k || !v || !A || !gamma || !dq || !dk || !dv || !dgamma || !scratch)
         return fail(CCNET_E_NULLPTR, "cca_backward_pm: null tensor");
     if (int e = check_pm_problem<FT>("cca_backward_pm: strip length / channel divisibility (see ccnet_cca.h)", B, C, Cq, H, W)) return e;
     if (int e = check_pm_view<FT>("cca_backward_pm: dy view", dy_bs, dy_ps, C, H, W)) return e;
@@ -977,19 +942,16 @@ int cca_backward_pm(const char *name, const FT *dy, const FT *q, const FT *k, co
     const int overlap = g_planes_overlap.load() < 0 ? 1 : g_planes_overlap.load();
     SideFork sf(stream);
     if (overlap == 2) sf.fork();
-    // folded softmax backward: the dA launch also leaves sum_j P t per (pixel, branch); no softmax-backward launch, no dE
-    float *ddot = fold_ddot_of(workspace, B, H, W);
-    int e = gweight_pm<false, FT>(dy, v, scratch, nullptr, B, C, H, W, dy_bs, dy_ps, v_bs, v_ps, stream, A, ddot);
+    int e = gweight_pm<false, FT>(dy, v, scratch, B, C, H, W, dy_bs, dy_ps, v_bs, v_ps, stream);
     if (overlap == 1) sf.fork();
-    if (!e) e = gmap_pm<true, FT>(A, cca::PartsArgs{stats, nullptr, nullptr}, dy, nullptr, gamma, dv, partial, B, C, H, W, dy_bs, dy_ps, 0L, 0, dv_bs, dv_ps, sf.stream());
-    // dgamma = sum A t and dE = gamma * A * (t - sum_s A t) are formed on the way (fold_finalize + the dq | dk prologues); the
-    // fixed-order sum of the dgamma partials rides on the dq | dk column launch
-    DeferredSum red;
-    cca::PartsArgs de{};
-    if (!e) e = fold_finalize(A, stats, gamma, dgamma, workspace, B, H, W, stream, &de, &red);
+    if (!e) e = gmap_pm<true, FT>(A, dy, nullptr, gamma, dv, partial, B, C, H, W, dy_bs, dy_ps, 0L, 0, dv_bs, dv_ps, sf.stream());
+    // dgamma = sum A t;  dE = gamma * A * (t - sum_s A t), in place
+    // (the fixed-order sum of the dgamma partials rides on the dq | dk column launch: one launch less)
+    DeferredSum red{static_cast<const float *>(workspace), 0, dgamma};
+    if (!e) e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, sm, B, H, W, stream, KSplit(), &red.n);
     // the column partials of dq and dk sit side by side in their own region
     if (!e) e = gmap_dual_pm<FT>(scratch, k, q, dq, dk, partial_qk_of(partial, B, C, H, W), B, Cq, H, W, k_bs, k_ps, q_bs, q_ps,
-                                 dq_bs, dq_ps, dk_bs, dk_ps, stream, red, de);
+                                 dq_bs, dq_ps, dk_bs, dk_ps, stream, red);
     return sf.join(e);
 }
 }  // namespace
@@ -1000,39 +962,39 @@ static size_t ws_pm_bytes(int B, int C, int Cq, int H, int W, int backward) {
 }
 
 int ccnet_cca_forward_pm_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v, const uint16_t *x,
-                              const float *gamma, uint16_t *y, float *A, float *stats, int B, int C, int Cq, int H, int W,
+                              const float *gamma, uint16_t *y, float *A, int B, int C, int Cq, int H, int W,
                               long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long x_bs, int x_ps,
                               long y_bs, int y_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
     return cca_forward_pm<bf16_t>("cca_forward_pm_bf16", (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)x,
-                                  gamma, (bf16_t *)y, A, stats, B, C, Cq, H, W, q_bs, q_ps, k_bs, k_ps, v_bs, v_ps, x_bs, x_ps, y_bs, y_ps,
+                                  gamma, (bf16_t *)y, A, B, C, Cq, H, W, q_bs, q_ps, k_bs, k_ps, v_bs, v_ps, x_bs, x_ps, y_bs, y_ps,
                                   workspace, workspace_bytes, stream);
 }
 int ccnet_cca_forward_pm_f32(const float *q, const float *k, const float *v, const float *x,
-                             const float *gamma, float *y, float *A, float *stats, int B, int C, int Cq, int H, int W,
+                             const float *gamma, float *y, float *A, int B, int C, int Cq, int H, int W,
                              long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long x_bs, int x_ps,
                              long y_bs, int y_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
-    return cca_forward_pm<float>("cca_forward_pm_f32", q, k, v, x, gamma, y, A, stats, B, C, Cq, H, W, q_bs, q_ps, k_bs, k_ps, v_bs, v_ps,
+    return cca_forward_pm<float>("cca_forward_pm_f32", q, k, v, x, gamma, y, A, B, C, Cq, H, W, q_bs, q_ps, k_bs, k_ps, v_bs, v_ps,
                                  x_bs, x_ps, y_bs, y_ps, workspace, workspace_bytes, stream);
 }
 
 int ccnet_cca_backward_pm_bf16(const uint16_t *dy, const uint16_t *q, const uint16_t *k, const uint16_t *v,
-                               const float *A, const float *stats, const float *gamma, uint16_t *dq, uint16_t *dk, uint16_t *dv,
+                               const float *A, const float *gamma, uint16_t *dq, uint16_t *dk, uint16_t *dv,
                                float *dgamma, float *scratch, int B, int C, int Cq, int H, int W,
                                long dy_bs, int dy_ps, long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
                                long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
                                void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
     return cca_backward_pm<bf16_t>("cca_backward_pm_bf16", (const bf16_t *)dy, (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)v,
-                                   A, stats, gamma, (bf16_t *)dq, (bf16_t *)dk, (bf16_t *)dv, dgamma, scratch, B, C, Cq, H, W,
+                                   A, gamma, (bf16_t *)dq, (bf16_t *)dk, (bf16_t *)dv, dgamma, scratch, B, C, Cq, H, W,
                                    dy_bs, dy_ps, q_bs, q_ps, k_bs, k_ps, v_bs, v_ps, dq_bs, dq_ps, dk_bs, dk_ps, dv_bs, dv_ps,
                                    workspace, workspace_bytes, stream);
 }
 int ccnet_cca_backward_pm_f32(const float *dy, const float *q, const float *k, const float *v,
-                              const float *A, const float *stats, const float *gamma, float *dq, float *dk, float *dv,
+                              const float *A, const float *gamma, float *dq, float *dk, float *dv,
                               float *dgamma, float *scratch, int B, int C, int Cq, int H, int W,
                               long dy_bs, int dy_ps, long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
                               long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
                               void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
-    return cca_backward_pm<float>("cca_backward_pm_f32", dy, q, k, v, A, stats, gamma, dq, dk, dv, dgamma, scratch, B, C, Cq, H, W,
+    return cca_backward_pm<float>("cca_backward_pm_f32", dy, q, k, v, A, gamma, dq, dk, dv, dgamma, scratch, B, C, Cq, H, W,
                                   dy_bs, dy_ps, q_bs, q_ps, k_bs, k_ps, v_bs, v_ps, dq_bs, dq_ps, dk_bs, dk_ps, dv_bs, dv_ps,
                                   workspace, workspace_bytes, stream);
 }
@@ -1070,49 +1032,49 @@ bool plane_layout(int layout, int C, cca::PlaneLayout *pl) {
 // workgroups per CU.  P = 132 (strips 101 .. 132): the ring kernel with two slots and two workgroups per CU, the row passes with
 // ONE workgroup per CU (two plane tiles + the output image are 104 KB).
 template <int P, bool TRANS>
-int launch_gmap3_planes(const float *T, cca::PartsArgs stats, const bf16p_t *F, const float *gamma, float *out, float *partial, int B, int C, int H, int W,
+int launch_gmap3_planes(const float *T, const bf16p_t *F, const float *gamma, float *out, float *partial, int B, int C, int H, int W,
                         long fbs, int fps, long obs, int ops, bool row_too, ccnet_stream_t stream) {
     const long pbs = (long)H * W * C;
     const GmapPlan gr = gmap_plan(B * H, C);
     const int ring = g_planes_ring.load();
     if constexpr (P > 100) {
         const GmapPlan gc = gmap_plan(B * W, C);
-        CCA_LAUNCH((cca::gmap3_kernel<P, false, TRANS, false, 2, 2>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS), stream, T, col_parts(stats), F,
+        CCA_LAUNCH((cca::gmap3_kernel<P, false, TRANS, false, 2, 2>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS), stream, T, F,
                    (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0, pbs, C, gc.n_whole, gc.split);
         return launch_status("gmap3_planes(column)");
     } else {
     if (ring == 2) {                        // three workgroups per CU, two ring slots
         const GmapPlan gc = gmap_plan(B * W, C, 3);
-        CCA_LAUNCH((cca::gmap3_kernel<100, false, TRANS, false, 2, 3>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS), stream, T, col_parts(stats), F,
+        CCA_LAUNCH((cca::gmap3_kernel<100, false, TRANS, false, 2, 3>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS), stream, T, F,
                    (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0, pbs, C, gc.n_whole, gc.split);
     } else {
         const GmapPlan gc = gmap_plan(B * W, C);
-        CCA_LAUNCH((cca::gmap3_kernel<100, false, TRANS, false>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS), stream, T, col_parts(stats), F,
+        CCA_LAUNCH((cca::gmap3_kernel<100, false, TRANS, false>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS), stream, T, F,
                    (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0, pbs, C, gc.n_whole, gc.split);
     }
     if (int e = launch_status("gmap3_planes(column)")) return e;
     // (row passes: the accumulator-layout addend prefetch of gmap3 is still slower than gmap_kernel's output image --
     // 121 vs 103 us at the headline shape, profiles/r03e_bench.json -- so only "planes_ring" 1 uses it there)
     if (!row_too || ring != 1) return 0;
-    CCA_LAUNCH((cca::gmap3_kernel<100, true, TRANS, true>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS), stream, T, row_parts(stats), F,
+    CCA_LAUNCH((cca::gmap3_kernel<100, true, TRANS, true>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS), stream, T, F,
                (const float *)partial, gamma, out, C, H, W, fbs, fps, pbs, C, obs, ops, gr.n_whole, gr.split);
     return launch_status("gmap3_planes(row)");
     }
 }
 template <int P, bool TRANS, bool NCHW>
-int launch_gmap_planes_p(const float *T, cca::PartsArgs stats, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
+int launch_gmap_planes_p(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
                          int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
     constexpr int WPC = P > 100 ? 1 : 2;
     const long pbs = (long)H * W * C;
     const GmapPlan gc = gmap_plan(B * W, C), gr = gmap_plan(B * H, C, WPC);
     const int ring = P > 100 ? 2 : g_planes_ring.load();
     if (ring) {
-        if (int e = launch_gmap3_planes<P, TRANS>(T, stats, F, gamma, out, partial, B, C, H, W, fbs, fps, obs, ops, !NCHW, stream)) return e;
+        if (int e = launch_gmap3_planes<P, TRANS>(T, F, gamma, out, partial, B, C, H, W, fbs, fps, obs, ops, !NCHW, stream)) return e;
         if (!NCHW && ring == 1) return 0;
     } else {
         if constexpr (P <= 100) {
             CCA_LAUNCH((cca::gmap_kernel<100, false, TRANS, false, bf16p_t, float>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS),
-                       stream, T, col_parts(stats), F, (const float *)nullptr, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0,
+                       stream, T, F, (const float *)nullptr, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0,
                        0L, 0, pbs, C, gc.n_whole, gc.split, cca::GmapJob<bf16p_t, float>{});
             if (int e = launch_status("gmap_planes(column)")) return e;
         }
@@ -1120,7 +1082,7 @@ int launch_gmap_planes_p(const float *T, cca::PartsArgs stats, const bf16p_t *F,
     cca::GmapJob<bf16p_t, float> job{};
     if (NCHW && g_planes_xcd.load() && (B * H) % 8 == 0 && gr.n_whole % 8 == 0) job.xcd = B * H / 8;
     CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, bf16p_t, float, NCHW, false, WPC>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS),
-               stream, T, row_parts(stats), F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C, rbs, rps, obs, ops,
+               stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C, rbs, rps, obs, ops,
                gr.n_whole, gr.split, job);
     return launch_status("gmap_planes(row)");
 }
@@ -1131,7 +1093,7 @@ int launch_gmap_planes_p(const float *T, cca::PartsArgs stats, const bf16p_t *F,
 // P = 100 with blocks of <= 100 positions where four of them cover the row (W <= 400): the 100-position kernels keep their
 // attention fragments in 96 registers and run two workgroups per CU; at 132 positions they take 192 and run one (1 wave per SIMD)
 template <int P, bool TRANS, bool NCHW>
-int launch_gmap_planes_long_rows_p(const float *T, cca::PartsArgs stats, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
+int launch_gmap_planes_long_rows_p(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
                                    int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops,
                                    ccnet_stream_t stream) {
     constexpr int WPC = P > 100 ? 1 : 2;
@@ -1144,78 +1106,64 @@ int launch_gmap_planes_long_rows_p(const float *T, cca::PartsArgs stats, const b
         job.jblk = j;
         if (j + 1 < nb)
             CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, bf16p_t, float, false, false, WPC, true>), dim3((unsigned)gr.grid),
-                       dim3(cca::GS_THREADS), stream, T, row_parts(stats), F, (const float *)partial, (const float *)nullptr, gamma, partial, C, H, W,
+                       dim3(cca::GS_THREADS), stream, T, F, (const float *)partial, (const float *)nullptr, gamma, partial, C, H, W,
                        fbs, fps, pbs, C, 0L, 0, pbs, C, gr.n_whole, gr.split, job);
         else
             CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, bf16p_t, float, NCHW, false, WPC, true>), dim3((unsigned)gr.grid),
-                       dim3(cca::GS_THREADS), stream, T, row_parts(stats), F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C,
+                       dim3(cca::GS_THREADS), stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C,
                        rbs, rps, obs, ops, gr.n_whole, gr.split, job);
         if (int e = launch_status("gmap_planes(long rows)")) return e;
     }
     return 0;
 }
 template <bool TRANS, bool NCHW>
-int launch_gmap_planes_long_rows(const float *T, cca::PartsArgs stats, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
+int launch_gmap_planes_long_rows(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
                                  int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops,
                                  ccnet_stream_t stream) {
-    if (int e = launch_gmap3_planes<132, TRANS>(T, stats, F, gamma, out, partial, B, C, H, W, fbs, fps, 0L, 0, false, stream)) return e;
+    if (int e = launch_gmap3_planes<132, TRANS>(T, F, gamma, out, partial, B, C, H, W, fbs, fps, 0L, 0, false, stream)) return e;
     if (W <= 400)
-        return launch_gmap_planes_long_rows_p<100, TRANS, NCHW>(T, stats, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
-    return launch_gmap_planes_long_rows_p<132, TRANS, NCHW>(T, stats, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+        return launch_gmap_planes_long_rows_p<100, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+    return launch_gmap_planes_long_rows_p<132, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
 }
 template <bool TRANS, bool NCHW>
-int launch_gmap_planes(const float *T, cca::PartsArgs stats, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
+int launch_gmap_planes(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
                        int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
     // (rows of 101 .. 132 positions stay whole on the 132-position kernels: as two blocks on the 100-position ones the extra pass
     // over the partial costs more than the second workgroup per CU returns -- (16,512,129,129) 3.55 -> 3.70 ms, profiles/r04f_planes_129.txt)
     if (W > 132)
-        return launch_gmap_planes_long_rows<TRANS, NCHW>(T, stats, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+        return launch_gmap_planes_long_rows<TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
     if ((H > W ? H : W) <= 100)
-        return launch_gmap_planes_p<100, TRANS, NCHW>(T, stats, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
-    return launch_gmap_planes_p<132, TRANS, NCHW>(T, stats, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+        return launch_gmap_planes_p<100, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+    return launch_gmap_planes_p<132, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
 }
 // strips 101 .. 132 with fp32 q | k: the energies and dq | dk kernels of the pixel-major fp32 family at 132 positions (one
 // workgroup per CU for the latter: fp32 tiles)
-// ``stats``: the two-stage softmax (whole strips: the kernel finishes each branch, cca_common.hpp).  Long rows are computed as
-// (query block, key block) tiles -- no workgroup sees a whole row -- so they keep the classic form: raw energies, one softmax
-// launch, and NEUTRAL statistics (every consumer's factor is exactly 1).
-// ``raw``: the statistics buffer of the two-stage form; ``neutral_scales``: where the long-row (classic) form writes (1, 1).
-// *two_stage tells the caller which form ran.
-int gweight_energies_f32(const float *q, const float *k, float *A, float *raw, float *neutral_scales, bool *two_stage,
-                         int B, int Cq, int H, int W, long qbs, int qps, long kbs, int kps, ccnet_stream_t stream) {
-    float *stats = raw;
-    *two_stage = W <= 132;
-    if ((H > W ? H : W) <= 100) return gweight_pm<true, float>(q, k, A, stats, B, Cq, H, W, qbs, qps, kbs, kps, stream);
+int gweight_energies_f32(const float *q, const float *k, float *A, int B, int Cq, int H, int W, long qbs, int qps, long kbs, int kps,
+                         ccnet_stream_t stream) {
+    if ((H > W ? H : W) <= 100) return gweight_pm<true, float>(q, k, A, B, Cq, H, W, qbs, qps, kbs, kps, stream);
     if (W > 132) {          // long rows: nb x nb blocks per row strip, whole column strips
         const int nb = long_blocks(W);
         const dim3 grid((unsigned)(B * (W + H * nb * nb))), block(cca::GM_THREADS);
-        CCA_LAUNCH((cca::gweight_kernel<132, true, float, true, true>), grid, block, stream, q, k, A, (float *)nullptr, (const float *)nullptr, (float *)nullptr, Cq, H, W, qbs, qps, kbs, kps, nb);
-        if (int e = launch_status("gweight_energies(long rows)")) return e;
-        if (int e = softmax_forward(A, A, B, H, W, stream)) return e;
-        if (neutral_scales) {
-            const int npix = B * H * W;
-            CCA_LAUNCH(cca::neutral_scales_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), stream, neutral_scales, npix);
-            return launch_status("neutral_scales");
-        }
-        return 0;
+        CCA_LAUNCH((cca::gweight_kernel<132, true, float, true, true>), grid, block, stream, q, k, A, Cq, H, W, qbs, qps, kbs, kps, nb);
+        return launch_status("gweight_energies(long rows)");
     }
     const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
-    if (Cq <= cca::GM_CG) CCA_LAUNCH((cca::gweight_kernel<132, true, float, true>), grid, block, stream, q, k, A, stats, (const float *)nullptr, (float *)nullptr, Cq, H, W, qbs, qps, kbs, kps);
-    else                  CCA_LAUNCH((cca::gweight_kernel<132, true, float, false>), grid, block, stream, q, k, A, stats, (const float *)nullptr, (float *)nullptr, Cq, H, W, qbs, qps, kbs, kps);
+    if (Cq <= cca::GM_CG) CCA_LAUNCH((cca::gweight_kernel<132, true, float, true>), grid, block, stream, q, k, A, Cq, H, W, qbs, qps, kbs, kps);
+    else                  CCA_LAUNCH((cca::gweight_kernel<132, true, float, false>), grid, block, stream, q, k, A, Cq, H, W, qbs, qps, kbs, kps);
     return launch_status("gweight_energies(132)");
 }
 int gmap_dual_f32(const float *dE, const float *k, const float *q, float *dq, float *dk, float *partial, int B, int Cq, int H, int W,
                   long kbs, int kps, long qbs, int qps, long dqbs, int dqps, long dkbs, int dkps, ccnet_stream_t stream,
-                  const DeferredSum &red, const cca::PartsArgs &de) {
+                  const DeferredSum &red) {
     if ((H > W ? H : W) <= 100)
-        return gmap_dual_pm<float>(dE, k, q, dq, dk, partial, B, Cq, H, W, kbs, kps, qbs, qps, dqbs, dqps, dkbs, dkps, stream, red, de);
+        return gmap_dual_pm<float>(dE, k, q, dq, dk, partial, B, Cq, H, W, kbs, kps, qbs, qps, dqbs, dqps, dkbs, dkps, stream, red);
     const long pbs = (long)H * W * Cq;
     float *pq = partial, *pk = partial + (size_t)B * pbs;
     const GmapPlan gc = gmap_plan(B * W, Cq, 1), gr = gmap_plan(B * H, Cq, 1);
     cca::GmapJob<float, float> jc{q, nullptr, pk, qbs, pbs, qps, Cq, gc.grid};
     jc.red_src = red.src; jc.red_n = red.n; jc.red_dst = red.dst;
     CCA_LAUNCH((cca::gmap_kernel<132, false, false, false, float, float, false, true, 1>), dim3(cca::gmap_dual_grid(gc.grid)), dim3(cca::GS_THREADS),
-               stream, dE, de, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
+               stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
                0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
     if (int e = launch_status("gmap_dual_f32(column, 132)")) return e;
     if (W > 132) {          // long rows: one launch per block of the contracted positions, the partials updated in place
@@ -1227,11 +1175,11 @@ int gmap_dual_f32(const float *dE, const float *k, const float *q, float *dq, fl
             const cca::GmapJob<float, float> jl{q, pk, last ? dk : pk, qbs, last ? dkbs : pbs, qps, last ? dkps : Cq, gl.grid, nb, j};
             if (p100)
                 CCA_LAUNCH((cca::gmap_kernel<100, true, false, true, float, float, false, true, 2, true>), dim3(cca::gmap_dual_grid(gl.grid)),
-                           dim3(cca::GS_THREADS), stream, dE, de, k, (const float *)pq, (const float *)nullptr, (const float *)nullptr,
+                           dim3(cca::GS_THREADS), stream, dE, k, (const float *)pq, (const float *)nullptr, (const float *)nullptr,
                            last ? dq : pq, Cq, H, W, kbs, kps, pbs, Cq, 0L, 0, last ? dqbs : pbs, last ? dqps : Cq, gl.n_whole, gl.split, jl);
             else
                 CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, float, float, false, true, 1, true>), dim3(cca::gmap_dual_grid(gl.grid)),
-                           dim3(cca::GS_THREADS), stream, dE, de, k, (const float *)pq, (const float *)nullptr, (const float *)nullptr,
+                           dim3(cca::GS_THREADS), stream, dE, k, (const float *)pq, (const float *)nullptr, (const float *)nullptr,
                            last ? dq : pq, Cq, H, W, kbs, kps, pbs, Cq, 0L, 0, last ? dqbs : pbs, last ? dqps : Cq, gl.n_whole, gl.split, jl);
             if (int e = launch_status("gmap_dual_f32(long rows)")) return e;
         }
@@ -1239,7 +1187,7 @@ int gmap_dual_f32(const float *dE, const float *k, const float *q, float *dq, fl
     }
     const cca::GmapJob<float, float> jr{q, pk, dk, qbs, dkbs, qps, dkps, gr.grid};
     CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, float, float, false, true, 1>), dim3(cca::gmap_dual_grid(gr.grid)), dim3(cca::GS_THREADS),
-               stream, dE, de, k, (const float *)pq, (const float *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
+               stream, dE, k, (const float *)pq, (const float *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
                0L, 0, dqbs, dqps, gr.n_whole, gr.split, jr);
     return launch_status("gmap_dual_f32(row, 132)");
 }
@@ -1248,7 +1196,7 @@ size_t planes_bytes(int B, int C, int H, int W) { return (size_t)B * H * W * 2 *
 }  // extern "C++"
 
 static size_t ws_planes_bytes(int B, int C, int Cq, int H, int W, int backward) {
-    const size_t base = pm_workspace_bytes(B, C, Cq, H, W, backward);       /* (forward: column partial | raw statistics) */
+    const size_t base = pm_workspace_bytes(B, C, Cq, H, W, backward);
     if (!base) return 0;
     return align256(base) + (backward ? planes_bytes(B, C, H, W) : 0);                       /* + dy as planes */
 }
@@ -1262,13 +1210,12 @@ size_t ccnet_cca_workspace_bytes(int entry, int B, int C, int Cq, int H, int W) 
     case CCNET_WS_PM_BACKWARD: return ws_pm_bytes(B, C, Cq, H, W, 1);
     case CCNET_WS_PLANES_FORWARD: return ws_planes_bytes(B, C, Cq, H, W, 0);
     case CCNET_WS_PLANES_BACKWARD: return ws_planes_bytes(B, C, Cq, H, W, 1);
-    case CCNET_WS_ATTENTION_PM: return (B > 0 && H > 0 && W > 0) ? parts_raw_bytes(B, H, W) : 0;
     }
     return 0;
 }
 
-static int split_planes_impl(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, int src_ps,
-                             long dst_bs, int dst_ps, int layout, const float *bias, ccnet_stream_t stream, int max_wgs) {
+int ccnet_cca_split_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, int src_ps,
+                               long dst_bs, int dst_ps, int layout, const float *bias, ccnet_stream_t stream) {
     if (int e = check_shape(B, C, H, W)) return e;
     if (!src || !dst) return fail(CCNET_E_NULLPTR, "split_planes: null tensor");
     cca::PlaneLayout pl;
@@ -1277,14 +1224,9 @@ static int split_planes_impl(const float *src, uint16_t *dst, int B, int C, int 
     if (int e = check_planes_view("split_planes: destination view (C % 8, pixel stride >= planes * C)", dst_bs, dst_ps, C, H, W, pl.width / C)) return e;
     const int hw = H * W;
     const long items = (long)hw * (C / 8);
-    unsigned gx = (unsigned)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
-    if (max_wgs > 0 && gx * (unsigned)B > (unsigned)max_wgs) gx = (unsigned)((max_wgs + B - 1) / B);     // (grid-stride loop inside)
+    const unsigned gx = (unsigned)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
     CCA_LAUNCH(cca::pm_split_kernel, dim3(gx, (unsigned)B), dim3(256), stream, src, (bf16p_t *)dst, C, hw, src_bs, src_ps, dst_bs, dst_ps, pl, bias);
     return launch_status("split_planes");
-}
-int ccnet_cca_split_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, int src_ps,
-                               long dst_bs, int dst_ps, int layout, const float *bias, ccnet_stream_t stream) {
-    return split_planes_impl(src, dst, B, C, H, W, src_bs, src_ps, dst_bs, dst_ps, layout, bias, stream, 0);
 }
 
 int ccnet_cca_nchw_to_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, long dst_bs, int dst_ps,
@@ -1302,12 +1244,12 @@ int ccnet_cca_nchw_to_planes_f32(const float *src, uint16_t *dst, int B, int C, 
 }
 
 int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v, const float *v_bias, uint16_t *v_planes,
-                                 const float *x, const float *gamma, float *y, float *A, float *stats,
+                                 const float *x, const float *gamma, float *y, float *A,
                                  int B, int C, int Cq, int H, int W,
                                  long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long vp_bs, int vp_ps,
                                  void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
     if (int e = require_both_branches("cca_forward_planes_f32")) return e;
-    if (!q || !k || !v_planes || !x || !gamma || !y || !A || !stats) return fail(CCNET_E_NULLPTR, "cca_forward_planes: null tensor");
+    if (!q || !k || !v_planes || !x || !gamma || !y || !A) return fail(CCNET_E_NULLPTR, "cca_forward_planes: null tensor");
     if (int e = check_planes_problem("cca_forward_planes: columns <= 132, rows <= 528 (> 132: C/8 <= 64), C % 8 == 0, Cq % 4 == 0",
                                      B, C, Cq, H, W, true)) return e;
     if (int e = check_pm_view<float>("cca_forward_planes: q view", q_bs, q_ps, Cq, H, W)) return e;
@@ -1317,64 +1259,45 @@ int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v,
     if ((double)C * H * W >= 536870912.0) return fail(CCNET_E_BADSHAPE, "cca_forward_planes: image exceeds 2^29 elements");
     if (!workspace || workspace_bytes < ws_planes_bytes(B, C, Cq, H, W, 0))
         return fail(CCNET_E_WORKSPACE, "cca_forward_planes: workspace missing or too small");
-    // v (fp32, the value slice of the projection) -> planes: a pure streaming pass that is independent of the affinity launch
-    // (latency- and matrix-pipe bound, HBM mostly idle): it runs on the library's side stream NEXT TO it and joins before the
-    // aggregation reads the planes ("planes_overlap" 0: on the caller's stream, first)
-    // "planes_split": 0 the caller's stream, before the affinity launch; 1 side stream, launched before it; 2 side stream,
-    // launched AFTER it (the affinity workgroups take their slots first, the split's fill what is left); 3 as 2 with the split's
-    // grid capped at two workgroups per CU
-    SideFork sf(stream);
-    int e = 0;
-    const int how = (v && g_planes_overlap.load() != 0) ? g_planes_split.load() : 0;
-    if (how) sf.fork();
-    if (v && how <= 1) e = split_planes_impl(v, v_planes, B, C, H, W, v_bs, v_ps, vp_bs, vp_ps, CCNET_PLANES_HL, v_bias, sf.stream(), 0);
-    float *raw = parts_raw_of(workspace, B, C, H, W);
-    bool two_stage = false;
-    if (!e) e = gweight_energies_f32(q, k, A, raw, stats, &two_stage, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream);
-    if (!e && v && how >= 2)
-        e = split_planes_impl(v, v_planes, B, C, H, W, v_bs, v_ps, vp_bs, vp_ps, CCNET_PLANES_HL, v_bias, sf.stream(), how == 3 ? 2 * num_cus() : 0);
-    e = sf.join(e);
-    if (e) return e;
+    // v (fp32, the value slice of the projection) -> planes, inside the entry point (every pass the op needs belongs to
+    // the op).  On the caller's stream: running it on the side stream NEXT TO the affinity launch was measured and lost
+    // (fwd 0.334 -> 0.346 ms, three launch orders / a capped grid: profiles/r04m_ab_two_stage_lds_staging.txt, "split-*" rows).
+    if (v)
+        if (int e = ccnet_cca_split_planes_f32(v, v_planes, B, C, H, W, v_bs, v_ps, vp_bs, vp_ps, CCNET_PLANES_HL, v_bias, stream)) return e;
+    if (int e = gweight_energies_f32(q, k, A, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
+    if (int e = softmax_forward(A, A, B, H, W, stream)) return e;
     const long img = (long)C * H * W;
-    const cca::PartsArgs pa = two_stage ? cca::PartsArgs{nullptr, raw, stats} : cca::PartsArgs{stats, nullptr, nullptr};
-    return launch_gmap_planes<false, true>(A, pa, (const bf16p_t *)v_planes, x, gamma, y, (float *)workspace, B, C, H, W, vp_bs, vp_ps,
+    return launch_gmap_planes<false, true>(A, (const bf16p_t *)v_planes, x, gamma, y, (float *)workspace, B, C, H, W, vp_bs, vp_ps,
                                            img, 0, img, 0, stream);
 }
 
-/* The saved pair (A, stats) alone -- what the pixel-major / split-plane forwards leave for their backward -- rebuilt from q, k:
- * the host calls it in the backward pass when it chose NOT to keep the pair (recompute instead of save). */
-int ccnet_cca_attention_pm(const void *q, const void *k, float *A, float *stats, int bf16, int B, int Cq, int H, int W,
-                           long q_bs, int q_ps, long k_bs, int k_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
+/* The attention tensor alone from pixel-major q, k views (what the pixel-major / split-plane forwards leave in ``A``): the host
+ * calls it in the backward pass when it did NOT keep A (recompute instead of save). */
+int ccnet_cca_attention_pm(const void *q, const void *k, float *A, int bf16, int B, int Cq, int H, int W,
+                           long q_bs, int q_ps, long k_bs, int k_ps, ccnet_stream_t stream) {
     if (int e = require_both_branches("cca_attention_pm")) return e;
-    if (!q || !k || !A || !stats) return fail(CCNET_E_NULLPTR, "cca_attention_pm: null tensor");
-    if (!workspace || workspace_bytes < parts_raw_bytes(B, H, W)) return fail(CCNET_E_WORKSPACE, "cca_attention_pm: workspace missing or too small");
-    float *raw = static_cast<float *>(workspace);
-    const int npix = B * H * W;
-    bool two_stage = true;
+    if (!q || !k || !A) return fail(CCNET_E_NULLPTR, "cca_attention_pm: null tensor");
     if (bf16) {
         if (int e = check_pm_problem<bf16_t>("cca_attention_pm: strip length / channel divisibility (see ccnet_cca.h)", B, Cq, Cq, H, W)) return e;
         if (int e = check_pm_view<bf16_t>("cca_attention_pm: q view", q_bs, q_ps, Cq, H, W)) return e;
         if (int e = check_pm_view<bf16_t>("cca_attention_pm: k view", k_bs, k_ps, Cq, H, W)) return e;
-        if (int e = gweight_pm<true, bf16_t>((const bf16_t *)q, (const bf16_t *)k, A, raw, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
+        if (int e = gweight_pm<true, bf16_t>((const bf16_t *)q, (const bf16_t *)k, A, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
     } else {
         if (int e = check_planes_problem("cca_attention_pm: columns <= 132, rows <= 528 (> 132: C/8 <= 64), Cq % 4 == 0", B, 8 * Cq, Cq, H, W, true)) return e;
         if (int e = check_pm_view<float>("cca_attention_pm: q view", q_bs, q_ps, Cq, H, W)) return e;
         if (int e = check_pm_view<float>("cca_attention_pm: k view", k_bs, k_ps, Cq, H, W)) return e;
-        if (int e = gweight_energies_f32((const float *)q, (const float *)k, A, raw, stats, &two_stage, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
+        if (int e = gweight_energies_f32((const float *)q, (const float *)k, A, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
     }
-    if (!two_stage) return 0;                      // (long rows: classic attention, neutral factors already written)
-    // the factors the forward's first consumer would have written (same arithmetic: parts_scales)
-    CCA_LAUNCH(cca::parts_finalize_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), stream, (const float *)raw, stats, npix);
-    return launch_status("parts_finalize");
+    return softmax_forward(A, A, B, H, W, stream);
 }
 
 int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *k, const uint16_t *v_planes, const float *A,
-                                  const float *stats, const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
+                                  const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
                                   int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps,
                                   long v_bs, int v_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
                                   void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
     if (int e = require_both_branches("cca_backward_planes_f32")) return e;
-    if (!dy || !q || !k || !v_planes || !A || !stats || !gamma || !dq || !dk || !dv || !dgamma || !scratch)
+    if (!dy || !q || !k || !v_planes || !A || !gamma || !dq || !dk || !dv || !dgamma || !scratch)
         return fail(CCNET_E_NULLPTR, "cca_backward_planes: null tensor");
     if (int e = check_planes_problem("cca_backward_planes: columns <= 132, rows <= 528 (> 132: C/8 <= 64), C % 8 == 0, Cq % 4 == 0",
                                      B, C, Cq, H, W, true)) return e;
@@ -1400,43 +1323,37 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
     SideFork sf(stream);
     if (overlap == 2) sf.fork();
     // t = un-scaled dA (the adjoint of the aggregation, functions.py:46-47), dv = gamma * A^T-weighted dy
-    // whole strips (W <= 132): the softmax backward is FOLDED into the dA epilogue, a per-pixel finalize and the dq | dk prologues;
-    // long rows (blocked dA tiles see only part of a query's slots) keep the classic softmax-backward launch
-    const bool fold = W <= 132;
-    float *ddot = fold_ddot_of(workspace, B, H, W);
     int e = 0;
     if (W > 132) {           // long rows: nb x nb (query block, key block) tiles per row strip
         const int nb = long_blocks(W);
         const dim3 grid((unsigned)(B * (W + H * nb * nb))), block(cca::GM_THREADS);
-        CCA_LAUNCH((cca::gweight_kernel<132, false, bf16p_t, false, true>), grid, block, stream, dyp, vp, scratch, (float *)nullptr, (const float *)nullptr, (float *)nullptr, C, H, W, dbs, 2 * C,
+        CCA_LAUNCH((cca::gweight_kernel<132, false, bf16p_t, false, true>), grid, block, stream, dyp, vp, scratch, C, H, W, dbs, 2 * C,
                    v_bs, v_ps, nb);
         e = launch_status("gweight_planes(dA, long rows)");
     } else if ((H > W ? H : W) > 100) {
         const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
-        CCA_LAUNCH((cca::gweight_kernel<132, false, bf16p_t, false>), grid, block, stream, dyp, vp, scratch, (float *)nullptr, A, ddot, C, H, W, dbs, 2 * C, v_bs, v_ps);
+        CCA_LAUNCH((cca::gweight_kernel<132, false, bf16p_t, false>), grid, block, stream, dyp, vp, scratch, C, H, W, dbs, 2 * C, v_bs, v_ps);
         e = launch_status("gweight_planes(dA, 132)");
     } else if (const int ps = g_planes_stream.load()) {
         // persistent: one workgroup per CU walks the strips of both branches, its ring runs across strip boundaries
         // (option values > 1 cap the number of workgroups: tests make one workgroup walk many strips)
         const int nstrips = B * (H + W), cus = ps > 1 ? ps : num_cus();
         const dim3 grid((unsigned)(nstrips < cus ? nstrips : cus)), block(cca::GM_THREADS);
-        CCA_LAUNCH((cca::gweight_stream_kernel<100>), grid, block, stream, dyp, vp, scratch, A, ddot, C, B, H, W, dbs, 2 * C, v_bs, v_ps);
+        CCA_LAUNCH((cca::gweight_stream_kernel<100>), grid, block, stream, dyp, vp, scratch, C, B, H, W, dbs, 2 * C, v_bs, v_ps);
         e = launch_status("gweight_stream(dA)");
     } else {
         const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
-        CCA_LAUNCH((cca::gweight_kernel<100, false, bf16p_t, false>), grid, block, stream, dyp, vp, scratch, (float *)nullptr, A, ddot, C, H, W, dbs, 2 * C, v_bs, v_ps);
+        CCA_LAUNCH((cca::gweight_kernel<100, false, bf16p_t, false>), grid, block, stream, dyp, vp, scratch, C, H, W, dbs, 2 * C, v_bs, v_ps);
         e = launch_status("gweight_planes(dA)");
     }
     if (overlap == 1) sf.fork();
-    if (!e) e = launch_gmap_planes<true, false>(A, cca::PartsArgs{stats, nullptr, nullptr}, dyp, nullptr, gamma, dv, partial, B, C, H, W, dbs, 2 * C, 0L, 0, dv_bs, dv_ps, sf.stream());
-    // dgamma = sum A t;  dE = gamma * A * (t - sum_s A t), in place; the fixed-order sum of the dgamma partials rides on the
-    // dq | dk column launch
+    if (!e) e = launch_gmap_planes<true, false>(A, dyp, nullptr, gamma, dv, partial, B, C, H, W, dbs, 2 * C, 0L, 0, dv_bs, dv_ps, sf.stream());
+    // dgamma = sum A t;  dE = gamma * A * (t - sum_s A t), in place
+    // (the fixed-order sum of the dgamma partials rides on the dq | dk column launch: one launch less)
     DeferredSum red{static_cast<const float *>(workspace), 0, dgamma};
-    cca::PartsArgs de{};
-    if (!e && fold) e = fold_finalize(A, stats, gamma, dgamma, workspace, B, H, W, stream, &de, &red);
-    if (!e && !fold) e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, sm, B, H, W, stream, KSplit(), stats, &red.n);
+    if (!e) e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, sm, B, H, W, stream, KSplit(), &red.n);
     if (!e) e = gmap_dual_f32(scratch, k, q, dq, dk, partial_qk_of(partial, B, C, H, W), B, Cq, H, W, k_bs, k_ps, q_bs, q_ps,
-                              dq_bs, dq_ps, dk_bs, dk_ps, stream, red, de);
+                              dq_bs, dq_ps, dk_bs, dk_ps, stream, red);
     return sf.join(e);
 }
 
@@ -1450,7 +1367,6 @@ const OptionRange *find_word_option(const std::string &n) {
         {"planes_stream", &g_planes_stream, 0, 1 << 20},
         {"planes_overlap", &g_planes_overlap, -1, 2},
         {"planes_xcd", &g_planes_xcd, 0, 1},
-        {"planes_split", &g_planes_split, 0, 3},
     };
     for (const OptionRange &o : table)
         if (n == o.name) return &o;

@@ -65,33 +65,6 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// TWO-STAGE SOFTMAX ("attention parts", round 4).  The joint softmax of functions.py:40 runs over the H column slots and
-// the W row slots of a pixel, which the affinity kernel produces in DIFFERENT workgroups (a column strip, a row strip).
-// Instead of writing raw energies and re-reading them in a softmax launch, the affinity kernel finishes each branch on its
-// own: it stores  P[pixel][slot] = exp(e - m_branch)  and, per pixel, the branch statistics
-//     stats[pixel] = (m_col, z_col, m_row, z_row)        m = max of the branch's energies, z = sum of its P
-// and every consumer of the attention applies the per-(pixel, branch) factor
-//     s_branch = exp(m_branch - m) / (z_col exp(m_col - m) + z_row exp(m_row - m)),   m = max(m_col, m_row)
-// while it loads its fragments:  A[pixel][slot] = P[pixel][slot] * s_branch(pixel)  -- the same value as exp(e - m) / Z up
-// to two roundings.  The masked column self slot holds exp(-inf) = 0 exactly.  A tensor whose statistics are the
-// neutral (0, 0.5, 0, 0.5) is a plain attention tensor (s = 1 exactly): what the blocked long-row forward writes.
-// ---------------------------------------------------------------------------------------------------------------
-// both factors of a pixel: ONE exponential (the branch that holds the joint maximum has exp(0) = 1) and one division
-__device__ __forceinline__ void parts_scales(const f32x4 st, float &s_col, float &s_row) {
-    const float d = st[0] - st[2];                                    // m_col - m_row  (-inf: a column branch with no live slot)
-    const float e = expf(-fabsf(d));
-    const float ec = d >= 0.f ? 1.f : e, er = d >= 0.f ? e : 1.f;
-    const float inv = 1.f / (st[1] * ec + st[3] * er);
-    s_col = ec * inv;
-    s_row = er * inv;
-}
-__device__ __forceinline__ float parts_scale(const f32x4 st, bool row) {
-    float sc, sr;
-    parts_scales(st, sc, sr);
-    return row ? sr : sc;
-}
-
 // Split-bf16: x = hi + lo + O(2^-17 |x|) with hi = bf16_rne(x), lo = bf16_rne(x - hi).  A product a*b is then
 // replaced by a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix pipe (16x the fp32 MFMA rate, 3 products:
 // ~5x net), fp32 accumulate; the dropped terms are O(2^-16 |a b|)  (SURVEY.md section 0, fact 5).

@@ -142,44 +142,6 @@ __device__ __forceinline__ u32x4 t16_frag(const float *tile, int ks, int nt, int
     return u32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
-// What a consumer of the two-stage softmax's tensor gets (all null: T is a plain tensor -- dA, dE, a classic attention):
-//   raw     (B, H*W, 4) branch statistics straight from the affinity kernel (m_col, z_col, m_row, z_row); only the FIRST
-//           consumer of a forward reads them -- the column pass of the aggregation, which visits every pixel exactly once --
-//   out     (B, H*W, 2) and writes the FINAL factors (s_col, s_row) of its pixels there (what the forward saves);
-//   scales  (B, H*W, 2) final factors, read by every later consumer.
-// Non-transposed passes (queries = the M side) never touch the attention fragments: out = s_i * sum_j P[i][j] F[j], the factor
-// joins gamma in the epilogue, its load is needed only there.  Transposed passes (queries = the contracted side) multiply
-// P[i][j] by s_i while they build their fragments: eight more 4-byte loads next to the eight of the values, no staging.
-// FOLDED SOFTMAX BACKWARD (the dq | dk launches; ``pexp`` given): T is the un-scaled map adjoint t = dA, ``pexp`` the forward's
-// un-normalised exponentials and ``fin`` (B, H*W, 2 branches, 2) = (g_b, D) per pixel and branch with g_b = gamma * s_branch and
-// D = sum_s A dA -- the softmax adjoint  dE[i][j] = g_i * P[i][j] * (t[i][j] - D_i)  is formed while the fragments are built
-// (non-transposed: P (t - D_i) in the fragments, g_i in the epilogue; transposed: the whole product per contracted position),
-// so neither dE nor a softmax-backward launch exists.
-struct PartsArgs {
-    const float *scales;
-    const float *raw;
-    float *out;
-    const float *pexp;
-    const float *fin;
-};
-__device__ __forceinline__ bool parts_any(const PartsArgs &pa) { return pa.scales != nullptr || pa.raw != nullptr; }
-// buffer view of one image's final factors (transposed passes: branch-free loads, out-of-range lanes read 0)
-__device__ __forceinline__ FBuf parts_scales_buf(const PartsArgs &pa, size_t img_pix0, int HW, const float *any_valid) {
-    return make_fbuf(pa.scales ? pa.scales + img_pix0 * 2 : any_valid, pa.scales ? (size_t)HW * 8 : 4);
-}
-// factor of query pixel ``pix`` (image-relative) for the branch, non-transposed passes; ``write``: this lane stores the pixel's final pair
-__device__ __forceinline__ float parts_query_scale(const PartsArgs &pa, size_t img_pix0, int pix, bool ok, bool row, bool write) {
-    if (pa.raw) {                                   // (wave-uniform)
-        f32x4 st = f32x4{0.f, 1.f, 0.f, 1.f};
-        if (ok) __builtin_memcpy(&st, pa.raw + (img_pix0 + pix) * 4, 16);
-        float sc, sr;
-        parts_scales(st, sc, sr);
-        if (ok && write && pa.out) { pa.out[(img_pix0 + pix) * 2] = sc; pa.out[(img_pix0 + pix) * 2 + 1] = sr; }
-        return ok ? (row ? sr : sc) : 0.f;
-    }
-    return ok ? pa.scales[(img_pix0 + pix) * 2 + (row ? 1 : 0)] : 0.f;
-}
-
 // FT: feature element, OT: output element; the addend (ADD) is fp32 pixel-major with its own strides; resid (may be
 // null) has the output's type.  4 wavefronts, two workgroups per CU: wavefront w owns the M tiles (16
 // strip positions each) t = w, w + 4, w + 8 of all four 16-channel N tiles, and keeps their attention fragments -- hi and
@@ -229,8 +191,7 @@ inline unsigned gmap_dual_grid(int nwg) { return 16u * (unsigned)((nwg + 7) / 8)
 // WPC: workgroups per CU the LDS budget is checked for (2 everywhere except the 132-position kernels on fp32 / split-plane
 // features, whose two feature tiles + output image take 104 KB: one workgroup per CU)
 template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT, bool NCHW = false, bool DUAL = false, int WPC = 2, bool LONG = false>
-__global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__restrict__ T, const PartsArgs pa,
-                                                              const FT *__restrict__ F,
+__global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__restrict__ T, const FT *__restrict__ F,
                                                               const float *__restrict__ addend,
                                                               const OT *__restrict__ resid,
                                                               const float *__restrict__ gamma, OT *out,
@@ -277,7 +238,8 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
         // go round-robin over the 8 XCDs, so XCD x = id & 7 takes the strips [x * xcd, (x + 1) * xcd) -- at 8 images of 97 rows
         // one image per XCD -- the whole ones first in ITS dispatch order, then its share of the cut ones.  Neighbouring NCHW
         // rows share their boundary cache lines (a row of 97 floats is 388 B at arbitrary alignment): on one XCD the second
-        // touch of such a line is an L2 hit and the two partial writes merge there.
+        // touch of such a line is an L2 hit and the two partial writes merge there (forward row pass 155 -> 148 us, same run:
+        // profiles/r04m_ab_*.txt).
         const int x = id & 7, idx = id >> 3, nw8 = n_whole >> 3;
         if (idx < nw8) {
             id = x * j1.xcd + idx;
@@ -337,14 +299,6 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
         }
     };
     issue_feat(cg0);
-    const bool parts = parts_any(pa);               // two-stage softmax: T holds un-normalised exponentials (see PartsArgs)
-    const bool defly = pa.pexp != nullptr;          // folded softmax backward: dE is formed here from t, P and (g, D)
-    const size_t img_pix0 = (size_t)b * HW;
-    const FBuf Sb = parts_scales_buf(pa, img_pix0, HW, T);
-    const FBuf Pb = make_fbuf(defly ? pa.pexp + (size_t)b * HW * S : T, defly ? (size_t)HW * S * sizeof(float) : 4);
-    const FBuf Gb = make_fbuf(defly ? pa.fin + img_pix0 * 4 : T, defly ? (size_t)HW * 16 : 4);
-    const int gbr = ROW ? 8 : 0;                     // byte offset of this branch's (g, D) pair inside a pixel's 16 bytes
-    float qs[TPW];                                   // non-transposed: the factor of this lane's query row of each owned tile
 
     // ---- the strip's attention block -> MFMA fragments in registers.  Fragment (tile t, k-step ks) of lane (ln, lg):
     // ---- P_g[m][32 ks + 8 lg + e] (TRANS: P_g[32 ks + 8 lg + e][m]), m = 16 t + ln, e < 8; zero beyond the strip
@@ -353,14 +307,6 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
 #pragma unroll
     for (int a = 0; a < TPW; ++a) {
         const int t = wv + GS_WAVES * a, m = 16 * t + ln;
-        qs[a] = 1.f;
-        if (parts && !trans) qs[a] = parts_query_scale(pa, img_pix0, pixM + m * pstep, m < Lm, ROW, lg == 0);
-        float Dm = 0.f;
-        if (defly && !trans) {                              // this lane's query row: g_i joins the epilogue, D_i the fragments
-            const f32x2 gd = fbuf_load_x2(Gb, m < Lm ? (pixM + m * pstep) * 16 + gbr : kOobOffset, 0);
-            qs[a] = gd[0];
-            Dm = gd[1];
-        }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             float x[8];
@@ -372,38 +318,10 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                     const f32x4 v = fbuf_load_x4(Tb, (m < Lm && k0 + 4 < Lk) ? base + 16 : kOobOffset, 0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { x[e] = k0 + e < Lk ? u[e] : 0.f; x[4 + e] = k0 + 4 + e < Lk ? v[e] : 0.f; }
-                    if (defly) {
-                        const f32x4 pu = fbuf_load_x4(Pb, (m < Lm && k0 < Lk) ? base : kOobOffset, 0);
-                        const f32x4 pv = fbuf_load_x4(Pb, (m < Lm && k0 + 4 < Lk) ? base + 16 : kOobOffset, 0);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            x[e] = k0 + e < Lk ? pu[e] * (x[e] - Dm) : 0.f;
-                            x[4 + e] = k0 + 4 + e < Lk ? pv[e] * (x[4 + e] - Dm) : 0.f;
-                        }
-                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
                         x[e] = fbuf_load(Tb, (m < Lm && k0 + e < Lk) ? ((pixK + (k0 + e) * pstep) * S + aM + m) * 4 : kOobOffset, 0);
-                    if (defly) {            // (all value loads issued first, branch-free)
-                        float pe[8];
-                        f32x2 gd[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            pe[e] = fbuf_load(Pb, (m < Lm && k0 + e < Lk) ? ((pixK + (k0 + e) * pstep) * S + aM + m) * 4 : kOobOffset, 0);
-                            gd[e] = fbuf_load_x2(Gb, k0 + e < Lk ? (pixK + (k0 + e) * pstep) * 16 + gbr : kOobOffset, 0);
-                        }
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) x[e] = pe[e] * (x[e] - gd[e][1]) * gd[e][0];
-                    }
-                    if (parts) {            // (all eight value loads are issued: now a factor per contracted position)
-                        float sq[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            sq[e] = fbuf_load(Sb, k0 + e < Lk ? ((pixK + (k0 + e) * pstep) * 2 + (ROW ? 1 : 0)) * 4 : kOobOffset, 0);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) x[e] *= sq[e];
-                    }
                 }
             } else {
 #pragma unroll
@@ -416,17 +334,6 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
         const int kt = 32 * kp.nbf + lg;
         at[a] = fbuf_load(Tb, (kp.tail && m < Lm && kt < Lk) ? (trans ? ((pixK + kt * pstep) * S + aM + m) * 4
                                                                        : ((pixM + m * pstep) * S + aK + kt) * 4) : kOobOffset, 0);
-        if (parts && trans) at[a] *= fbuf_load(Sb, (kp.tail && kt < Lk) ? ((pixK + kt * pstep) * 2 + (ROW ? 1 : 0)) * 4 : kOobOffset, 0);
-        if (defly) {
-            const bool okt = kp.tail && m < Lm && kt < Lk;
-            const float pt = fbuf_load(Pb, okt ? (trans ? ((pixK + kt * pstep) * S + aM + m) * 4 : ((pixM + m * pstep) * S + aK + kt) * 4) : kOobOffset, 0);
-            if (trans) {
-                const f32x2 gd = fbuf_load_x2(Gb, okt ? (pixK + kt * pstep) * 16 + gbr : kOobOffset, 0);
-                at[a] = pt * (at[a] - gd[1]) * gd[0];
-            } else {
-                at[a] = pt * (at[a] - Dm);
-            }
-        }
     }
 
     // this lane's slice of store instruction k of its wave: pixel position and first channel (within the group)
@@ -547,9 +454,9 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                         if constexpr (NCHW) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
-                                CCA_LDS_ST(oimg + oimg_nchw_idx<P>(16 * nt + 4 * lg + q, i), alpha * qs[a] * acc[a][n][q] + addp[a][nt][q]);
+                                CCA_LDS_ST(oimg + oimg_nchw_idx<P>(16 * nt + 4 * lg + q, i), alpha * acc[a][n][q] + addp[a][nt][q]);
                         } else {
-                            lds_store_x4(oimg + i * OPX + 16 * nt + 4 * lg, (alpha * qs[a]) * acc[a][n]);
+                            lds_store_x4(oimg + i * OPX + 16 * nt + 4 * lg, alpha * acc[a][n]);
                         }
                     }
                 }
@@ -647,8 +554,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
 // FT = bf16p_t (split planes: hi | lo tiles, three products) or bf16_t (bf16 features, BASELINE configs[4]: one tile, the two
 // products with the attention's hi and lo halves); the output is fp32 pixel-major either way (the column partial).
 template <int P, bool ROW, bool TRANS, bool ADD, int NBUF = 3, int WPC = 2, typename FT = bf16p_t>
-__global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__restrict__ T, const PartsArgs pa,
-                                                               const FT *__restrict__ F,
+__global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__restrict__ T, const FT *__restrict__ F,
                                                                const float *__restrict__ addend, const float *__restrict__ gamma,
                                                                float *__restrict__ out, int C, int H, int W, long fbs, int fps,
                                                                long abs_, int aps, long obs, int ops, int n_whole, int split) {
@@ -699,10 +605,6 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
     };
     issue_feat(cg0, lds);
     if (D > 1 && cg0 + 1 < cg1) issue_feat(cg0 + 1, lds + FSZ);
-    const bool parts = parts_any(pa);               // two-stage softmax: T holds un-normalised exponentials (see PartsArgs)
-    const size_t img_pix0 = (size_t)b * HW;
-    const FBuf Sb = parts_scales_buf(pa, img_pix0, HW, T);
-    float qs[TPW];                                   // non-transposed: the factor of this lane's query row of each owned tile
 
     // the strip's attention block -> MFMA fragments in registers (as gmap_kernel)
     u32x4 ah[TPW][NKS], al[TPW][NKS];
@@ -710,8 +612,6 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
 #pragma unroll
     for (int a = 0; a < TPW; ++a) {
         const int t = wv + GS_WAVES * a, m = 16 * t + ln;
-        qs[a] = 1.f;
-        if (parts && !TRANS) qs[a] = parts_query_scale(pa, img_pix0, pix0 + m * pstep, m < L, ROW, lg == 0);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             float x[8];
@@ -727,14 +627,6 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
                         x[e] = fbuf_load(Tb, (m < L && k0 + e < L) ? ((pix0 + (k0 + e) * pstep) * S + a_off + m) * 4 : kOobOffset, 0);
-                    if (parts) {            // (all eight value loads are issued: now a factor per contracted position)
-                        float sq[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            sq[e] = fbuf_load(Sb, k0 + e < L ? ((pix0 + (k0 + e) * pstep) * 2 + (ROW ? 1 : 0)) * 4 : kOobOffset, 0);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) x[e] *= sq[e];
-                    }
                 }
             } else {
 #pragma unroll
@@ -747,7 +639,6 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
         const int kt = 32 * kp.nbf + lg;
         at[a] = fbuf_load(Tb, (kp.tail && m < L && kt < L) ? (TRANS ? ((pix0 + kt * pstep) * S + a_off + m) * 4
                                                                      : ((pix0 + m * pstep) * S + a_off + kt) * 4) : kOobOffset, 0);
-        if (parts && TRANS) at[a] *= fbuf_load(Sb, (kp.tail && kt < L) ? ((pix0 + kt * pstep) * 2 + (ROW ? 1 : 0)) * 4 : kOobOffset, 0);
     }
 
     // stores / addend loads of a group: one 16-byte access per owned M tile and N tile whose channels exist (both
@@ -837,7 +728,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
                 for (int nt = 0; nt < 4; ++nt) {
                     const int c = cg * GM_CG + 16 * nt + 4 * lg;
                     if (cg * GM_CG + 16 * nt < C) {
-                        f32x4 u = (alpha * qs[a]) * acc[a][nt];
+                        f32x4 u = alpha * acc[a][nt];
                         if constexpr (ADD) u += addp[SL][a][nt];
                         fbuf_store_x4(Ob, u, (i < L && c < C) ? ((pix0 + i * pstep) * ops + c) * 4 : kOobOffset, 0);
                     }
@@ -955,9 +846,7 @@ __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float *__rest
 // T[query block I][key block J] of a row strip from the X tile of block I and the Y tile of block J; column strips (<= P) stay whole.
 template <int P, bool MASK, typename FT, bool SINGLE, bool LONG = false>
 __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(const FT *__restrict__ X, const FT *__restrict__ Y,
-                                                                              float *__restrict__ T, float *__restrict__ stats,
-                                                                              const float *__restrict__ Pexp, float *__restrict__ ddot,
-                                                                              int Cx, int H, int W,
+                                                                              float *__restrict__ T, int Cx, int H, int W,
                                                                               long xbs, int xps, long ybs, int yps, int nb = 1) {
     constexpr bool BF = GTile<FT>::BF;
     constexpr bool PL = std::is_same<FT, bf16p_t>::value;     // split planes: an operand tile = hi image | lo image (bf16 tile geometry)
@@ -1113,65 +1002,6 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
         }
     }
     if constexpr (!BF && MASK) mfma_f32_result_fence();
-    // two-stage softmax (``stats`` given; whole strips only): this branch's half of functions.py:40 is finished here -- the
-    // accumulators become exp(e - m_branch) and (m_branch, z_branch) of every query go to stats (see parts_scale).  A query's
-    // keys are the 16 lanes ln of its lane group x the NT tiles: the row reductions are 4-step butterflies inside 16 lanes.
-    bool parts = false;
-    if constexpr (MASK && !LONG) parts = stats != nullptr;
-    if (parts) {
-        float *Sg = stats + (size_t)b * HW * 4 + (row ? 2 : 0);
-#pragma unroll
-        for (int a = 0; a < NTR; ++a)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = 16 * (wv + GM_WAVES * a) + 4 * lg + q;
-                float m = -INFINITY;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int j = 16 * t + ln;
-                    if (j >= Lk || (!row && i == j)) acc[a][t][q] = -INFINITY;       // beyond the strip; functions.py:11-12
-                    m = fmaxf(m, acc[a][t][q]);
-                }
-#pragma unroll
-                for (int sh = 1; sh < 16; sh <<= 1) m = fmaxf(m, shfl_xor(m, sh));
-                const float mm = m == -INFINITY ? 0.f : m;                            // (a branch with no live slot: P = 0, z = 0)
-                float z = 0.f;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float pv = fast_expf(acc[a][t][q] - mm);
-                    acc[a][t][q] = pv;
-                    z += pv;
-                }
-#pragma unroll
-                for (int sh = 1; sh < 16; sh <<= 1) z += shfl_xor(z, sh);
-                if (ln == 0 && i < L) {
-                    Sg[(size_t)(pix0 + i * pstep) * 4] = m;
-                    Sg[(size_t)(pix0 + i * pstep) * 4 + 1] = z;
-                }
-            }
-    }
-    // folded softmax backward (dA launches, whole strips; see gweight_stream_kernel): ddot[pixel(i)][branch] = sum_j Pexp[i][j] T[i][j]
-    if constexpr (!MASK && !LONG) {
-        if (Pexp) {
-            const float *Pg = Pexp + (size_t)b * HW * S;
-            float *Dg = ddot + (size_t)b * HW * 2 + (row ? 1 : 0);
-#pragma unroll
-            for (int a = 0; a < NTR; ++a)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = 16 * (wv + GM_WAVES * a) + 4 * lg + q;
-                    float d = 0.f;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const int j = 16 * t + ln;
-                        if (i < L && j < Lk) d += Pg[(size_t)(pix0 + i * pstep) * S + a_off + j] * acc[a][t][q];
-                    }
-#pragma unroll
-                    for (int sh = 1; sh < 16; sh <<= 1) d += shfl_xor(d, sh);
-                    if (ln == 0 && i < L) Dg[(size_t)(pix0 + i * pstep) * 2] = d;
-                }
-        }
-    }
     // D[m = query position 16 ti + 4 lg + q][n = key position 16 t + ln] -> T rows (64-byte runs per query)
     float *Tg = T + (size_t)b * HW * S;
 #pragma unroll
@@ -1183,7 +1013,7 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
                 const int i = 16 * (wv + GM_WAVES * a) + 4 * lg + q, j = 16 * t + ln;
                 if (i < L && j < Lk) {
                     float val = acc[a][t][q];
-                    if (MASK && !parts && !row && i == j) val = -INFINITY;  // functions.py:11-12 (column self slot)
+                    if (MASK && !row && i == j) val = -INFINITY;            // functions.py:11-12 (column self slot)
                     Tg[(size_t)(pix0 + i * pstep) * S + a_off + j] = val;
                 }
             }
@@ -1205,8 +1035,7 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
 // bf16 / P = 100 instantiation came out with 256 VGPRs and 13 spilled)
 template <int P, typename FT = bf16p_t>
 __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT *__restrict__ X, const FT *__restrict__ Y,
-                                                                        float *__restrict__ T, const float *__restrict__ Pexp,
-                                                                        float *__restrict__ ddot, int Cx, int B, int H, int W,
+                                                                        float *__restrict__ T, int Cx, int B, int H, int W,
                                                                         long xbs, int xps, long ybs, int yps) {
     constexpr int NPL = std::is_same<FT, bf16p_t>::value ? 2 : 1;        // planes per operand
     static_assert(NPL == 2 || std::is_same<FT, bf16_t>::value, "gweight_stream: bf16p_t or bf16_t operands");
@@ -1258,25 +1087,8 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
             for (int q = 0; q < 4; ++q) rows += 16 * (wv + GM_WAVES * a) + q < L ? 1 : 0;
         return rows * ((L + 15) / 16);
     };
-    // FOLDED SOFTMAX BACKWARD (Pexp given): a strip's epilogue also forms, per query i of the strip,
-    //     ddot[pixel(i)][branch] = sum_j Pexp[i][j] * T[i][j]          (the branch's share of sum_s A dA, up to the factor s_i)
-    // from the accumulators and the un-normalised exponentials of the block (one 4-byte load per accumulator value, issued at
-    // the top of the strip's LAST stage so that they land behind its MFMAs).  Those loads are ordinary loads the compiler waits
-    // for with vmcnt(0) -- which would also drain any ring fill issued after them -- so a last stage issues its ring fill AFTER
-    // the epilogue instead of before the MFMAs: the ring runs one stage shallower for one stage per strip.
-    const bool dots = Pexp != nullptr;
-    auto nrowstores = [&](int L) {                                          // ddot stores of a strip: one per (owned tile row, q) in range
-        int rows = 0;
-#pragma unroll
-        for (int a = 0; a < NTR; ++a)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) rows += 16 * (wv + GM_WAVES * a) + q < L ? 1 : 0;
-        return rows;
-    };
     auto stores_after = [&](int m) {                                        // stores issued at the end of iteration m
-        if (m < 0 || m % nch != nch - 1) return 0;
-        const int L = strip_of(m).L;
-        return nstores(L) + (dots ? nrowstores(L) : 0);
+        return (m >= 0 && m % nch == nch - 1) ? nstores(strip_of(m).L) : 0;
     };
     auto frag = [&](const float *tile, int pixel_, int kk) {               // 8 consecutive channels of one position: 16 bytes
         const int pixel = pixel_ < 8 * NPB ? pixel_ : 0;
@@ -1297,14 +1109,12 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
         if (n == 0) {
             barrier_dma_keep<0>();
         } else {
-            // (with dots a last stage issues stores(m) BEFORE fill(m + D): the stores of iteration n - D are then older than fill(n))
-            int keep = dots ? 0 : stores_after(n - D);
+            int keep = 0;
 #pragma unroll
-            for (int d = 1; d < D; ++d) keep += stores_after(n - d) + (n + d < total ? npw : 0);
+            for (int d = 1; d <= D; ++d) keep += stores_after(n - d) + (d < D && n + d < total ? npw : 0);
             barrier_dma_keep_n(keep);
         }
-        const bool last = ch == nch - 1;
-        if (!(dots && last) && n + D < total) issue(n + D);
+        if (n + D < total) issue(n + D);
         if (ch == 0) {
             cur = strip_of(n);
 #pragma unroll
@@ -1313,19 +1123,6 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
                 for (int t = 0; t < NT; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         const int L = cur.L;
-        float pv[NTR][4][NT];
-        if (dots && last) {
-            const FBuf Pb = make_fbuf(Pexp + (size_t)cur.b * HW * S, (size_t)HW * S * sizeof(float));
-#pragma unroll
-            for (int a = 0; a < NTR; ++a)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const int i = 16 * (wv + GM_WAVES * a) + 4 * lg + q, j = 16 * t + ln;
-                        pv[a][q][t] = fbuf_load(Pb, (i < L && j < L) ? ((cur.pix0 + i * cur.pstep) * S + cur.a_off + j) * 4 : kOobOffset, 0);
-                    }
-        }
         const float *xh = lds + (n % NBUF) * STG, *xl = xh + (NPL - 1) * TSB, *yh = xh + NPL * TSB, *yl = yh + (NPL - 1) * TSB;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {                                    // two k-steps of 32 channels
@@ -1353,24 +1150,7 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
                 }
             }
         }
-        if (last) {
-            if (dots) {
-                const FBuf Db = make_fbuf(ddot + (size_t)cur.b * HW * 2, (size_t)HW * 2 * sizeof(float));
-#pragma unroll
-                for (int a = 0; a < NTR; ++a)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float d = 0.f;
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) d += pv[a][q][t] * acc[a][t][q];      // (beyond the strip: 0 * 0)
-#pragma unroll
-                        for (int sh = 1; sh < 16; sh <<= 1) d += shfl_xor(d, sh);
-                        if (16 * (wv + GM_WAVES * a) + q < L) {             // (wave-uniform: lane (ln, lg) = (0, 0) is in range)
-                            const int i = 16 * (wv + GM_WAVES * a) + 4 * lg + q;
-                            fbuf_store(Db, d, (ln == 0 && i < L) ? ((cur.pix0 + i * cur.pstep) * 2 + (cur.a_off ? 1 : 0)) * 4 : kOobOffset, 0);
-                        }
-                    }
-            }
+        if (ch == nch - 1) {
             // D[m = query position 16 ti + 4 lg + q][n = key position 16 t + ln] -> T rows (64-byte runs per query)
             const FBuf Tb = make_fbuf(T + (size_t)cur.b * HW * S, (size_t)HW * S * sizeof(float));
 #pragma unroll
@@ -1387,7 +1167,6 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
                         }
                     }
                 }
-            if (dots && n + D < total) issue(n + D);                        // (the delayed ring fill of this stage)
         }
     }
 }

@@ -42,10 +42,6 @@ __device__ __forceinline__ void mfma_f32_result_fence() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// exp() on the hardware's exp2 unit (v_exp_f32 after one multiply): relative error ~|x| 2^-24 + 1 ulp -- ~1e-6 for the
-// exponents a softmax keeps (|x| < 16); what the two-stage softmax epilogue of the affinity kernel uses (28 per lane)
-__device__ __forceinline__ float fast_expf(float x) { return __expf(x); }
-
 // tell the compiler a value is wave-uniform (it is: derived from the wave id) so it lives in SGPRs
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -69,10 +65,6 @@ __device__ __forceinline__ float fbuf_load(const FBuf &b, int voff_bytes, int so
 }
 __device__ __forceinline__ f32x4 fbuf_load_x4(const FBuf &b, int voff_bytes, int soff_bytes) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, voff_bytes, soff_bytes, 0));
-}
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 fbuf_load_x2(const FBuf &b, int voff_bytes, int soff_bytes) {
-    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(b, voff_bytes, soff_bytes, 0));
 }
 // stores whose per-lane offset is out of range (kOobOffset) are dropped by the buffer range check
 __device__ __forceinline__ void fbuf_store(const FBuf &b, float v, int voff_bytes, int soff_bytes) {

@@ -81,14 +81,11 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_fwd_generic_kernel(const flo
 // dgamma are produced; each wavefront adds its pixels in a fixed order: deterministic.
 constexpr int SM_MAX_BLOCKS = 2048;
 
-// ``stats`` (may be null): A holds the un-normalised exponentials of the two-stage softmax (cca_common.hpp) and stats the final
-// per-pixel factors (s_col, s_row): slots below ``hsplit`` take the pixel's column factor, the others its row factor.
 template <int NREG>
 __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_kernel(const float *A, const float *dA,
                                                                const float *gamma, float *dE,
                                                                float *partials, int npix, int S,
-                                                               int nslab, const float *extra, long slab_stride,
-                                                               const float *stats, int hsplit) {
+                                                               int nslab, const float *extra, long slab_stride) {
     __shared__ float red[SM_WAVES];
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
     const float g = gamma ? gamma[0] : 1.f;
@@ -99,15 +96,10 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_kernel(const float *A, c
         float *o = dE + (size_t)pix * S;
         float av[NREG], dv[NREG];
         float rsum = 0.f;
-        float sc = 1.f, sr = 1.f;
-        if (stats) {
-            sc = stats[(size_t)pix * 2];
-            sr = stats[(size_t)pix * 2 + 1];
-        }
 #pragma unroll
         for (int r = 0; r < NREG; ++r) {
             const int s = lane + r * kWave;
-            av[r] = (s < S) ? a[s] * (s < hsplit ? sc : sr) : 0.f;
+            av[r] = (s < S) ? a[s] : 0.f;
             dv[r] = (s < S) ? d[s] : 0.f;
             for (int sl = 1; sl < nslab; ++sl)
                 if (s < S) dv[r] += extra[(size_t)(sl - 1) * slab_stride + (size_t)pix * S + s];
@@ -136,8 +128,7 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_kernel(const float *A, c
 __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_generic_kernel(const float *A, const float *dA,
                                                                        const float *gamma, float *dE,
                                                                        float *partials, int npix, int S,
-                                                                       int nslab, const float *extra, long slab_stride,
-                                                                       const float *stats, int hsplit) {
+                                                                       int nslab, const float *extra, long slab_stride) {
     __shared__ float red[SM_WAVES];
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
     const float g = gamma ? gamma[0] : 1.f;
@@ -151,15 +142,10 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_generic_kernel(const flo
             for (int sl = 1; sl < nslab; ++sl) x += extra[(size_t)(sl - 1) * slab_stride + (size_t)pix * S + s];
             return x;
         };
-        float sc = 1.f, sr = 1.f;
-        if (stats) {
-            sc = stats[(size_t)pix * 2];
-            sr = stats[(size_t)pix * 2 + 1];
-        }
         float rsum = 0.f;
-        for (int s = lane; s < S; s += kWave) rsum += a[s] * (s < hsplit ? sc : sr) * dval(s);
+        for (int s = lane; s < S; s += kWave) rsum += a[s] * dval(s);
         rsum = wave_sum(rsum);
-        for (int s = lane; s < S; s += kWave) o[s] = g * a[s] * (s < hsplit ? sc : sr) * (dval(s) - rsum);
+        for (int s = lane; s < S; s += kWave) o[s] = g * a[s] * (dval(s) - rsum);
         wsum += rsum;
     }
     if (partials) {
@@ -171,56 +157,6 @@ __global__ __launch_bounds__(SM_BLOCK) void softmax_bwd_generic_kernel(const flo
             partials[blockIdx.x] = t;
         }
     }
-}
-
-// factors under which a plain attention tensor reads as itself through the two-stage consumers
-__global__ __launch_bounds__(256) void neutral_scales_kernel(float *scales, int npix) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < npix) {
-        scales[2 * (size_t)i] = 1.f;
-        scales[2 * (size_t)i + 1] = 1.f;
-    }
-}
-
-// raw branch statistics (m_col, z_col, m_row, z_row) -> final factors (s_col, s_row): what the forward's first consumer writes
-// on its way; a launch of its own only where the pair is rebuilt without a consumer (ccnet_cca_attention_pm)
-__global__ __launch_bounds__(256) void parts_finalize_kernel(const float *raw, float *scales, int npix) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < npix) {
-        f32x4 st;
-        __builtin_memcpy(&st, raw + 4 * (size_t)i, 16);
-        float sc, sr;
-        parts_scales(st, sc, sr);
-        scales[2 * (size_t)i] = sc;
-        scales[2 * (size_t)i + 1] = sr;
-    }
-}
-
-// FOLDED SOFTMAX BACKWARD, the per-pixel step between the dA launch and the dq | dk launches: the branch dots the dA kernels
-// left in ``ddot`` (B H W, 2) and the forward's factors ``scales`` (B H W, 2) give
-//     D = s_col * ddot_col + s_row * ddot_row  (= sum_s A dA),   fin[pixel][branch] = (gamma * s_branch, D)
-// and the workgroup's share of dgamma = sum_pixels D goes to partials[blockIdx.x] (summed in a fixed order by the dq | dk column
-// launch, GmapJob::red_*).  One thread per pixel.
-constexpr int FIN_BLOCK = 256;
-__global__ __launch_bounds__(FIN_BLOCK) void parts_backward_finalize_kernel(const float *scales, const float *ddot, const float *gamma,
-                                                                            float *fin, float *partials, int npix) {
-    __shared__ float red[FIN_BLOCK];
-    const int i = blockIdx.x * FIN_BLOCK + threadIdx.x;
-    const float g = gamma ? gamma[0] : 1.f;
-    float D = 0.f;
-    if (i < npix) {
-        const float sc = scales[2 * (size_t)i], sr = scales[2 * (size_t)i + 1];
-        D = sc * ddot[2 * (size_t)i] + sr * ddot[2 * (size_t)i + 1];
-        f32x4 o = f32x4{g * sc, D, g * sr, D};
-        __builtin_memcpy(fin + 4 * (size_t)i, &o, 16);
-    }
-    red[threadIdx.x] = D;
-    __syncthreads();
-    for (int s = FIN_BLOCK / 2; s >= 1; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && partials) partials[blockIdx.x] = red[0];
 }
 
 // fixed-order reduction of the per-workgroup partial sums -> out[0]  (single workgroup)

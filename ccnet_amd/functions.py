@@ -390,16 +390,16 @@ class CrissCrossPMFunction(torch.autograd.Function):
                                f"{_PM_DTYPES[qkv.dtype][1]}; got C = {C}, Cq = {cq}, H = {H}, W = {W}")
         lib = _lib.get_lib()
         y = torch.empty((B, H, W, C), device=x.device, dtype=qkv.dtype)
-        A, stats = _empty_parts(B, H, W, x.device)
+        A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
         _ws, ws_ptr, nbytes = _workspace(lib.ccnet_cca_pm_workspace_bytes(B, C, cq, H, W, 0), x.device)
         p = qkv.data_ptr()
         fwd = getattr(lib, "ccnet_cca_forward_pm_" + tag)
         with torch.cuda.device(x.device):
             lib.check(fwd(p, p + es * cq, p + 2 * es * cq, x.data_ptr(), gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
-                          stats.data_ptr(), B, C, cq, H, W, q_bs, q_ps, q_bs, q_ps, q_bs, q_ps, x_bs, x_ps, H * W * C, C,
+                          B, C, cq, H, W, q_bs, q_ps, q_bs, q_ps, q_bs, q_ps, x_bs, x_ps, H * W * C, C,
                           ws_ptr, nbytes, _stream()), "cca_forward_pm_" + tag)
         ctx.recompute = bool(recompute)
-        ctx.save_for_backward(*((qkv, gamma) if ctx.recompute else (qkv, A, stats, gamma)))
+        ctx.save_for_backward(*((qkv, gamma) if ctx.recompute else (qkv, A, gamma)))
         ctx.cq = cq
         return y
 
@@ -409,14 +409,14 @@ class CrissCrossPMFunction(torch.autograd.Function):
         cq = ctx.cq
         lib = _lib.get_lib()
         if ctx.recompute:
-            # the pair (P, stats) rebuilt by the forward's own affinity kernel: bit-identical to what a saving forward kept
+            # the attention rebuilt by the forward's own affinity + softmax kernels: bit-identical to what a saving forward kept
             qkv, gamma = ctx.saved_tensors
             B, H, W, ct = qkv.shape
             es, tag = _PM_DTYPES[qkv.dtype][0], _PM_DTYPES[qkv.dtype][3]
             p = qkv.data_ptr()
-            A, stats = _attention_pm(lib, p, p + es * cq, tag == "bf16", B, cq, H, W, qkv.stride(0), qkv.stride(2), qkv.device)
+            A = _attention_pm(lib, p, p + es * cq, tag == "bf16", B, cq, H, W, qkv.stride(0), qkv.stride(2), qkv.device)
         else:
-            qkv, A, stats, gamma = ctx.saved_tensors
+            qkv, A, gamma = ctx.saved_tensors
         dy, dy_bs, dy_ps = _pm_view("grad_output", dy, qkv.dtype)
         B, H, W, ct = qkv.shape
         C = ct - 2 * cq
@@ -429,7 +429,7 @@ class CrissCrossPMFunction(torch.autograd.Function):
         bs, ps = qkv.stride(0), qkv.stride(2)
         bwd = getattr(lib, "ccnet_cca_backward_pm_" + tag)
         with torch.cuda.device(qkv.device):
-            lib.check(bwd(dy.data_ptr(), p, p + es * cq, p + 2 * es * cq, A.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
+            lib.check(bwd(dy.data_ptr(), p, p + es * cq, p + 2 * es * cq, A.data_ptr(), gamma.data_ptr(),
                           g, g + es * cq, g + 2 * es * cq, dgamma.data_ptr(), scratch.data_ptr(), B, C, cq, H, W,
                           dy_bs, dy_ps, bs, ps, bs, ps, bs, ps, H * W * ct, ct, H * W * ct, ct, H * W * ct, ct,
                           ws_ptr, nbytes, _stream()), "cca_backward_pm_" + tag)
@@ -512,28 +512,13 @@ class CrissCrossModuleFunction(torch.autograd.Function):
 PLANES_HL, PLANES_HLH, PLANES_HHL = 2, 3, 4          # include/ccnet_cca.h CCNET_PLANES_*
 
 
-def _empty_parts(B, H, W, device):
-    """what a pixel-major / split-plane forward saves instead of the attention tensor: P (B,H,W,H+W) un-normalised
-    exponentials + stats (B,H,W,2) = the per-pixel factors (s_col, s_row) -- the two-stage softmax of include/ccnet_cca.h"""
-    return (torch.empty((B, H, W, H + W), device=device, dtype=torch.float32),
-            torch.empty((B, H, W, 2), device=device, dtype=torch.float32))
-
-
-def attention_from_parts(P: torch.Tensor, stats: torch.Tensor) -> torch.Tensor:
-    """The attention tensor of functions.py:40 from the pair the fast routes keep: A[pixel][slot] = P[pixel][slot] * s_col(pixel)
-    for the H column slots, * s_row(pixel) for the W row slots (include/ccnet_cca.h, "two-stage softmax")."""
-    H = P.shape[1]
-    return torch.cat([P[..., :H] * stats[..., 0:1], P[..., H:] * stats[..., 1:2]], dim=-1)
-
-
 def _attention_pm(lib, qptr, kptr, bf16, B, cq, H, W, bs, ps, device):
-    """(P, stats) rebuilt from q, k (recompute instead of save): ccnet_cca_attention_pm + its small workspace"""
-    A, stats = _empty_parts(B, H, W, device)
+    """A rebuilt from pixel-major q, k views (recompute instead of save): ccnet_cca_attention_pm"""
+    A = torch.empty((B, H, W, H + W), device=device, dtype=torch.float32)
     with torch.cuda.device(device):
-        _ws, wsp, wsn = _workspace(lib.ccnet_cca_workspace_bytes(_lib.CCNET_WS_ATTENTION_PM, B, 0, 0, H, W), device)
-        lib.check(lib.ccnet_cca_attention_pm(qptr, kptr, A.data_ptr(), stats.data_ptr(), int(bf16), B, cq, H, W, bs, ps, bs, ps,
-                                             wsp, wsn, _stream()), "cca_attention_pm")
-    return A, stats
+        lib.check(lib.ccnet_cca_attention_pm(qptr, kptr, A.data_ptr(), int(bf16), B, cq, H, W, bs, ps, bs, ps, _stream()),
+                  "cca_attention_pm")
+    return A
 
 
 def split_planes(t: torch.Tensor, c0: int, C: int, layout: int = PLANES_HL, dtype=torch.int16, bias=None) -> torch.Tensor:
@@ -621,9 +606,9 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
     producers (one pass over x, one over dqkv); fp32 accumulation, relative error ~1e-5 (the lo x lo term is dropped).
 
     Kept for the backward: the q | k slice (a copy: the packed projection, four fifths of it the value slice nobody reads
-    again, is released), v as planes, x (or, with ``split_gemm``, its three planes instead), and the attention as the parts of
-    the two-stage softmax (P, stats) -- or, with ``recompute``, nothing of the attention: the backward rebuilds the pair from
-    q | k with the forward's own kernel (bit-identical, one affinity launch)."""
+    again, is released), v as planes, x (or, with ``split_gemm``, its three planes instead), and the attention tensor -- or,
+    with ``recompute``, nothing of the attention: the backward rebuilds it from q | k with the forward's own kernels
+    (bit-identical, one affinity + softmax launch pair)."""
 
     @staticmethod
     def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma, split_gemm=False, recompute=False, cache=None):
@@ -644,14 +629,14 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
             v_bias = None
         lib = _lib.get_lib()
         y = torch.empty_like(x)
-        A, stats = _empty_parts(B, H, W, x.device)
+        A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
         vpl = torch.empty((B, H, W, 2, C), device=x.device, dtype=torch.int16)
         p, bs, ps = qkv.data_ptr(), hw * ct, ct
         with torch.cuda.device(x.device):
             _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0), x.device)
             lib.check(lib.ccnet_cca_forward_planes_f32(p, p + 4 * cq, p + 8 * cq, None if v_bias is None else v_bias.data_ptr(),
                                                        vpl.data_ptr(), x.data_ptr(), gamma.data_ptr(), y.data_ptr(),
-                                                       A.data_ptr(), stats.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps, bs, ps,
+                                                       A.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps, bs, ps,
                                                        hw * 2 * C, 2 * C, wsp, wsn, _stream()), "cca_forward_planes")
         if not any(ctx.needs_input_grad):
             return y
@@ -661,7 +646,7 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
         ctx.cache = cache
         keep = [x3 if split_gemm else x, qk, vpl, gamma, wq, bq, wk, bk, wv, bv]
         if not ctx.recompute:
-            keep += [A, stats]
+            keep += [A]
         ctx.save_for_backward(*keep)
         ctx.cq, ctx.geom = cq, (B, C, H, W)
         return y
@@ -678,16 +663,16 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
         pc = (ctx.cache if ctx.cache is not None else _ProjectionCache()).get(wq, bq, wk, bk, wv, bv, ctx.split_gemm)
         p, bs, ps = qk.data_ptr(), hw * 2 * cq, 2 * cq
         if ctx.recompute:
-            A, stats = _attention_pm(lib, p, p + 4 * cq, False, B, cq, H, W, bs, ps, dy.device)
+            A = _attention_pm(lib, p, p + 4 * cq, False, B, cq, H, W, bs, ps, dy.device)
         else:
-            A, stats = ctx.saved_tensors[10:12]
+            A = ctx.saved_tensors[10]
         dqkv = torch.empty((B, hw, ct), device=dy.device, dtype=torch.float32)
         dgamma = torch.empty_like(gamma)
         scratch = torch.empty_like(A)
         g, gbs = dqkv.data_ptr(), hw * ct
         with torch.cuda.device(dy.device):
             _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 1), dy.device)
-            lib.check(lib.ccnet_cca_backward_planes_f32(dy.data_ptr(), p, p + 4 * cq, vpl.data_ptr(), A.data_ptr(), stats.data_ptr(),
+            lib.check(lib.ccnet_cca_backward_planes_f32(dy.data_ptr(), p, p + 4 * cq, vpl.data_ptr(), A.data_ptr(),
                                                         gamma.data_ptr(), g, g + 4 * cq, g + 8 * cq, dgamma.data_ptr(),
                                                         scratch.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps, hw * 2 * C, 2 * C,
                                                         gbs, ct, gbs, ct, gbs, ct, wsp, wsn, _stream()), "cca_backward_planes")
@@ -741,8 +726,8 @@ class CrissCrossAttention(nn.Module):
     #: activation memory (networks/ccnet.py:118-119 applies the module R times): when True the
     #: (B,H,W,H+W) attention tensor is NOT kept for backward -- it is recomputed from q, k (one affinity + softmax
     #: launch pair, ~8 % of a fwd+bwd) -- so an application holds q, k, v only.  Every fp32 / bf16 node honours it (round 4: the
-    #: split-plane and pixel-major nodes rebuild the two-stage pair (P, stats) with the forward's own affinity kernel -- one
-    #: launch, bit-identical gradients).  Under torch.no_grad() / eval nothing is kept either way.
+    #: split-plane and pixel-major nodes rebuild A with the forward's own affinity + softmax kernels: bit-identical gradients).
+    #: Under torch.no_grad() / eval nothing is kept either way.
     recompute_attention = False
 
     #: fp32 NCHW inputs (no autocast; columns <= 132, rows <= 528 positions -- see ``planes_cover``): the SPLIT-PLANE node

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CCNET_CCA_VERSION 200          /* 0.2.0: two-stage softmax (stats), fp32 v in the split-plane forward, option ABI */
+#define CCNET_CCA_VERSION 200          /* 0.2.0: fp32 v into the split-plane forward, ccnet_cca_attention_pm, option ABI with out-parameters */
 
 #define CCNET_E_BADSHAPE   (-1)        /* non-positive dimension, or a size the kernels cannot index */
 #define CCNET_E_NULLPTR    (-2)        /* a required pointer is NULL */
@@ -97,7 +97,6 @@ const char *ccnet_cca_last_error_string(void);
 #define CCNET_WS_PM_BACKWARD      4    /* ccnet_cca_backward_pm_{bf16,f32} */
 #define CCNET_WS_PLANES_FORWARD   5    /* ccnet_cca_forward_planes_f32 */
 #define CCNET_WS_PLANES_BACKWARD  6    /* ccnet_cca_backward_planes_f32 */
-#define CCNET_WS_ATTENTION_PM     7    /* ccnet_cca_attention_pm (C, Cq ignored) */
 size_t      ccnet_cca_workspace_bytes(int entry, int B, int C, int Cq, int H, int W);
 
 /* Affinity: replaces functions.py:30-34 (layout shuffles), :38 (bmm + INF), :39 (bmm), :40 (cat
@@ -187,27 +186,17 @@ int ccnet_cca_backward_strided_f32(const float *dy, const float *q, const float 
  * as one  x^T W^T  GEMM: q, k, v are then channel slices of ONE (B, H*W, 2*Cq + C) projection and no copy is made.
  * The attention tensor A (B, H, W, H+W), the scratch tensor, gamma, dgamma and every accumulation are fp32; products
  * of the bf16 features are exact on the matrix pipe; outputs are rounded to nearest even once, on store.
- * TWO-STAGE SOFTMAX (version 200; pixel-major and split-plane entry points): the softmax of functions.py:40 is never a
- * launch of its own.  The affinity kernel finishes each branch of a pixel where it is computed (a column strip, a row strip):
- * ``A`` receives the UN-NORMALISED exponentials  P[pixel][slot] = exp(e - m_branch(pixel))  and a workspace the branch
- * statistics (m, z = sum of P); the first consumer (the column pass of the aggregation) turns them into the per-pixel factors
- *     s_branch = exp(m_branch - m) / (z_col exp(m_col - m) + z_row exp(m_row - m)),   m = max(m_col, m_row)
- * which land in ``stats`` (B, H*W, 2) fp32 = (s_col, s_row).  The attention of the reference is
- *     A_ref[pixel][slot] = P[pixel][slot] * s_branch(pixel)          (``ccnet_amd.functions.attention_from_parts`` on the host);
- * every consumer applies the factor on its way (non-transposed passes in their epilogue, transposed ones while they build
- * their fragments); the masked column self slot holds exactly 0.  The pair (A, stats) is what the forward saves for the
- * backward.  Maps with rows beyond 132 positions keep the classic form: A = the attention, stats = (1, 1).
  * Constraints: max(H, W) <= 132, C % 8 == 0, Cq % 8 == 0, every bs / ps a multiple of 8, pointers 16-byte aligned.
  * y = gamma * (column + row aggregation) + x       (functions.py:46-49)
- * ``workspace``: ccnet_cca_workspace_bytes(CCNET_WS_PM_FORWARD / _BACKWARD, ...) bytes (forward: fp32 column partials + the
- * raw branch statistics; backward: + softmax partials; bf16 and fp32 views alike). */
+ * ``workspace``: ccnet_cca_workspace_bytes(CCNET_WS_PM_FORWARD / _BACKWARD, ...) bytes (fp32 column partials; + softmax
+ * partials; bf16 and fp32 views alike). */
 int ccnet_cca_forward_pm_bf16(const uint16_t *q, const uint16_t *k, const uint16_t *v, const uint16_t *x,
-                              const float *gamma, uint16_t *y, float *A, float *stats, int B, int C, int Cq, int H, int W,
+                              const float *gamma, uint16_t *y, float *A, int B, int C, int Cq, int H, int W,
                               long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long x_bs, int x_ps,
                               long y_bs, int y_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
 /* ``scratch``: B*H*W*(H+W) floats (dA, then dE in place). */
 int ccnet_cca_backward_pm_bf16(const uint16_t *dy, const uint16_t *q, const uint16_t *k, const uint16_t *v,
-                               const float *A, const float *stats, const float *gamma, uint16_t *dq, uint16_t *dk, uint16_t *dv,
+                               const float *A, const float *gamma, uint16_t *dq, uint16_t *dk, uint16_t *dv,
                                float *dgamma, float *scratch, int B, int C, int Cq, int H, int W,
                                long dy_bs, int dy_ps, long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
                                long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
@@ -219,11 +208,11 @@ int ccnet_cca_backward_pm_bf16(const uint16_t *dy, const uint16_t *q, const uint
  * same arguments, semantics and workspace as the bf16 pair.  (What the module runs for channels_last fp32 inputs; NCHW fp32
  * inputs take the split-plane path below.) */
 int ccnet_cca_forward_pm_f32(const float *q, const float *k, const float *v, const float *x,
-                             const float *gamma, float *y, float *A, float *stats, int B, int C, int Cq, int H, int W,
+                             const float *gamma, float *y, float *A, int B, int C, int Cq, int H, int W,
                              long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long x_bs, int x_ps,
                              long y_bs, int y_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
 int ccnet_cca_backward_pm_f32(const float *dy, const float *q, const float *k, const float *v,
-                              const float *A, const float *stats, const float *gamma, float *dq, float *dk, float *dv,
+                              const float *A, const float *gamma, float *dq, float *dk, float *dv,
                               float *dgamma, float *scratch, int B, int C, int Cq, int H, int W,
                               long dy_bs, int dy_ps, long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps,
                               long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
@@ -257,11 +246,11 @@ int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W);
  *   per workgroup; every row pass (aggregation, dv, dq | dk) runs once per block of the CONTRACTED positions, updating its fp32
  *   partial in place, the last one writes the output.
  * ccnet_cca_forward_planes_f32 / _backward_planes_f32: functions.py:38-49 and its autograd with q, k fp32 pixel-major
- *   views (exact fp32 energies), the module's x / y / dy NCHW fp32, dq | dk | dv fp32 pixel-major views, A (two-stage: see
- *   above) / stats / scratch fp32.  The forward takes v the way its producer leaves it -- ``v``: the fp32 pixel-major value
+ *   views (exact fp32 energies), the module's x / y / dy NCHW fp32, dq | dk | dv fp32 pixel-major views, A / scratch
+ *   (B,H,W,H+W) fp32 as everywhere.  The forward takes v the way its producer leaves it -- ``v``: the fp32 pixel-major value
  *   slice of the projection (functions.py:35), ``v_bias``: C floats added while splitting, or NULL -- and WRITES ``v_planes``
- *   (the split runs on the library's side stream next to the affinity launch and joins before the aggregation), which the
- *   caller keeps for the backward; with ``v`` == NULL, ``v_planes`` is an input that already holds the planes.
+ *   (its first launch), which the caller keeps for the backward; with ``v`` == NULL, ``v_planes`` is an input that already
+ *   holds the planes.
  *   Workspace: CCNET_WS_PLANES_FORWARD / _BACKWARD (backward: holds the fp32 column partial and dy as planes).
  *   Arithmetic: energies exact fp32; every other contraction split-bf16 x3 with fp32 accumulation (the lo x lo term,
  *   2^-18 relative, is dropped) -- the CCNET_PRECISION_* knob does not apply here. */
@@ -273,18 +262,18 @@ int ccnet_cca_split_planes_f32(const float *src, uint16_t *dst, int B, int C, in
 int ccnet_cca_nchw_to_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, long dst_bs,
                                  int dst_ps, int layout, ccnet_stream_t stream);
 int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v, const float *v_bias, uint16_t *v_planes,
-                                 const float *x, const float *gamma, float *y, float *A, float *stats,
+                                 const float *x, const float *gamma, float *y, float *A,
                                  int B, int C, int Cq, int H, int W,
                                  long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long vp_bs, int vp_ps,
                                  void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
-/* (A, stats) of the two-stage softmax alone, from pixel-major q, k views (``bf16`` != 0: bf16 views as in the *_pm_bf16 entry
- * points, else fp32 views as in the *_pm_f32 / *_planes_f32 ones): exactly what those forwards leave in ``A`` and ``stats``.  The
- * host calls it in the backward pass when it did NOT keep the pair between forward and backward (recompute instead of save:
- * SURVEY.md 8(f) rank 4, networks/ccnet.py:118-119 -- R applications of the module hold R attention tensors). */
-int ccnet_cca_attention_pm(const void *q, const void *k, float *A, float *stats, int bf16, int B, int Cq, int H, int W,
-                           long q_bs, int q_ps, long k_bs, int k_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
+/* The attention tensor alone from pixel-major q, k views (``bf16`` != 0: bf16 views as in the *_pm_bf16 entry points, else fp32
+ * views as in the *_pm_f32 / *_planes_f32 ones): exactly what those forwards leave in ``A``.  The host calls it in the backward
+ * pass when it did NOT keep A between forward and backward (recompute instead of save: SURVEY.md 8(f) rank 4,
+ * networks/ccnet.py:118-119 -- R applications of the module hold R attention tensors). */
+int ccnet_cca_attention_pm(const void *q, const void *k, float *A, int bf16, int B, int Cq, int H, int W,
+                           long q_bs, int q_ps, long k_bs, int k_ps, ccnet_stream_t stream);
 int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *k, const uint16_t *v_planes, const float *A,
-                                  const float *stats, const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
+                                  const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
                                   int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps,
                                   long v_bs, int v_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
                                   void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
@@ -306,10 +295,9 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
  *                    stream (forked from ``stream`` by an event, joined before the call returns: the caller's stream sees
  *                    one ordered operation and a stream capture stays one graph): 2 next to dA, softmax-backward and
  *                    dq | dk; 1 next to softmax-backward and dq | dk only; 0 everything on ``stream``; -1 (default) what
- *                    measured best per family (2 on split planes, 1 on the bf16 / fp32 pixel-major entries).  Any value but 0
- *                    also lets the split-plane FORWARD run its v -> planes pass on the side stream next to the affinity launch.
- *   "planes_xcd"   1: the NCHW row pass of the split-plane forward decodes its strips XCD-aware (consecutive rows of an image
- *                    on one XCD, whose L2 then merges the boundary lines neighbouring NCHW rows share); 0 (default): linear. */
+ *                    measured best per family (2 on split planes, 1 on the bf16 / fp32 pixel-major entries).
+ *   "planes_xcd"   1 (default): the NCHW row pass of the split-plane forward decodes its strips XCD-aware (consecutive rows of an
+ *                    image on one XCD, whose L2 then merges the boundary lines neighbouring NCHW rows share); 0: linear. */
 int ccnet_cca_set_option(const char *name, int value, int *previous);
 int ccnet_cca_get_option(const char *name, int *value);
 

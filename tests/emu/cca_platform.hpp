@@ -56,7 +56,6 @@ __device__ inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     return d;
 }
 
-__device__ inline float fast_expf(float x) { return expf(x); }
 __device__ inline void mfma_f32_result_fence() {}
 __device__ inline void wait_vmem_all() {}
 __device__ inline int uniform(int v) { return v; }
@@ -123,10 +122,6 @@ __device__ inline f32x4 fbuf_load_x4(const FBuf &b, int voff_bytes, int soff_byt
     f32x4 v;
     for (int e = 0; e < 4; ++e) v[e] = fbuf_load(b, voff_bytes + 4 * e, soff_bytes);
     return v;
-}
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ inline f32x2 fbuf_load_x2(const FBuf &b, int voff_bytes, int soff_bytes) {
-    return f32x2{fbuf_load(b, voff_bytes, soff_bytes), fbuf_load(b, voff_bytes + 4, soff_bytes)};
 }
 __device__ inline void fbuf_store(const FBuf &b, float v, int voff_bytes, int soff_bytes) {
     const uint32_t o = (uint32_t)voff_bytes + (uint32_t)soff_bytes;

@@ -42,38 +42,6 @@ def _p(a):
     return None if a is None else a.ctypes.data
 
 
-def attention_from_parts(P, stats):
-    """The attention of functions.py:40 out of the two-stage softmax's pair (include/ccnet_cca.h, version 200): P (B, H, W, H+W)
-    un-normalised exponentials, stats (B, H, W, 2) = the per-pixel factors (s_col, s_row)."""
-    H = P.shape[1]
-    A = np.empty_like(P)
-    A[..., :H] = P[..., :H] * stats[..., 0:1]
-    A[..., H:] = P[..., H:] * stats[..., 1:2]
-    return A
-
-
-class PartsArray(np.ndarray):
-    """What a pixel-major / split-plane forward saves for its backward -- (P, stats) -- presented to the tests as the attention
-    tensor it stands for (the array's values are ``attention_from_parts(P, stats)``)."""
-
-    def __new__(cls, P, stats):
-        obj = np.asarray(attention_from_parts(P, stats)).view(cls)
-        obj.P, obj.stats = P, stats
-        return obj
-
-    def __array_finalize__(self, obj):
-        if obj is not None:
-            self.P, self.stats = getattr(obj, "P", None), getattr(obj, "stats", None)
-
-
-def _parts_of(A):
-    """(P, stats) to hand to a backward: the saved parts, or a plain attention array under neutral statistics"""
-    if isinstance(A, PartsArray) and A.P is not None:
-        return A.P, A.stats
-    A = np.ascontiguousarray(A, np.float32)
-    return A, np.ones(A.shape[:3] + (2,), np.float32)
-
-
 class EmuOps:
     """numpy front-end of the emulated C ABI; every method mirrors one entry point."""
 
@@ -212,17 +180,16 @@ class EmuOps:
         C = ct - 2 * cq
         y = np.zeros((B, H, W, C), qkv.dtype)
         A = np.full((B, H, W, H + W), np.nan, np.float32)
-        stats = np.full((B, H, W, 2), np.nan, np.float32)
         f32 = qkv.dtype == np.float32
         es = 4 if f32 else 2
         fwd = self.lib.ccnet_cca_forward_pm_f32 if f32 else self.lib.ccnet_cca_forward_pm_bf16
         nbytes = self.lib.ccnet_cca_pm_workspace_bytes(B, C, cq, H, W, 0)
         ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
         base, bs = qkv.ctypes.data, H * W * ct
-        self.lib.check(fwd(base, base + es * cq, base + 2 * es * cq, _p(x), _p(gamma), _p(y), _p(A), _p(stats),
+        self.lib.check(fwd(base, base + es * cq, base + 2 * es * cq, _p(x), _p(gamma), _p(y), _p(A),
                                                           B, C, cq, H, W, bs, ct, bs, ct, bs, ct,
                                                           H * W * x.shape[3], x.shape[3], H * W * C, C, _p(ws), nbytes, None))
-        return y, PartsArray(A, stats)
+        return y, A
 
     def cca_backward_pm_bf16(self, dy, qkv, A, gamma, cq):
         """dy: uint16 (B, H, W, C); returns (dqkv bits packed like qkv, dgamma)."""
@@ -230,7 +197,6 @@ class EmuOps:
         C = ct - 2 * cq
         dqkv = np.zeros_like(qkv)
         dgamma = np.full(1, np.nan, np.float32)
-        A, stats = _parts_of(A)
         scratch = np.full_like(A, np.nan)
         nbytes = self.lib.ccnet_cca_pm_workspace_bytes(B, C, cq, H, W, 1)
         ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
@@ -238,7 +204,7 @@ class EmuOps:
         f32 = qkv.dtype == np.float32
         es = 4 if f32 else 2
         bwd = self.lib.ccnet_cca_backward_pm_f32 if f32 else self.lib.ccnet_cca_backward_pm_bf16
-        self.lib.check(bwd(_p(dy), base, base + es * cq, base + 2 * es * cq, _p(A), _p(stats), _p(gamma),
+        self.lib.check(bwd(_p(dy), base, base + es * cq, base + 2 * es * cq, _p(A), _p(gamma),
                                                            g, g + es * cq, g + 2 * es * cq, _p(dgamma), _p(scratch),
                                                            B, C, cq, H, W, H * W * C, C, bs, ct, bs, ct, bs, ct,
                                                            bs, ct, bs, ct, bs, ct, _p(ws), nbytes, None))
@@ -269,29 +235,27 @@ class EmuOps:
         C = v_planes.shape[4]
         y = np.full((B, C, H, W), np.nan, np.float32)
         A = np.full((B, H, W, H + W), np.nan, np.float32)
-        stats = np.full((B, H, W, 2), np.nan, np.float32)
         nbytes = self.lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0)
         ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
         base, bs = qkv.ctypes.data, H * W * ct
         self.lib.check(self.lib.ccnet_cca_forward_planes_f32(base, base + 4 * cq, base + 8 * cq if v_from_qkv else None, _p(v_bias),
-                                                             _p(v_planes), _p(x), _p(gamma), _p(y), _p(A), _p(stats),
+                                                             _p(v_planes), _p(x), _p(gamma), _p(y), _p(A),
                                                              B, C, cq, H, W, bs, ct, bs, ct, bs, ct, H * W * 2 * C, 2 * C,
                                                              _p(ws), nbytes, None))
-        return y, PartsArray(A, stats)
+        return y, A
 
     def cca_backward_planes(self, dy, qkv, v_planes, A, gamma, cq):
         B, H, W, ct = qkv.shape
         C = v_planes.shape[4]
         dqkv = np.full((B, H, W, 2 * cq + C), np.nan, np.float32)
         dgamma = np.full(1, np.nan, np.float32)
-        A, stats = _parts_of(A)
         scratch = np.full_like(A, np.nan)
         nbytes = self.lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 1)
         ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
         base, g, bs = qkv.ctypes.data, dqkv.ctypes.data, H * W * ct
         dct = 2 * cq + C
         dbs = H * W * dct
-        self.lib.check(self.lib.ccnet_cca_backward_planes_f32(_p(dy), base, base + 4 * cq, _p(v_planes), _p(A), _p(stats), _p(gamma),
+        self.lib.check(self.lib.ccnet_cca_backward_planes_f32(_p(dy), base, base + 4 * cq, _p(v_planes), _p(A), _p(gamma),
                                                               g, g + 4 * cq, g + 8 * cq, _p(dgamma), _p(scratch),
                                                               B, C, cq, H, W, bs, ct, bs, ct, H * W * 2 * C, 2 * C,
                                                               dbs, dct, dbs, dct, dbs, dct, _p(ws), nbytes, None))

@@ -540,7 +540,7 @@ def test_split_plane_core_logit_scale_sweep_at_the_headline_geometry(lib, dev):
         got = {"y": wl.y, "dq": nchw(wl.dqkv[..., :cq]), "dk": nchw(wl.dqkv[..., cq:2 * cq]), "dv": nchw(wl.dqkv[..., 2 * cq:])}
         ref = {"y": yo, "dq": go["dq"], "dk": go["dk"], "dv": go["dv"]}
         rows[s] = {n: (err(got[n], ref[n]), err(got[n], ref[n]) / float(ref[n].abs().max())) for n in got}
-        assert err(wl.attention(), Ao) < TIGHT
+        assert err(wl.A, Ao) < TIGHT
         del wl
     for s, r in rows.items():
         print(f"logit-scale sweep: q, k x {s}: max-abs (relative to |ref|max)", {n: f"{a:.1e} ({b:.1e})" for n, (a, b) in r.items()})
@@ -679,7 +679,7 @@ def test_split_plane_core_at_the_headline_shape_against_the_oracle(lib, dev):
         sl = slice(i, i + 1)
         yo, Ao = O.cca_core_forward(q[sl], k[sl], v[sl], wl.x[sl].cpu(), torch.tensor([0.5]))
         go = O.cca_core_backward(wl.dy[sl].cpu(), q[sl], k[sl], v[sl], Ao, torch.tensor([0.5]))
-        e = {"y": err(wl.y[sl], yo), "A": err(wl.attention()[sl], Ao), "dq": err(nchw(wl.dqkv[sl][..., :cq]), go["dq"]),
+        e = {"y": err(wl.y[sl], yo), "A": err(wl.A[sl], Ao), "dq": err(nchw(wl.dqkv[sl][..., :cq]), go["dq"]),
              "dk": err(nchw(wl.dqkv[sl][..., cq:2 * cq]), go["dk"]), "dv": err(nchw(wl.dqkv[sl][..., 2 * cq:]), go["dv"])}
         for n, val in e.items():
             worst[n] = max(worst.get(n, 0.0), val)
@@ -888,8 +888,8 @@ def test_recompute_attention_matches_saved_attention_and_keeps_less(lib, dev):
     """SURVEY 8(f) rank 4 / networks/ccnet.py:118-119: with ``recompute_attention`` the module keeps q, k, v only and
     rebuilds the attention in backward -- same kernels, so every gradient is bit-identical; the autograd graph holds no
     (B,H,W,H+W) tensor; under no_grad nothing is kept at all.  EVERY route honours the flag: the
-    split-plane node and the pixel-major bf16 / fp32 nodes rebuild the two-stage pair (P, stats) with the forward's own
-    affinity kernel, the NCHW strip nodes their attention tensor."""
+    split-plane node and the pixel-major bf16 / fp32 nodes rebuild A with the forward's own affinity + softmax kernels
+    (ccnet_cca_attention_pm), the NCHW strip nodes with theirs."""
     from ccnet_amd import CrissCrossAttention
     lib.ccnet_cca_set_impl(0)
     torch.manual_seed(4)

@@ -38,8 +38,7 @@ def test_device_library_exports_every_declared_symbol(device_lib_path):
     assert lib.ccnet_ca_forward_f32(None, None, None, 1, 1, 2, 2, 0, None) == -2
     assert lib.ccnet_ca_forward_f32(None, None, None, 0, 1, 2, 2, 0, None) == -1
     assert "ccnet_cca" in lib.last_error()
-    npix = 8 * 97 * 97          # dgamma partials (256-aligned) | the folded softmax-backward's branch dots and (g, D) pairs
-    assert lib.ccnet_ca_softmax_backward_workspace_bytes(8, 97, 97) == (((npix + 3) // 4) * 4 + 255) // 256 * 256 + npix * 6 * 4
+    assert lib.ccnet_ca_softmax_backward_workspace_bytes(8, 97, 97) == ((8 * 97 * 97 + 3) // 4) * 4
 
 
 def test_device_library_contains_gfx950_code_object(device_lib_path):
@@ -236,7 +235,7 @@ def test_options_and_workspace_sizes_are_host_logic_behind_two_entry_points(devi
     lib = _lib.get_lib()
     assert len(_lib.declared_symbols()) <= 30
     for name, default in (("impl", _lib.CCNET_IMPL_AUTO), ("precision", _lib.CCNET_PRECISION_DEFAULT), ("branch_mask", 3),
-                          ("planes_ring", 2), ("planes_stream", 1), ("planes_overlap", -1), ("planes_xcd", 1), ("planes_split", 1)):
+                          ("planes_ring", 2), ("planes_stream", 1), ("planes_overlap", -1), ("planes_xcd", 1)):
         assert lib.get_option(name) == default, name
     assert lib.set_option("planes_overlap", 0) == -1 and lib.get_option("planes_overlap") == 0
     assert lib.set_option("planes_overlap", -1) == 0
@@ -256,14 +255,12 @@ def test_options_and_workspace_sizes_are_host_logic_behind_two_entry_points(devi
     px = B * H * W * 4
     sm = lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
     assert sm > 0 and lib.ccnet_cca_workspace_bytes(_lib.CCNET_WS_SOFTMAX_BACKWARD, B, 0, 0, H, W) == sm
-    fwd = (px * C + 255) // 256 * 256 + px * 4                                                  # the column partial | raw branch statistics
-    assert lib.ccnet_cca_pm_workspace_bytes(B, C, Cq, H, W, 0) == fwd
+    assert lib.ccnet_cca_pm_workspace_bytes(B, C, Cq, H, W, 0) == px * C                       # the column partial
     pmb = lib.ccnet_cca_pm_workspace_bytes(B, C, Cq, H, W, 1)
     assert pmb >= sm + px * C + px * 2 * Cq                                                     # + softmax slabs + the dq | dk partials
     plb = lib.ccnet_cca_planes_workspace_bytes(B, C, Cq, H, W, 1)
     assert plb >= pmb + B * H * W * 2 * C * 2                                                   # + dy as planes
-    assert lib.ccnet_cca_planes_workspace_bytes(B, C, Cq, H, W, 0) == (fwd + 255) // 256 * 256
-    assert lib.ccnet_cca_workspace_bytes(_lib.CCNET_WS_ATTENTION_PM, B, 0, 0, H, W) == px * 4
+    assert lib.ccnet_cca_planes_workspace_bytes(B, C, Cq, H, W, 0) == px * C
     assert lib.ccnet_cca_workspace_bytes(99, B, C, Cq, H, W) == 0 and lib.ccnet_cca_workspace_bytes(_lib.CCNET_WS_PM_FORWARD, 0, C, Cq, H, W) == 0
 
 

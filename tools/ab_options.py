@@ -18,13 +18,11 @@ DEFAULT_SETS = {
     "default": {},
     "no-xcd": {"planes_xcd": 0},
     "one-stream": {"planes_overlap": 0},
-    "split-main": {"planes_split": 0},
-    "split-after": {"planes_split": 2},
-    "split-after-capped": {"planes_split": 3},
+    "overlap-1": {"planes_overlap": 1},
 }
 lib = _lib.get_lib()
 dev = torch.device("cuda:0")
-BASE = {"planes_ring": 2, "planes_stream": 1, "planes_overlap": -1, "planes_xcd": 1, "planes_split": 1}
+BASE = {"planes_ring": 2, "planes_stream": 1, "planes_overlap": -1, "planes_xcd": 1}
 wl = bench.PlanesWorkload(lib, B, C, H, W, dev, 1234)
 ref = None
 for rnd in range(2):                       # two rounds: the order of the sets must not matter
