@@ -287,9 +287,10 @@ class PixelMajorBF16Workload:
 class PlanesWorkload:
     """The fp32 core on the SPLIT-PLANE path (include/ccnet_cca.h): the step's inputs are what the reference's op gets --
     q | k | v fp32 (pixel-major channel slices of the packed projection, functions.py:29-37), x / dy NCHW fp32 -- and EVERY pass
-    the op needs is inside the step (round 3 split v outside it): the forward entry point turns the fp32 value slice
-    into bf16 hi | lo planes itself (its first launch), the backward does the same for dy.  Outputs:
-    y NCHW, dq | dk | dv fp32 pixel-major, dgamma."""
+    the op needs is inside the step (round 3 split v into planes outside it).  Strips <= 100 -- the headline -- run the
+    PLANE-FREE form: v is never split into planes, its consumers read fp32 tiles and split per fragment; larger maps have the
+    forward entry point write the planes (its first launch).  dy is transposed out of NCHW into planes inside the backward.
+    Outputs: y NCHW, dq | dk | dv fp32 pixel-major, dgamma."""
 
     def __init__(self, lib, B, C, H, W, device, seed):
         self.lib, self.shape = lib, (B, C, H, W)
@@ -304,7 +305,9 @@ class PlanesWorkload:
         self.A = torch.empty(B, H, W, H + W, device=device)
         self.scratch = torch.empty_like(self.A)
         self.dgamma = torch.empty(1, device=device)
-        self.vpl = torch.empty(B, H, W, 2, C, dtype=torch.int16, device=device)     # written by the forward, read by the backward
+        # strips <= 100: the plane-free form (v is read as fp32 by every consumer); else the forward writes planes for the backward
+        self.direct = max(H, W) <= 100
+        self.vpl = None if self.direct else torch.empty(B, H, W, 2, C, dtype=torch.int16, device=device)
         self.fws_bytes = lib.ccnet_cca_planes_workspace_bytes(B, C, Cq, H, W, 0)
         self.ws_bytes = lib.ccnet_cca_planes_workspace_bytes(B, C, Cq, H, W, 1)
         self.ws = torch.empty(max(self.fws_bytes, self.ws_bytes) // 4 + 64, device=device)
@@ -316,18 +319,11 @@ class PlanesWorkload:
         self.forward()
         self.backward()
 
-    def split(self):
-        """the v -> planes pass alone (what the forward runs on its side stream), for ``producer_split_ms``"""
-        B, C, H, W = self.shape
-        L, cq, ct = self.lib, C // 8, self.ct
-        L.check(L.ccnet_cca_split_planes_f32(self.qkv.data_ptr() + 8 * cq, self.vpl.data_ptr(), B, C, H, W, H * W * ct, ct,
-                                             H * W * 2 * C, 2 * C, 2, None, self.stream()), "split_planes")
-
     def forward(self):
         B, C, H, W = self.shape
         L, cq, ct, p = self.lib, C // 8, self.ct, self.qkv.data_ptr()
         bs = H * W * ct
-        L.check(L.ccnet_cca_forward_planes_f32(p, p + 4 * cq, p + 8 * cq, None, self.vpl.data_ptr(), self.x.data_ptr(),
+        L.check(L.ccnet_cca_forward_planes_f32(p, p + 4 * cq, p + 8 * cq, None, None if self.direct else self.vpl.data_ptr(), self.x.data_ptr(),
                                                self.gamma.data_ptr(), self.y.data_ptr(), self.A.data_ptr(),
                                                B, C, cq, H, W, bs, ct, bs, ct, bs, ct, H * W * 2 * C, 2 * C,
                                                self.ws.data_ptr(), self.fws_bytes, self.stream()),
@@ -337,9 +333,10 @@ class PlanesWorkload:
         B, C, H, W = self.shape
         L, cq, ct, p, g = self.lib, C // 8, self.ct, self.qkv.data_ptr(), self.dqkv.data_ptr()
         bs = H * W * ct
-        L.check(L.ccnet_cca_backward_planes_f32(self.dy.data_ptr(), p, p + 4 * cq, self.vpl.data_ptr(), self.A.data_ptr(),
+        L.check(L.ccnet_cca_backward_planes_f32(self.dy.data_ptr(), p, p + 4 * cq, p + 8 * cq if self.direct else None,
+                                                None if self.direct else self.vpl.data_ptr(), self.A.data_ptr(),
                                                 self.gamma.data_ptr(), g, g + 4 * cq, g + 8 * cq,
-                                                self.dgamma.data_ptr(), self.scratch.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct,
+                                                self.dgamma.data_ptr(), self.scratch.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct, bs, ct,
                                                 H * W * 2 * C, 2 * C, bs, ct, bs, ct, bs, ct, self.ws.data_ptr(), self.ws_bytes,
                                                 self.stream()),
                 "cca_backward_planes")
@@ -502,13 +499,13 @@ def planes_launch_bytes(B, C, H, W):
     fc, fq, att = 4 * P * C, 4 * P * Cq, 4 * P * S
     # (label, algorithmic bytes, regex of the launch's kernel name as rocprofv3 spells it: the key of the PMC traffic summary --
     #  the launch profiler only knows the SOURCE spelling of the launch, template parameters by name)
-    return [
-        ("v fp32 -> planes", 2 * fc, r"pm_split_kernel"),
+    split = [("v fp32 -> planes", 2 * fc, r"pm_split_kernel")] if max(H, W) > 100 else []
+    return split + [
         ("energies q.k (both branches)", 2 * fq + att, r"gweight_kernel<\d+, true, float"),
         ("softmax", 2 * att, r"softmax_fwd_kernel"),
         ("aggregation, column pass (v, A/2 -> partial)", 2 * fc + att // 2, r"gmap3_kernel<\d+, false, false, false"),
         ("aggregation, row pass (v, A/2, partial, x -> y NCHW)", 4 * fc + att // 2,
-         r"gmap_kernel<\d+, true, false, true, cca::bf16p_t, float, true"),
+         r"gmap_kernel<\d+, true, false, true, (cca::bf16p_t|float), float, true"),
         ("dy NCHW -> planes", 2 * fc, r"nchw_to_planes_kernel"),
         ("dA = dy.v (both branches)", 2 * fc + att, r"gweight_stream_kernel|gweight_kernel<\d+, false, cca::bf16p_t"),
         ("dv, column pass (dy, A/2 -> partial)", 2 * fc + att // 2, r"gmap3_kernel<\d+, false, true, false"),
@@ -989,7 +986,7 @@ def main(argv=None, workload_factory=None):
     value = aggregate_value(nbytes, args.steps, world, secs)
     ms = secs / args.steps * 1e3
     impl = "injected" if lib is None else ("pixel-major bf16 mfma" if bf16 else
-                                           "split-plane mfma (v, dy split into bf16 hi|lo planes INSIDE the step)" if isinstance(wl, PlanesWorkload) else
+                                           "split-bf16 x3 mfma: v read as fp32 tiles (no split pass), dy transposed into bf16 hi|lo planes inside the step" if isinstance(wl, PlanesWorkload) else
                                            "mfma-strip" if lib.ccnet_cca_shape_uses_mfma(B, C, H, W) else "direct")
     out = {
         "metric": metric_label(C, H, W),
@@ -1043,7 +1040,6 @@ def main(argv=None, workload_factory=None):
         out["gpu_state_under_load"] = gpu_state_under_load(step, local)
         if isinstance(wl, PlanesWorkload):
             out["roofline"] = planes_roofline(lib, wl, ms, out.get("launch_ms", []))
-            out["producer_split_ms"] = round(time_region(wl.split, 20), 4)
             out["strips_family"] = strips_family_summary(lib, B, C, H, W, device)
         else:
             roof, rows = roofline_object(wl, ms)

@@ -1136,6 +1136,23 @@ int launch_gmap_planes(const float *T, const bf16p_t *F, const float *resid, con
         return launch_gmap_planes_p<100, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
     return launch_gmap_planes_p<132, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
 }
+// The forward aggregation on fp32 pixel-major v AS IT IS (strips <= 100): F32T tiles, hi | lo split per fragment -- no planes
+// tensor, no split pass.  Column strips -> fp32 partial (ring kernel, three workgroups per CU), row strips add it and the NCHW
+// residual and write NCHW y.
+int launch_gmap_direct_f32(const float *T, const float *v, const float *resid, const float *gamma, float *out, float *partial,
+                           int B, int C, int H, int W, long fbs, int fps, long rbs, long obs, ccnet_stream_t stream) {
+    const long pbs = (long)H * W * C;
+    const GmapPlan gc = gmap_plan(B * W, C, 3), gr = gmap_plan(B * H, C, 2);
+    CCA_LAUNCH((cca::gmap3_kernel<100, false, false, false, 2, 3, float>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS), stream, T, v,
+               (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0, pbs, C, gc.n_whole, gc.split);
+    if (int e = launch_status("gmap3_direct(column)")) return e;
+    cca::GmapJob<float, float> job{};
+    if (g_planes_xcd.load() && (B * H) % 8 == 0 && gr.n_whole % 8 == 0) job.xcd = B * H / 8;
+    CCA_LAUNCH((cca::gmap_kernel<100, true, false, true, float, float, true, false, 2>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS),
+               stream, T, v, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C, rbs, 0, obs, 0,
+               gr.n_whole, gr.split, job);
+    return launch_status("gmap_direct(row)");
+}
 // strips 101 .. 132 with fp32 q | k: the energies and dq | dk kernels of the pixel-major fp32 family at 132 positions (one
 // workgroup per CU for the latter: fp32 tiles)
 int gweight_energies_f32(const float *q, const float *k, float *A, int B, int Cq, int H, int W, long qbs, int qps, long kbs, int kps,
@@ -1249,24 +1266,28 @@ int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v,
                                  long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long vp_bs, int vp_ps,
                                  void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
     if (int e = require_both_branches("cca_forward_planes_f32")) return e;
-    if (!q || !k || !v_planes || !x || !gamma || !y || !A) return fail(CCNET_E_NULLPTR, "cca_forward_planes: null tensor");
+    if (!q || !k || (!v_planes && !v) || !x || !gamma || !y || !A) return fail(CCNET_E_NULLPTR, "cca_forward_planes: null tensor");
     if (int e = check_planes_problem("cca_forward_planes: columns <= 132, rows <= 528 (> 132: C/8 <= 64), C % 8 == 0, Cq % 4 == 0",
                                      B, C, Cq, H, W, true)) return e;
+    const bool direct = !v_planes;                 // v stays the fp32 tensor it is: no planes, no split pass
+    if (direct && ((H > W ? H : W) > 100 || v_bias))
+        return fail(CCNET_E_BADSHAPE, "cca_forward_planes: the plane-free form (v_planes == NULL) serves strips <= 100 without a bias");
     if (int e = check_pm_view<float>("cca_forward_planes: q view", q_bs, q_ps, Cq, H, W)) return e;
     if (int e = check_pm_view<float>("cca_forward_planes: k view", k_bs, k_ps, Cq, H, W)) return e;
     if (v) if (int e = check_pm_view<float>("cca_forward_planes: v view (fp32 pixel-major)", v_bs, v_ps, C, H, W)) return e;
-    if (int e = check_planes_view("cca_forward_planes: v planes view", vp_bs, vp_ps, C, H, W)) return e;
+    if (!direct) if (int e = check_planes_view("cca_forward_planes: v planes view", vp_bs, vp_ps, C, H, W)) return e;
     if ((double)C * H * W >= 536870912.0) return fail(CCNET_E_BADSHAPE, "cca_forward_planes: image exceeds 2^29 elements");
     if (!workspace || workspace_bytes < ws_planes_bytes(B, C, Cq, H, W, 0))
         return fail(CCNET_E_WORKSPACE, "cca_forward_planes: workspace missing or too small");
     // v (fp32, the value slice of the projection) -> planes, inside the entry point (every pass the op needs belongs to
     // the op).  On the caller's stream: running it on the side stream NEXT TO the affinity launch was measured and lost
     // (fwd 0.334 -> 0.346 ms, three launch orders / a capped grid: profiles/r04m_ab_two_stage_lds_staging.txt, "split-*" rows).
-    if (v)
+    if (v && !direct)
         if (int e = ccnet_cca_split_planes_f32(v, v_planes, B, C, H, W, v_bs, v_ps, vp_bs, vp_ps, CCNET_PLANES_HL, v_bias, stream)) return e;
     if (int e = gweight_energies_f32(q, k, A, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
     if (int e = softmax_forward(A, A, B, H, W, stream)) return e;
     const long img = (long)C * H * W;
+    if (direct) return launch_gmap_direct_f32(A, v, x, gamma, y, (float *)workspace, B, C, H, W, v_bs, v_ps, img, img, stream);
     return launch_gmap_planes<false, true>(A, (const bf16p_t *)v_planes, x, gamma, y, (float *)workspace, B, C, H, W, vp_bs, vp_ps,
                                            img, 0, img, 0, stream);
 }
@@ -1291,19 +1312,23 @@ int ccnet_cca_attention_pm(const void *q, const void *k, float *A, int bf16, int
     return softmax_forward(A, A, B, H, W, stream);
 }
 
-int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *k, const uint16_t *v_planes, const float *A,
-                                  const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
+int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *k, const float *v, const uint16_t *v_planes,
+                                  const float *A, const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
                                   int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps,
-                                  long v_bs, int v_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
+                                  long v_bs, int v_ps, long vp_bs, int vp_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
                                   void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
     if (int e = require_both_branches("cca_backward_planes_f32")) return e;
-    if (!dy || !q || !k || !v_planes || !A || !gamma || !dq || !dk || !dv || !dgamma || !scratch)
+    if (!dy || !q || !k || (!v_planes && !v) || !A || !gamma || !dq || !dk || !dv || !dgamma || !scratch)
         return fail(CCNET_E_NULLPTR, "cca_backward_planes: null tensor");
+    const bool direct = !v_planes;                 // v as the fp32 pixel-major tensor (what a plane-free forward leaves)
+    if (direct && (H > W ? H : W) > 100)
+        return fail(CCNET_E_BADSHAPE, "cca_backward_planes: the plane-free form (v_planes == NULL) serves strips <= 100");
     if (int e = check_planes_problem("cca_backward_planes: columns <= 132, rows <= 528 (> 132: C/8 <= 64), C % 8 == 0, Cq % 4 == 0",
                                      B, C, Cq, H, W, true)) return e;
     if (int e = check_pm_view<float>("cca_backward_planes: q view", q_bs, q_ps, Cq, H, W)) return e;
     if (int e = check_pm_view<float>("cca_backward_planes: k view", k_bs, k_ps, Cq, H, W)) return e;
-    if (int e = check_planes_view("cca_backward_planes: v planes view", v_bs, v_ps, C, H, W)) return e;
+    if (direct) { if (int e = check_pm_view<float>("cca_backward_planes: v view (fp32 pixel-major)", v_bs, v_ps, C, H, W)) return e; }
+    else if (int e = check_planes_view("cca_backward_planes: v planes view", vp_bs, vp_ps, C, H, W)) return e;
     if (int e = check_pm_view<float>("cca_backward_planes: dq view", dq_bs, dq_ps, Cq, H, W)) return e;
     if (int e = check_pm_view<float>("cca_backward_planes: dk view", dk_bs, dk_ps, Cq, H, W)) return e;
     if (int e = check_pm_view<float>("cca_backward_planes: dv view", dv_bs, dv_ps, C, H, W)) return e;
@@ -1328,22 +1353,24 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
         const int nb = long_blocks(W);
         const dim3 grid((unsigned)(B * (W + H * nb * nb))), block(cca::GM_THREADS);
         CCA_LAUNCH((cca::gweight_kernel<132, false, bf16p_t, false, true>), grid, block, stream, dyp, vp, scratch, C, H, W, dbs, 2 * C,
-                   v_bs, v_ps, nb);
+                   vp_bs, vp_ps, nb);
         e = launch_status("gweight_planes(dA, long rows)");
     } else if ((H > W ? H : W) > 100) {
         const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
-        CCA_LAUNCH((cca::gweight_kernel<132, false, bf16p_t, false>), grid, block, stream, dyp, vp, scratch, C, H, W, dbs, 2 * C, v_bs, v_ps);
+        CCA_LAUNCH((cca::gweight_kernel<132, false, bf16p_t, false>), grid, block, stream, dyp, vp, scratch, C, H, W, dbs, 2 * C, vp_bs, vp_ps);
         e = launch_status("gweight_planes(dA, 132)");
     } else if (const int ps = g_planes_stream.load()) {
         // persistent: one workgroup per CU walks the strips of both branches, its ring runs across strip boundaries
         // (option values > 1 cap the number of workgroups: tests make one workgroup walk many strips)
         const int nstrips = B * (H + W), cus = ps > 1 ? ps : num_cus();
         const dim3 grid((unsigned)(nstrips < cus ? nstrips : cus)), block(cca::GM_THREADS);
-        CCA_LAUNCH((cca::gweight_stream_kernel<100>), grid, block, stream, dyp, vp, scratch, C, B, H, W, dbs, 2 * C, v_bs, v_ps);
+        if (direct) CCA_LAUNCH((cca::gweight_stream_kernel<100, bf16p_t, float>), grid, block, stream, dyp, v, scratch, C, B, H, W, dbs, 2 * C, v_bs, v_ps);
+        else        CCA_LAUNCH((cca::gweight_stream_kernel<100>), grid, block, stream, dyp, vp, scratch, C, B, H, W, dbs, 2 * C, vp_bs, vp_ps);
         e = launch_status("gweight_stream(dA)");
     } else {
+        if (direct) return fail(CCNET_E_BADFLAGS, "cca_backward_planes: the plane-free form runs the persistent dA kernel (option planes_stream != 0)");
         const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
-        CCA_LAUNCH((cca::gweight_kernel<100, false, bf16p_t, false>), grid, block, stream, dyp, vp, scratch, C, H, W, dbs, 2 * C, v_bs, v_ps);
+        CCA_LAUNCH((cca::gweight_kernel<100, false, bf16p_t, false>), grid, block, stream, dyp, vp, scratch, C, H, W, dbs, 2 * C, vp_bs, vp_ps);
         e = launch_status("gweight_planes(dA)");
     }
     if (overlap == 1) sf.fork();

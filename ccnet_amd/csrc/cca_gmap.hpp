@@ -142,6 +142,36 @@ __device__ __forceinline__ u32x4 t16_frag(const float *tile, int ks, int nt, int
     return u32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// "F32T" tile: P positions x 64 channels of an fp32 PIXEL-MAJOR tensor as it lies in memory -- the value slice of the packed
+// projection, read WITHOUT a split pass (round 4: the v -> planes pass was 308 MB of traffic and 50 us of every forward) -- for
+// the dA contraction, whose fragments are ROWS of the tile (K = the channels of one position: two ds_read_b128 per lane; 8
+// consecutive lanes = 8 consecutive positions at one chunk).  Unpadded 1 KiB DMA pieces of 4 positions x 256 B (a position's 64
+// channels = one row of exactly 64 banks); the 16-byte chunk c4 of position j sits at slot c4 ^ f(j), f(j) = (j & 7) ^
+// (((j >> 3) & 3) << 2): eight consecutive positions meet eight different slots.  (The aggregation kernels, whose fragments run
+// down COLUMNS of the tile, read fp32 features through the padded GTile<float> pieces: constant strides, fewer address registers.)
+// The hi | lo split happens per fragment, in registers (v_cvt_pk_bf16_f32 + subtract + v_cvt_pk): the launches that consume the
+// tiles are HBM-bound with the matrix and vector pipes mostly idle.
+// ---------------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int f32t_pieces(int P) { return (P + 3) / 4; }
+__host__ __device__ constexpr int f32t_size(int P) { return f32t_pieces(P) * 256; }          // dwords
+__device__ __forceinline__ int f32t_swz(int j) { return (j & 7) ^ (((j >> 3) & 3) << 2); }
+__device__ __forceinline__ int f32t_idx(int j, int c) {                                       // dword index of (position j, channel c)
+    return j * 64 + ((((c >> 2) ^ f32t_swz(j)) << 2) | (c & 3));
+}
+__device__ __forceinline__ void f32t_dma_piece(const FBuf &src, float *img, int piece, int lane, int pix0, int pstep, int n,
+                                               int ps, int c0, int C) {
+    const int j = 4 * piece + (lane >> 4), c = c0 + 4 * ((lane & 15) ^ f32t_swz(j));
+    fbuf_load_to_lds_x4_uncounted(src, img + piece * 256, (j < n && c < C) ? ((pix0 + j * pstep) * ps + c) * 4 : kOobOffset);
+}
+// dA fragment: the 8 consecutive channels 32 kk + 8 (lane >> 4) .. + 7 of position ``pos``, split into bf16 hi | lo
+__device__ __forceinline__ BfSplit f32t_frag_channels(const float *tile, int pos, int kk, int lane) {
+    const int c = 32 * kk + 8 * (lane >> 4);
+    const f32x4 u = lds_load_x4(tile + f32t_idx(pos, c)), v = lds_load_x4(tile + f32t_idx(pos, c + 4));
+    const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+    return bf16_split8(x);
+}
+
 // FT: feature element, OT: output element; the addend (ADD) is fp32 pixel-major with its own strides; resid (may be
 // null) has the output's type.  4 wavefronts, two workgroups per CU: wavefront w owns the M tiles (16
 // strip positions each) t = w, w + 4, w + 8 of all four 16-channel N tiles, and keeps their attention fragments -- hi and
@@ -559,9 +589,13 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
                                                                float *__restrict__ out, int C, int H, int W, long fbs, int fps,
                                                                long abs_, int aps, long obs, int ops, int n_whole, int split) {
     constexpr int NT = (P + 15) / 16, TPW = (NT + GS_WAVES - 1) / GS_WAVES, NKS = P / 32;
+    constexpr bool F32 = std::is_same<FT, float>::value;                // fp32 pixel-major features (F32T tiles, split per fragment)
     constexpr int NPL = std::is_same<FT, bf16p_t>::value ? 2 : 1;       // planes per feature tile
-    static_assert(NPL == 2 || std::is_same<FT, bf16_t>::value, "gmap3: bf16p_t or bf16_t features");
-    constexpr int TSP = t16_size(P), FSZ = NPL * TSP, NPF = NPL * t16_pieces(P), D = NBUF - 1;
+    static_assert(NPL == 2 || F32 || std::is_same<FT, bf16_t>::value, "gmap3: bf16p_t, bf16_t or float features");
+    // (fp32 features: the padded 4-position pieces of GTile<float> -- a fragment's eight positions are two runs of four at a
+    //  constant 256-byte stride, i.e. two address registers + immediate offsets; the XOR-swizzled F32T tile needs an address per
+    //  position and pushed this kernel over the 168 VGPRs of three workgroups per CU)
+    constexpr int TSP = t16_size(P), FSZ = F32 ? GTile<float>::size(P) : NPL * TSP, NPF = F32 ? GTile<float>::pieces(P) : NPL * t16_pieces(P), D = NBUF - 1;
     static_assert(P % 4 == 0 && NBUF * FSZ * 4 * WPC <= 163840 && (NBUF == 2 || NBUF == 3), "gmap3: LDS of WPC workgroups per CU");
     // (the ring fills are LDS-DMAs the compiler does not see -- fbuf_load_to_lds_x4_uncounted, cca_platform.hpp: with the
     // builtin form it drained the fills of the next two tiles before every group's first transposing read)
@@ -584,7 +618,8 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
     const int a_off = ROW ? H : 0;
 
     const FBuf Tb = make_fbuf(T + (size_t)b * HW * S, (size_t)HW * S * sizeof(float));
-    const FBuf Fb = make_fbuf(reinterpret_cast<const float *>(F + (size_t)b * fbs), ((size_t)(HW - 1) * fps + NPL * C) * 2);
+    const FBuf Fb = make_fbuf(reinterpret_cast<const float *>(F + (size_t)b * fbs),
+                              F32 ? ((size_t)(HW - 1) * fps + C) * 4 : ((size_t)(HW - 1) * fps + NPL * C) * 2);
     const FBuf Ob = make_fbuf(out + (size_t)b * obs, ((size_t)(HW - 1) * ops + C) * sizeof(float));
     const FBuf Db = make_fbuf(ADD ? addend + (size_t)b * abs_ : T, ADD ? ((size_t)(HW - 1) * aps + C) * sizeof(float) : 4);
     const float alpha = gamma ? gamma[0] : 1.f;
@@ -598,8 +633,12 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
         for (int k = 0; k < (NPF + GS_WAVES - 1) / GS_WAVES; ++k) {
             const int it = wv + GS_WAVES * k;
             if (it < NPF) {                                                  // (wave-uniform)
-                const int plane = it >= NPF / NPL;
-                t16_dma_piece(Fb, dst + plane * TSP, it - plane * (NPF / NPL), lane, pix0, pstep, L, fps, cg * GM_CG, C, plane ? C : 0);
+                if constexpr (F32) {
+                    gtile_dma_piece<float>(Fb, dst, it, lane, pix0, pstep, L, fps, cg * GM_CG, C);
+                } else {
+                    const int plane = it >= NPF / NPL;
+                    t16_dma_piece(Fb, dst + plane * TSP, it - plane * (NPF / NPL), lane, pix0, pstep, L, fps, cg * GM_CG, C, plane ? C : 0);
+                }
             }
         }
     };
@@ -693,14 +732,24 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
             if (ks < kp.nbf) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    const u32x4 fh = t16_frag(img, ks, nt, lane);
-                    u32x4 fl = fh;
-                    if constexpr (NPL == 2) fl = t16_frag(img + TSP, ks, nt, lane);
+                    u32x4 fh, fl;
+                    if constexpr (F32) {
+                        float x[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = CCA_LDS_LD(img + gtile_f32_idx(32 * ks + 8 * lg + e, 16 * nt + ln));
+                        const BfSplit sp = bf16_split8(x);
+                        fh = sp.hi;
+                        fl = sp.lo;
+                    } else {
+                        fh = t16_frag(img, ks, nt, lane);
+                        fl = fh;
+                        if constexpr (NPL == 2) fl = t16_frag(img + TSP, ks, nt, lane);
+                    }
 #pragma unroll
                     for (int a = 0; a < TPW; ++a) {
                         if ((wv + GS_WAVES * a) * 16 < L) {
                             acc[a][nt] = mfma_bf16_16x16x32(fh, ah[a][ks], acc[a][nt]);
-                            if constexpr (NPL == 2) acc[a][nt] = mfma_bf16_16x16x32(fl, ah[a][ks], acc[a][nt]);
+                            if constexpr (NPL == 2 || F32) acc[a][nt] = mfma_bf16_16x16x32(fl, ah[a][ks], acc[a][nt]);
                             acc[a][nt] = mfma_bf16_16x16x32(fh, al[a][ks], acc[a][nt]);
                         }
                     }
@@ -711,8 +760,13 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
             const int pos = 32 * kp.nbf + lg;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                float fbv = __builtin_bit_cast(float, lds_load_u16(img, t16_byte(pos, 16 * nt + ln)) << 16);
-                if constexpr (NPL == 2) fbv += __builtin_bit_cast(float, lds_load_u16(img + TSP, t16_byte(pos, 16 * nt + ln)) << 16);
+                float fbv;
+                if constexpr (F32) {
+                    fbv = CCA_LDS_LD(img + gtile_f32_idx(pos, 16 * nt + ln));
+                } else {
+                    fbv = __builtin_bit_cast(float, lds_load_u16(img, t16_byte(pos, 16 * nt + ln)) << 16);
+                    if constexpr (NPL == 2) fbv += __builtin_bit_cast(float, lds_load_u16(img + TSP, t16_byte(pos, 16 * nt + ln)) << 16);
+                }
 #pragma unroll
                 for (int a = 0; a < TPW; ++a)
                     if ((wv + GS_WAVES * a) * 16 < L) acc[a][nt] = mfma_16x16x4(fbv, at[a], acc[a][nt]);
@@ -1033,15 +1087,20 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
 // FT = bf16p_t (split planes, three products per term) or bf16_t (bf16 features of BASELINE configs[4]: exact single products)
 // (launch bound "4 waves per SIMD": a REGISTER bound of 128 -- the LDS ring admits one workgroup per CU anyway; without it the
 // bf16 / P = 100 instantiation came out with 256 VGPRs and 13 spilled)
-template <int P, typename FT = bf16p_t>
-__global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT *__restrict__ X, const FT *__restrict__ Y,
+// YT = float: the Y operand (v) is read as the fp32 pixel-major tensor it is (F32T tiles, hi | lo split per fragment) -- X (dy)
+// stays planes: it has to be transposed out of NCHW anyway.
+template <int P, typename FT = bf16p_t, typename YT = FT>
+__global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT *__restrict__ X, const YT *__restrict__ Y,
                                                                         float *__restrict__ T, int Cx, int B, int H, int W,
                                                                         long xbs, int xps, long ybs, int yps) {
     constexpr int NPL = std::is_same<FT, bf16p_t>::value ? 2 : 1;        // planes per operand
     static_assert(NPL == 2 || std::is_same<FT, bf16_t>::value, "gweight_stream: bf16p_t or bf16_t operands");
     constexpr int TSB = t16_size(P), NPB = t16_pieces(P);                 // one plane tile: dwords, 1 KiB pieces
     constexpr int NT = (P + 15) / 16, NTR = (NT + GM_WAVES - 1) / GM_WAVES;
-    constexpr int STG = 2 * NPL * TSB, NPS = 2 * NPL * NPB;               // stage = X (hi | lo) | Y (hi | lo)
+    constexpr bool YF = std::is_same<YT, float>::value;
+    static_assert(!YF || (NPL == 2 && f32t_size(P) <= 2 * TSB), "gweight_stream: an fp32 Y tile takes the place of its two planes");
+    constexpr int NPY = YF ? f32t_pieces(P) : NPL * NPB;                  // DMA pieces of a Y tile
+    constexpr int STG = 2 * NPL * TSB, NPS = NPL * NPB + NPY;             // stage = X (hi | lo) | Y (hi | lo, or fp32)
     constexpr int NBUF = 4 * STG * 4 <= 163840 ? 4 : 3, D = NBUF - 1;     // as many stages as fit: D of them in flight
     static_assert(NBUF * STG * 4 <= 163840, "gweight_stream: three stages must fit the LDS");
     __shared__ __attribute__((aligned(16))) float lds[NBUF * STG];
@@ -1066,15 +1125,19 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
         const Strip st = strip_of(n);
         const int ch = n % nch;
         const FBuf Xb = make_fbuf(reinterpret_cast<const float *>(X + (size_t)st.b * xbs), ((size_t)(HW - 1) * xps + NPL * Cx) * 2);
-        const FBuf Yb = make_fbuf(reinterpret_cast<const float *>(Y + (size_t)st.b * ybs), ((size_t)(HW - 1) * yps + NPL * Cx) * 2);
+        const FBuf Yb = make_fbuf(reinterpret_cast<const float *>(Y + (size_t)st.b * ybs),
+                                  YF ? ((size_t)(HW - 1) * yps + Cx) * 4 : ((size_t)(HW - 1) * yps + NPL * Cx) * 2);
         float *dst = lds + (n % NBUF) * STG;
 #pragma unroll
         for (int k = 0; k < (NPS + GM_WAVES - 1) / GM_WAVES; ++k) {
             const int it = wv + GM_WAVES * k;
             if (it < NPS) {                                                 // (wave-uniform)
                 const int op = it >= NPL * NPB, r = it - op * NPL * NPB, plane = r >= NPB;
-                t16_dma_piece<false>(op ? Yb : Xb, dst + (NPL * op + plane) * TSB, r - plane * NPB, lane, st.pix0, st.pstep, st.L,
-                              op ? yps : xps, ch * GM_CG, Cx, plane ? Cx : 0);
+                if (YF && op)
+                    f32t_dma_piece(Yb, dst + NPL * TSB, r, lane, st.pix0, st.pstep, st.L, yps, ch * GM_CG, Cx);
+                else
+                    t16_dma_piece<false>(op ? Yb : Xb, dst + (NPL * op + plane) * TSB, r - plane * NPB, lane, st.pix0, st.pstep, st.L,
+                                  op ? yps : xps, ch * GM_CG, Cx, plane ? Cx : 0);
             }
         }
     };
@@ -1135,9 +1198,17 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (t * 16 < L) {
-                    const u32x4 bh = frag(yh, 16 * t + ln, kk);
-                    u32x4 bl = bh;
-                    if constexpr (NPL == 2) bl = frag(yl, 16 * t + ln, kk);
+                    u32x4 bh, bl;
+                    if constexpr (YF) {
+                        const int pos = 16 * t + ln;
+                        const BfSplit sp = f32t_frag_channels(yh, pos < 4 * NPY ? pos : 0, kk, lane);
+                        bh = sp.hi;
+                        bl = sp.lo;
+                    } else {
+                        bh = frag(yh, 16 * t + ln, kk);
+                        bl = bh;
+                        if constexpr (NPL == 2) bl = frag(yl, 16 * t + ln, kk);
+                    }
 #pragma unroll
                     for (int a = 0; a < NTR; ++a)
                         if ((wv + GM_WAVES * a) * 16 < L) {

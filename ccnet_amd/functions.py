@@ -593,11 +593,12 @@ class _ProjectionCache:
 class CrissCrossPlanesModuleFunction(torch.autograd.Function):
     """The whole module as ONE autograd node on the SPLIT-PLANE path (fp32, no autocast), the module's own tensors NCHW:
     the stacked projection is the GEMM ``x^T W^T`` whose (B, HW, 2Cq + C) output holds the pixel-major q | k | v; the core's
-    forward entry point takes the fp32 value slice as it is and splits it into bf16 hi | lo planes itself (on the library's side
-    stream, next to the affinity launch; the projection's value bias is added there), which is what the aggregation
-    (functions.py:42-47) and the dA contraction of its adjoint read -- three exact bf16 products per term, no per-fragment
-    split in any inner loop; dy is split once inside the backward; q, k stay fp32 (exact energies).  ``dx = dy + W^T dqkv^T``
-    is one GEMM with beta = 1 writing NCHW.
+    forward entry point takes the fp32 value slice as it is: maps with strips <= 100 (the headline geometry) run the PLANE-FREE
+    form -- the aggregation (functions.py:42-47) and the dA contraction of its adjoint read v as fp32 tiles and split every
+    fragment into bf16 hi | lo in registers; larger maps have the entry point split v into planes first (its first launch; the
+    projection's value bias is added there).  dy is transposed out of NCHW into planes once inside the backward; q, k stay fp32
+    (exact energies); three exact bf16 products per term everywhere else.  ``dx = dy + W^T dqkv^T`` is one GEMM with beta = 1
+    writing NCHW.
 
     ``split_gemm``: the three projection GEMMs (functions.py:29-35 and their adjoints) run split-bf16 x3 as well -- ONE stock
     bf16 -> fp32 GEMM each on K-concatenated three-plane operands (x.w ~ xh.wh + xh.wl + xl.wh: rows [xh | xh | xl] of x
@@ -605,8 +606,8 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
     row by row over 3 B HW rows, with x's planes for the weight gradient).  The planes are written by the library's
     producers (one pass over x, one over dqkv); fp32 accumulation, relative error ~1e-5 (the lo x lo term is dropped).
 
-    Kept for the backward: the q | k slice (a copy: the packed projection, four fifths of it the value slice nobody reads
-    again, is released), v as planes, x (or, with ``split_gemm``, its three planes instead), and the attention tensor -- or,
+    Kept for the backward: the packed projection (plane-free form), or a copy of its q | k fifth + v as planes (the projection
+    is released); x (or, with ``split_gemm``, its three planes instead); and the attention tensor -- or,
     with ``recompute``, nothing of the attention: the backward rebuilds it from q | k with the forward's own kernels
     (bit-identical, one affinity + softmax launch pair)."""
 
@@ -618,33 +619,41 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
         ct = 2 * cq + C
         pc = (cache if cache is not None else _ProjectionCache()).get(wq, bq, wk, bk, wv, bv, split_gemm)
         x3 = None
+        direct = max(H, W) <= 100           # strips <= 100: the plane-free form of the core (v stays fp32, no split pass)
         if split_gemm:
             x3 = nchw_to_planes(x, PLANES_HHL, torch.bfloat16)                              # (B, H, W, 3, C): xh | xh | xl
-            qkv = torch.mm(x3.view(B * hw, 3 * C), pc["w3"], out_dtype=torch.float32).view(B, hw, ct)
-            # the bias without a pass over the whole output: q | k in place (a fifth of it), v where its slice is split
-            qkv[..., :2 * cq].add_(pc["bqk"])
-            v_bias = pc["bv"]
+            if direct:                      # the whole bias in the GEMM's epilogue
+                qkv = torch.addmm(pc["b"], x3.view(B * hw, 3 * C), pc["w3"], out_dtype=torch.float32).view(B, hw, ct)
+                v_bias = None
+            else:
+                qkv = torch.mm(x3.view(B * hw, 3 * C), pc["w3"], out_dtype=torch.float32).view(B, hw, ct)
+                # the bias without a pass over the whole output: q | k in place (a fifth of it), v where its slice is split
+                qkv[..., :2 * cq].add_(pc["bqk"])
+                v_bias = pc["bv"]
         else:
             qkv = torch.baddbmm(pc["b"].view(1, 1, -1), x.view(B, C, hw).transpose(1, 2), pc["w"].t().unsqueeze(0).expand(B, -1, -1))
             v_bias = None
         lib = _lib.get_lib()
         y = torch.empty_like(x)
         A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
-        vpl = torch.empty((B, H, W, 2, C), device=x.device, dtype=torch.int16)
+        vpl = None if direct else torch.empty((B, H, W, 2, C), device=x.device, dtype=torch.int16)
         p, bs, ps = qkv.data_ptr(), hw * ct, ct
         with torch.cuda.device(x.device):
             _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0), x.device)
             lib.check(lib.ccnet_cca_forward_planes_f32(p, p + 4 * cq, p + 8 * cq, None if v_bias is None else v_bias.data_ptr(),
-                                                       vpl.data_ptr(), x.data_ptr(), gamma.data_ptr(), y.data_ptr(),
+                                                       None if direct else vpl.data_ptr(), x.data_ptr(), gamma.data_ptr(), y.data_ptr(),
                                                        A.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps, bs, ps,
                                                        hw * 2 * C, 2 * C, wsp, wsn, _stream()), "cca_forward_planes")
         if not any(ctx.needs_input_grad):
             return y
-        qk = qkv[..., :2 * cq].contiguous()               # (B, HW, 2Cq): all the backward reads of the projection
+        # plane-free: the packed projection itself is kept (its value slice is read again by the dA contraction); otherwise a copy
+        # of the q | k fifth + the planes, and the projection is released
+        qk = qkv if direct else qkv[..., :2 * cq].contiguous()
         ctx.recompute = bool(recompute)
         ctx.split_gemm = bool(split_gemm)
         ctx.cache = cache
-        keep = [x3 if split_gemm else x, qk, vpl, gamma, wq, bq, wk, bk, wv, bv]
+        ctx.direct = direct
+        keep = [x3 if split_gemm else x, qk, qk if direct else vpl, gamma, wq, bq, wk, bk, wv, bv]
         if not ctx.recompute:
             keep += [A]
         ctx.save_for_backward(*keep)
@@ -661,7 +670,8 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
         hw, ct = H * W, 2 * cq + C
         lib = _lib.get_lib()
         pc = (ctx.cache if ctx.cache is not None else _ProjectionCache()).get(wq, bq, wk, bk, wv, bv, ctx.split_gemm)
-        p, bs, ps = qk.data_ptr(), hw * 2 * cq, 2 * cq
+        direct = ctx.direct
+        p, bs, ps = (qk.data_ptr(), hw * ct, ct) if direct else (qk.data_ptr(), hw * 2 * cq, 2 * cq)
         if ctx.recompute:
             A = _attention_pm(lib, p, p + 4 * cq, False, B, cq, H, W, bs, ps, dy.device)
         else:
@@ -672,9 +682,10 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
         g, gbs = dqkv.data_ptr(), hw * ct
         with torch.cuda.device(dy.device):
             _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 1), dy.device)
-            lib.check(lib.ccnet_cca_backward_planes_f32(dy.data_ptr(), p, p + 4 * cq, vpl.data_ptr(), A.data_ptr(),
+            lib.check(lib.ccnet_cca_backward_planes_f32(dy.data_ptr(), p, p + 4 * cq, p + 8 * cq if direct else None,
+                                                        None if direct else vpl.data_ptr(), A.data_ptr(),
                                                         gamma.data_ptr(), g, g + 4 * cq, g + 8 * cq, dgamma.data_ptr(),
-                                                        scratch.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps, hw * 2 * C, 2 * C,
+                                                        scratch.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps, bs, ps, hw * 2 * C, 2 * C,
                                                         gbs, ct, gbs, ct, gbs, ct, wsp, wsn, _stream()), "cca_backward_planes")
         db = dqkv.sum(dim=(0, 1))
         if ctx.split_gemm:

@@ -250,7 +250,9 @@ int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W);
  *   (B,H,W,H+W) fp32 as everywhere.  The forward takes v the way its producer leaves it -- ``v``: the fp32 pixel-major value
  *   slice of the projection (functions.py:35), ``v_bias``: C floats added while splitting, or NULL -- and WRITES ``v_planes``
  *   (its first launch), which the caller keeps for the backward; with ``v`` == NULL, ``v_planes`` is an input that already
- *   holds the planes.
+ *   holds the planes.  PLANE-FREE FORM (``v_planes`` == NULL, strips <= 100, no ``v_bias``): v is consumed as the fp32 tensor it
+ *   is -- the aggregation and (backward: pass the same ``v``, ``v_planes`` == NULL) the dA contraction split every fragment into
+ *   bf16 hi | lo in registers; no planes tensor, no split pass (308 MB less traffic per forward); same arithmetic, same bits.
  *   Workspace: CCNET_WS_PLANES_FORWARD / _BACKWARD (backward: holds the fp32 column partial and dy as planes).
  *   Arithmetic: energies exact fp32; every other contraction split-bf16 x3 with fp32 accumulation (the lo x lo term,
  *   2^-18 relative, is dropped) -- the CCNET_PRECISION_* knob does not apply here. */
@@ -272,10 +274,10 @@ int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v,
  * networks/ccnet.py:118-119 -- R applications of the module hold R attention tensors). */
 int ccnet_cca_attention_pm(const void *q, const void *k, float *A, int bf16, int B, int Cq, int H, int W,
                            long q_bs, int q_ps, long k_bs, int k_ps, ccnet_stream_t stream);
-int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *k, const uint16_t *v_planes, const float *A,
-                                  const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
+int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *k, const float *v, const uint16_t *v_planes,
+                                  const float *A, const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
                                   int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps,
-                                  long v_bs, int v_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
+                                  long v_bs, int v_ps, long vp_bs, int vp_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
                                   void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
 
 /* Options by name.  Both calls return a STATUS (0, or CCNET_E_BADFLAGS for an unknown name / a value outside the option's

@@ -229,24 +229,25 @@ class EmuOps:
 
     def cca_forward_planes(self, qkv, v_planes, x, gamma, cq, v_from_qkv=False, v_bias=None):
         """qkv: float32 (B, H, W, ct) packed pixel-major projection (q | k read from it); v_planes uint16 (B, H, W, 2, C): the
-        pre-split value planes, or (``v_from_qkv``) an OUTPUT the entry point fills from the fp32 value slice of qkv (+ v_bias);
-        x float32 NCHW; returns (y NCHW, A)."""
+        pre-split value planes, or (``v_from_qkv``) an OUTPUT the entry point fills from the fp32 value slice of qkv (+ v_bias),
+        or None: the PLANE-FREE form (v read as fp32 out of qkv, nothing written); x float32 NCHW; returns (y NCHW, A)."""
         B, H, W, ct = qkv.shape
-        C = v_planes.shape[4]
+        C = ct - 2 * cq
         y = np.full((B, C, H, W), np.nan, np.float32)
         A = np.full((B, H, W, H + W), np.nan, np.float32)
         nbytes = self.lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0)
         ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
         base, bs = qkv.ctypes.data, H * W * ct
-        self.lib.check(self.lib.ccnet_cca_forward_planes_f32(base, base + 4 * cq, base + 8 * cq if v_from_qkv else None, _p(v_bias),
-                                                             _p(v_planes), _p(x), _p(gamma), _p(y), _p(A),
+        self.lib.check(self.lib.ccnet_cca_forward_planes_f32(base, base + 4 * cq, base + 8 * cq if (v_from_qkv or v_planes is None) else None,
+                                                             _p(v_bias), _p(v_planes), _p(x), _p(gamma), _p(y), _p(A),
                                                              B, C, cq, H, W, bs, ct, bs, ct, bs, ct, H * W * 2 * C, 2 * C,
                                                              _p(ws), nbytes, None))
         return y, A
 
     def cca_backward_planes(self, dy, qkv, v_planes, A, gamma, cq):
+        """``v_planes`` None: the plane-free form (v read as fp32 out of qkv)"""
         B, H, W, ct = qkv.shape
-        C = v_planes.shape[4]
+        C = ct - 2 * cq
         dqkv = np.full((B, H, W, 2 * cq + C), np.nan, np.float32)
         dgamma = np.full(1, np.nan, np.float32)
         scratch = np.full_like(A, np.nan)
@@ -255,9 +256,10 @@ class EmuOps:
         base, g, bs = qkv.ctypes.data, dqkv.ctypes.data, H * W * ct
         dct = 2 * cq + C
         dbs = H * W * dct
-        self.lib.check(self.lib.ccnet_cca_backward_planes_f32(_p(dy), base, base + 4 * cq, _p(v_planes), _p(A), _p(gamma),
+        self.lib.check(self.lib.ccnet_cca_backward_planes_f32(_p(dy), base, base + 4 * cq, base + 8 * cq if v_planes is None else None,
+                                                              _p(v_planes), _p(A), _p(gamma),
                                                               g, g + 4 * cq, g + 8 * cq, _p(dgamma), _p(scratch),
-                                                              B, C, cq, H, W, bs, ct, bs, ct, H * W * 2 * C, 2 * C,
+                                                              B, C, cq, H, W, bs, ct, bs, ct, bs, ct, H * W * 2 * C, 2 * C,
                                                               dbs, dct, dbs, dct, dbs, dct, _p(ws), nbytes, None))
         return dqkv, dgamma
 

@@ -714,3 +714,38 @@ def test_split_plane_forward_takes_fp32_v_and_recomputes_its_saved_pair(ops, sha
     finally:
         ops.lib.set_option("planes_xcd", prev)
     assert prev == 1 and np.array_equal(y, y3)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 96, 17, 20), (1, 64, 9, 1), (1, 160, 33, 18), (1, 64, 2, 99), (1, 64, 100, 3),
+                                   (1, 64, 3, 97), (2, 128, 8, 5), (1, 512, 6, 5)])
+def test_plane_free_form_is_bit_identical_to_the_plane_form(ops, shape):
+    """ABI 200, plane-free form of ccnet_cca_{forward,backward}_planes_f32 (v_planes == NULL, strips <= 100): v is read as the fp32
+    pixel-major tensor it is (F32T tiles), every fragment is split into bf16 hi | lo in registers -- the same split the planes
+    hold, the same products in the same order: y, A, dq | dk | dv and dgamma are BIT-IDENTICAL to the plane form.  Also with the
+    persistent dA kernel capped at three workgroups (a ring of fp32 Y tiles across strip boundaries)."""
+    B, C, H, W = shape
+    cq = max(C // 8, 4)
+    c = rand_case(B, C, H, W, seed=123)
+    rng = np.random.default_rng(11)
+    qk = rng.standard_normal((B, 2 * cq, H, W), dtype=np.float32) * np.float32(0.4)
+    qkv = np.ascontiguousarray(np.concatenate([_pm(qk), _pm(c["v"])], axis=3))
+    vpl = ops.split_planes(qkv, C, c0=2 * cq)
+    y, A = ops.cca_forward_planes(qkv, vpl, c["x"], c["gamma"], cq)
+    y2, A2 = ops.cca_forward_planes(qkv, None, c["x"], c["gamma"], cq)
+    # a strip whose length leaves a k remainder of 1 .. 4 (97 .. 100, 1 .. 4, 33 ..) finishes with one exact-f32 MFMA step: there the
+    # plane form multiplies hi + lo, the plane-free form the fp32 value itself (2^-17 closer to the truth) -- everything else is
+    # the same products in the same order
+    tail = any(0 < (n % 32) <= 4 for n in (H, W))
+    same = (lambda a, b: maxerr(a, b) <= 4e-6 * max(1.0, float(np.abs(b).max()))) if tail else np.array_equal
+    assert np.array_equal(A, A2) and same(y2, y)
+    ref = ops.cca_backward_planes(c["dy"], qkv, vpl, A, c["gamma"], cq)
+    for opt in (1, 3):
+        prev = ops.lib.set_option("planes_stream", opt)
+        try:
+            got = ops.cca_backward_planes(c["dy"], qkv, None, A, c["gamma"], cq)
+        finally:
+            ops.lib.set_option("planes_stream", prev)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), opt          # (dA contracts over channels: no tail)
+    with pytest.raises(RuntimeError):            # the plane-free form stops at 100 positions
+        big = np.zeros((1, 101, 2, 2 * cq + C), np.float32)
+        ops.cca_forward_planes(big, None, np.zeros((1, C, 101, 2), np.float32), c["gamma"], cq)

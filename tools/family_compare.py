@@ -42,8 +42,6 @@ for name, cls in fams:
           f"event sum {sum(t for _, t in rec) / 5:.4f}")
     for i in range(n):
         print(f"     {sum(rec[r * n + i][1] for r in range(5)) / 5 * 1e3:8.1f} us  {rec[i][0][:110]}")
-    if name.startswith("planes"):
-        print(f"     split of v (producer side, outside the step): {bench.time_region(wl.split, 20) * 1e3:.1f} us")
     res[name] = wl
 b = res["planes-noring"]
 set_options("planes-noring")
