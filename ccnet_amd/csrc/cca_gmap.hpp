@@ -164,14 +164,6 @@ __device__ __forceinline__ void f32t_dma_piece(const FBuf &src, float *img, int 
     const int j = 4 * piece + (lane >> 4), c = c0 + 4 * ((lane & 15) ^ f32t_swz(j));
     fbuf_load_to_lds_x4_uncounted(src, img + piece * 256, (j < n && c < C) ? ((pix0 + j * pstep) * ps + c) * 4 : kOobOffset);
 }
-// dA fragment: the 8 consecutive channels 32 kk + 8 (lane >> 4) .. + 7 of position ``pos``, split into bf16 hi | lo
-__device__ __forceinline__ BfSplit f32t_frag_channels(const float *tile, int pos, int kk, int lane) {
-    const int c = 32 * kk + 8 * (lane >> 4);
-    const f32x4 u = lds_load_x4(tile + f32t_idx(pos, c)), v = lds_load_x4(tile + f32t_idx(pos, c + 4));
-    const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
-    return bf16_split8(x);
-}
-
 // FT: feature element, OT: output element; the addend (ADD) is fp32 pixel-major with its own strides; resid (may be
 // null) has the output's type.  4 wavefronts, two workgroups per CU: wavefront w owns the M tiles (16
 // strip positions each) t = w, w + 4, w + 8 of all four 16-channel N tiles, and keeps their attention fragments -- hi and
@@ -1187,6 +1179,23 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
         }
         const int L = cur.L;
         const float *xh = lds + (n % NBUF) * STG, *xl = xh + (NPL - 1) * TSB, *yh = xh + NPL * TSB, *yl = yh + (NPL - 1) * TSB;
+        if constexpr (YF) {
+            // the landed fp32 Y tile -> bf16 hi | lo IN PLACE, each value split ONCE (eight wavefronts read every Y fragment: split
+            // per fragment read, the vector pipe became the bound -- 203 us against 155 us with planes).  A thread owns whole
+            // (position, 8-channel) items: 32 bytes in, the hi chunk and the lo chunk out to the same 32 bytes -- no thread reads
+            // what another writes, one barrier hands the converted tile to the multiply.
+            float *yt = lds + (n % NBUF) * STG + NPL * TSB;
+            for (int it = tid; it < 4 * NPY * 8; it += GM_THREADS) {
+                const int j = it >> 3, q8 = it & 7;
+                float *p0 = yt + f32t_idx(j, 8 * q8), *p1 = yt + f32t_idx(j, 8 * q8 + 4);
+                const f32x4 u = lds_load_x4(p0), v = lds_load_x4(p1);
+                const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+                const BfSplit sp = bf16_split8(x);
+                lds_store_x4(p0, __builtin_bit_cast(f32x4, sp.hi));
+                lds_store_x4(p1, __builtin_bit_cast(f32x4, sp.lo));
+            }
+            barrier_lds_only();
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {                                    // two k-steps of 32 channels
             u32x4 ah[NTR], al[NTR];
@@ -1199,11 +1208,10 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
             for (int t = 0; t < NT; ++t) {
                 if (t * 16 < L) {
                     u32x4 bh, bl;
-                    if constexpr (YF) {
-                        const int pos = 16 * t + ln;
-                        const BfSplit sp = f32t_frag_channels(yh, pos < 4 * NPY ? pos : 0, kk, lane);
-                        bh = sp.hi;
-                        bl = sp.lo;
+                    if constexpr (YF) {           // (converted in place above: the hi chunk, and next to it the lo chunk)
+                        const int pos = 16 * t + ln < 4 * NPY ? 16 * t + ln : 0, c = 32 * kk + 8 * lg;
+                        bh = __builtin_bit_cast(u32x4, lds_load_x4(yh + f32t_idx(pos, c)));
+                        bl = __builtin_bit_cast(u32x4, lds_load_x4(yh + f32t_idx(pos, c + 4)));
                     } else {
                         bh = frag(yh, 16 * t + ln, kk);
                         bl = bh;

@@ -694,7 +694,7 @@ def test_split_plane_core_at_the_headline_shape_against_the_oracle(lib, dev):
     wl.direct, wl.vpl = False, torch.empty(B, H, W, 2, C, dtype=torch.int16, device=dev)
     wl.step()
     torch.cuda.synchronize()
-    assert torch.equal(wl.dqkv, g1) and err(wl.y, y1) < 1e-5
+    assert torch.equal(wl.dqkv, g1) and err(wl.y, y1) < 5e-5          # (the k-tail of a 97-long strip: up to 4 x |v| 2^-17 per output)
 
 
 def test_pixel_major_bf16_module_route_and_full_size(lib, dev):
