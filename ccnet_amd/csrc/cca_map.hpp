@@ -173,16 +173,6 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
         }
         __syncthreads();                                  // images consumed: the LDS becomes the chunk buffers
     }
-#ifdef CCA_ABL_PROLOGUE_ONLY
-    {
-        float sum = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < M_KS; ++ks)
-#pragma unroll
-            for (int t = 0; t < kMaxTiles; ++t) sum += bf[BF ? 0 : ks][t];
-        if (sum != 123.456f) return;
-    }
-#endif
 
     // masked DMA lanes leave their LDS slots untouched, and slots just past a strip are read as K padding (and then
     // discarded): start from an all-zero LDS so that what is read there is at least defined
@@ -225,12 +215,6 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
         const int rem = feat ? q - QA : q;
         const int pr = rem / PIECES4, m = rem % PIECES4;
         if (!(FULL || m < npieces4)) return;
-#ifdef CCA_ABL_NOFEAT
-        if (feat) return;
-#endif
-#ifdef CCA_ABL_NOADD
-        if (!feat) return;
-#endif
         const int cc = wv + pr * NS;
         const int c = (feat ? chn : ch) * M_MC + cc;
         float *dst = lds + (feat ? (buf ^ 1) : 2) * BUF + cc * CP + m * 256;
@@ -304,11 +288,7 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                 // this k-step's share of the DMA pieces: next feature chunk + this chunk's addend tile
 #pragma unroll
                 for (int q = qlo(ks, M_KS); q < qlo(ks + 1, M_KS); ++q) dma_piece(q, ch, chn, buf);
-#ifdef CCA_ABL_NOMFMA
-                if (ks < 2) {
-#else
                 if (FULL || ks < nks) {
-#endif
                     const int koff = ROW ? ks * 4 : ks * 4 * NS + (wv ^ col_swizzle<NS>(ks * 4));
                     const float araw = CCA_LDS_LD(ab + koff);
                     // K padding: zero the A operand as well as the B fragment (see the bf16 path); only the last
@@ -391,9 +371,6 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                             const int rem = L - k * NS, nr = rem < NS ? rem : NS;      // rem <= 0 beyond the last band
                             if (r < NS * nr) {
                                 const f32x4 val = lds_load_x4(&src[e0]);
-#ifdef CCA_ABL_NOSTORE
-                                if (val[0] != 123.456f) continue;
-#endif
                                 fbuf_store_x4(Ob, val, 4 * (k * NS * W + g0 * nr + r), soff);
                             }
                         }
@@ -411,9 +388,6 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                                 f32x4 val;
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) val[i] = alpha * CCA_LDS_LD(&res[s4 * L + 4 * w4 + i]);
-#ifdef CCA_ABL_NOSTORE
-                                if (val[0] != 123.456f) continue;
-#endif
                                 if (has_add) val += lds_load_x4(&add[4 * pidx]);
                                 fbuf_store_x4(Ob, val, 4 * ((g0 + s4) * W + 4 * w4), soff);
                             }
@@ -447,9 +421,6 @@ __device__ __forceinline__ void map_strip_body(float *lds, const float *__restri
                         // launch gathers its addend from it (slow path: per-element index arithmetic)
                         const int e = m * 64 + lane;
                         float val = alpha * CCA_LDS_LD(&src[e]);
-#ifdef CCA_ABL_NOSTORE
-                        if (val != 123.456f) continue;
-#endif
                         if constexpr (!ROW) {
                             const int pos = e / NS, gg = (e % NS) ^ col_swizzle<NS>(pos);
                             const bool ok = pos < L && gg < gvalid;

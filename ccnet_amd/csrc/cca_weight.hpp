@@ -106,11 +106,9 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
     issue(nchunks > 1 ? c_begin + W_KC : c_begin, 1);
     for (int n = 0; n < nchunks; ++n) {
         // chunk n landed; chunk n+1 (the newest QT pieces of every wave) may still be in flight
-#ifndef CCA_ABL_W_NOBARRIER
         // (the counted wait needs every wave to have issued exactly QT pieces per chunk: full tiles of full strips)
         if (FULL && gvalid == NS) barrier_dma_keep<QT>();
         else                      __syncthreads();
-#endif
         // chunk n+2 -> buffer (n+2) % 3, last read in iteration n-1 (past the end: re-fetch the last chunk, harmless)
         const int c1 = (c_begin + (n + 2) * W_KC < lastc) ? c_begin + (n + 2) * W_KC : lastc;
         const int bnext = (n + 2) % 3, bcur = n % 3;
@@ -148,26 +146,16 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
 #pragma unroll
                 for (int t = 0; t < kMaxTiles; ++t)
                     if (CCA_TILE_ON(t)) {
-#ifdef CCA_ABL_W_NOLDS
-                        const float v = 0.001f * (float)(lane + t + ks + n);
-#else
                         const float v = CCA_LDS_LD(xs + ks * 4 * CP + t * tstep);
-#endif
                         a[t] = kin ? v : 0.f;
                     }
 #pragma unroll
                 for (int rn = 0; rn < kMaxTiles; ++rn) {
                     const int sidx = ks * kMaxTiles + rn;
-#ifndef CCA_ABL_W_NODMA
 #pragma unroll
                     for (int q = sidx * QT / SLOTS; q < (sidx + 1) * QT / SLOTS; ++q) dma_piece(q, c1, bnext);
-#endif
                     if (CCA_TILE_ON(rn)) {
-#ifdef CCA_ABL_W_NOLDS
-                        const float bb = 0.002f * (float)(lane + rn + ks + n);
-#else
                         const float bb = CCA_LDS_LD(ys + ks * 4 * CP + rn * tstep);
-#endif
 #pragma unroll
                         for (int rm = 0; rm < kMaxTiles; ++rm)
                             if (CCA_TILE_ON(rm)) acc[rm][rn] = mfma_16x16x4(a[rm], bb, acc[rm][rn]);
