@@ -33,3 +33,30 @@ for B in (1, 2, 4, 8):
           f"split-bf16 GEMMs (default) {row[3]:.3f} ms | pixel-major family, channels_last tensors {row[2]:.3f} ms   (max |diff| vs "
           f"strip node: fp32 GEMMs y {d[0]:.1e} dx {d[1]:.1e} dWv {d[2]:.1e}; split GEMMs y {d3[0]:.1e} dx {d3[1]:.1e} dWv {d3[2]:.1e})",
           flush=True)
+
+# ---- round 4: the default module eager vs captured into two hipGraphs (ccnet_amd.graph_module), and the GPU time of its launches ----
+from ccnet_amd import graph_module
+from ccnet_amd import _lib as _L
+lib = _L.get_lib()
+for B in (1, 2, 4):
+    torch.manual_seed(0)
+    m = CrissCrossAttention(C).to(dev)
+    with torch.no_grad():
+        m.gamma.fill_(0.5)
+    x = torch.randn(B, C, H, W, device=dev, requires_grad=True)
+    dy = torch.randn(B, C, H, W, device=dev)
+
+    def one(f):
+        y = f(x)
+        y.backward(dy)
+
+    for _ in range(3):
+        one(m)
+    t_eager = bench.time_region(lambda: one(m), 30)
+    g = graph_module(m, x.detach().clone().requires_grad_(True))
+    for _ in range(3):
+        one(g)
+    t_graph = bench.time_region(lambda: one(g), 30)
+    rec = lib.profile_launches(lambda: one(m))
+    print(f"B={B}: default module fwd+bwd eager {t_eager:.3f} ms | graphed (ccnet_amd.graph_module) {t_graph:.3f} ms | the library's own "
+          f"{len(rec)} launches sum to {sum(t for _, t in rec):.3f} ms (the GEMMs and reductions of the projections are torch's)", flush=True)
