@@ -32,10 +32,10 @@ std::atomic<int> g_branch_mask{CCNET_BRANCH_BOTH};     // profiling aid: which b
 // fully coalesced, so the 5x cheaper MFMA phase shows), the column launches gain nothing (they are bound by the L2
 // request rate of their 32-byte segments).  Only strips 97..100 long have a split-bf16 kernel.
 std::atomic<int> g_map_bf16{1};
-// arithmetic of the K = C weight kernel (ca_map_backward's dA, 15 GFLOP, matrix-pipe bound in f32):
-// 1 (default) = packed split-bf16 (one bf16 MFMA per tile and 8-channel chunk), 0 = exact f32.
-// The affinity kernel (ca_forward, K = C/8) always runs exact f32: its energies feed exp().
-std::atomic<int> g_weight_bf16{1};
+// The weight kernels of this family (ca_forward, and ca_map_backward's dA) run exact f32.  (Rounds 1-3 shipped a packed split-bf16
+// dA variant -- 135 us against 250 us at the headline shape -- whose 196 stationary accumulators + packing temporaries spilled 126
+// VGPRs; round 4 retired it: the module's default fp32 routes run the split-plane kernels of cca_gmap.hpp, this family is the
+// reference-shaped exact one: VERDICT r3 item 8.)
 
 // development / A-B options (ccnet_cca_set_option): "planes_ring" 0 = gmap_kernel (two tiles, output image in LDS) for every
 // split-plane pass, 1 = the passes with a pixel-major output run gmap3_kernel (three-tile ring, stores from the accumulators,
@@ -275,8 +275,6 @@ int launch_weight_ns(const float *X, const float *Y, float *T, int B, int Cx, in
 template <bool MASK>
 int launch_weight_pair(const float *X, const float *Y, float *T, int B, int Cx, int H, int W,
                        ccnet_stream_t stream, const char *what, long xbs, long ybs, const KSplit &ks = KSplit()) {
-    if (!MASK && g_weight_bf16.load() == 1)
-        return launch_weight_ns<8, false, true>(X, Y, T, B, Cx, H, W, stream, what, xbs, ybs, ks);
     return launch_weight_ns<8, MASK, false>(X, Y, T, B, Cx, H, W, stream, what, xbs, ybs, ks);
 }
 
@@ -444,11 +442,8 @@ int ca_backward_impl(const float *dE, const float *q, const float *k, float *dq,
     const int impl = pick_impl(H, W);
     if (impl < 0) return impl;
     if (impl == 1) {
-        // dq (non-transposed) and dk (transposed) share one launch per branch.  split-bf16 here costs accuracy where
-        // it is scarcest (dq/dk reach |50| at the headline shape: 6-8e-4 max-abs against the 1e-3 bar, measured) and
-        // bought nothing inside the step, so it is used only under CCNET_PRECISION_BF16X3
-        if (g_map_bf16.load() == 2 && map_bf16(H, W, true))
-            return launch_map_dual_ns<8, true>(dE, k, dq, q, dk, B, Cq, H, W, stream, "ca_backward(dq,dk)", kbs, dqbs, qbs, dkbs);
+        // dq (non-transposed) and dk (transposed) share one launch per branch; exact f32 (a split-bf16 variant cost accuracy
+        // where it is scarcest -- 6-8e-4 max-abs on dq / dk -- bought nothing inside the step, and was retired in round 4)
         return launch_map_dual_ns<8, false>(dE, k, dq, q, dk, B, Cq, H, W, stream, "ca_backward(dq,dk)", kbs, dqbs, qbs, dkbs);
     }
     if (impl == 2) {
@@ -541,16 +536,16 @@ static int set_impl(int impl) {
 }
 static int get_impl(void) { return g_impl.load(); }
 static int set_precision(int precision) {
-    const int mb = g_map_bf16.load(), wb = g_weight_bf16.load();
-    const int prev = mb == 2 ? CCNET_PRECISION_BF16X3 : (mb == 1 || wb ? CCNET_PRECISION_DEFAULT : CCNET_PRECISION_F32);
-    if (precision == CCNET_PRECISION_F32)     { g_map_bf16.store(0); g_weight_bf16.store(0); }
-    if (precision == CCNET_PRECISION_DEFAULT) { g_map_bf16.store(1); g_weight_bf16.store(1); }
-    if (precision == CCNET_PRECISION_BF16X3)  { g_map_bf16.store(2); g_weight_bf16.store(1); }
+    const int mb = g_map_bf16.load();
+    const int prev = mb == 2 ? CCNET_PRECISION_BF16X3 : (mb == 1 ? CCNET_PRECISION_DEFAULT : CCNET_PRECISION_F32);
+    if (precision == CCNET_PRECISION_F32)     g_map_bf16.store(0);
+    if (precision == CCNET_PRECISION_DEFAULT) g_map_bf16.store(1);
+    if (precision == CCNET_PRECISION_BF16X3)  g_map_bf16.store(2);
     return prev;
 }
 static int get_precision(void) {
-    const int mb = g_map_bf16.load(), wb = g_weight_bf16.load();
-    return mb == 2 ? CCNET_PRECISION_BF16X3 : (mb == 1 || wb ? CCNET_PRECISION_DEFAULT : CCNET_PRECISION_F32);
+    const int mb = g_map_bf16.load();
+    return mb == 2 ? CCNET_PRECISION_BF16X3 : (mb == 1 ? CCNET_PRECISION_DEFAULT : CCNET_PRECISION_F32);
 }
 static int set_branch_mask(int mask) {
     if (mask >= 1 && mask <= 3) return g_branch_mask.exchange(mask);

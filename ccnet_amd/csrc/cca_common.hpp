@@ -83,25 +83,6 @@ __device__ __forceinline__ BfSplit bf16_split8(const float (&x)[8]) {
     return s;
 }
 
-// "Packed" split-bf16: the four products of ONE channel are laid along the K axis of a single
-// v_mfma_f32_16x16x32_bf16 (8 channels x 4 k-slots):
-//     A side (a_hi, a_lo, a_hi, a_lo)   B side (b_hi, b_hi, b_lo, b_lo)   ->  (a_hi + a_lo) * (b_hi + b_lo)
-// so a K = 8-channel chunk needs one MFMA instead of two f32 k-steps (4x fewer matrix-pipe cycles) while the LDS
-// image stays 8 channels deep; what is lost is only the 2^-18 |x| residual of the two-term split of each operand.
-// A lane holds the slots of channels 2 (l >> 4) and 2 (l >> 4) + 1.
-__device__ __forceinline__ u32x4 bf16_pack_a(float x0, float x1) {
-    const uint32_t h0 = cvt_pk_bf16(x0, x0), h1 = cvt_pk_bf16(x1, x1);                   // (hi, hi)
-    const float r0 = x0 - __builtin_bit_cast(float, h0 << 16), r1 = x1 - __builtin_bit_cast(float, h1 << 16);
-    const uint32_t l0 = cvt_pk_bf16(r0, r0), l1 = cvt_pk_bf16(r1, r1);                    // (lo, lo)
-    const uint32_t d0 = (h0 & 0xffffu) | (l0 << 16), d1 = (h1 & 0xffffu) | (l1 << 16);    // (hi, lo)
-    return u32x4{d0, d0, d1, d1};
-}
-__device__ __forceinline__ u32x4 bf16_pack_b(float y0, float y1) {
-    const uint32_t h0 = cvt_pk_bf16(y0, y0), h1 = cvt_pk_bf16(y1, y1);                   // (hi, hi)
-    const float r0 = y0 - __builtin_bit_cast(float, h0 << 16), r1 = y1 - __builtin_bit_cast(float, h1 << 16);
-    return u32x4{h0, cvt_pk_bf16(r0, r0), h1, cvt_pk_bf16(r1, r1)};                       // (hi, hi), (lo, lo)
-}
-
 // XCD-aware workgroup order.  The dispatcher places workgroup L on XCD L % 8, each with a private 4 MiB L2
 // (MI355X_MICROARCH.md, workgroup dispatch).  Neighbouring strip tiles of one image share every 128-byte
 // line of the column branch (a tile only uses 4*NS bytes of it), so they must sit on the SAME XCD or each

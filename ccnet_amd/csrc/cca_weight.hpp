@@ -34,8 +34,8 @@ __host__ __device__ constexpr int w_lds_floats(int ns) { return 6 * w_op(ns); } 
 
 // FULL: compile-time shape -- all 7x7 tiles, every DMA piece issued (strips at least kFullMinStrip long, see
 //       cca_common.hpp) -> counted-vmcnt pipeline, no per-tile guards in the hot loop
-// BF: packed split-bf16 (one v_mfma_f32_16x16x32_bf16 per tile and 8-channel chunk, see bf16_pack_a/b) instead
-//     of two exact f32 k-steps
+// BF: always false since round 4 (the packed split-bf16 variant spilled 126 VGPRs and was retired; the parameter stays so
+//     that the launch code keeps its shape)
 template <int NS, bool ROW, bool MASK, bool FULL, bool BF>
 __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, const float *__restrict__ X,
                                                   const float *__restrict__ Y, float *__restrict__ T,
@@ -115,30 +115,6 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
         if (active) {
             const float *xs = lds + (bcur * 2 + 0) * OP + fr;
             const float *ys = lds + (bcur * 2 + 1) * OP + fr;
-            if constexpr (BF) {
-                // lane (position l & 15, k group l >> 4) carries channels 2 (l >> 4) and 2 (l >> 4) + 1 of the chunk
-                const int cpair = (2 * lk - lk) * CP;                    // fr already holds lk * CP
-                const bool kin0 = c_begin + n * W_KC + 2 * lk < Cx, kin1 = c_begin + n * W_KC + 2 * lk + 1 < Cx;
-                u32x4 af[kMaxTiles];
-#pragma unroll
-                for (int t = 0; t < kMaxTiles; ++t)
-                    if (CCA_TILE_ON(t)) {
-                        const float x0 = CCA_LDS_LD(xs + cpair + t * tstep), x1 = CCA_LDS_LD(xs + cpair + CP + t * tstep);
-                        af[t] = bf16_pack_a(kin0 ? x0 : 0.f, kin1 ? x1 : 0.f);
-                    }
-#pragma unroll
-                for (int rn = 0; rn < kMaxTiles; ++rn) {
-#pragma unroll
-                    for (int q = rn * QT / kMaxTiles; q < (rn + 1) * QT / kMaxTiles; ++q) dma_piece(q, c1, bnext);
-                    if (CCA_TILE_ON(rn)) {
-                        const float y0 = CCA_LDS_LD(ys + cpair + rn * tstep), y1 = CCA_LDS_LD(ys + cpair + CP + rn * tstep);
-                        const u32x4 bb = bf16_pack_b(y0, y1);
-#pragma unroll
-                        for (int rm = 0; rm < kMaxTiles; ++rm)
-                            if (CCA_TILE_ON(rm)) acc[rm][rn] = mfma_bf16_16x16x32(af[rm], bb, acc[rm][rn]);
-                    }
-                }
-            } else {
 #pragma unroll
             for (int ks = 0; ks < W_KC / 4; ++ks) {
                 const bool kin = c_begin + n * W_KC + ks * 4 + lk < Cx;   // channels beyond Cx hold clamped data: zero A
@@ -161,7 +137,6 @@ __device__ __forceinline__ void weight_strip_body(float *lds, int b, int tile, c
                             if (CCA_TILE_ON(rm)) acc[rm][rn] = mfma_16x16x4(a[rm], bb, acc[rm][rn]);
                     }
                 }
-            }
             }
         } else {
             issue(c1, bnext);                 // strips outside the image still own DMA channels

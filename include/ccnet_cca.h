@@ -62,15 +62,14 @@ extern "C" {
  * they compute the energies in exact fp32 and EVERY other contraction (dq / dk included) as split-bf16 x3 -- callers that
  * pin CCNET_PRECISION_F32 or CCNET_IMPL_DIRECT for validation must call the strip / direct entry points; the Python module
  * reads the two knobs (ccnet_cca_get_option) and routes accordingly.
- * The three C-sized contractions of the strip family may split
- * every fp32 operand into bf16 hi + lo and evaluate the products on the bf16 matrix pipe with fp32 accumulation
- * (relative error ~2^-17 per product; measured max-abs error at (8,512,97,97): 2e-4 on dq/dk, 3e-5 on y/dv,
- * inside the 1e-3 fp32 parity bar):
+ * The two aggregation-type contractions of the strip family (ca_map_forward, ca_map_backward's dv) may split every fp32 operand
+ * into bf16 hi + lo and evaluate the products on the bf16 matrix pipe with fp32 accumulation (relative error ~2^-17 per product;
+ * measured max-abs error at (8,512,97,97): 3e-5 on y / dv, inside the 1e-3 fp32 parity bar); its affinity, dA and dq / dk kernels
+ * are exact fp32 in every mode (round 4 retired the packed split-bf16 dA kernel: it spilled 126 VGPRs):
  *   F32      exact fp32 everywhere
- *   DEFAULT  split-bf16 in ca_map_backward's dA kernel (matrix-pipe bound in f32) and in the ROW launches of the
- *            aggregation kernels; exact fp32 in their column launches (no gain there)
- *   BF16X3   split-bf16 in every kernel that has such a variant
- * The split variants exist for strips 97..100 long (aggregation) / any shape (dA); other shapes run exact fp32. */
+ *   DEFAULT  split-bf16 in the ROW launches of the aggregation kernels; exact fp32 in their column launches (no gain there)
+ *   BF16X3   split-bf16 in both launches of the aggregation kernels
+ * The split variants exist for strips 97..100 long; other shapes run exact fp32. */
 #define CCNET_PRECISION_F32     0
 #define CCNET_PRECISION_BF16X3  1
 #define CCNET_PRECISION_DEFAULT 2

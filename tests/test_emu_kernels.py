@@ -224,7 +224,7 @@ def test_split_bf16_option_at_97(ops):
     ops.set_impl(MFMA)
     prev = 0
     try:
-      for prec in (2, 1):        # 2 = default (packed split-bf16 in the dA kernel only), 1 = split-bf16 everywhere it exists
+      for prec in (2, 1):        # 2 = default (split-bf16 in the row launches of the aggregation kernels), 1 = in both launches
         ops.lib.ccnet_cca_set_precision(prec)
         for shape, seed in (((1, 32, 97, 97), 3), ((1, 16, 100, 98), 4), ((2, 24, 17, 20), 5)):
             c = rand_case(*shape, seed=seed)
