@@ -51,6 +51,9 @@ std::atomic<int> g_planes_overlap{-1};
 // "planes_xcd" 1 (default): the final NCHW row pass of the split-plane forward decodes its strips from an XCD-aware id (consecutive
 // rows of an image on ONE XCD): the 388-byte NCHW rows of x / y share every boundary line with their neighbour row
 std::atomic<int> g_planes_xcd{1};
+// "dqdk_exact" 1: ca_backward of the fp32 pixel-major / split-plane routes (strips <= 100) multiplies in exact fp32 instead of
+// split-bf16 x3: dq / dk errors drop to those of the upstream dA contraction (2e-4 at the headline shape) for +25 us per launch
+std::atomic<int> g_dqdk_exact{0};
 
 int fail(int code, const char *what) {
     char buf[256];
@@ -815,11 +818,27 @@ int launch_gmap_dual_pm(const float *dE, const FT *k, const FT *q, FT *dq, FT *d
     const GmapPlan gc = gmap_plan(B * W, Cq), gr = gmap_plan(B * H, Cq);
     cca::GmapJob<FT, float> jc{q, nullptr, pk, qbs, pbs, qps, Cq, gc.grid};
     jc.red_src = red.src; jc.red_n = red.n; jc.red_dst = red.dst;
+    constexpr bool F32 = std::is_same<FT, float>::value;
+    const bool exact = F32 && g_dqdk_exact.load() != 0;
+    if constexpr (F32) {
+        if (exact)
+            CCA_LAUNCH((cca::gmap_kernel<P, false, false, false, FT, float, false, true, 2, false, true>), dim3(cca::gmap_dual_grid(gc.grid)),
+                       dim3(cca::GS_THREADS), stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W,
+                       kbs, kps, 0L, 0, 0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
+    }
+    if (!exact)
     CCA_LAUNCH((cca::gmap_kernel<P, false, false, false, FT, float, false, true>), dim3(cca::gmap_dual_grid(gc.grid)), dim3(cca::GS_THREADS),
                stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
                0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
     if (int e = launch_status("gmap_dual_pm(column)")) return e;
     const cca::GmapJob<FT, FT> jr{q, pk, dk, qbs, dkbs, qps, dkps, gr.grid};
+    if constexpr (F32) {
+        if (exact)
+            CCA_LAUNCH((cca::gmap_kernel<P, true, false, true, FT, FT, false, true, 2, false, true>), dim3(cca::gmap_dual_grid(gr.grid)),
+                       dim3(cca::GS_THREADS), stream, dE, k, (const float *)pq, (const FT *)nullptr, (const float *)nullptr, dq, Cq, H, W,
+                       kbs, kps, pbs, Cq, 0L, 0, dqbs, dqps, gr.n_whole, gr.split, jr);
+    }
+    if (!exact)
     CCA_LAUNCH((cca::gmap_kernel<P, true, false, true, FT, FT, false, true>), dim3(cca::gmap_dual_grid(gr.grid)), dim3(cca::GS_THREADS),
                stream, dE, k, (const float *)pq, (const FT *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
                0L, 0, dqbs, dqps, gr.n_whole, gr.split, jr);
@@ -1389,6 +1408,7 @@ const OptionRange *find_word_option(const std::string &n) {
         {"planes_stream", &g_planes_stream, 0, 1 << 20},
         {"planes_overlap", &g_planes_overlap, -1, 2},
         {"planes_xcd", &g_planes_xcd, 0, 1},
+        {"dqdk_exact", &g_dqdk_exact, 0, 1},
     };
     for (const OptionRange &o : table)
         if (n == o.name) return &o;

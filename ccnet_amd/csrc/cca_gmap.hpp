@@ -212,7 +212,8 @@ inline unsigned gmap_dual_grid(int nwg) { return 16u * (unsigned)((nwg + 7) / 8)
 
 // WPC: workgroups per CU the LDS budget is checked for (2 everywhere except the 132-position kernels on fp32 / split-plane
 // features, whose two feature tiles + output image take 104 KB: one workgroup per CU)
-template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT, bool NCHW = false, bool DUAL = false, int WPC = 2, bool LONG = false>
+template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT, bool NCHW = false, bool DUAL = false, int WPC = 2, bool LONG = false,
+          bool EXACT_F32 = false>
 __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__restrict__ T, const FT *__restrict__ F,
                                                               const float *__restrict__ addend,
                                                               const OT *__restrict__ resid,
@@ -222,6 +223,15 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                                                               GmapJob<FT, OT> j1) {
     constexpr bool BF = GTile<FT>::BF, OBF = std::is_same<OT, bf16_t>::value;
     constexpr bool PL = std::is_same<FT, bf16p_t>::value;             // split planes: hi tile | lo tile, T16 geometry
+    // EXACT_F32 (option "dqdk_exact"): ca_backward on fp32 q | k multiplies in exact fp32 (v_mfma_f32_16x16x4_f32, a fmaf chain).
+    // As split-bf16 x3 (the default) these two launches put 5.5e-4 of the 1e-3 parity budget on dq at the headline shape and leave
+    // the absolute bar at ~2 x the default logit scale (tests: logit-scale sweep); exact, they take 66 us each instead of 41 us
+    // (profiles/r04q_ab_exact_dqdk.txt) -- a 4.7 x longer matrix phase on launches with one channel group per strip.  The
+    // contraction runs in the order k = 16 j + 4 lg + e (j: block of 16 positions, lg: the lane's k group, e < 4), so that a
+    // non-transposed lane still loads its attention values 16 bytes at a time.
+    static_assert(!EXACT_F32 || (DUAL && !BF && !PL), "gmap: the exact-f32 form exists for ca_backward on fp32 features");
+    constexpr bool EXACT = EXACT_F32;
+    constexpr int NKB = (P + 15) / 16, NKF = EXACT ? 4 * NKB : 1;
     constexpr int TSP = t16_size(P);
     const int dual_id = (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7));
     const bool job1 = DUAL && ((blockIdx.x >> 3) & 1) != 0;           // (wave-uniform)
@@ -324,10 +334,35 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
 
     // ---- the strip's attention block -> MFMA fragments in registers.  Fragment (tile t, k-step ks) of lane (ln, lg):
     // ---- P_g[m][32 ks + 8 lg + e] (TRANS: P_g[32 ks + 8 lg + e][m]), m = 16 t + ln, e < 8; zero beyond the strip
-    u32x4 ah[TPW][NKS], al[TPW][NKS];
+    u32x4 ah[TPW][EXACT ? 1 : NKS], al[TPW][EXACT ? 1 : NKS];
     float at[TPW];
+    float af[TPW][NKF];                                               // EXACT: the block's values in contraction order
+    if constexpr (EXACT) {
 #pragma unroll
-    for (int a = 0; a < TPW; ++a) {
+        for (int a = 0; a < TPW; ++a) {
+            const int t = wv + GS_WAVES * a, m = 16 * t + ln;
+#pragma unroll
+            for (int j = 0; j < NKB; ++j) {
+                const int k0 = 16 * j + 4 * lg;
+                if (16 * j < Lk && 16 * t < Lm) {                     // wave-uniform
+                    if (!trans) {
+                        const f32x4 u = fbuf_load_x4(Tb, (m < Lm && k0 < Lk) ? ((pixM + m * pstep) * S + aK + k0) * 4 : kOobOffset, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) af[a][4 * j + e] = k0 + e < Lk ? u[e] : 0.f;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            af[a][4 * j + e] = fbuf_load(Tb, (m < Lm && k0 + e < Lk) ? ((pixK + (k0 + e) * pstep) * S + aM + m) * 4 : kOobOffset, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) af[a][4 * j + e] = 0.f;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < (EXACT ? 0 : TPW); ++a) {
         const int t = wv + GS_WAVES * a, m = 16 * t + ln;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
@@ -416,8 +451,29 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
             for (int a = 0; a < TPW; ++a)
 #pragma unroll
                 for (int n = 0; n < NTH; ++n) acc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (EXACT) {
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
+                for (int j = 0; j < NKB; ++j) {
+                    if (16 * j < Lk) {                                // wave-uniform
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int pos = 16 * j + 4 * lg + e;
+#pragma unroll
+                            for (int n = 0; n < NTH; ++n) {
+                                const int nt = nh * NTH + n;
+                                const float raw = CCA_LDS_LD(img + gtile_f32_idx(pos < 4 * NPF ? pos : 0, 16 * nt + ln));
+                                const float fbv = pos < Lk ? raw : 0.f;        // (beyond the strip: never a stale or non-finite value)
+#pragma unroll
+                                for (int a = 0; a < TPW; ++a)
+                                    if ((wv + GS_WAVES * a) * 16 < Lm) acc[a][n] = mfma_16x16x4(fbv, af[a][4 * j + e], acc[a][n]);
+                            }
+                        }
+                    }
+                }
+                mfma_f32_result_fence();
+            }
+#pragma unroll
+            for (int ks = 0; ks < (EXACT ? 0 : NKS); ++ks) {
                 if (ks < kp.nbf) {
 #pragma unroll
                     for (int n = 0; n < NTH; ++n) {
@@ -450,7 +506,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                     }
                 }
             }
-            if (kp.tail) {
+            if (!EXACT && kp.tail) {
                 const int pos = 32 * kp.nbf + lg;
 #pragma unroll
                 for (int n = 0; n < NTH; ++n) {

@@ -298,7 +298,12 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
  *                    dq | dk; 1 next to softmax-backward and dq | dk only; 0 everything on ``stream``; -1 (default) what
  *                    measured best per family (2 on split planes, 1 on the bf16 / fp32 pixel-major entries).
  *   "planes_xcd"   1 (default): the NCHW row pass of the split-plane forward decodes its strips XCD-aware (consecutive rows of an
- *                    image on one XCD, whose L2 then merges the boundary lines neighbouring NCHW rows share); 0: linear. */
+ *                    image on one XCD, whose L2 then merges the boundary lines neighbouring NCHW rows share); 0: linear.
+ *   "dqdk_exact"   1: ca_backward of the fp32 pixel-major / split-plane entry points (strips <= 100) multiplies in exact fp32
+ *                    (v_mfma_f32_16x16x4_f32) instead of split-bf16 x3 -- for callers whose logits are hotter than the default
+ *                    initialisation's: with q, k ~ N(0, s^2) at C/8 = 64 the default arithmetic keeps max |d dq| <= 1e-3 up to
+ *                    s ~ 1.5 (5.5e-4 at s = 1; everywhere ~1e-5 of max |dq|: it is a relative error), the exact form up to
+ *                    s ~ 3; +25 us per launch at (8,512,97,97).  0 (default). */
 int ccnet_cca_set_option(const char *name, int value, int *previous);
 int ccnet_cca_get_option(const char *name, int *value);
 

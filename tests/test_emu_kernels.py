@@ -749,3 +749,32 @@ def test_plane_free_form_is_bit_identical_to_the_plane_form(ops, shape):
     with pytest.raises(RuntimeError):            # the plane-free form stops at 100 positions
         big = np.zeros((1, 101, 2, 2 * cq + C), np.float32)
         ops.cca_forward_planes(big, None, np.zeros((1, C, 101, 2), np.float32), c["gamma"], cq)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 96, 17, 20), (1, 64, 3, 97), (1, 64, 100, 3)])
+def test_exact_f32_ca_backward_option(ops, shape):
+    """Option "dqdk_exact": ca_backward of the fp32 pixel-major / split-plane routes in exact fp32 (v_mfma_f32_16x16x4_f32, the
+    contraction in blocks of 16 positions): dq / dk against the oracle noticeably tighter than the split-bf16 default's bar, dv and
+    dgamma untouched (bit-identical), and the default restored afterwards."""
+    B, C, H, W = shape
+    cq = C // 8
+    c = rand_case(*shape, seed=77)
+    qkv = np.ascontiguousarray(np.concatenate([_pm(c["q"]), _pm(c["k"]), _pm(c["v"])], axis=3))
+    y, A = ops.cca_forward_planes(qkv, None, c["x"], c["gamma"], cq)
+    ref = ops.cca_backward_planes(c["dy"], qkv, None, A, c["gamma"], cq)
+    prev = ops.lib.set_option("dqdk_exact", 1)
+    try:
+        got = ops.cca_backward_planes(c["dy"], qkv, None, A, c["gamma"], cq)
+        got_pm = ops.cca_backward_pm_bf16(_pm(c["dy"]), qkv, A, c["gamma"], cq)          # (fp32 qkv: the pixel-major fp32 entry points)
+    finally:
+        ops.lib.set_option("dqdk_exact", prev)
+    assert prev == 0 and ops.lib.get_option("dqdk_exact") == 0
+    yo, Ao = O.cca_core_forward(T(c["q"]), T(c["k"]), T(c["v"]), T(c["x"]), T(c["gamma"]))
+    go = O.cca_core_backward(T(c["dy"]), T(c["q"]), T(c["k"]), T(c["v"]), Ao, T(c["gamma"]))
+    nchw = lambda a: np.transpose(a, (0, 3, 1, 2))                                 # noqa: E731
+    assert np.array_equal(got[0][..., 2 * cq:], ref[0][..., 2 * cq:]) and np.array_equal(got[1], ref[1])
+    for dq in (got[0], got_pm[0]):
+        for name, sl in (("dq", slice(0, cq)), ("dk", slice(cq, 2 * cq))):
+            e_exact = maxerr(nchw(dq[..., sl]), go[name].numpy())
+            e_split = maxerr(nchw(ref[0][..., sl]), go[name].numpy())
+            assert e_exact < 2e-4 * max(1.0, float(go[name].abs().max())) and e_exact <= e_split * 1.5 + 1e-6, (name, e_exact, e_split)

@@ -518,7 +518,8 @@ def test_split_plane_module_node_matches_the_oracle_and_the_other_nodes(lib, dev
             assert e < bars[n.split(".")[-1]], (variant, n, e)
 
 
-def test_split_plane_core_logit_scale_sweep_at_the_headline_geometry(lib, dev):
+@pytest.mark.parametrize("exact", [0, 1])
+def test_split_plane_core_logit_scale_sweep_at_the_headline_geometry(lib, dev, exact):
     """where does the default arithmetic (split-bf16 x3 everywhere but the energies) leave the 1e-3 bar?
     q, k ~ N(0, s^2) at C/8 = 64 channels give logits of standard deviation 8 s^2: s = 1 is already a peaky softmax, trained
     CCNet logits are not bounded by it.  One image of (.,512,97,97) through the split-plane C ABI per scale; max-abs error of
@@ -532,8 +533,12 @@ def test_split_plane_core_logit_scale_sweep_at_the_headline_geometry(lib, dev):
     for s in (1.0, 1.5, 2.0, 3.0):
         wl = bench.PlanesWorkload(lib, B, C, H, W, dev, 99)
         wl.qkv[..., :2 * cq] *= s
-        wl.step()
-        torch.cuda.synchronize()
+        prev = lib.set_option("dqdk_exact", exact)          # 1: ca_backward in exact fp32 (include/ccnet_cca.h)
+        try:
+            wl.step()
+            torch.cuda.synchronize()
+        finally:
+            lib.set_option("dqdk_exact", prev)
         q, k, v = nchw(wl.qkv[..., :cq]), nchw(wl.qkv[..., cq:2 * cq]), nchw(wl.qkv[..., 2 * cq:])
         yo, Ao = O.cca_core_forward(q, k, v, wl.x.cpu(), torch.tensor([0.5]))
         go = O.cca_core_backward(wl.dy.cpu(), q, k, v, Ao, torch.tensor([0.5]))
@@ -543,7 +548,7 @@ def test_split_plane_core_logit_scale_sweep_at_the_headline_geometry(lib, dev):
         assert err(wl.A, Ao) < TIGHT
         del wl
     for s, r in rows.items():
-        print(f"logit-scale sweep: q, k x {s}: max-abs (relative to |ref|max)", {n: f"{a:.1e} ({b:.1e})" for n, (a, b) in r.items()})
+        print(f"logit-scale sweep (dqdk_exact = {exact}): q, k x {s}: max-abs (relative to |ref|max)", {n: f"{a:.1e} ({b:.1e})" for n, (a, b) in r.items()})
     # the absolute north_star bar holds at the reference's own initialisation scale and one step beyond; everywhere the error
     # stays a fixed fraction of the gradient's magnitude (that is what the arithmetic bounds) -- include/ccnet_cca.h states it
     for s in (1.0, 1.5):
