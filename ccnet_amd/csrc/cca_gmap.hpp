@@ -1191,6 +1191,14 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
     };
     // result stores this wavefront issues for a strip of length L: one per (owned tile row, q, key tile) that has a lane in range
     auto nstores = [&](int L) {
+        if constexpr (YF) {                                                 // (fp32 Y: a wavefront owns a COLUMN of tiles, see the multiply)
+            int rows = 0;
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rows += 16 * ti + q < L ? 1 : 0;
+            return 16 * wv < L ? rows : 0;
+        }
         int rows = 0;
 #pragma unroll
         for (int a = 0; a < NTR; ++a)
@@ -1235,25 +1243,29 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
         }
         const int L = cur.L;
         const float *xh = lds + (n % NBUF) * STG, *xl = xh + (NPL - 1) * TSB, *yh = xh + NPL * TSB, *yl = yh + (NPL - 1) * TSB;
-        if constexpr (YF) {
-            // the landed fp32 Y tile -> bf16 hi | lo IN PLACE, each value split ONCE (eight wavefronts read every Y fragment: split
-            // per fragment read, the vector pipe became the bound -- 203 us against 155 us with planes).  A thread owns whole
-            // (position, 8-channel) items: 32 bytes in, the hi chunk and the lo chunk out to the same 32 bytes -- no thread reads
-            // what another writes, one barrier hands the converted tile to the multiply.
-            float *yt = lds + (n % NBUF) * STG + NPL * TSB;
-            for (int it = tid; it < 4 * NPY * 8; it += GM_THREADS) {
-                const int j = it >> 3, q8 = it & 7;
-                float *p0 = yt + f32t_idx(j, 8 * q8), *p1 = yt + f32t_idx(j, 8 * q8 + 4);
-                const f32x4 u = lds_load_x4(p0), v = lds_load_x4(p1);
-                const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
-                const BfSplit sp = bf16_split8(x);
-                lds_store_x4(p0, __builtin_bit_cast(f32x4, sp.hi));
-                lds_store_x4(p1, __builtin_bit_cast(f32x4, sp.lo));
-            }
-            barrier_lds_only();
-        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {                                    // two k-steps of 32 channels
+            if constexpr (YF) {
+                // fp32 Y: the wavefront owns the COLUMN of tiles over key tile wv -- acc[0][ti] = (query tile ti, key tile wv) -- so it
+                // splits ONE Y fragment per k-step in registers (its own key tile: 2 x 16 bytes out of LDS, v_cvt_pk + subtract) and
+                // reads the seven X fragments as plane chunks.  (Owning a ROW of tiles, as the plane form does, every wavefront
+                // splits all seven Y fragments: 203 us against 155 us; splitting the tile once in LDS in place: 179 us.)
+                static_assert(!YF || NT <= GM_WAVES, "gweight_stream: one key tile per wavefront");
+                const int pos = 16 * wv + ln < 4 * NPY ? 16 * wv + ln : 0, c = 32 * kk + 8 * lg;
+                const f32x4 u = lds_load_x4(yh + f32t_idx(pos, c)), v = lds_load_x4(yh + f32t_idx(pos, c + 4));
+                const float yx[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+                const BfSplit sp = bf16_split8(yx);
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) {
+                    if (ti * 16 < L && wv * 16 < L) {
+                        const u32x4 xa = frag(xh, 16 * ti + ln, kk), xb = frag(xl, 16 * ti + ln, kk);
+                        acc[0][ti] = mfma_bf16_16x16x32(xa, sp.hi, acc[0][ti]);
+                        acc[0][ti] = mfma_bf16_16x16x32(xa, sp.lo, acc[0][ti]);
+                        acc[0][ti] = mfma_bf16_16x16x32(xb, sp.hi, acc[0][ti]);
+                    }
+                }
+                continue;
+            }
             u32x4 ah[NTR], al[NTR];
 #pragma unroll
             for (int a = 0; a < NTR; ++a) {
@@ -1264,11 +1276,7 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
             for (int t = 0; t < NT; ++t) {
                 if (t * 16 < L) {
                     u32x4 bh, bl;
-                    if constexpr (YF) {           // (converted in place above: the hi chunk, and next to it the lo chunk)
-                        const int pos = 16 * t + ln < 4 * NPY ? 16 * t + ln : 0, c = 32 * kk + 8 * lg;
-                        bh = __builtin_bit_cast(u32x4, lds_load_x4(yh + f32t_idx(pos, c)));
-                        bl = __builtin_bit_cast(u32x4, lds_load_x4(yh + f32t_idx(pos, c + 4)));
-                    } else {
+                    {
                         bh = frag(yh, 16 * t + ln, kk);
                         bl = bh;
                         if constexpr (NPL == 2) bl = frag(yl, 16 * t + ln, kk);
@@ -1288,8 +1296,19 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
         if (ch == nch - 1) {
             // D[m = query position 16 ti + 4 lg + q][n = key position 16 t + ln] -> T rows (64-byte runs per query)
             const FBuf Tb = make_fbuf(T + (size_t)cur.b * HW * S, (size_t)HW * S * sizeof(float));
+            if constexpr (YF) {                 // acc[0][ti]: query tile ti x key tile wv
 #pragma unroll
-            for (int a = 0; a < NTR; ++a)
+                for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (16 * wv < L && 16 * ti + q < L) {               // (wave-uniform: lane (ln, lg) = (0, 0) is in range)
+                            const int i = 16 * ti + 4 * lg + q, j = 16 * wv + ln;
+                            fbuf_store(Tb, acc[0][ti][q], (i < L && j < L) ? ((cur.pix0 + i * cur.pstep) * S + cur.a_off + j) * 4 : kOobOffset, 0);
+                        }
+                    }
+            }
+#pragma unroll
+            for (int a = 0; a < (YF ? 0 : NTR); ++a)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (16 * (wv + GM_WAVES * a) + q < L) {                 // (wave-uniform: lanes lg = 0 are in range)
