@@ -53,10 +53,11 @@ for B in (1, 2, 4):
     for _ in range(3):
         one(m)
     t_eager = bench.time_region(lambda: one(m), 30)
+    rec = lib.profile_launches(lambda: one(m))      # (before graph_module: make_graphed_callables replaces m.forward)
+    torch.cuda.synchronize()
     g = graph_module(m, x.detach().clone().requires_grad_(True))
     for _ in range(3):
         one(g)
     t_graph = bench.time_region(lambda: one(g), 30)
-    rec = lib.profile_launches(lambda: one(m))
     print(f"B={B}: default module fwd+bwd eager {t_eager:.3f} ms | graphed (ccnet_amd.graph_module) {t_graph:.3f} ms | the library's own "
           f"{len(rec)} launches sum to {sum(t for _, t in rec):.3f} ms (the GEMMs and reductions of the projections are torch's)", flush=True)
