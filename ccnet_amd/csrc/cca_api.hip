@@ -1024,12 +1024,14 @@ int check_planes_view(const char *what, long bs, int ps, int C, int H, int W, in
     if ((double)H * W * ps >= 1073741824.0) return fail(CCNET_E_BADSHAPE, what);            /* 2-byte elements, 31-bit offsets */
     return 0;
 }
-// ``long_rows``: the forward also takes ROW strips of 133 .. 528 positions (columns <= 132) as 2 .. 4 blocks (cca::long_block)
-int check_planes_problem(const char *what, int B, int C, int Cq, int H, int W, bool long_rows = false) {
+// ``long_strips``: the entry point also takes strips of 133 .. 528 positions -- rows, columns or both -- as 2 .. 4 blocks
+// (cca::long_block)
+int check_planes_problem(const char *what, int B, int C, int Cq, int H, int W, bool long_strips = false) {
     if (int e = check_shape(B, C, H, W)) return e;
     if (int e = check_shape(B, Cq, H, W)) return e;
-    if (H > 132 || W > (long_rows ? 4 * 132 : 132) || C % 8 || Cq % 4) return fail(CCNET_E_BADSHAPE, what);
-    if (W > 132 && Cq > cca::GM_CG) return fail(CCNET_E_BADSHAPE, what);       /* (the blocked energies kernel: one 64-channel chunk) */
+    const int lim = long_strips ? 4 * 132 : 132;
+    if (H > lim || W > lim || C % 8 || Cq % 4) return fail(CCNET_E_BADSHAPE, what);
+    if ((W > 132 || H > 132) && Cq > cca::GM_CG) return fail(CCNET_E_BADSHAPE, what);   /* (the blocked energies kernel: one 64-channel chunk) */
     return 0;
 }
 inline int long_blocks(int L) { return (L + 131) / 132; }
@@ -1075,12 +1077,25 @@ int launch_gmap3_planes(const float *T, const bf16p_t *F, const float *gamma, fl
     return launch_status("gmap3_planes(row)");
     }
 }
+// the row pass of whole row strips (<= P positions): adds the column partial (+ the NCHW residual) and writes the output
+template <int P, bool TRANS, bool NCHW>
+int launch_gmap_planes_row_p(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
+                             int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
+    constexpr int WPC = P > 100 ? 1 : 2;
+    const long pbs = (long)H * W * C;
+    const GmapPlan gr = gmap_plan(B * H, C, WPC);
+    cca::GmapJob<bf16p_t, float> job{};
+    if (NCHW && g_planes_xcd.load() && (B * H) % 8 == 0 && gr.n_whole % 8 == 0) job.xcd = B * H / 8;
+    CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, bf16p_t, float, NCHW, false, WPC>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS),
+               stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C, rbs, rps, obs, ops,
+               gr.n_whole, gr.split, job);
+    return launch_status("gmap_planes(row)");
+}
 template <int P, bool TRANS, bool NCHW>
 int launch_gmap_planes_p(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
                          int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
-    constexpr int WPC = P > 100 ? 1 : 2;
     const long pbs = (long)H * W * C;
-    const GmapPlan gc = gmap_plan(B * W, C), gr = gmap_plan(B * H, C, WPC);
+    const GmapPlan gc = gmap_plan(B * W, C);
     const int ring = P > 100 ? 2 : g_planes_ring.load();
     if (ring) {
         if (int e = launch_gmap3_planes<P, TRANS>(T, F, gamma, out, partial, B, C, H, W, fbs, fps, obs, ops, !NCHW, stream)) return e;
@@ -1093,15 +1108,10 @@ int launch_gmap_planes_p(const float *T, const bf16p_t *F, const float *resid, c
             if (int e = launch_status("gmap_planes(column)")) return e;
         }
     }
-    cca::GmapJob<bf16p_t, float> job{};
-    if (NCHW && g_planes_xcd.load() && (B * H) % 8 == 0 && gr.n_whole % 8 == 0) job.xcd = B * H / 8;
-    CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, bf16p_t, float, NCHW, false, WPC>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS),
-               stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C, rbs, rps, obs, ops,
-               gr.n_whole, gr.split, job);
-    return launch_status("gmap_planes(row)");
+    return launch_gmap_planes_row_p<P, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
 }
-// aggregation (or its dv adjoint, TRANS) with LONG rows (133 .. 528 positions, columns <= 132): the column pass as ever (its
-// strips are columns); the row pass as nb launches, one per block of the CONTRACTED positions: partial += gamma * (attention
+// aggregation (or its dv adjoint, TRANS) with LONG rows (133 .. 528 positions), after the column pass has left its fp32 partial:
+// the row pass as nb launches, one per block of the CONTRACTED positions: partial += gamma * (attention
 // block) . (feature block) in place, the last one writes the output (NCHW: + the residual).  A workgroup owns one OUTPUT block of
 // a row strip.
 // P = 100 with blocks of <= 100 positions where four of them cover the row (W <= 400): the 100-position kernels keep their
@@ -1130,25 +1140,54 @@ int launch_gmap_planes_long_rows_p(const float *T, const bf16p_t *F, const float
     }
     return 0;
 }
-template <bool TRANS, bool NCHW>
-int launch_gmap_planes_long_rows(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
-                                 int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops,
-                                 ccnet_stream_t stream) {
-    if (int e = launch_gmap3_planes<132, TRANS>(T, F, gamma, out, partial, B, C, H, W, fbs, fps, 0L, 0, false, stream)) return e;
-    if (W <= 400)
-        return launch_gmap_planes_long_rows_p<100, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
-    return launch_gmap_planes_long_rows_p<132, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+// LONG columns (133 .. 528 positions; round 4: maps whose BOTH sides exceed 132 -- the reference's multi-scale whole-image
+// evaluation, evaluate.py:146-166 at scales > 1 -- no longer fall to the windowed / any-shape strip kernels): the column pass as
+// nb launches of gmap_kernel, one per block of the contracted positions; the first one starts the partial, the others update it
+// in place.  A workgroup owns one OUTPUT block of a column strip.  Blocks of <= 100 positions (two workgroups per CU) up to 400.
+template <int P, bool TRANS>
+int launch_gmap_planes_long_cols_p(const float *T, const bf16p_t *F, const float *gamma, float *partial, int B, int C, int H, int W,
+                                   long fbs, int fps, ccnet_stream_t stream) {
+    constexpr int WPC = P > 100 ? 1 : 2;
+    const int nb = (H + P - 1) / P;
+    const long pbs = (long)H * W * C;
+    const GmapPlan gc = gmap_plan(B * W * nb, C, WPC);
+    for (int j = 0; j < nb; ++j) {
+        cca::GmapJob<bf16p_t, float> job{};
+        job.nb = nb;
+        job.jblk = j;
+        if (j == 0)
+            CCA_LAUNCH((cca::gmap_kernel<P, false, TRANS, false, bf16p_t, float, false, false, WPC, true>), dim3((unsigned)gc.grid),
+                       dim3(cca::GS_THREADS), stream, T, F, (const float *)nullptr, (const float *)nullptr, gamma, partial, C, H, W,
+                       fbs, fps, 0L, 0, 0L, 0, pbs, C, gc.n_whole, gc.split, job);
+        else
+            CCA_LAUNCH((cca::gmap_kernel<P, false, TRANS, true, bf16p_t, float, false, false, WPC, true>), dim3((unsigned)gc.grid),
+                       dim3(cca::GS_THREADS), stream, T, F, (const float *)partial, (const float *)nullptr, gamma, partial, C, H, W,
+                       fbs, fps, pbs, C, 0L, 0, pbs, C, gc.n_whole, gc.split, job);
+        if (int e = launch_status("gmap_planes(long columns)")) return e;
+    }
+    return 0;
 }
 template <bool TRANS, bool NCHW>
 int launch_gmap_planes(const float *T, const bf16p_t *F, const float *resid, const float *gamma, float *out, float *partial,
                        int B, int C, int H, int W, long fbs, int fps, long rbs, int rps, long obs, int ops, ccnet_stream_t stream) {
     // (rows of 101 .. 132 positions stay whole on the 132-position kernels: as two blocks on the 100-position ones the extra pass
     // over the partial costs more than the second workgroup per CU returns -- (16,512,129,129) 3.55 -> 3.70 ms, profiles/r04f_planes_129.txt)
-    if (W > 132)
-        return launch_gmap_planes_long_rows<TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
-    if ((H > W ? H : W) <= 100)
-        return launch_gmap_planes_p<100, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
-    return launch_gmap_planes_p<132, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+    if (H <= 132 && W <= 132) {
+        if ((H > W ? H : W) <= 100)
+            return launch_gmap_planes_p<100, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+        return launch_gmap_planes_p<132, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+    }
+    // column pass -> fp32 partial
+    int e;
+    if (H > 400)      e = launch_gmap_planes_long_cols_p<132, TRANS>(T, F, gamma, partial, B, C, H, W, fbs, fps, stream);
+    else if (H > 132) e = launch_gmap_planes_long_cols_p<100, TRANS>(T, F, gamma, partial, B, C, H, W, fbs, fps, stream);
+    else              e = launch_gmap3_planes<132, TRANS>(T, F, gamma, out, partial, B, C, H, W, fbs, fps, 0L, 0, false, stream);
+    if (e) return e;
+    // row pass(es): += the partial (+ the NCHW residual) -> the output
+    if (W > 400) return launch_gmap_planes_long_rows_p<132, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+    if (W > 132) return launch_gmap_planes_long_rows_p<100, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+    if (W > 100) return launch_gmap_planes_row_p<132, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
+    return launch_gmap_planes_row_p<100, TRANS, NCHW>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
 }
 // The forward aggregation on fp32 pixel-major v AS IT IS (strips <= 100): F32T tiles, hi | lo split per fragment -- no planes
 // tensor, no split pass.  Column strips -> fp32 partial (ring kernel, three workgroups per CU), row strips add it and the NCHW
@@ -1172,11 +1211,11 @@ int launch_gmap_direct_f32(const float *T, const float *v, const float *resid, c
 int gweight_energies_f32(const float *q, const float *k, float *A, int B, int Cq, int H, int W, long qbs, int qps, long kbs, int kps,
                          ccnet_stream_t stream) {
     if ((H > W ? H : W) <= 100) return gweight_pm<true, float>(q, k, A, B, Cq, H, W, qbs, qps, kbs, kps, stream);
-    if (W > 132) {          // long rows: nb x nb blocks per row strip, whole column strips
-        const int nb = long_blocks(W);
-        const dim3 grid((unsigned)(B * (W + H * nb * nb))), block(cca::GM_THREADS);
-        CCA_LAUNCH((cca::gweight_kernel<132, true, float, true, true>), grid, block, stream, q, k, A, Cq, H, W, qbs, qps, kbs, kps, nb);
-        return launch_status("gweight_energies(long rows)");
+    if (W > 132 || H > 132) {          // long strips: blocks x blocks tiles per strip of a branch that exceeds 132 positions
+        const int nb = long_blocks(W), nbc = long_blocks(H);
+        const dim3 grid((unsigned)(B * (W * nbc * nbc + H * nb * nb))), block(cca::GM_THREADS);
+        CCA_LAUNCH((cca::gweight_kernel<132, true, float, true, true>), grid, block, stream, q, k, A, Cq, H, W, qbs, qps, kbs, kps, nb, nbc);
+        return launch_status("gweight_energies(long strips)");
     }
     const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
     if (Cq <= cca::GM_CG) CCA_LAUNCH((cca::gweight_kernel<132, true, float, true>), grid, block, stream, q, k, A, Cq, H, W, qbs, qps, kbs, kps);
@@ -1190,13 +1229,35 @@ int gmap_dual_f32(const float *dE, const float *k, const float *q, float *dq, fl
         return gmap_dual_pm<float>(dE, k, q, dq, dk, partial, B, Cq, H, W, kbs, kps, qbs, qps, dqbs, dqps, dkbs, dkps, stream, red);
     const long pbs = (long)H * W * Cq;
     float *pq = partial, *pk = partial + (size_t)B * pbs;
-    const GmapPlan gc = gmap_plan(B * W, Cq, 1), gr = gmap_plan(B * H, Cq, 1);
-    cca::GmapJob<float, float> jc{q, nullptr, pk, qbs, pbs, qps, Cq, gc.grid};
-    jc.red_src = red.src; jc.red_n = red.n; jc.red_dst = red.dst;
-    CCA_LAUNCH((cca::gmap_kernel<132, false, false, false, float, float, false, true, 1>), dim3(cca::gmap_dual_grid(gc.grid)), dim3(cca::GS_THREADS),
-               stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
-               0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
-    if (int e = launch_status("gmap_dual_f32(column, 132)")) return e;
+    const GmapPlan gr = gmap_plan(B * H, Cq, 1);
+    if (H > 132) {          // long columns: one launch per block of the contracted positions; the first starts the partials
+        const bool p100 = H <= 400;
+        const int nb = p100 ? (H + 99) / 100 : long_blocks(H);
+        const GmapPlan gl = gmap_plan(B * W * nb, Cq, p100 ? 2 : 1);
+        for (int j = 0; j < nb; ++j) {
+            cca::GmapJob<float, float> jl{q, j ? pk : nullptr, pk, qbs, pbs, qps, Cq, gl.grid, nb, j};
+            if (j == 0) { jl.red_src = red.src; jl.red_n = red.n; jl.red_dst = red.dst; }
+            const float *add = j ? pq : nullptr;
+            const long abs_ = j ? pbs : 0L;
+            const int aps = j ? Cq : 0;
+#define CCA_DUAL_COL(PP, ADD, WPC)                                                                                                    \
+            CCA_LAUNCH((cca::gmap_kernel<PP, false, false, ADD, float, float, false, true, WPC, true>), dim3(cca::gmap_dual_grid(gl.grid)), \
+                       dim3(cca::GS_THREADS), stream, dE, k, add, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, \
+                       abs_, aps, 0L, 0, pbs, Cq, gl.n_whole, gl.split, jl)
+            if (p100) { if (j) CCA_DUAL_COL(100, true, 2); else CCA_DUAL_COL(100, false, 2); }
+            else      { if (j) CCA_DUAL_COL(132, true, 1); else CCA_DUAL_COL(132, false, 1); }
+#undef CCA_DUAL_COL
+            if (int e = launch_status("gmap_dual_f32(long columns)")) return e;
+        }
+    } else {
+        const GmapPlan gc = gmap_plan(B * W, Cq, 1);
+        cca::GmapJob<float, float> jc{q, nullptr, pk, qbs, pbs, qps, Cq, gc.grid};
+        jc.red_src = red.src; jc.red_n = red.n; jc.red_dst = red.dst;
+        CCA_LAUNCH((cca::gmap_kernel<132, false, false, false, float, float, false, true, 1>), dim3(cca::gmap_dual_grid(gc.grid)), dim3(cca::GS_THREADS),
+                   stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
+                   0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
+        if (int e = launch_status("gmap_dual_f32(column, 132)")) return e;
+    }
     if (W > 132) {          // long rows: one launch per block of the contracted positions, the partials updated in place
         const bool p100 = W <= 400;          // (blocks of <= 100 positions on the two-workgroups-per-CU kernels, see launch_gmap_planes_long_rows)
         const int nb = p100 ? (W + 99) / 100 : long_blocks(W);
@@ -1281,7 +1342,7 @@ int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v,
                                  void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
     if (int e = require_both_branches("cca_forward_planes_f32")) return e;
     if (!q || !k || (!v_planes && !v) || !x || !gamma || !y || !A) return fail(CCNET_E_NULLPTR, "cca_forward_planes: null tensor");
-    if (int e = check_planes_problem("cca_forward_planes: columns <= 132, rows <= 528 (> 132: C/8 <= 64), C % 8 == 0, Cq % 4 == 0",
+    if (int e = check_planes_problem("cca_forward_planes: strips <= 528 positions (> 132: C/8 <= 64), C % 8 == 0, Cq % 4 == 0",
                                      B, C, Cq, H, W, true)) return e;
     const bool direct = !v_planes;                 // v stays the fp32 tensor it is: no planes, no split pass
     if (direct && ((H > W ? H : W) > 100 || v_bias))
@@ -1318,7 +1379,7 @@ int ccnet_cca_attention_pm(const void *q, const void *k, float *A, int bf16, int
         if (int e = check_pm_view<bf16_t>("cca_attention_pm: k view", k_bs, k_ps, Cq, H, W)) return e;
         if (int e = gweight_pm<true, bf16_t>((const bf16_t *)q, (const bf16_t *)k, A, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
     } else {
-        if (int e = check_planes_problem("cca_attention_pm: columns <= 132, rows <= 528 (> 132: C/8 <= 64), Cq % 4 == 0", B, 8 * Cq, Cq, H, W, true)) return e;
+        if (int e = check_planes_problem("cca_attention_pm: strips <= 528 positions (> 132: C/8 <= 64), Cq % 4 == 0", B, 8 * Cq, Cq, H, W, true)) return e;
         if (int e = check_pm_view<float>("cca_attention_pm: q view", q_bs, q_ps, Cq, H, W)) return e;
         if (int e = check_pm_view<float>("cca_attention_pm: k view", k_bs, k_ps, Cq, H, W)) return e;
         if (int e = gweight_energies_f32((const float *)q, (const float *)k, A, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
@@ -1337,7 +1398,7 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
     const bool direct = !v_planes;                 // v as the fp32 pixel-major tensor (what a plane-free forward leaves)
     if (direct && (H > W ? H : W) > 100)
         return fail(CCNET_E_BADSHAPE, "cca_backward_planes: the plane-free form (v_planes == NULL) serves strips <= 100");
-    if (int e = check_planes_problem("cca_backward_planes: columns <= 132, rows <= 528 (> 132: C/8 <= 64), C % 8 == 0, Cq % 4 == 0",
+    if (int e = check_planes_problem("cca_backward_planes: strips <= 528 positions (> 132: C/8 <= 64), C % 8 == 0, Cq % 4 == 0",
                                      B, C, Cq, H, W, true)) return e;
     if (int e = check_pm_view<float>("cca_backward_planes: q view", q_bs, q_ps, Cq, H, W)) return e;
     if (int e = check_pm_view<float>("cca_backward_planes: k view", k_bs, k_ps, Cq, H, W)) return e;
@@ -1363,12 +1424,12 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
     if (overlap == 2) sf.fork();
     // t = un-scaled dA (the adjoint of the aggregation, functions.py:46-47), dv = gamma * A^T-weighted dy
     int e = 0;
-    if (W > 132) {           // long rows: nb x nb (query block, key block) tiles per row strip
-        const int nb = long_blocks(W);
-        const dim3 grid((unsigned)(B * (W + H * nb * nb))), block(cca::GM_THREADS);
+    if (W > 132 || H > 132) {           // long strips: (query block, key block) tiles per strip
+        const int nb = long_blocks(W), nbc = long_blocks(H);
+        const dim3 grid((unsigned)(B * (W * nbc * nbc + H * nb * nb))), block(cca::GM_THREADS);
         CCA_LAUNCH((cca::gweight_kernel<132, false, bf16p_t, false, true>), grid, block, stream, dyp, vp, scratch, C, H, W, dbs, 2 * C,
-                   vp_bs, vp_ps, nb);
-        e = launch_status("gweight_planes(dA, long rows)");
+                   vp_bs, vp_ps, nb, nbc);
+        e = launch_status("gweight_planes(dA, long strips)");
     } else if ((H > W ? H : W) > 100) {
         const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
         CCA_LAUNCH((cca::gweight_kernel<132, false, bf16p_t, false>), grid, block, stream, dyp, vp, scratch, C, H, W, dbs, 2 * C, vp_bs, vp_ps);

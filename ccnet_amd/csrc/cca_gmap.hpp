@@ -253,7 +253,9 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     constexpr int CPI = P <= 128 ? 2 : 1, LPC = kWave / CPI;          // NCHW: channels per store instruction, lanes per channel (4 positions each)
     constexpr int NSX = GM_CG / CPI / GS_WAVES;                       // NCHW: store instructions per wave and group
     static_assert(!NCHW || (ROW && ADD && !OBF && !TRANS && !DUAL), "gmap: the NCHW epilogue belongs to the final fp32 row pass");
-    static_assert(!LONG || (ROW && ADD), "gmap: blocked long strips exist for the row passes (their addend chains the key blocks)");
+    // (LONG: the key blocks of a strip are separate launches chained through the addend; the FIRST block of a column pass starts the
+    //  partial and has none)
+    static_assert(!LONG || ADD || !ROW, "gmap: the key blocks of a blocked row strip are chained through the addend");
     static_assert(!PL || !OBF, "gmap: split-plane features produce fp32 outputs");
     static_assert(P % 4 == 0 && (2 * FSZ + OIMG) * 4 * WPC <= 163840, "gmap: LDS of WPC workgroups per CU");
     __shared__ __attribute__((aligned(16))) float lds[2 * FSZ + OIMG];
@@ -944,12 +946,13 @@ __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float *__rest
 // ---------------------------------------------------------------------------------------------------------------
 // SINGLE: the contraction is one 64-channel chunk (the energies, K = C/8 <= 64): no double buffering, half the LDS, and
 // two (fp32) or more workgroups per CU overlap their latency chains.
-// LONG (row strips of 133 .. 4 x 132 positions, ``nb`` blocks each -- see long_block): a workgroup computes the block
-// T[query block I][key block J] of a row strip from the X tile of block I and the Y tile of block J; column strips (<= P) stay whole.
+// LONG (strips of 133 .. 4 x 132 positions: row strips in ``nb`` blocks each, column strips in ``nbc`` -- see long_block; a branch
+// whose strips fit P has one block): a workgroup computes the block T[query block I][key block J] of a strip from the X tile of
+// block I and the Y tile of block J.
 template <int P, bool MASK, typename FT, bool SINGLE, bool LONG = false>
 __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(const FT *__restrict__ X, const FT *__restrict__ Y,
                                                                               float *__restrict__ T, int Cx, int H, int W,
-                                                                              long xbs, int xps, long ybs, int yps, int nb = 1) {
+                                                                              long xbs, int xps, long ybs, int yps, int nb = 1, int nbc = 1) {
     constexpr bool BF = GTile<FT>::BF;
     constexpr bool PL = std::is_same<FT, bf16p_t>::value;     // split planes: an operand tile = hi image | lo image (bf16 tile geometry)
     static_assert(!(PL && MASK), "gweight: the energies are computed from fp32 q, k (exact products)");
@@ -973,17 +976,19 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
     CCA_LDS_REGISTER(lds);
     const int HW = H * W, S = H + W;
     const int id = xcd_logical_id(blockIdx.x, gridDim.x);
-    const int nbb = LONG ? nb * nb : 1;
-    const int per_image = W + H * nbb;                        // W column strips, then H row strips (LONG: nb x nb blocks each)
+    const int nbr2 = LONG ? nb * nb : 1, nbc2 = LONG ? nbc * nbc : 1;
+    const int per_image = W * nbc2 + H * nbr2;                // W column strips, then H row strips (LONG: blocks x blocks tiles each)
     const int b = id / per_image, r = id - b * per_image;
-    const bool row = r >= W;
-    const int blk = (LONG && row) ? (r - W) % nbb : 0;
-    const int g = row ? (r - W) / nbb : r;
+    const bool row = r >= W * nbc2;
+    const int nbs = LONG ? (row ? nb : nbc) : 1, nbb = nbs * nbs;           // blocks of this strip
+    const int rs = row ? r - W * nbc2 : r;
+    const int blk = LONG ? rs % nbb : 0;
+    const int g = rs / nbb;
     const int Ls = row ? W : H;                               // the strip; this workgroup's query / key ranges:
-    const int lb = (LONG && row) ? long_block(Ls, nb) : 0;
-    const int i0 = (LONG && row) ? (blk / nb) * lb : 0, j0 = (LONG && row) ? (blk % nb) * lb : 0;
-    const int L = (LONG && row) ? (Ls - i0 < lb ? Ls - i0 : lb) : Ls;      // query positions (rows of T)
-    const int Lk = (LONG && row) ? (Ls - j0 < lb ? Ls - j0 : lb) : Ls;     // key positions (slots)
+    const int lb = LONG ? long_block(Ls, nbs) : 0;
+    const int i0 = LONG ? (blk / nbs) * lb : 0, j0 = LONG ? (blk % nbs) * lb : 0;
+    const int L = LONG ? (Ls - i0 < lb ? Ls - i0 : lb) : Ls;               // query positions (rows of T)
+    const int Lk = LONG ? (Ls - j0 < lb ? Ls - j0 : lb) : Ls;              // key positions (slots)
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
     const int ln = lane & 15, lg = lane >> 4;
     const int pstep = row ? 1 : W;
@@ -1115,7 +1120,7 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
                 const int i = 16 * (wv + GM_WAVES * a) + 4 * lg + q, j = 16 * t + ln;
                 if (i < L && j < Lk) {
                     float val = acc[a][t][q];
-                    if (MASK && !row && i == j) val = -INFINITY;            // functions.py:11-12 (column self slot)
+                    if (MASK && !row && i0 + i == j0 + j) val = -INFINITY;  // functions.py:11-12 (column self slot)
                     Tg[(size_t)(pix0 + i * pstep) * S + a_off + j] = val;
                 }
             }

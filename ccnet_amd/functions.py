@@ -554,15 +554,16 @@ def _split_weight(w: torch.Tensor):
     return hi, (w - hi.float()).to(torch.bfloat16)
 
 
-def planes_cover(B, C, Cq, H, W):
+def planes_cover(B, C, Cq, H, W, long_columns=False):
     """geometry of the split-plane kernels (csrc/cca_gmap.hpp, bf16p_t): strips up to 132 positions, and -- as long as the
     columns fit 132 and C/8 <= 64 -- ROWS of up to 4 x 132 positions, which run as blocks (the 129 x 257 feature map of the
-    reference's whole-image evaluation, evaluate.py:102-143, 246)."""
-    if C % 8 or Cq % 4 or H * W * (C + 2 * Cq) >= 2 ** 29:
+    reference's whole-image evaluation, evaluate.py:102-143, 246).  ``long_columns``: also COLUMNS of up to 4 x 132 positions
+    (blocked column passes: maps whose both sides exceed 132 -- multi-scale whole-image evaluation, evaluate.py:146-166)."""
+    if C % 8 or Cq % 4 or H * W * (C + 2 * Cq) >= 2 ** 29 or H * W * (H + W) >= 2 ** 29:
         return False
     if max(H, W) <= 132:
         return True
-    return H <= 132 and W <= 4 * 132 and Cq <= 64
+    return (H <= 132 or (long_columns and H <= 4 * 132)) and W <= 4 * 132 and Cq <= 64
 
 
 class _ProjectionCache:
@@ -741,7 +742,7 @@ class CrissCrossAttention(nn.Module):
     #: Under torch.no_grad() / eval nothing is kept either way.
     recompute_attention = False
 
-    #: fp32 NCHW inputs (no autocast; columns <= 132, rows <= 528 positions -- see ``planes_cover``): the SPLIT-PLANE node
+    #: fp32 NCHW inputs (no autocast; strips <= 528 positions -- see ``planes_cover``): the SPLIT-PLANE node
     #: (``CrissCrossPlanesModuleFunction``: q | k | v out of one GEMM pixel-major, v and dy pre-split into bf16 hi | lo planes,
     #: x / y / dy NCHW).  Measured on MI355X, core fwd+bwd at (8,512,97,97): 0.75-0.78 ms vs 0.88-0.90 ms on the NCHW strips of
     #: the same boxes (profiles/r03q_bench.json, r03z_bench.json); whole-image inference (1,512,129,257): 0.475 vs 1.18 ms.
@@ -796,6 +797,9 @@ class CrissCrossAttention(nn.Module):
             # column kernels runs as its transpose: two transposing copies each way instead of the windowed strip kernels
             if fast_ok and not cl and self.fuse_module_backward and self.split_planes and planes_cover(B, C, cq, W, H):
                 return "f32-planes-transposed"
+            # both sides beyond 132 positions (up to 528): the same node, its column passes in blocks as well
+            if fast_ok and not cl and self.fuse_module_backward and self.split_planes and planes_cover(B, C, cq, H, W, True):
+                return "f32-planes"
             if self.fuse_projections and self.fuse_module_backward:
                 return "f32-strips-node"
         if self.fuse_projections and self._fusable():

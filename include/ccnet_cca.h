@@ -239,11 +239,12 @@ int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W);
  *   x.w ~ xh.wh + xh.wl + xl.wh is ONE GEMM with K = 3C on rows [xh | xh | xl] x [wh | wl | wh]): CCNET_PLANES_HLH =
  *   hi | lo | hi, CCNET_PLANES_HHL = hi | hi | lo (pixel stride >= 3 C).  Paired row by row, HLH x HHL gives the three
  *   products as well (the weight gradient as one GEMM over 3 B H W rows).
- * LONG ROWS: both entry points also take maps whose ROWS have 133 .. 528 positions while the columns fit 132
- *   (H <= 132 < W <= 528, C/8 <= 64) -- the 129 x 257 map of the reference's whole-image evaluation (evaluate.py:102-143).
- *   A row strip is cut into blocks of <= 132 positions: the energies / dA kernels compute one (query block, key block) tile pair
- *   per workgroup; every row pass (aggregation, dv, dq | dk) runs once per block of the CONTRACTED positions, updating its fp32
- *   partial in place, the last one writes the output.
+ * LONG STRIPS: both entry points also take maps whose rows, columns or both have 133 .. 528 positions (max(H, W) <= 528,
+ *   C/8 <= 64) -- the 129 x 257 map of the reference's whole-image evaluation (evaluate.py:102-143) and the 193 x 385 ..
+ *   257 x 513 maps of its multi-scale variant (evaluate.py:146-166, scales 1.5 .. 2).  A long strip is cut into blocks of
+ *   <= 132 positions: the energies / dA kernels compute one (query block, key block) tile pair per workgroup; every pass of
+ *   a branch with long strips (aggregation, dv, dq | dk) runs once per block of the CONTRACTED positions, updating its fp32
+ *   partial in place -- a workgroup owns one OUTPUT block of a strip -- and the last row launch writes the output.
  * ccnet_cca_forward_planes_f32 / _backward_planes_f32: functions.py:38-49 and its autograd with q, k fp32 pixel-major
  *   views (exact fp32 energies), the module's x / y / dy NCHW fp32, dq | dk | dv fp32 pixel-major views, A / scratch
  *   (B,H,W,H+W) fp32 as everywhere.  The forward takes v the way its producer leaves it -- ``v``: the fp32 pixel-major value

@@ -628,7 +628,11 @@ def test_split_plane_core_matches_the_fp32_pixel_major_core_and_the_oracle(ops, 
 
 
 @pytest.mark.parametrize("shape", [(1, 64, 3, 133), (2, 64, 5, 140), (1, 128, 2, 257), (1, 64, 4, 264), (1, 64, 2, 299), (1, 64, 132, 133),
-                                   (1, 64, 2, 404), (1, 64, 1, 528)])      # rows > 400: blocks of <= 132 on the 132-position kernels
+                                   (1, 64, 2, 404), (1, 64, 1, 528),       # rows > 400: blocks of <= 132 on the 132-position kernels
+                                   # long COLUMNS (blocked column passes), alone and together with long rows
+                                   # (both sides beyond 400 positions -- 132-position blocks in both branches -- run on the GPU only:
+                                   #  minutes in the emulator)
+                                   (1, 64, 133, 3), (2, 64, 140, 5), (1, 64, 257, 2), (1, 64, 404, 1), (1, 64, 134, 97), (1, 64, 135, 140)])
 def test_split_plane_core_with_long_rows_matches_the_oracle(ops, shape):
     """ccnet_cca_forward_planes_f32 with ROW strips of 133 .. 528 positions (the 129 x 257 map of the reference's whole-image
     evaluation, evaluate.py:102-143): a row strip is cut into blocks of <= 132 positions (cca::long_block); the energies kernel
@@ -653,7 +657,12 @@ def test_split_plane_core_with_long_rows_matches_the_oracle(ops, shape):
     go = O.cca_core_backward(T(c["dy"]), T(c["q"]), T(c["k"]), T(c["v"]), Ao, T(c["gamma"]))
     for name, got in (("dq", dqkv[..., :cq]), ("dk", dqkv[..., cq:2 * cq]), ("dv", dqkv[..., 2 * cq:])):
         assert maxerr(nchw(got), go[name].numpy()) < 5e-4 * max(1.0, float(go[name].abs().max())), name
-    assert abs(float(dg[0]) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
+    # dgamma = sum over every pixel and slot of A t: on the larger maps a sum of ~1e5 in absolute terms that cancels to ~1 -- the bar
+    # is the fp32 bar on the value or 2e-7 of the sum of magnitudes, whichever is larger
+    dy_, v_ = T(c["dy"]), T(c["v"])
+    t_ = torch.cat([torch.einsum("bchw,bcjw->bhwj", dy_, v_), torch.einsum("bchw,bchj->bhwj", dy_, v_)], 3)
+    l1 = float((Ao * t_).abs().sum())
+    assert abs(float(dg[0]) - float(go["dgamma"])) < max(1e-3 * max(1.0, abs(float(go["dgamma"]))), 2e-7 * l1)
     dqkv2, _ = ops.cca_backward_planes(c["dy"], qkv, vpl, A, c["gamma"], cq)
     assert np.array_equal(dqkv, dqkv2)
 

@@ -556,12 +556,15 @@ def test_split_plane_core_logit_scale_sweep_at_the_headline_geometry(lib, dev, e
     assert all(b < 1e-4 for r in rows.values() for _, b in r.values()), rows
 
 
-@pytest.mark.parametrize("shape", [(1, 512, 129, 257), (2, 256, 97, 193), (1, 64, 132, 400)])
+@pytest.mark.parametrize("shape", [(1, 512, 129, 257), (2, 256, 97, 193), (1, 64, 132, 400),
+                                   # both sides beyond 132 (multi-scale whole-image evaluation, evaluate.py:146-166): blocked column passes too
+                                   (1, 512, 161, 321), (1, 64, 257, 513), (1, 128, 402, 134), (2, 64, 133, 135)])
 def test_long_rows_run_the_plane_kernels_and_match_the_oracle(lib, dev, shape):
     """evaluate.py:102-143,246: whole-image inference puts a 129 x 257 map through the module.  The split-plane path takes such
     rows in blocks of <= 132 positions, forward and backward: y (no_grad and with autograd) against the oracle at the north_star
     bar (projections at their default initialisation) and against the NCHW strip / windowed kernels; dx and the seven parameter
-    gradients against the strip node."""
+    gradients against the strip node.  Round 4 (second half): maps whose COLUMNS exceed 132 positions as well take the same node
+    (the column passes in blocks)."""
     from ccnet_amd import CrissCrossAttention
     B, C, H, W = shape
     torch.manual_seed(11)

@@ -278,7 +278,9 @@ def test_module_routing_table(device_lib_path):
         ("f32 NCHW 129x129 (plane kernels padded to 132 positions)", lambda: m.route(nchw(2, 129, 129))): "f32-planes",
         ("f32 NCHW 129x257 (rows in blocks of <= 132 positions)", lambda: m.route(nchw(2, 129, 257))): "f32-planes",
         ("f32 NCHW 97x193", lambda: m.route(nchw(1, 97, 193))): "f32-planes",
-        ("f32 NCHW 161x321 (columns beyond 132)", lambda: m.route(nchw(1, 161, 321))): "f32-strips-node",
+        ("f32 NCHW 161x321 (both sides beyond 132: column AND row passes in blocks)", lambda: m.route(nchw(1, 161, 321))): "f32-planes",
+        ("f32 NCHW 257x513 (evaluate.py:146-166 at scale 2)", lambda: m.route(nchw(1, 257, 513))): "f32-planes",
+        ("f32 NCHW 600x140 (columns beyond 4 blocks)", lambda: m.route(nchw(1, 600, 140))): "f32-strips-node",
         ("f32 NCHW 257x129 (tall: runs as its transpose)", lambda: m.route(nchw(1, 257, 129))): "f32-planes-transposed",
         ("f32 NCHW 129x600 (rows beyond 4 blocks)", lambda: m.route(nchw(1, 129, 600))): "f32-strips-node",
         ("f32 channels_last", lambda: m.route(cl(2, 33, 18))): "f32-channels-last",
@@ -286,7 +288,7 @@ def test_module_routing_table(device_lib_path):
     for (what, fn), want in table.items():
         assert fn() == want, what
     with torch.no_grad():       # inference (evaluate.py:246) takes the same routes
-        assert m.route(nchw(1, 129, 257)) == "f32-planes" and m.route(nchw(1, 161, 321)) == "f32-strips-node"
+        assert m.route(nchw(1, 129, 257)) == "f32-planes" and m.route(nchw(1, 161, 321)) == "f32-planes"
     m.to(torch.bfloat16)
     assert m.route(cl(2, 129, 129, torch.bfloat16)) == "bf16-pixel-major"
     assert m.route(nchw(1, 330, 9, torch.bfloat16)) == "packed-strips"           # any-shape fp32 kernels through fp32 copies
