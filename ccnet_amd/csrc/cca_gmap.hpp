@@ -852,7 +852,10 @@ __global__ __launch_bounds__(256) void nchw_to_pm_kernel(const float *__restrict
                                                          long sbs, long dbs, int dps) {
     __shared__ float tile[64 * 65];
     const int ntp = (HW + 63) / 64;
-    const int b = blockIdx.x / ntp, p0 = (blockIdx.x - b * ntp) * 64, c0 = blockIdx.y * 64;
+    // (XCD-aware tile order: see nchw_to_planes_kernel)
+    const int lid = xcd_logical_id((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+    const int ncg = (int)gridDim.y, tix = lid % ntp, rest = lid / ntp;
+    const int b = rest / ncg, p0 = tix * 64, c0 = (rest - b * ncg) * 64;
     const FBuf Sb = make_fbuf(src + (size_t)b * sbs, (size_t)C * HW * sizeof(float));
     const FBuf Db = make_fbuf(dst + (size_t)b * dbs, ((size_t)(HW - 1) * dps + C) * sizeof(float));
     const int tid = threadIdx.x;
@@ -914,7 +917,13 @@ __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float *__rest
                                                              long sbs, long dbs, int dps, PlaneLayout pl) {
     __shared__ float tile[64 * 65];
     const int ntp = (HW + 63) / 64;
-    const int b = blockIdx.x / ntp, p0 = (blockIdx.x - b * ntp) * 64, c0 = blockIdx.y * 64;
+    // a channel's run of 64 pixels is 256 B at arbitrary alignment (HW is odd at 97 x 97): three 128-byte lines, the outer two
+    // shared with the neighbouring pixel tiles.  Workgroup ids go round-robin over the 8 XCDs (private L2s): with neighbouring
+    // tiles on neighbouring ids every boundary line was fetched from HBM twice (PMC: 384 MB for 308).  Every XCD now takes a
+    // contiguous range of (image, channel group, pixel tile) ids, tile fastest: the second touch of a line is an L2 hit.
+    const int lid = xcd_logical_id((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+    const int ncg = (int)gridDim.y, tix = lid % ntp, rest = lid / ntp;
+    const int b = rest / ncg, p0 = tix * 64, c0 = (rest - b * ncg) * 64;
     const FBuf Sb = make_fbuf(src + (size_t)b * sbs, (size_t)C * HW * sizeof(float));
     const FBuf Db = make_fbuf(reinterpret_cast<const float *>(dst + (size_t)b * dbs), ((size_t)(HW - 1) * dps + pl.width) * 2);
     const int tid = threadIdx.x;
