@@ -554,16 +554,16 @@ def _split_weight(w: torch.Tensor):
     return hi, (w - hi.float()).to(torch.bfloat16)
 
 
-def planes_cover(B, C, Cq, H, W, long_columns=False):
-    """geometry of the split-plane kernels (csrc/cca_gmap.hpp, bf16p_t): strips up to 132 positions, and -- as long as the
-    columns fit 132 and C/8 <= 64 -- ROWS of up to 4 x 132 positions, which run as blocks (the 129 x 257 feature map of the
-    reference's whole-image evaluation, evaluate.py:102-143, 246).  ``long_columns``: also COLUMNS of up to 4 x 132 positions
-    (blocked column passes: maps whose both sides exceed 132 -- multi-scale whole-image evaluation, evaluate.py:146-166)."""
+def planes_cover(B, C, Cq, H, W):
+    """geometry of the split-plane kernels (csrc/cca_gmap.hpp, bf16p_t): strips up to 132 positions, and -- as long as
+    C/8 <= 64 -- rows and / or columns of up to 4 x 132 positions, which run as blocks (the 129 x 257 feature map of the
+    reference's whole-image evaluation, evaluate.py:102-143, 246; both sides beyond 132 at the larger scales of its multi-scale
+    variant, evaluate.py:146-166)."""
     if C % 8 or Cq % 4 or H * W * (C + 2 * Cq) >= 2 ** 29 or H * W * (H + W) >= 2 ** 29:
         return False
     if max(H, W) <= 132:
         return True
-    return (H <= 132 or (long_columns and H <= 4 * 132)) and W <= 4 * 132 and Cq <= 64
+    return max(H, W) <= 4 * 132 and Cq <= 64
 
 
 class _ProjectionCache:
@@ -766,7 +766,6 @@ class CrissCrossAttention(nn.Module):
         "bf16-pixel-major": "one x^T W^T projection + pixel-major bf16 MFMA kernels (BASELINE configs[4])",
         "f32-channels-last": "one x^T W^T projection + pixel-major fp32 kernels, channels_last in / out",
         "f32-planes": "one autograd node: projection GEMM, v / dy as bf16 hi | lo planes, NCHW x / y / dy",
-        "f32-planes-transposed": "the same node on the spatially transposed input (maps taller than 132 whose width fits 132)",
         "f32-strips-node": "one autograd node on the NCHW strip kernels (honours recompute_attention)",
         "packed-strips": "stacked conv2d + NCHW strip kernels through channel-slice strides (any float dtype, autocast)",
         "separate-strips": "three convolutions + NCHW strip / windowed / any-shape kernels (functions.py:29-35 as written)",
@@ -790,15 +789,10 @@ class CrissCrossAttention(nn.Module):
             cl = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
             if fast_ok and cl and self.pixel_major_for_channels_last and pm_covers(torch.float32, B, C, cq, H, W):
                 return "f32-channels-last"
+            # (strips beyond 132 positions -- rows, columns or both, up to 528 -- run in blocks.  Round 3 ran a TALL map whose width
+            # fits 132 on its spatial transpose, two transposing copies each way; the blocked column passes are faster:
+            # (1,512,257,129) inference 0.63 -> 0.47 ms, fwd+bwd 1.85 -> 1.52 ms, profiles/r04lc_tall_map_ab.txt -- that route is gone.)
             if fast_ok and not cl and self.fuse_module_backward and self.split_planes and planes_cover(B, C, cq, H, W):
-                return "f32-planes"
-            # the op commutes with the spatial transposition (a pixel attends its column and its row, itself once: which of
-            # the two branches carries the masked self slot does not change the softmax), so a TALL map whose width fits the
-            # column kernels runs as its transpose: two transposing copies each way instead of the windowed strip kernels
-            if fast_ok and not cl and self.fuse_module_backward and self.split_planes and planes_cover(B, C, cq, W, H):
-                return "f32-planes-transposed"
-            # both sides beyond 132 positions (up to 528): the same node, its column passes in blocks as well
-            if fast_ok and not cl and self.fuse_module_backward and self.split_planes and planes_cover(B, C, cq, H, W, True):
                 return "f32-planes"
             if self.fuse_projections and self.fuse_module_backward:
                 return "f32-strips-node"
@@ -826,12 +820,8 @@ class CrissCrossAttention(nn.Module):
             xp = x.permute(0, 2, 3, 1)
             qkv = torch.nn.functional.linear(xp, self._stacked_weight().flatten(1), self._stacked_bias())
             return CrissCrossPMFunction.apply(qkv, xp, self.gamma, cq, self.recompute_attention).permute(0, 3, 1, 2)
-        if r in ("f32-planes", "f32-planes-transposed"):
+        if r == "f32-planes":
             split_gemm = self.split_bf16_projections and x.shape[0] * x.shape[2] * x.shape[3] >= self.split_bf16_min_pixels
-            if r == "f32-planes-transposed":
-                xt = x.transpose(2, 3).contiguous()
-                return CrissCrossPlanesModuleFunction.apply(xt, *params, self.gamma, split_gemm, self.recompute_attention,
-                                                            self._projection_cache()).transpose(2, 3).contiguous()
             return CrissCrossPlanesModuleFunction.apply(x, *params, self.gamma, split_gemm, self.recompute_attention,
                                                         self._projection_cache())
         if r == "f32-strips-node":

@@ -630,10 +630,10 @@ def test_long_rows_at_random_geometries_match_the_strip_kernels(lib, dev):
             assert err(a[i], b[i]) < 1e-3 * max(1.0, float(b[i].abs().max())), (B, C, H, W, i)
 
 
-def test_tall_maps_run_as_their_transpose(lib, dev):
-    """A map taller than 132 whose width fits the column kernels takes the split-plane node on its spatial transpose (the op
-    commutes with it: each pixel attends its row and its column, itself once).  y, dx and the parameter gradients against the NCHW
-    strip / windowed kernels on the untransposed map, y against the oracle."""
+def test_tall_maps_run_the_plane_kernels_with_blocked_columns(lib, dev):
+    """A map taller than 132 whose width fits the row kernels takes the split-plane node with its COLUMN passes in blocks (round 3
+    ran it on its spatial transpose; the blocked column passes are faster).  y, dx and the parameter gradients against the NCHW
+    strip / windowed kernels, y against the oracle."""
     from ccnet_amd import CrissCrossAttention
     B, C, H, W = 1, 128, 200, 60
     torch.manual_seed(13)
@@ -645,7 +645,7 @@ def test_tall_maps_run_as_their_transpose(lib, dev):
     outs = {}
     for planes in (True, False):
         m.split_planes = planes
-        assert (m.route(x) == "f32-planes-transposed") == planes
+        assert (m.route(x) == "f32-planes") == planes
         m.zero_grad(set_to_none=True)
         xi = x.clone().requires_grad_(True)
         y = m(xi)

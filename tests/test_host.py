@@ -281,7 +281,7 @@ def test_module_routing_table(device_lib_path):
         ("f32 NCHW 161x321 (both sides beyond 132: column AND row passes in blocks)", lambda: m.route(nchw(1, 161, 321))): "f32-planes",
         ("f32 NCHW 257x513 (evaluate.py:146-166 at scale 2)", lambda: m.route(nchw(1, 257, 513))): "f32-planes",
         ("f32 NCHW 600x140 (columns beyond 4 blocks)", lambda: m.route(nchw(1, 600, 140))): "f32-strips-node",
-        ("f32 NCHW 257x129 (tall: runs as its transpose)", lambda: m.route(nchw(1, 257, 129))): "f32-planes-transposed",
+        ("f32 NCHW 257x129 (tall: column passes in blocks)", lambda: m.route(nchw(1, 257, 129))): "f32-planes",
         ("f32 NCHW 129x600 (rows beyond 4 blocks)", lambda: m.route(nchw(1, 129, 600))): "f32-strips-node",
         ("f32 channels_last", lambda: m.route(cl(2, 33, 18))): "f32-channels-last",
     }
