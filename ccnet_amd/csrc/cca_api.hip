@@ -51,6 +51,7 @@ std::atomic<int> g_planes_overlap{-1};
 // "planes_xcd" 1 (default): the final NCHW row pass of the split-plane forward decodes its strips from an XCD-aware id (consecutive
 // rows of an image on ONE XCD): the 388-byte NCHW rows of x / y share every boundary line with their neighbour row
 std::atomic<int> g_planes_xcd{1};
+std::atomic<int> g_energy_tail{1};          // the fp32 energies launch cuts the strips beyond its whole rounds into tile-row parts
 // "dqdk_exact" 1: ca_backward of the fp32 pixel-major / split-plane routes (strips <= 100) multiplies in exact fp32 instead of
 // split-bf16 x3: dq / dk errors drop to those of the upstream dA contraction (2e-4 at the headline shape) for +25 us per launch
 std::atomic<int> g_dqdk_exact{0};
@@ -861,6 +862,19 @@ int gweight_pm(const FT *X, const FT *Y, float *T, int B, int Cx, int H, int W, 
     // configs[4] -- profiles/r03j_bf16_compare.txt -- wavefront 0 owns two of the nine tile rows and every barrier waits for it)
     const dim3 grid((unsigned)(B * (H + W))), block(cca::GM_THREADS);
     const bool single = Cx <= cca::GM_CG;           // one chunk: the single-buffered form (more workgroups per CU)
+    if constexpr (MASK && std::is_same<FT, float>::value) {
+        // the fp32 energies at the headline geometry: three 52.8 KB workgroups per CU, every one the same latency chain -- the strips
+        // beyond the whole rounds are cut into tile-row parts (gweight_kernel, n_whole) so that the last round is a short one
+        if (single && (H > W ? H : W) <= 100 && g_energy_tail.load()) {
+            const int strips = B * (H + W), slots = 3 * num_cus(), nt = (100 + 15) / 16;       // (tile rows of the 100-position kernel)
+            const int n_whole = strips / slots * slots, rem = strips - n_whole;
+            if (n_whole > 0 && rem > 0 && rem * nt <= slots / 2) {
+                CCA_LAUNCH((cca::gweight_kernel<100, MASK, FT, true>), dim3((unsigned)(n_whole + rem * nt)), block, stream, X, Y, T, Cx, H, W,
+                           xbs, xps, ybs, yps, 1, 1, n_whole);
+                return launch_status("gweight_pm(energies, tail parts)");
+            }
+        }
+    }
 #define CCA_GWEIGHT(P_)                                                                                                   \
     do {                                                                                                                  \
         if (single) CCA_LAUNCH((cca::gweight_kernel<P_, MASK, FT, true>), grid, block, stream, X, Y, T, Cx, H, W, xbs, xps, ybs, yps); \
@@ -1469,6 +1483,7 @@ const OptionRange *find_word_option(const std::string &n) {
         {"planes_stream", &g_planes_stream, 0, 1 << 20},
         {"planes_overlap", &g_planes_overlap, -1, 2},
         {"planes_xcd", &g_planes_xcd, 0, 1},
+        {"energy_tail", &g_energy_tail, 0, 1},
         {"dqdk_exact", &g_dqdk_exact, 0, 1},
     };
     for (const OptionRange &o : table)

@@ -961,11 +961,13 @@ __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float *__rest
 template <int P, bool MASK, typename FT, bool SINGLE, bool LONG = false>
 __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(const FT *__restrict__ X, const FT *__restrict__ Y,
                                                                               float *__restrict__ T, int Cx, int H, int W,
-                                                                              long xbs, int xps, long ybs, int yps, int nb = 1, int nbc = 1) {
+                                                                              long xbs, int xps, long ybs, int yps, int nb = 1, int nbc = 1,
+                                                                              int n_whole = 0) {
     constexpr bool BF = GTile<FT>::BF;
     constexpr bool PL = std::is_same<FT, bf16p_t>::value;     // split planes: an operand tile = hi image | lo image (bf16 tile geometry)
     static_assert(!(PL && MASK), "gweight: the energies are computed from fp32 q, k (exact products)");
     constexpr bool EXACT = !BF && !PL && MASK;          // the energies feed exp(): exact fp32 products
+    constexpr bool EXACT_PART = EXACT && SINGLE && !LONG;   // (the form that takes tail parts, see n_whole)
     constexpr bool PRESPLIT = !BF && !PL && !MASK;      // fp32 dA: tiles are split into bf16 hi / lo images once per chunk
     // split planes: T16 tile geometry (unpadded 1 KiB pieces, cca_gmap's plane tiles) so that THREE stages of X hi | X lo |
     // Y hi | Y lo fit the 160 KB (159,744 B at P = 100): two stages in flight while one is multiplied (with two stages the
@@ -984,7 +986,15 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
     __shared__ __attribute__((aligned(16))) float lds[LDS];
     CCA_LDS_REGISTER(lds);
     const int HW = H * W, S = H + W;
-    const int id = xcd_logical_id(blockIdx.x, gridDim.x);
+    // TAIL PARTS (the fp32 energies, n_whole > 0): the launch's workgroups are latency chains of equal length, so 1552 strips on 768
+    // slots take THREE rounds for 2.02 rounds of work.  The strips beyond the whole rounds are cut by query tile row: workgroup
+    // n_whole + NT s + r computes tile row r of strip n_whole + s, its key tiles spread over the wavefronts -- the same fill, a
+    // seventh of the multiply and of the stores: a short last round (dispatched last: the cut is made on the LINEAR id).
+    constexpr int NTP = (P + 15) / 16;
+    const bool part = EXACT_PART && n_whole > 0 && (int)blockIdx.x >= n_whole;
+    const int trow = part ? ((int)blockIdx.x - n_whole) % NTP : 0;
+    const int id = part ? n_whole + ((int)blockIdx.x - n_whole) / NTP
+                        : xcd_logical_id(blockIdx.x, (EXACT_PART && n_whole > 0) ? n_whole : (int)gridDim.x);
     const int nbr2 = LONG ? nb * nb : 1, nbc2 = LONG ? nbc * nbc : 1;
     const int per_image = W * nbc2 + H * nbr2;                // W column strips, then H row strips (LONG: blocks x blocks tiles each)
     const int b = id / per_image, r = id - b * per_image;
@@ -1056,17 +1066,17 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
                 float af[NTR];
 #pragma unroll
                 for (int a = 0; a < NTR; ++a) {
-                    const int px = 16 * (wv + GM_WAVES * a) + ln;
+                    const int px = 16 * (part ? trow : wv + GM_WAVES * a) + ln;
                     af[a] = CCA_LDS_LD(xb + gtile_f32_idx(px < NPF * 4 ? px : 0, 4 * ks + lg));
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    if (t * 16 < Lk) {
+                    if (t * 16 < Lk && (!part || t == wv)) {             // (a tail part: wavefront w multiplies key tile w of ITS row)
                         const int px = 16 * t + ln;
                         const float bv = CCA_LDS_LD(yb + gtile_f32_idx(px < NPF * 4 ? px : 0, 4 * ks + lg));
 #pragma unroll
                         for (int a = 0; a < NTR; ++a)
-                            if ((wv + GM_WAVES * a) * 16 < L) acc[a][t] = mfma_16x16x4(af[a], bv, acc[a][t]);
+                            if ((part ? a == 0 : (wv + GM_WAVES * a) * 16 < L)) acc[a][t] = mfma_16x16x4(af[a], bv, acc[a][t]);
                     }
                 }
             }
@@ -1126,8 +1136,8 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int i = 16 * (wv + GM_WAVES * a) + 4 * lg + q, j = 16 * t + ln;
-                if (i < L && j < Lk) {
+                const int i = 16 * (part ? trow : wv + GM_WAVES * a) + 4 * lg + q, j = 16 * t + ln;
+                if (i < L && j < Lk && (!part || (a == 0 && t == wv))) {
                     float val = acc[a][t][q];
                     if (MASK && !row && i0 + i == j0 + j) val = -INFINITY;  // functions.py:11-12 (column self slot)
                     Tg[(size_t)(pix0 + i * pstep) * S + a_off + j] = val;

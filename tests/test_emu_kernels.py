@@ -787,3 +787,31 @@ def test_exact_f32_ca_backward_option(ops, shape):
             e_exact = maxerr(nchw(dq[..., sl]), go[name].numpy())
             e_split = maxerr(nchw(ref[0][..., sl]), go[name].numpy())
             assert e_exact < 2e-4 * max(1.0, float(go[name].abs().max())) and e_exact <= e_split * 1.5 + 1e-6, (name, e_exact, e_split)
+
+
+@pytest.mark.parametrize("shape", [(20, 64, 20, 19), (4, 32, 97, 98)])
+def test_energies_tail_parts_are_bit_identical_to_one_workgroup_per_strip(ops, shape):
+    """Option "energy_tail" (default on): the fp32 energies launch cuts the strips beyond its whole rounds of workgroups (3 per CU:
+    768 slots on the 256 CUs the emulator reports) into tile-row parts whose key tiles are spread over the wavefronts.  Same products
+    in the same order per output: the attention tensor must be bit-identical to the one-workgroup-per-strip launch, with the masked
+    column self slot an exact zero."""
+    B, C, H, W = shape
+    cq = C // 8
+    assert B * (H + W) > 768 and B * (H + W) % 768                       # a remainder exists: the tail path runs
+    rng = np.random.default_rng(17)
+    qk = rng.standard_normal((B, H, W, 2 * cq), dtype=np.float32)
+    base, bs, ct = qk.ctypes.data, H * W * 2 * cq, 2 * cq
+    outs = []
+    for opt in (1, 0):
+        prev = ops.lib.set_option("energy_tail", opt)
+        try:
+            A = np.full((B, H, W, H + W), np.nan, np.float32)
+            ops.lib.check(ops.lib.ccnet_cca_attention_pm(base, base + 4 * cq, A.ctypes.data, 0, B, cq, H, W, bs, ct, bs, ct, None))
+        finally:
+            ops.lib.set_option("energy_tail", prev)
+        outs.append(A)
+    assert np.array_equal(outs[0], outs[1]) and np.all(np.isfinite(outs[0]))
+    assert np.all(outs[0][:, np.arange(H), :, np.arange(H)] == 0)
+    _, Ao = O.cca_core_forward(T(np.transpose(qk[..., :cq], (0, 3, 1, 2))), T(np.transpose(qk[..., cq:], (0, 3, 1, 2))),
+                               torch.zeros(B, 8, H, W), torch.zeros(B, 8, H, W), torch.zeros(1))
+    assert maxerr(outs[0], Ao.numpy()) < 2e-6
