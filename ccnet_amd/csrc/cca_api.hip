@@ -51,6 +51,12 @@ std::atomic<int> g_planes_overlap{-1};
 // "planes_xcd" 1 (default): the final NCHW row pass of the split-plane forward decodes its strips from an XCD-aware id (consecutive
 // rows of an image on ONE XCD): the 388-byte NCHW rows of x / y share every boundary line with their neighbour row
 std::atomic<int> g_planes_xcd{1};
+// "da_stages": ring stages of the persistent dA kernel (plane-free form).  Three fill the CU's LDS (159,744 B): the dv column pass on
+// the side stream could not place a single workgroup next to it and in fact WAITED for the dA workgroups to exit (kernel-trace
+// timeline: its 69 us of work spanned 223 us).  With two stages (106,496 B) one 53,248-byte column workgroup fits per CU and the two
+// launches really run together: backward 0.451 -> 0.404 ms, step 0.727-0.749 -> 0.683-0.692 ms in the same run
+// (profiles/r04lg_ab_dA_two_stages.txt); alone the two-stage kernel is no slower (151.6 vs 159.8 us).
+std::atomic<int> g_da_stages{2};
 std::atomic<int> g_energy_tail{1};          // the fp32 energies launch cuts the strips beyond its whole rounds into tile-row parts
 // "dqdk_exact" 1: ca_backward of the fp32 pixel-major / split-plane routes (strips <= 100) multiplies in exact fp32 instead of
 // split-bf16 x3: dq / dk errors drop to those of the upstream dA contraction (2e-4 at the headline shape) for +25 us per launch
@@ -1453,7 +1459,9 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
         // (option values > 1 cap the number of workgroups: tests make one workgroup walk many strips)
         const int nstrips = B * (H + W), cus = ps > 1 ? ps : num_cus();
         const dim3 grid((unsigned)(nstrips < cus ? nstrips : cus)), block(cca::GM_THREADS);
-        if (direct) CCA_LAUNCH((cca::gweight_stream_kernel<100, bf16p_t, float>), grid, block, stream, dyp, v, scratch, C, B, H, W, dbs, 2 * C, v_bs, v_ps);
+        if (direct && g_da_stages.load() == 2)
+            CCA_LAUNCH((cca::gweight_stream_kernel<100, bf16p_t, float, 2>), grid, block, stream, dyp, v, scratch, C, B, H, W, dbs, 2 * C, v_bs, v_ps);
+        else if (direct) CCA_LAUNCH((cca::gweight_stream_kernel<100, bf16p_t, float>), grid, block, stream, dyp, v, scratch, C, B, H, W, dbs, 2 * C, v_bs, v_ps);
         else        CCA_LAUNCH((cca::gweight_stream_kernel<100>), grid, block, stream, dyp, vp, scratch, C, B, H, W, dbs, 2 * C, vp_bs, vp_ps);
         e = launch_status("gweight_stream(dA)");
     } else {
@@ -1484,6 +1492,7 @@ const OptionRange *find_word_option(const std::string &n) {
         {"planes_overlap", &g_planes_overlap, -1, 2},
         {"planes_xcd", &g_planes_xcd, 0, 1},
         {"energy_tail", &g_energy_tail, 0, 1},
+        {"da_stages", &g_da_stages, 2, 3},
         {"dqdk_exact", &g_dqdk_exact, 0, 1},
     };
     for (const OptionRange &o : table)

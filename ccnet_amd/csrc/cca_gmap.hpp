@@ -1161,7 +1161,9 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
 // bf16 / P = 100 instantiation came out with 256 VGPRs and 13 spilled)
 // YT = float: the Y operand (v) is read as the fp32 pixel-major tensor it is (F32T tiles, hi | lo split per fragment) -- X (dy)
 // stays planes: it has to be transposed out of NCHW anyway.
-template <int P, typename FT = bf16p_t, typename YT = FT>
+// NB: ring stages (0 = as many as fit the LDS: three at P = 100).  NB = 2 leaves 53 KB of the CU's LDS free: a column-pass workgroup
+// of the dv launch (gmap3_kernel<..., 2, 3>: 53,248 B) then runs NEXT TO the persistent workgroup instead of waiting for it to exit.
+template <int P, typename FT = bf16p_t, typename YT = FT, int NB = 0>
 __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT *__restrict__ X, const YT *__restrict__ Y,
                                                                         float *__restrict__ T, int Cx, int B, int H, int W,
                                                                         long xbs, int xps, long ybs, int yps) {
@@ -1173,8 +1175,8 @@ __global__ __launch_bounds__(GM_THREADS, 4) void gweight_stream_kernel(const FT 
     static_assert(!YF || (NPL == 2 && f32t_size(P) <= 2 * TSB), "gweight_stream: an fp32 Y tile takes the place of its two planes");
     constexpr int NPY = YF ? f32t_pieces(P) : NPL * NPB;                  // DMA pieces of a Y tile
     constexpr int STG = 2 * NPL * TSB, NPS = NPL * NPB + NPY;             // stage = X (hi | lo) | Y (hi | lo, or fp32)
-    constexpr int NBUF = 4 * STG * 4 <= 163840 ? 4 : 3, D = NBUF - 1;     // as many stages as fit: D of them in flight
-    static_assert(NBUF * STG * 4 <= 163840, "gweight_stream: three stages must fit the LDS");
+    constexpr int NBUF = NB ? NB : 4 * STG * 4 <= 163840 ? 4 : 3, D = NBUF - 1;     // as many stages as fit: D of them in flight
+    static_assert(NBUF >= 2 && NBUF * STG * 4 <= 163840, "gweight_stream: the stages must fit the LDS");
     __shared__ __attribute__((aligned(16))) float lds[NBUF * STG];
     CCA_LDS_REGISTER(lds);
     const int HW = H * W, S = H + W;

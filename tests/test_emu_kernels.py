@@ -748,13 +748,15 @@ def test_plane_free_form_is_bit_identical_to_the_plane_form(ops, shape):
     same = (lambda a, b: maxerr(a, b) <= 4e-6 * max(1.0, float(np.abs(b).max()))) if tail else np.array_equal
     assert np.array_equal(A, A2) and same(y2, y)
     ref = ops.cca_backward_planes(c["dy"], qkv, vpl, A, c["gamma"], cq)
-    for opt in (1, 3):
-        prev = ops.lib.set_option("planes_stream", opt)
+    for opt, stages in ((1, 2), (3, 2), (3, 3)):         # ("da_stages": the ring of the persistent kernel, two stages by default)
+        prev, prev_st = ops.lib.set_option("planes_stream", opt), ops.lib.set_option("da_stages", stages)
         try:
             got = ops.cca_backward_planes(c["dy"], qkv, None, A, c["gamma"], cq)
         finally:
             ops.lib.set_option("planes_stream", prev)
-        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), opt          # (dA contracts over channels: no tail)
+            ops.lib.set_option("da_stages", prev_st)
+        assert prev_st == 2
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), (opt, stages)   # (dA contracts over channels: no tail)
     with pytest.raises(RuntimeError):            # the plane-free form stops at 100 positions
         big = np.zeros((1, 101, 2, 2 * cq + C), np.float32)
         ops.cca_forward_planes(big, None, np.zeros((1, C, 101, 2), np.float32), c["gamma"], cq)
