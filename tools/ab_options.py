@@ -19,7 +19,7 @@ DEFAULT_SETS = {
     "v-as-planes": {"_direct": 0},           # the forward splits v into planes first (what maps beyond 100 positions run)
     "no-xcd": {"planes_xcd": 0},
     "no-energy-tail": {"energy_tail": 0},
-    "dA-3-stages": {"da_stages": 2},         # the persistent dA kernel with three ring stages: it fills the LDS, nothing runs next to it
+    "dA-3-stages": {"da_stages": 3},         # the persistent dA kernel with three ring stages: it fills the LDS, nothing runs next to it
     "dA-3-stages-1s": {"da_stages": 3, "planes_overlap": 0},    # the energies launch as one workgroup per strip (2.02 rounds -> three)
     "one-stream": {"planes_overlap": 0},
     "overlap-1": {"planes_overlap": 1},
