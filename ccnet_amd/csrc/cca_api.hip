@@ -57,6 +57,7 @@ std::atomic<int> g_planes_xcd{1};
 // launches really run together: backward 0.451 -> 0.404 ms, step 0.727-0.749 -> 0.683-0.692 ms in the same run
 // (profiles/r04lg_ab_dA_two_stages.txt); alone the two-stage kernel is no slower (151.6 vs 159.8 us).
 std::atomic<int> g_da_stages{2};
+std::atomic<int> g_dqdk_wpc3{1};            // "dqdk_wpc3": ca_backward of the fp32 routes at C/8 <= 64 on the three-workgroups-per-CU form of gmap_kernel
 std::atomic<int> g_energy_tail{1};          // the fp32 energies launch cuts the strips beyond its whole rounds into tile-row parts
 // "dqdk_exact" 1: ca_backward of the fp32 pixel-major / split-plane routes (strips <= 100) multiplies in exact fp32 instead of
 // split-bf16 x3: dq / dk errors drop to those of the upstream dA contraction (2e-4 at the headline shape) for +25 us per launch
@@ -827,6 +828,24 @@ int launch_gmap_dual_pm(const float *dE, const FT *k, const FT *q, FT *dq, FT *d
     jc.red_src = red.src; jc.red_n = red.n; jc.red_dst = red.dst;
     constexpr bool F32 = std::is_same<FT, float>::value;
     const bool exact = F32 && g_dqdk_exact.load() != 0;
+    if constexpr (F32 && P <= 100) {
+        // one channel group per strip (C/8 <= 64, the reference's geometry): the three-workgroups-per-CU form -- these launches are
+        // latency chains (attention block -> one tile -> one multiply -> stores), more of them per CU is what shortens them
+        if (!exact && Cq <= cca::GM_CG && g_dqdk_wpc3.load()) {
+            const GmapPlan gc3 = gmap_plan(B * W, Cq, 3), gr3 = gmap_plan(B * H, Cq, 3);
+            cca::GmapJob<FT, float> jc3 = jc;
+            jc3.nwg = gc3.grid;
+            CCA_LAUNCH((cca::gmap_kernel<P, false, false, false, FT, float, false, true, 3>), dim3(cca::gmap_dual_grid(gc3.grid)), dim3(cca::GS_THREADS),
+                       stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
+                       0L, 0, pbs, Cq, gc3.n_whole, gc3.split, jc3);
+            if (int e = launch_status("gmap_dual_pm(column, 3 per CU)")) return e;
+            const cca::GmapJob<FT, FT> jr3{q, pk, dk, qbs, dkbs, qps, dkps, gr3.grid};
+            CCA_LAUNCH((cca::gmap_kernel<P, true, false, true, FT, FT, false, true, 3>), dim3(cca::gmap_dual_grid(gr3.grid)), dim3(cca::GS_THREADS),
+                       stream, dE, k, (const float *)pq, (const FT *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
+                       0L, 0, dqbs, dqps, gr3.n_whole, gr3.split, jr3);
+            return launch_status("gmap_dual_pm(row, 3 per CU)");
+        }
+    }
     if constexpr (F32) {
         if (exact)
             CCA_LAUNCH((cca::gmap_kernel<P, false, false, false, FT, float, false, true, 2, false, true>), dim3(cca::gmap_dual_grid(gc.grid)),
@@ -1492,6 +1511,7 @@ const OptionRange *find_word_option(const std::string &n) {
         {"planes_overlap", &g_planes_overlap, -1, 2},
         {"planes_xcd", &g_planes_xcd, 0, 1},
         {"energy_tail", &g_energy_tail, 0, 1},
+        {"dqdk_wpc3", &g_dqdk_wpc3, 0, 1},
         {"da_stages", &g_da_stages, 2, 3},
         {"dqdk_exact", &g_dqdk_exact, 0, 1},
     };

@@ -257,10 +257,17 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     //  partial and has none)
     static_assert(!LONG || ADD || !ROW, "gmap: the key blocks of a blocked row strip are chained through the addend");
     static_assert(!PL || !OBF, "gmap: split-plane features produce fp32 outputs");
-    static_assert(P % 4 == 0 && (2 * FSZ + OIMG) * 4 * WPC <= 163840, "gmap: LDS of WPC workgroups per CU");
-    __shared__ __attribute__((aligned(16))) float lds[2 * FSZ + OIMG];
+    // WPC = 3 (ca_backward at C/8 <= 64: ONE channel group per strip, so nothing is ever prefetched): a single feature slot + the
+    // output image = 53.6 KB, three workgroups per CU, <= 168 VGPRs (the four N tiles accumulated two at a time, no residual slices)
+    constexpr bool ONEG = WPC == 3;
+    static_assert(!ONEG || (DUAL && !BF && !PL && !EXACT_F32 && P <= 100), "gmap: the one-group form exists for ca_backward on fp32 q | k");
+    constexpr int NSLOT = ONEG ? 1 : 2;
+    // the residual slices (x of functions.py:49 in the output's layout) exist for the final row passes of the all-pixel-major families
+    constexpr bool RES = ROW && ADD && !NCHW && !DUAL && !PL;
+    static_assert(P % 4 == 0 && (NSLOT * FSZ + OIMG) * 4 * WPC <= 163840, "gmap: LDS of WPC workgroups per CU");
+    __shared__ __attribute__((aligned(16))) float lds[NSLOT * FSZ + OIMG];
     CCA_LDS_REGISTER(lds);
-    float *const FB = lds, *const oimg = lds + 2 * FSZ;
+    float *const FB = lds, *const oimg = lds + NSLOT * FSZ;
     const int HW = H * W, S = H + W;
     const int L = ROW ? W : H, G = ROW ? H : W;
     // workgroups are dispatched in index order, two per CU: the first n_whole take a whole strip each, the remaining
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                 t16_dma_piece(Fb, FB + ((cg - cg0) & 1) * FSZ + plane * TSP, it - plane * (NPF / 2), lane, pixK, pstep, Lk, fps,
                               cg * GM_CG, C, plane ? C : 0);
             } else {
-                gtile_dma_piece<FT>(Fb, FB + ((cg - cg0) & 1) * FSZ, it, lane, pixK, pstep, Lk, fps, cg * GM_CG, C);
+                gtile_dma_piece<FT>(Fb, FB + (ONEG ? 0 : (cg - cg0) & 1) * FSZ, it, lane, pixK, pstep, Lk, fps, cg * GM_CG, C);
             }
         }
     };
@@ -403,12 +410,12 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     int nstore_nchw = 0;
 
     for (int cg = cg0; cg < cg1; ++cg) {
-        const float *img = FB + ((cg - cg0) & 1) * FSZ;
+        const float *img = FB + (ONEG ? 0 : (cg - cg0) & 1) * FSZ;
         // tile cg landed, every wave is done with group cg - 1; the stores of group cg - 1 (the most recent vector
         // memory operations of this wave) may stay in flight
         if (cg == cg0) barrier_dma_keep<0>();
         else           barrier_dma_keep_n(NCHW ? nstore_nchw : nstore);
-        if (cg + 1 < cg1) issue_feat(cg + 1);
+        if (!ONEG && cg + 1 < cg1) issue_feat(cg + 1);
         // the fp32 addend / bf16 residual slices this lane will store over: in registers by the time the tiles are done
         f32x4 add0[NSI], add1[NSI];
         u32x4 res[NSI];
@@ -439,13 +446,13 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                 add0[k] = fbuf_load_x4(Db, ok ? (pix * aps + c) * 4 : kOobOffset, 0);
                 if (OBF) add1[k] = fbuf_load_x4(Db, ok ? (pix * aps + c + 4) * 4 : kOobOffset, 0);
             }
-            res[k] = __builtin_bit_cast(u32x4, fbuf_load_x4(Rb, (ok && resid) ? (pix * rps + c) * (int)sizeof(OT) : kOobOffset, 0));
+            if constexpr (RES) res[k] = __builtin_bit_cast(u32x4, fbuf_load_x4(Rb, (ok && resid) ? (pix * rps + c) * (int)sizeof(OT) : kOobOffset, 0));
         }
         // D^T[m = channel][n = strip position] = features^T x attention^T: a lane ends up with 4 consecutive channels of
         // one position (one ds_write_b128 into the pixel-major output image)
         // (three M tiles per wavefront = strips longer than 128: the four N tiles are accumulated two at a time, so that the
         // accumulators -- live together with 96 fragment and up to 60 prefetch registers -- take 24 VGPRs instead of 48)
-        constexpr int NH = TPW >= 3 ? 2 : 1, NTH = 4 / NH;
+        constexpr int NH = (TPW >= 3 || ONEG) ? 2 : 1, NTH = 4 / NH;
 #pragma unroll
         for (int nh = 0; nh < NH; ++nh) {
             f32x4 acc[TPW][NTH];
@@ -597,16 +604,18 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                     if constexpr (OBF) {
                         f32x4 v = lds_load_x4(s + 4);
                         if (ADD) v += add1[k];
+                        if constexpr (RES) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {              // + the bf16 residual (x of functions.py:49)
-                            const float lo = __builtin_bit_cast(float, res[k][e] << 16), hi = __builtin_bit_cast(float, res[k][e] & 0xffff0000u);
-                            if (e < 2) { u[2 * e] += lo; u[2 * e + 1] += hi; } else { v[2 * e - 4] += lo; v[2 * e - 3] += hi; }
+                            for (int e = 0; e < 4; ++e) {              // + the bf16 residual (x of functions.py:49)
+                                const float lo = __builtin_bit_cast(float, res[k][e] << 16), hi = __builtin_bit_cast(float, res[k][e] & 0xffff0000u);
+                                if (e < 2) { u[2 * e] += lo; u[2 * e + 1] += hi; } else { v[2 * e - 4] += lo; v[2 * e - 3] += hi; }
+                            }
                         }
                         const f32x4 packed = __builtin_bit_cast(f32x4, u32x4{cvt_pk_bf16(u[0], u[1]), cvt_pk_bf16(u[2], u[3]),
                                                                              cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])});
                         fbuf_store_x4(Ob, packed, ((pixM + i * pstep) * ops + c) * 2, 0);
                     } else {
-                        u += __builtin_bit_cast(f32x4, res[k]);          // (+ the fp32 residual; zeros when there is none)
+                        if constexpr (RES) u += __builtin_bit_cast(f32x4, res[k]);          // (+ the fp32 residual; zeros when there is none)
                         fbuf_store_x4(Ob, u, ((pixM + i * pstep) * ops + c) * 4, 0);
                     }
                 }

@@ -303,6 +303,9 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
  *   "da_stages"    2 (default) / 3: LDS ring stages of the persistent dA kernel of the plane-free backward.  Three fill the CU's LDS,
  *                    so the dv column pass on the side stream waits for its workgroups to exit; two leave room for one column
  *                    workgroup per CU and the launches overlap for real (backward 0.45 -> 0.40 ms at the headline shape).
+ *   "dqdk_wpc3"    1 (default): ca_backward of the fp32 pixel-major / split-plane entries at strips <= 100 and C/8 <= 64 (one channel
+ *                    group per strip) runs the one-slot form of its kernel: 53.6 KB of LDS, <= 168 VGPRs, three workgroups per CU
+ *                    instead of two (these launches are latency chains); 0: the two-slot form.  Same arithmetic, same bits.
  *   "energy_tail"  1 (default): the fp32 energies launch of the pixel-major / split-plane entries (strips <= 100, C/8 <= 64) cuts the
  *                    strips beyond its whole rounds of workgroups into tile-row parts (a short last round); 0: one workgroup per strip.
  *   "dqdk_exact"   1: ca_backward of the fp32 pixel-major / split-plane entry points (strips <= 100) multiplies in exact fp32

@@ -817,3 +817,24 @@ def test_energies_tail_parts_are_bit_identical_to_one_workgroup_per_strip(ops, s
     _, Ao = O.cca_core_forward(T(np.transpose(qk[..., :cq], (0, 3, 1, 2))), T(np.transpose(qk[..., cq:], (0, 3, 1, 2))),
                                torch.zeros(B, 8, H, W), torch.zeros(B, 8, H, W), torch.zeros(1))
     assert maxerr(outs[0], Ao.numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 128, 17, 20), (1, 64, 3, 97), (1, 512, 6, 5)])
+def test_ca_backward_three_workgroups_per_cu_form_is_bit_identical(ops, shape):
+    """Option "dqdk_wpc3" (default on): at C/8 <= 64 a strip of ca_backward is ONE channel group, and the dq | dk launches run the
+    one-slot form of gmap_kernel (a single feature tile + the output image: three workgroups per CU, the N tiles accumulated two at a
+    time, no residual slices).  Same products in the same order: dq | dk | dv and dgamma bit-identical to the two-slot form."""
+    B, C, H, W = shape
+    cq = C // 8
+    c = rand_case(*shape, seed=202)
+    qkv = np.ascontiguousarray(np.concatenate([_pm(c["q"]), _pm(c["k"]), _pm(c["v"])], axis=3))
+    y, A = ops.cca_forward_planes(qkv, None, c["x"], c["gamma"], cq)
+    outs = []
+    for opt in (1, 0):
+        prev = ops.lib.set_option("dqdk_wpc3", opt)
+        try:
+            outs.append(ops.cca_backward_planes(c["dy"], qkv, None, A, c["gamma"], cq))
+        finally:
+            ops.lib.set_option("dqdk_wpc3", prev)
+        assert prev == 1
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])

@@ -19,6 +19,7 @@ DEFAULT_SETS = {
     "v-as-planes": {"_direct": 0},           # the forward splits v into planes first (what maps beyond 100 positions run)
     "no-xcd": {"planes_xcd": 0},
     "no-energy-tail": {"energy_tail": 0},
+    "dqdk-2-per-cu": {"dqdk_wpc3": 0},       # ca_backward on the two-slot / two-workgroups-per-CU form
     "dA-3-stages": {"da_stages": 3},         # the persistent dA kernel with three ring stages: it fills the LDS, nothing runs next to it
     "dA-3-stages-1s": {"da_stages": 3, "planes_overlap": 0},    # the energies launch as one workgroup per strip (2.02 rounds -> three)
     "one-stream": {"planes_overlap": 0},
@@ -26,7 +27,7 @@ DEFAULT_SETS = {
 }
 lib = _lib.get_lib()
 dev = torch.device("cuda:0")
-BASE = {"planes_ring": 2, "planes_stream": 1, "planes_overlap": -1, "planes_xcd": 1, "energy_tail": 1, "da_stages": 2}
+BASE = {"planes_ring": 2, "planes_stream": 1, "planes_overlap": -1, "planes_xcd": 1, "energy_tail": 1, "da_stages": 2, "dqdk_wpc3": 1}
 wl = bench.PlanesWorkload(lib, B, C, H, W, dev, 1234)
 ref = None
 for rnd in range(2):                       # two rounds: the order of the sets must not matter
@@ -51,7 +52,7 @@ for rnd in range(2):                       # two rounds: the order of the sets m
         gms = bench.time_region(g.replay, 50)
         del g
         print(f"== round {rnd} {name:16s} {opts}: eager {ms:.4f} ms  graph {gms:.4f} ms  fwd {fwd:.4f}  bwd {bwd:.4f}  bit-identical to first: {same}", flush=True)
-        if rnd == 0 and name in ("one-stream", "dA-3-stages-1s"):
+        if rnd == 0 and name in ("one-stream",):
             if name == "v-as-planes":
                 lib.set_option("planes_overlap", 0)
             rec = lib.profile_launches(lambda: [wl.step() for _ in range(5)])
