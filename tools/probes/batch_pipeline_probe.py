@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Probe: does running the split-plane step as TWO image halves on two streams (each half its own launch chain, so one half's
-latency-bound launches -- energies, softmax, dq | dk -- overlap the other half's HBM-bound ones) beat one chain over the
-whole batch?  Pure host-side experiment on the shipped entry points; results must be bit-identical.
+"""Probe: does running the split-plane FORWARD as several image groups on two streams (each group its own launch chain, so one
+group's latency-bound launches -- energies, softmax -- overlap another group's HBM-bound aggregation passes) beat one chain over the
+whole batch?  Pure host-side experiment on the shipped entry points (ABI 200, plane-free form); results must be bit-identical.
 usage: batch_pipeline_probe.py [B C H W]"""
 import os
 import sys
@@ -19,59 +19,50 @@ wl = bench.PlanesWorkload(lib, B, C, H, W, dev, 1234)
 cq, ct = C // 8, wl.ct
 side = torch.cuda.Stream()
 ev_f, ev_j = torch.cuda.Event(), torch.cuda.Event()
-halves = [(0, B // 2), (B // 2, B - B // 2)]
-fws = [torch.empty(lib.ccnet_cca_planes_workspace_bytes(n, C, cq, H, W, 0) // 4 + 64, device=dev) for _, n in halves]
-bws = [torch.empty(lib.ccnet_cca_planes_workspace_bytes(n, C, cq, H, W, 1) // 4 + 64, device=dev) for _, n in halves]
-dgam = torch.empty(2, device=dev)
 
 
-def fwd_half(i, stream):
-    b0, n = halves[i]
+def groups(n):
+    k, out, b0 = B // n, [], 0
+    for i in range(n):
+        nb = k + (1 if i < B - k * n else 0)
+        out.append((b0, nb))
+        b0 += nb
+    return out
+
+
+def fwd_group(b0, n, ws, stream):
     bs = H * W * ct
     p = wl.qkv[b0:].data_ptr()
-    lib.check(lib.ccnet_cca_forward_planes_f32(p, p + 4 * cq, wl.vpl[b0:].data_ptr(), wl.x[b0:].data_ptr(), wl.gamma.data_ptr(),
-                                               wl.y[b0:].data_ptr(), wl.A[b0:].data_ptr(), n, C, cq, H, W, bs, ct, bs, ct,
-                                               H * W * 2 * C, 2 * C, fws[i].data_ptr(), fws[i].numel() * 4, stream), "fwd half")
+    lib.check(lib.ccnet_cca_forward_planes_f32(p, p + 4 * cq, p + 8 * cq, None, None, wl.x[b0:].data_ptr(), wl.gamma.data_ptr(),
+                                               wl.y[b0:].data_ptr(), wl.A[b0:].data_ptr(), n, C, cq, H, W, bs, ct, bs, ct, bs, ct,
+                                               H * W * 2 * C, 2 * C, ws.data_ptr(), ws.numel() * 4, stream), "fwd group")
 
 
-def bwd_half(i, stream):
-    b0, n = halves[i]
-    bs = H * W * ct
-    p, g = wl.qkv[b0:].data_ptr(), wl.dqkv[b0:].data_ptr()
-    lib.check(lib.ccnet_cca_backward_planes_f32(wl.dy[b0:].data_ptr(), p, p + 4 * cq, wl.vpl[b0:].data_ptr(), wl.A[b0:].data_ptr(),
-                                                wl.gamma.data_ptr(), g, g + 4 * cq, g + 8 * cq, dgam[i:].data_ptr(),
-                                                wl.scratch[b0:].data_ptr(), n, C, cq, H, W, bs, ct, bs, ct, H * W * 2 * C, 2 * C,
-                                                bs, ct, bs, ct, bs, ct, bws[i].data_ptr(), bws[i].numel() * 4, stream), "bwd half")
+def make(n):
+    gs = groups(n)
+    wss = [torch.empty(lib.ccnet_cca_planes_workspace_bytes(nb, C, cq, H, W, 0) // 4 + 64, device=dev) for _, nb in gs]
+
+    def run():
+        main = torch.cuda.current_stream()
+        ev_f.record(main)
+        side.wait_event(ev_f)
+        for i, (b0, nb) in enumerate(gs):                    # groups alternate between the two streams
+            fwd_group(b0, nb, wss[i], (main if i % 2 == 0 else side).cuda_stream)
+        ev_j.record(side)
+        main.wait_event(ev_j)
+    return run
 
 
-def two_chains(fn):
-    main = torch.cuda.current_stream()
-    ev_f.record(main)
-    side.wait_event(ev_f)
-    fn(0, main.cuda_stream)
-    fn(1, side.cuda_stream)
-    ev_j.record(side)
-    main.wait_event(ev_j)
-
-
-def step_split():
-    two_chains(fwd_half)
-    two_chains(bwd_half)
-
-
-for ov in (-1, 0):
-    lib.set_option("planes_overlap", ov)
-    for _ in range(5):
-        wl.step(); step_split()
+for _ in range(5):
+    wl.forward()
+torch.cuda.synchronize()
+ref = (wl.y.clone(), wl.A.clone())
+print(f"one chain over the batch: fwd {bench.time_region(wl.forward, 30):.4f} ms")
+for n in (2, 4, 8):
+    run = make(n)
+    wl.y.zero_()
+    for _ in range(3):
+        run()
     torch.cuda.synchronize()
-    wl.step(); torch.cuda.synchronize()
-    ref = (wl.y.clone(), wl.dqkv.clone(), wl.A.clone())
-    wl.y.zero_(); wl.dqkv.zero_()
-    step_split(); torch.cuda.synchronize()
-    same = all(torch.equal(a, b) for a, b in zip(ref, (wl.y, wl.dqkv, wl.A)))
-    print(f"planes_overlap={ov}: one chain  step {bench.time_region(wl.step, 30):.4f}  fwd {bench.time_region(wl.forward, 30):.4f}  "
-          f"bwd {bench.time_region(wl.backward, 30):.4f} ms")
-    print(f"planes_overlap={ov}: two halves step {bench.time_region(step_split, 30):.4f}  "
-          f"fwd {bench.time_region(lambda: two_chains(fwd_half), 30):.4f}  bwd {bench.time_region(lambda: two_chains(bwd_half), 30):.4f} ms"
-          f"   bit-identical y / dqkv / A: {same}")
-lib.set_option("planes_overlap", -1)
+    same = torch.equal(ref[0], wl.y) and torch.equal(ref[1], wl.A)
+    print(f"{n} image groups on two streams: fwd {bench.time_region(run, 30):.4f} ms   bit-identical y / A: {same}")
