@@ -57,7 +57,8 @@ for _ in range(5):
     wl.forward()
 torch.cuda.synchronize()
 ref = (wl.y.clone(), wl.A.clone())
-print(f"one chain over the batch: fwd {bench.time_region(wl.forward, 30):.4f} ms")
+g0 = bench.capture_step_graph(wl.forward)          # (replayed graphs: the eager numbers carry the host's launch overhead, 8 .. 32 launches)
+print(f"one chain over the batch: fwd eager {bench.time_region(wl.forward, 30):.4f} ms, graph replay {bench.time_region(g0.replay, 50):.4f} ms")
 for n in (2, 4, 8):
     run = make(n)
     wl.y.zero_()
@@ -65,4 +66,7 @@ for n in (2, 4, 8):
         run()
     torch.cuda.synchronize()
     same = torch.equal(ref[0], wl.y) and torch.equal(ref[1], wl.A)
-    print(f"{n} image groups on two streams: fwd {bench.time_region(run, 30):.4f} ms   bit-identical y / A: {same}")
+    g = bench.capture_step_graph(run)
+    print(f"{n} image groups on two streams: fwd eager {bench.time_region(run, 30):.4f} ms, graph replay {bench.time_region(g.replay, 50):.4f} ms"
+          f"   bit-identical y / A: {same}")
+    del g
