@@ -1047,6 +1047,34 @@ def test_side_stream_overlap_is_result_neutral_and_captures_into_one_graph(lib, 
         lib.set_option("planes_overlap", -1)
 
 
+def test_launch_form_options_are_result_neutral_at_the_headline_geometry(lib, dev):
+    """Round 4, second half: "da_stages" (ring stages of the persistent dA kernel: two leave LDS for a dv column workgroup next to it),
+    "dqdk_wpc3" (ca_backward on the one-slot, three-workgroups-per-CU form), "energy_tail" (the energies launch cuts the strips beyond
+    its whole rounds into tile-row parts) and "planes_xcd" only move work: every combination tried gives the bits of the defaults, at
+    the headline geometry (1552 strips: the energies tail path runs), eagerly and graph-replayed."""
+    import bench
+    defaults = {"da_stages": 2, "dqdk_wpc3": 1, "energy_tail": 1, "planes_xcd": 1}
+    wl = bench.PlanesWorkload(lib, 8, 512, 97, 97, dev, 33)
+    try:
+        for k, v in defaults.items():
+            assert lib.get_option(k) == v, k
+        wl.step()
+        torch.cuda.synchronize()
+        ref = [t.clone() for t in (wl.y, wl.dqkv, wl.dgamma, wl.A)]
+        for opts in ({"da_stages": 3}, {"dqdk_wpc3": 0}, {"energy_tail": 0}, {"da_stages": 3, "dqdk_wpc3": 0, "energy_tail": 0, "planes_xcd": 0}):
+            for k, v in {**defaults, **opts}.items():
+                lib.set_option(k, v)
+            for run in (wl.step, bench.capture_step_graph(wl.step).replay):
+                for t in (wl.y, wl.dqkv, wl.A):
+                    t.zero_()
+                run()
+                torch.cuda.synchronize()
+                assert all(torch.equal(a, b) for a, b in zip((wl.y, wl.dqkv, wl.dgamma, wl.A), ref)), opts
+    finally:
+        for k, v in defaults.items():
+            lib.set_option(k, v)
+
+
 def _random_pm_shapes(n, longest, align, seed):
     rng = np.random.default_rng(seed)
     shapes = []
