@@ -1289,9 +1289,16 @@ int gmap_dual_f32(const float *dE, const float *k, const float *q, float *dq, fl
             if (int e = launch_status("gmap_dual_f32(long columns)")) return e;
         }
     } else {
-        const GmapPlan gc = gmap_plan(B * W, Cq, 1);
+        // (C/8 <= 64: one channel group per strip -> the one-slot form, two workgroups per CU; see gmap_kernel, ONEG)
+        const bool one = Cq <= cca::GM_CG && g_dqdk_wpc3.load() != 0;
+        const GmapPlan gc = gmap_plan(B * W, Cq, one ? 2 : 1);
         cca::GmapJob<float, float> jc{q, nullptr, pk, qbs, pbs, qps, Cq, gc.grid};
         jc.red_src = red.src; jc.red_n = red.n; jc.red_dst = red.dst;
+        if (one)
+            CCA_LAUNCH((cca::gmap_kernel<132, false, false, false, float, float, false, true, 2>), dim3(cca::gmap_dual_grid(gc.grid)), dim3(cca::GS_THREADS),
+                       stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
+                       0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
+        else
         CCA_LAUNCH((cca::gmap_kernel<132, false, false, false, float, float, false, true, 1>), dim3(cca::gmap_dual_grid(gc.grid)), dim3(cca::GS_THREADS),
                    stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
                    0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
@@ -1315,6 +1322,14 @@ int gmap_dual_f32(const float *dE, const float *k, const float *q, float *dq, fl
             if (int e = launch_status("gmap_dual_f32(long rows)")) return e;
         }
         return 0;
+    }
+    if (Cq <= cca::GM_CG && g_dqdk_wpc3.load() != 0) {
+        const GmapPlan gr2 = gmap_plan(B * H, Cq, 2);
+        const cca::GmapJob<float, float> jr2{q, pk, dk, qbs, dkbs, qps, dkps, gr2.grid};
+        CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, float, float, false, true, 2>), dim3(cca::gmap_dual_grid(gr2.grid)), dim3(cca::GS_THREADS),
+                   stream, dE, k, (const float *)pq, (const float *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
+                   0L, 0, dqbs, dqps, gr2.n_whole, gr2.split, jr2);
+        return launch_status("gmap_dual_f32(row, 132, one slot)");
     }
     const cca::GmapJob<float, float> jr{q, pk, dk, qbs, dkbs, qps, dkps, gr.grid};
     CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, float, float, false, true, 1>), dim3(cca::gmap_dual_grid(gr.grid)), dim3(cca::GS_THREADS),

@@ -259,8 +259,9 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     static_assert(!PL || !OBF, "gmap: split-plane features produce fp32 outputs");
     // WPC = 3 (ca_backward at C/8 <= 64: ONE channel group per strip, so nothing is ever prefetched): a single feature slot + the
     // output image = 53.6 KB, three workgroups per CU, <= 168 VGPRs (the four N tiles accumulated two at a time, no residual slices)
-    constexpr bool ONEG = WPC == 3;
-    static_assert(!ONEG || (DUAL && !BF && !PL && !EXACT_F32 && P <= 100), "gmap: the one-group form exists for ca_backward on fp32 q | k");
+    // (at 101 .. 132 positions the same form is WPC = 2 -- 70.7 KB, 180 / 228 VGPRs -- where the two-slot one ran ONE workgroup per CU)
+    constexpr bool ONEG = WPC == 3 || (DUAL && !BF && !PL && !EXACT_F32 && !LONG && P > 100 && WPC == 2);
+    static_assert(!ONEG || (DUAL && !BF && !PL && !EXACT_F32), "gmap: the one-group form exists for ca_backward on fp32 q | k");
     constexpr int NSLOT = ONEG ? 1 : 2;
     // the residual slices (x of functions.py:49 in the output's layout) exist for the final row passes of the all-pixel-major families
     constexpr bool RES = ROW && ADD && !NCHW && !DUAL && !PL;

@@ -35,7 +35,7 @@ for rnd in range(2):                       # two rounds: the order of the sets m
         for k, v in {**BASE, **opts}.items():
             if not k.startswith("_"):
                 lib.set_option(k, v)
-        wl.direct = bool(opts.get("_direct", 1))
+        wl.direct = bool(opts.get("_direct", 1)) and max(H, W) <= 100          # (the plane-free form serves strips <= 100)
         if not wl.direct and wl.vpl is None:
             wl.vpl = torch.empty(B, H, W, 2, C, dtype=torch.int16, device=dev)
         for _ in range(5):
