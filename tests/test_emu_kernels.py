@@ -691,7 +691,7 @@ def test_streaming_dA_kernel_walks_many_strips_per_workgroup(ops, shape):
         assert np.array_equal(dqkv, outs[0][0]) and np.array_equal(dg, outs[0][1])
 
 
-@pytest.mark.parametrize("shape", [(2, 128, 8, 5), (1, 64, 3, 97), (1, 64, 2, 140)])
+@pytest.mark.parametrize("shape", [(2, 128, 8, 5), (1, 64, 3, 97), (1, 64, 2, 140), (1, 32, 133, 5)])       # (the last one: blocked COLUMNS)
 def test_split_plane_forward_takes_fp32_v_and_recomputes_its_saved_pair(ops, shape):
     """ABI 200: (i) ccnet_cca_forward_planes_f32 with the fp32 value slice (+ the projection's value bias) as its input -- the
     split runs inside the entry point -- is bit-identical to handing it planes split beforehand; (ii) ccnet_cca_attention_pm
