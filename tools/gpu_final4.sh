@@ -13,6 +13,7 @@ cp "$R/gpurun_out/pmc_$TAG/summary.json" "$OUT/pmc_step_summary.json" 2>/dev/nul
 echo "== PMC passes (bf16 configs[4] step)"; bash tools/pmc.sh "${TAG}_bf16" --script tools/pm_bf16_time.py > "$OUT/pmc_bf16.log" 2>&1; tail -2 "$OUT/pmc_bf16.log"
 cp "$R/gpurun_out/pmc_${TAG}_bf16/summary.json" "$OUT/bf16_config5_pmc_summary.json" 2>/dev/null
 echo "== stress (run-to-run bit identity under HBM load)"; timeout 600 python tools/stress_pm.py 100 > "$OUT/stress_pm.log" 2>&1; tail -3 "$OUT/stress_pm.log"
+echo "== kernel-trace timelines (eager / graph-replayed steps: who really overlaps whom)"; bash tools/timeline.sh "$TAG" > "$OUT/timeline.log" 2>&1; tail -3 "$OUT/timeline_graph.txt"
 echo "== bench, bf16 configs[4] as the measured workload"; timeout 600 python bench.py --dtype bf16 --steps 30 --warmup 5 --no-train --no-cpu-baseline > "$OUT/bench_bf16.json" 2> "$OUT/bench_bf16.err"; head -c 600 "$OUT/bench_bf16.json"; echo
 # keep the payload small
 find "$R/gpurun_out/pmc_$TAG" "$R/gpurun_out/pmc_${TAG}_bf16" -name "*.csv" -size +5M -delete 2>/dev/null
