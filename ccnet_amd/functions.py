@@ -767,6 +767,7 @@ class CrissCrossAttention(nn.Module):
         "f32-channels-last": "one x^T W^T projection + pixel-major fp32 kernels, channels_last in / out",
         "f32-planes": "one autograd node: projection GEMM, v / dy as bf16 hi | lo planes, NCHW x / y / dy",
         "f32-strips-node": "one autograd node on the NCHW strip kernels (honours recompute_attention)",
+        "f32-planes-cast": "half-precision (or autocast) inputs whose strips exceed the bf16 kernels' 132 positions: the f32-planes node on fp32 copies",
         "packed-strips": "stacked conv2d + NCHW strip kernels through channel-slice strides (any float dtype, autocast)",
         "separate-strips": "three convolutions + NCHW strip / windowed / any-shape kernels (functions.py:29-35 as written)",
     }
@@ -796,6 +797,13 @@ class CrissCrossAttention(nn.Module):
                 return "f32-planes"
             if self.fuse_projections and self.fuse_module_backward:
                 return "f32-strips-node"
+        # half-precision activations (or fp32 under autocast) on a map beyond the bf16 kernels' 132 positions -- mixed-precision
+        # whole-image evaluation, evaluate.py:102-166 -- used to fall to the windowed / any-shape strip kernels through fp32 copies;
+        # the blocked plane kernels take such maps (strips <= 528): the fp32 node on fp32 copies of x and of the parameters
+        half = x.dtype in (torch.bfloat16, torch.float16) or (x.dtype == torch.float32 and torch.is_autocast_enabled())
+        if (half and fast_ok and self.fuse_module_backward and self.split_planes and self._fusable() and max(H, W) > 132
+                and planes_cover(B, C, cq, H, W)):
+            return "f32-planes-cast"
         if self.fuse_projections and self._fusable():
             return "packed-strips"
         return "separate-strips"
@@ -824,6 +832,12 @@ class CrissCrossAttention(nn.Module):
             split_gemm = self.split_bf16_projections and x.shape[0] * x.shape[2] * x.shape[3] >= self.split_bf16_min_pixels
             return CrissCrossPlanesModuleFunction.apply(x, *params, self.gamma, split_gemm, self.recompute_attention,
                                                         self._projection_cache())
+        if r == "f32-planes-cast":
+            with torch.autocast(device_type="cuda", enabled=False):          # (the node's GEMMs are its own: fp32 / split-bf16 x3)
+                split_gemm = self.split_bf16_projections and x.shape[0] * x.shape[2] * x.shape[3] >= self.split_bf16_min_pixels
+                y = CrissCrossPlanesModuleFunction.apply(x.float().contiguous(), *(p.float() for p in params), self.gamma.float(),
+                                                         split_gemm, self.recompute_attention, None)
+            return y.to(x.dtype)
         if r == "f32-strips-node":
             return CrissCrossModuleFunction.apply(x, *params, self.gamma, self.recompute_attention)
         if r == "packed-strips":

@@ -352,6 +352,44 @@ def test_channels_last_and_autocast_inputs_are_accepted(lib, dev):
     assert y_ac.dtype == torch.float32 and err(y_ac, y_ref) < 0.1       # bf16 projections, fp32 attention core
 
 
+@pytest.mark.parametrize("shape,mode", [((1, 256, 129, 257), "bf16"), ((1, 128, 161, 140), "bf16"), ((1, 128, 97, 193), "autocast")])
+def test_half_precision_inputs_on_long_maps_take_the_blocked_plane_kernels(lib, dev, shape, mode):
+    """Mixed-precision whole-image evaluation (evaluate.py:102-166 under bf16): a bf16 module / an fp32 module under autocast on a map
+    beyond the bf16 kernels' 132 positions runs the f32-planes node on fp32 copies (route ``f32-planes-cast``; round 3: windowed /
+    any-shape strip kernels through fp32 copies).  y against the oracle on the SAME (bf16-rounded) parameters and input within the
+    output's own rounding; gradients flow to x and to the (bf16) parameters."""
+    from ccnet_amd import CrissCrossAttention
+    B, C, H, W = shape
+    torch.manual_seed(17)
+    m = CrissCrossAttention(C).to(dev)
+    with torch.no_grad():
+        m.gamma.fill_(0.5)
+    x = torch.randn(B, C, H, W, device=dev)
+    if mode == "bf16":
+        m = m.to(torch.bfloat16)
+        x = x.to(torch.bfloat16)
+        assert m.route(x) == "f32-planes-cast"
+        xi = x.clone().requires_grad_(True)
+        y = m(xi)
+    else:
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            assert m.route(xi) == "f32-planes-cast"
+            y = m(xi)
+    assert y.dtype == x.dtype and y.shape == x.shape
+    y.float().sum().backward()
+    assert xi.grad is not None and bool(torch.isfinite(xi.grad.float()).all())
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad.float()).all()) for p in m.parameters())
+    with torch.no_grad():
+        f = lambda t: t.detach().float().cpu()                              # noqa: E731
+        conv = lambda c: torch.nn.functional.conv2d(f(x), f(c.weight), f(c.bias))        # noqa: E731  (fp32 on the rounded values)
+        yo, _ = O.cca_core_forward(conv(m.query_conv), conv(m.key_conv), conv(m.value_conv), f(x), torch.tensor([0.5]))
+    bar = (2.0 ** -8) * yo.abs() + 1e-3 if mode == "bf16" else torch.full_like(yo, TOL)     # (bf16 output: one rounding of y)
+    excess = float(((f(y) - yo).abs() - bar).max())
+    print("half-precision long map", shape, mode, "max |y - oracle|", f"{err(f(y), yo):.1e}", "excess over the bar", f"{excess:.1e}")
+    assert excess <= 0.0
+
+
 def _bf16_core_inputs(B, C, H, W, dev, seed):
     q, k, v, x, dy = (t.to(dev).to(torch.bfloat16) for t in make_core_inputs(B, C, H, W, seed=seed))
     return q, k, v, x, dy

@@ -291,8 +291,11 @@ def test_module_routing_table(device_lib_path):
         assert m.route(nchw(1, 129, 257)) == "f32-planes" and m.route(nchw(1, 161, 321)) == "f32-planes"
     m.to(torch.bfloat16)
     assert m.route(cl(2, 129, 129, torch.bfloat16)) == "bf16-pixel-major"
-    assert m.route(nchw(1, 330, 9, torch.bfloat16)) == "packed-strips"           # any-shape fp32 kernels through fp32 copies
-    assert m.route(nchw(1, 200, 9, torch.bfloat16)) == "packed-strips"           # windowed fp32 kernels through fp32 copies
+    assert m.route(nchw(1, 129, 257, torch.bfloat16)) == "f32-planes-cast"      # beyond the bf16 kernels: blocked fp32 plane kernels on copies
+    assert m.route(nchw(1, 257, 513, torch.bfloat16)) == "f32-planes-cast"
+    assert m.route(nchw(1, 330, 9, torch.bfloat16)) == "f32-planes-cast"         # (round 3: any-shape fp32 kernels through fp32 copies)
+    assert m.route(nchw(1, 200, 9, torch.bfloat16)) == "f32-planes-cast"         # (round 3: windowed fp32 kernels through fp32 copies)
+    assert m.route(nchw(1, 600, 9, torch.bfloat16)) == "packed-strips"           # beyond 528 positions: any-shape fp32 kernels through fp32 copies
     m.to(torch.float32)
     m.split_planes = False
     assert m.route(nchw(2, 97, 97)) == "f32-strips-node" and m.route(nchw(8, 97, 97)) == "f32-strips-node"
