@@ -756,9 +756,9 @@ class CrissCrossAttention(nn.Module):
     split_bf16_min_pixels = 32768
     #: fp32 channels_last inputs run on the pixel-major family (x as (B, H, W, C) is then a free view: nothing is copied).
     pixel_major_for_channels_last = True
-    #: bf16 inputs: strips <= 132 (C, C/8 divisible by 8) run on the pixel-major bf16 MFMA kernels; every other geometry is
-    #: computed through fp32 copies on the fp32 kernels (round 2 also had any-shape bf16-I/O kernels for strips > 320:
-    #: 793 ms at configs[4], removed from the library in round 3).
+    #: bf16 inputs: strips <= 132 (C, C/8 divisible by 8) run on the pixel-major bf16 MFMA kernels; strips of 133 .. 528 positions
+    #: run the blocked fp32 plane kernels on fp32 copies (route ``f32-planes-cast``), anything else the strip family through fp32
+    #: copies (round 2 also had any-shape bf16-I/O kernels for strips > 320: 793 ms at configs[4], removed in round 3).
     native_bf16 = True
 
     #: route name -> what runs (``route(x)`` picks one; ``forward`` only dispatches on it)
