@@ -767,7 +767,7 @@ class CrissCrossAttention(nn.Module):
         "f32-channels-last": "one x^T W^T projection + pixel-major fp32 kernels, channels_last in / out",
         "f32-planes": "one autograd node: projection GEMM, v / dy as bf16 hi | lo planes, NCHW x / y / dy",
         "f32-strips-node": "one autograd node on the NCHW strip kernels (honours recompute_attention)",
-        "f32-planes-cast": "half-precision (or autocast) inputs whose strips exceed the bf16 kernels' 132 positions: the f32-planes node on fp32 copies",
+        "f32-planes-cast": "fp32 inputs under autocast, fp16 inputs, bf16 inputs beyond the bf16 kernels' 132 positions: the f32-planes node on fp32 copies, autocast off inside",
         "packed-strips": "stacked conv2d + NCHW strip kernels through channel-slice strides (any float dtype, autocast)",
         "separate-strips": "three convolutions + NCHW strip / windowed / any-shape kernels (functions.py:29-35 as written)",
     }
@@ -800,8 +800,13 @@ class CrissCrossAttention(nn.Module):
         # half-precision activations (or fp32 under autocast) on a map beyond the bf16 kernels' 132 positions -- mixed-precision
         # whole-image evaluation, evaluate.py:102-166 -- used to fall to the windowed / any-shape strip kernels through fp32 copies;
         # the blocked plane kernels take such maps (strips <= 528): the fp32 node on fp32 copies of x and of the parameters
+        # ... and an fp32 input under autocast (what RCCAModule hands this module in an autocast training run: InPlaceABNSync returns
+        # fp32) or an fp16 one (no native kernels) takes the same node at EVERY covered size: against stacked conv2d under autocast +
+        # the strip kernels, module fwd+bwd at (B,512,97,97) 0.54 -> 0.41 ms (B = 1), 1.83 -> 1.75 ms (B = 8), with fp32-accurate
+        # projections (profiles/r04lv_autocast_route_probe.txt)
         half = x.dtype in (torch.bfloat16, torch.float16) or (x.dtype == torch.float32 and torch.is_autocast_enabled())
-        if (half and fast_ok and self.fuse_module_backward and self.split_planes and self._fusable() and max(H, W) > 132
+        not_native = x.dtype != torch.bfloat16 or max(H, W) > 132 or not self.native_bf16
+        if (half and not_native and fast_ok and self.fuse_module_backward and self.split_planes and self._fusable()
                 and planes_cover(B, C, cq, H, W)):
             return "f32-planes-cast"
         if self.fuse_projections and self._fusable():

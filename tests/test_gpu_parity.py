@@ -352,7 +352,8 @@ def test_channels_last_and_autocast_inputs_are_accepted(lib, dev):
     assert y_ac.dtype == torch.float32 and err(y_ac, y_ref) < 0.1       # bf16 projections, fp32 attention core
 
 
-@pytest.mark.parametrize("shape,mode", [((1, 256, 129, 257), "bf16"), ((1, 128, 161, 140), "bf16"), ((1, 128, 97, 193), "autocast")])
+@pytest.mark.parametrize("shape,mode", [((1, 256, 129, 257), "bf16"), ((1, 128, 161, 140), "bf16"), ((1, 128, 97, 193), "autocast"),
+                                        ((2, 128, 97, 97), "autocast"), ((2, 128, 65, 97), "fp16")])      # (every covered size for these two)
 def test_half_precision_inputs_on_long_maps_take_the_blocked_plane_kernels(lib, dev, shape, mode):
     """Mixed-precision whole-image evaluation (evaluate.py:102-166 under bf16): a bf16 module / an fp32 module under autocast on a map
     beyond the bf16 kernels' 132 positions runs the f32-planes node on fp32 copies (route ``f32-planes-cast``; round 3: windowed /
@@ -365,9 +366,10 @@ def test_half_precision_inputs_on_long_maps_take_the_blocked_plane_kernels(lib, 
     with torch.no_grad():
         m.gamma.fill_(0.5)
     x = torch.randn(B, C, H, W, device=dev)
-    if mode == "bf16":
-        m = m.to(torch.bfloat16)
-        x = x.to(torch.bfloat16)
+    if mode in ("bf16", "fp16"):
+        dt = torch.bfloat16 if mode == "bf16" else torch.float16
+        m = m.to(dt)
+        x = x.to(dt)
         assert m.route(x) == "f32-planes-cast"
         xi = x.clone().requires_grad_(True)
         y = m(xi)
@@ -384,7 +386,8 @@ def test_half_precision_inputs_on_long_maps_take_the_blocked_plane_kernels(lib, 
         f = lambda t: t.detach().float().cpu()                              # noqa: E731
         conv = lambda c: torch.nn.functional.conv2d(f(x), f(c.weight), f(c.bias))        # noqa: E731  (fp32 on the rounded values)
         yo, _ = O.cca_core_forward(conv(m.query_conv), conv(m.key_conv), conv(m.value_conv), f(x), torch.tensor([0.5]))
-    bar = (2.0 ** -8) * yo.abs() + 1e-3 if mode == "bf16" else torch.full_like(yo, TOL)     # (bf16 output: one rounding of y)
+    ulp = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}.get(mode)
+    bar = ulp * yo.abs() + 1e-3 if ulp else torch.full_like(yo, TOL)         # (half-precision output: one rounding of y)
     excess = float(((f(y) - yo).abs() - bar).max())
     print("half-precision long map", shape, mode, "max |y - oracle|", f"{err(f(y), yo):.1e}", "excess over the bar", f"{excess:.1e}")
     assert excess <= 0.0
@@ -396,15 +399,16 @@ def _bf16_core_inputs(B, C, H, W, dev, seed):
 
 
 def test_bf16_module_beyond_every_strip_kernel_runs_through_fp32_copies(lib, dev):
-    """bf16 activations at a geometry no bf16 / MFMA kernel covers (strips > 320): the module computes through fp32 copies
-    on the any-shape fp32 kernels and hands back bf16 (round 2's any-shape bf16-I/O kernels were removed from the library)."""
+    """bf16 activations at a geometry no bf16 / MFMA kernel covers (strips > 528: the blocked plane kernels stop there): the module
+    computes through fp32 copies on the any-shape fp32 kernels and hands back bf16 (round 2's any-shape bf16-I/O kernels were
+    removed from the library)."""
     from ccnet_amd import CrissCrossAttention
     m = CrissCrossAttention(64).to(dev).to(torch.bfloat16)
     assert m._strip_kernels_cover(torch.empty(1, 64, 129, 129)) and not m._strip_kernels_cover(torch.empty(1, 64, 321, 20))
     with torch.no_grad():
         m.gamma.fill_(0.5)
-    xm = torch.randn(1, 64, 330, 9, device=dev, dtype=torch.bfloat16, requires_grad=True)
-    assert m.route(xm) == "packed-strips"
+    xm = torch.randn(1, 64, 600, 9, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    assert m.route(xm) == "packed-strips" and m.route(xm[:, :, :330]) == "f32-planes-cast"
     ym = m(xm)
     ym.sum().backward()
     assert ym.dtype == torch.bfloat16 and m.gamma.grad is not None and xm.grad is not None

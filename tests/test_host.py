@@ -296,6 +296,9 @@ def test_module_routing_table(device_lib_path):
     assert m.route(nchw(1, 330, 9, torch.bfloat16)) == "f32-planes-cast"         # (round 3: any-shape fp32 kernels through fp32 copies)
     assert m.route(nchw(1, 200, 9, torch.bfloat16)) == "f32-planes-cast"         # (round 3: windowed fp32 kernels through fp32 copies)
     assert m.route(nchw(1, 600, 9, torch.bfloat16)) == "packed-strips"           # beyond 528 positions: any-shape fp32 kernels through fp32 copies
+    m.to(torch.float16)
+    assert m.route(nchw(2, 97, 97, torch.float16)) == "f32-planes-cast"          # fp16: no native kernels, the fp32 node on copies
+    m.to(torch.float32)
     m.to(torch.float32)
     m.split_planes = False
     assert m.route(nchw(2, 97, 97)) == "f32-strips-node" and m.route(nchw(8, 97, 97)) == "f32-strips-node"
