@@ -807,6 +807,7 @@ class CrissCrossAttention(nn.Module):
         half = x.dtype in (torch.bfloat16, torch.float16) or (x.dtype == torch.float32 and torch.is_autocast_enabled())
         not_native = x.dtype != torch.bfloat16 or max(H, W) > 132 or not self.native_bf16
         if (half and not_native and fast_ok and self.fuse_module_backward and self.split_planes and self._fusable()
+                and self.query_conv.weight.device == x.device and x.shape[1] == self.query_conv.in_channels
                 and planes_cover(B, C, cq, H, W)):
             return "f32-planes-cast"
         if self.fuse_projections and self._fusable():
