@@ -16,7 +16,9 @@ cases = [("bf16 (16,512,129,129)", bench.PixelMajorBF16Workload(lib, 16, 512, 12
          ("f32 planes (1,512,97,97)", bench.PlanesWorkload(lib, 1, 512, 97, 97, dev, 10)),
          ("f32 planes (3,256,100,61)", bench.PlanesWorkload(lib, 3, 256, 100, 61, dev, 11)),
          ("f32 planes, long rows (2,512,129,257)", bench.PlanesWorkload(lib, 2, 512, 129, 257, dev, 12)),       # blocks of <= 100
-         ("f32 planes, long rows (1,128,60,500)", bench.PlanesWorkload(lib, 1, 128, 60, 500, dev, 13))]          # blocks of <= 132
+         ("f32 planes, long rows (1,128,60,500)", bench.PlanesWorkload(lib, 1, 128, 60, 500, dev, 13)),          # blocks of <= 132
+         ("f32 planes, long columns and rows (1,256,161,321)", bench.PlanesWorkload(lib, 1, 256, 161, 321, dev, 14)),   # blocked column passes too
+         ("f32 planes, long columns (1,128,402,97)", bench.PlanesWorkload(lib, 1, 128, 402, 97, dev, 15))]       # 132-position column blocks
 for name, wl in cases:
     outs = lambda: (wl.y, wl.dqkv, wl.dgamma, wl.A)          # noqa: E731
     wl.step(); torch.cuda.synchronize()
