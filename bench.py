@@ -469,27 +469,116 @@ def launch_accounting(lib, wl, graph, steps=20):
     return out
 
 
-def gpu_state_under_load(step, device_index=0, replays=1500):
+def gpu_state_under_load(step, device_index=0, replays=3000):
     """Clocks and power of the GPU WHILE the step is running (rocm-smi sampled against a queue of asynchronously enqueued
-    steps): boxes of the pool differ by up to 12 % on this workload with identical streaming-kernel times -- the slow ones run
-    every latency- / matrix-bound launch 10-35 % slower (profiles/r04b_*) -- and the shader clock under load is the first thing
-    to look at.  None when rocm-smi is not there."""
+    steps), the power CAP of the socket, and up to four power samples spread over the queue: rocm-smi's sclk is the REQUESTED
+    level -- what a wave really ran at is measured in-band by ``gpu_probe`` below.  None when rocm-smi is not there."""
     import re
+    num = lambda v: (lambda m: float(m.group(1)) if m else None)(re.search(r"([0-9.]+)", str(v)))   # noqa: E731
     try:
+        cap = None
+        try:
+            p = subprocess.run(["rocm-smi", "-d", str(device_index), "--showmaxpower", "--json"],
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20)
+            card = next(iter(json.loads(p.stdout).values()))
+            cap = next((num(v) for k, v in card.items() if "max" in k.lower() and "power" in k.lower()), None)
+        except Exception:
+            pass
         for _ in range(replays):
             step()
-        p = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower", "--showperflevel", "--json"],
-                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20)
-        busy = not torch.cuda.current_stream().query()          # (the queue must still be running when the sample returns)
+        samples, card, busy = [], {}, False
+        for _ in range(4):
+            p = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower", "--showperflevel", "--json"],
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20)
+            if torch.cuda.current_stream().query():              # (the queue must still be running when the sample returns)
+                break
+            busy = True
+            card = next(iter(json.loads(p.stdout).values()))
+            samples.append(num(card.get("Current Socket Graphics Package Power (W)", "")))
         torch.cuda.synchronize()
-        card = next(iter(json.loads(p.stdout).values()))
-        num = lambda k: (lambda m: float(m.group(1)) if m else None)(re.search(r"([0-9.]+)", str(card.get(k, ""))))   # noqa: E731
-        return {"sclk_mhz": num("sclk clock speed:"), "mclk_mhz": num("mclk clock speed:"), "fclk_mhz": num("fclk clock speed:"),
-                "socket_power_w": num("Current Socket Graphics Package Power (W)"), "perf_level": card.get("Performance Level"),
-                "sampled_while_busy": bool(busy)}
+        return {"sclk_mhz": num(card.get("sclk clock speed:", "")), "mclk_mhz": num(card.get("mclk clock speed:", "")),
+                "fclk_mhz": num(card.get("fclk clock speed:", "")),
+                "socket_power_w": samples[-1] if samples else None, "socket_power_w_samples": samples, "power_cap_w": cap,
+                "perf_level": card.get("Performance Level"), "sampled_while_busy": bool(busy)}
     except Exception as e:          # the metric does not depend on it
         torch.cuda.synchronize()
         return {"error": str(e)[:120]}
+
+
+def gpu_probe(lib, step, device, step_ms):
+    """In-band state of the device this line was measured on (csrc/cca_probe.hpp).  A wave reads shader
+    cycles (s_memtime) and the constant 100 MHz reference clock (s_memrealtime): the ratio of two deltas is the clock it really
+    ran at.  Reported: that clock with the GPU otherwise idle, under a matrix-pipe burn, and WHILE THE STEP RUNS (one sampling
+    wave per XCD next to a queue of replayed steps); the bf16 matrix rate of the burn; the issue -> landed time of the 25 KB
+    LDS-DMA tile fill every strip kernel waits for, alone and with 768 workgroups streaming such tiles (and the rate they
+    stream at); a float4 copy.  A box whose step is slow shows here WHY: clock under load, matrix rate, fill latency, copy."""
+    out = {}
+    NWG = 8
+    side = torch.cuda.Stream(device)
+    main = torch.cuda.current_stream()
+
+    def sample_clock(nsamples, interval_us, load):
+        buf = torch.zeros(2 * NWG * nsamples + NWG, dtype=torch.int64, device=device)
+        torch.cuda.synchronize()
+        load()                                                       # (asynchronous: enqueued on the current stream)
+        lib.check(lib.ccnet_cca_probe_clock(buf.data_ptr(), NWG, nsamples, int(interval_us * 100), side.cuda_stream), "probe_clock")
+        torch.cuda.synchronize()
+        v = buf.cpu().numpy()
+        sm = v[:2 * NWG * nsamples].reshape(NWG, nsamples, 2).astype("float64")
+        d = sm[:, 1:, :] - sm[:, :-1, :]
+        mhz = d[:, :, 0] / d[:, :, 1] * 100.0                        # shader cycles per 10 ns tick
+        flat = sorted(mhz.reshape(-1).tolist())
+        pick = lambda q: flat[min(len(flat) - 1, int(q * (len(flat) - 1)))]   # noqa: E731
+        per_xcc = {}
+        for wg in range(NWG):
+            per_xcc.setdefault(int(v[2 * NWG * nsamples + wg]), []).append(float(sorted(mhz[wg].tolist())[mhz.shape[1] // 2]))
+        return {"median": round(pick(0.5), 1), "p05": round(pick(0.05), 1), "min": round(flat[0], 1), "max": round(flat[-1], 1),
+                "per_xcc_median": {str(k): round(sum(x) / len(x), 1) for k, x in sorted(per_xcc.items())},
+                "window_ms": round(nsamples * interval_us * 1e-3, 2)}
+
+    try:
+        time.sleep(0.05)
+        out["clock_mhz_idle"] = sample_clock(200, 10, lambda: None)
+        # matrix-pipe burn: 512 workgroups x 4 waves (two waves per SIMD), ~10 ms
+        nwg, iters = 512, 40000
+        clk = torch.zeros(nwg * 4, dtype=torch.int64, device=device)
+        sink = torch.zeros(nwg * 256, device=device)
+        burn = lambda: lib.check(lib.ccnet_cca_probe_mfma(clk.data_ptr(), sink.data_ptr(), nwg, iters, main.cuda_stream), "probe_mfma")   # noqa: E731
+        burn()
+        torch.cuda.synchronize()
+        out["clock_mhz_mfma_burn"] = sample_clock(300, 10, burn)
+        c = clk.cpu().numpy().reshape(nwg, 4).astype("float64")
+        secs = (c[:, 3].max() - c[:, 1].min()) * 1e-8
+        out["mfma_bf16_tflops"] = round(nwg * 4 * iters * 131072.0 / secs / 1e12, 1)
+        out["mfma_burn_ms"] = round(secs * 1e3, 2)
+        # the step: a queue of replays next to one sampling wave per XCD
+        nrep = max(20, int(40.0 / max(step_ms, 0.05)))
+        out["clock_mhz_during_step"] = sample_clock(2000, 10, lambda: [step() for _ in range(nrep)])
+        out["clock_mhz_during_step"]["replays_enqueued"] = nrep
+        # tile fills (a column strip of the packed fp32 projection at W = 97: rows of 256 B, 97 * 640 * 4 B apart)
+        src = torch.empty(128 * 1024 * 1024, device=device).normal_()
+        stride = 97 * 640 * 4
+        for label, n, reps in (("idle", 1, 300), ("loaded", 768, 200)):
+            ck = torch.zeros(n * 4, dtype=torch.int64, device=device)
+            for _ in range(2):
+                lib.check(lib.ccnet_cca_probe_dma(src.data_ptr(), src.numel() * 4, ck.data_ptr(), n, reps, stride, main.cuda_stream), "probe_dma")
+            torch.cuda.synchronize()
+            k = ck.cpu().numpy().reshape(n, 4).astype("float64")
+            span = (k[:, 3].max() - k[:, 2].min()) * 1e-8
+            out[f"tile_fill_{label}"] = {"us_per_fill": round(float(((k[:, 3] - k[:, 2]) / reps).mean()) * 1e-2, 2),
+                                         "shader_cycles_mean": round(float((k[:, 0] / reps).mean()), 0),
+                                         "shader_cycles_max": int(k[:, 1].max()),
+                                         "stream_tb_s": round(n * reps * 25600.0 / span / 1e12, 3), "workgroups": n}
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        out["copy_f32_gb_s"] = round(2 * src.numel() * 4 / (time_region(lambda: dst.copy_(src), 10) * 1e-3) / 1e9, 1)
+        del src, dst
+        out["how"] = ("shader cycles (s_memtime) / 100 MHz reference ticks (s_memrealtime) read by the waves themselves; "
+                      "ccnet_cca_probe_* in include/ccnet_cca.h")
+    except Exception as e:          # the metric does not depend on it
+        torch.cuda.synchronize()
+        out["error"] = str(e)[:200]
+    return out
 
 
 def planes_launch_bytes(B, C, H, W):
@@ -1038,6 +1127,7 @@ def main(argv=None, workload_factory=None):
         out["fwd_ms"], out["bwd_ms"] = round(fwd_ms, 4), round(bwd_ms, 4)
         out.update(launch_accounting(lib, wl, graph))
         out["gpu_state_under_load"] = gpu_state_under_load(step, local)
+        out["gpu_probe"] = gpu_probe(lib, step, device, ms)
         if isinstance(wl, PlanesWorkload):
             out["roofline"] = planes_roofline(lib, wl, ms, out.get("launch_ms", []))
             out["strips_family"] = strips_family_summary(lib, B, C, H, W, device)

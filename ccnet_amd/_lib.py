@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libccnet_cca.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ccnet_cca.h")
 
-CCNET_CCA_VERSION = 200        # include/ccnet_cca.h
+CCNET_CCA_VERSION = 210        # include/ccnet_cca.h
 CCNET_CA_ENERGY = 0
 CCNET_CA_SOFTMAX = 1
 CCNET_IMPL_AUTO = 0
@@ -58,6 +58,7 @@ _PROTOTYPES = {
     "ccnet_cca_backward_pm_f32": (c_int, [_P] * 11 + [c_int] * 5 + [c_long, c_int] * 7 + [_P, c_size_t, _P]),
     "ccnet_cca_split_planes_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_int, _P, _P]),
     "ccnet_cca_nchw_to_planes_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_long, c_long, c_int, c_int, _P]),
+    "ccnet_cca_pack_projection_f32": (c_int, [_P] * 10 + [c_int, c_int, _P]),
     "ccnet_cca_forward_planes_f32": (c_int, [_P] * 9 + [c_int] * 5 + [c_long, c_int] * 4 + [_P, c_size_t, _P]),
     "ccnet_cca_backward_planes_f32": (c_int, [_P] * 12 + [c_int] * 5 + [c_long, c_int] * 7 + [_P, c_size_t, _P]),
     "ccnet_cca_attention_pm": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, c_long, c_int, _P]),
@@ -65,6 +66,9 @@ _PROTOTYPES = {
     "ccnet_cca_mfma_selftest": (c_int, [_P, _P]),
     "ccnet_cca_set_option": (c_int, [c_char_p, c_int, ctypes.POINTER(c_int)]),
     "ccnet_cca_get_option": (c_int, [c_char_p, ctypes.POINTER(c_int)]),
+    "ccnet_cca_probe_clock": (c_int, [_P, c_int, c_int, c_int, _P]),
+    "ccnet_cca_probe_mfma": (c_int, [_P, _P, c_int, c_int, _P]),
+    "ccnet_cca_probe_dma": (c_int, [_P, c_size_t, _P, c_int, c_int, c_int, _P]),
     "ccnet_cca_profile_begin": (c_int, [c_int]),
     "ccnet_cca_profile_end": (c_int, [_P, _P, c_int, c_int]),
 }

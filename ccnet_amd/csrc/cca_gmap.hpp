@@ -203,6 +203,13 @@ struct GmapJob {
     int red_n;
     float *red_dst;
     int xcd;          // > 0: strips per XCD of the XCD-aware strip decode (non-DUAL launches; see the kernel)
+    // DUAL, "dqdk_exact" 2 (auto): the split-bf16 x3 row launch publishes max |dq|, |dk| (the bits of a non-negative float, atomic
+    // max: order-independent) in *stat -- workgroup 0 of the column launch before it zeroes the word -- and the EXACT_F32 launches
+    // that follow on the stream exit at once unless *gate > gate_min: the error of the x3 form is ~1.2e-5 of the gradient's
+    // magnitude (tests: logit-scale sweep), so only gradients beyond ~64 are redone in exact fp32
+    unsigned *stat;
+    const unsigned *gate;
+    unsigned gate_min;
 };
 // LONG strips: a strip of L > P positions is cut into nb blocks of ``long_block(L, nb)`` positions (the last one shorter).  A
 // workgroup then owns the QUERY block I of a strip and contracts over the KEY block J: out_I (+)= F_J . A_{I,J}^T; the key blocks
@@ -237,6 +244,9 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     const bool job1 = DUAL && ((blockIdx.x >> 3) & 1) != 0;           // (wave-uniform)
     const bool trans = DUAL ? job1 : TRANS;
     if (DUAL && dual_id >= j1.nwg) return;      // (padding of the last 16-block)
+    if constexpr (EXACT_F32) {
+        if (j1.gate && *j1.gate <= j1.gate_min) return;    // (wave-uniform; see GmapJob::gate)
+    }
     if (job1) {
         F = j1.F; addend = j1.addend; out = j1.out; fbs = j1.fbs; fps = j1.fps; obs = j1.obs; ops = j1.ops;
     }
@@ -309,6 +319,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
         t = wave_sum(t);
         if (lane == 0) j1.red_dst[0] = t;
     }
+    if (DUAL && !ROW && !EXACT_F32 && blockIdx.x == 0 && tid == 0 && j1.stat) *j1.stat = 0u;     // (see GmapJob::stat)
     const int pix0 = ROW ? g * W : g, pstep = ROW ? 1 : W;                             // pixel(i) = pix0 + i * pstep
     const int a_off = ROW ? H : 0;
     // query side (attention rows, outputs, addend, residual): positions i0 .. i0 + Lm; key side (attention columns, features):
@@ -409,6 +420,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     auto st_pos = [&](int k) { return SPX * (wv + GS_WAVES * k) + (OBF ? lane >> 3 : lane >> 4); };
     const int st_c = OBF ? 8 * (lane & 7) : 4 * (lane & 15);
     int nstore_nchw = 0;
+    float gmax = 0.f;                                                       // (GmapJob::stat: max |dq|, |dk| this lane stored)
 
     for (int cg = cg0; cg < cg1; ++cg) {
         const float *img = FB + (ONEG ? 0 : (cg - cg0) & 1) * FSZ;
@@ -617,10 +629,18 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                         fbuf_store_x4(Ob, packed, ((pixM + i * pstep) * ops + c) * 2, 0);
                     } else {
                         if constexpr (RES) u += __builtin_bit_cast(f32x4, res[k]);          // (+ the fp32 residual; zeros when there is none)
+                        if constexpr (DUAL && ROW && !EXACT_F32)
+                            gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(u[0]), fabsf(u[1]))), fmaxf(fabsf(u[2]), fabsf(u[3])));
                         fbuf_store_x4(Ob, u, ((pixM + i * pstep) * ops + c) * 4, 0);
                     }
                 }
             }
+        }
+    }
+    if constexpr (DUAL && ROW && !EXACT_F32 && !OBF) {
+        if (j1.stat) {                                                      // (wave-uniform)
+            gmax = wave_max(gmax);
+            if (lane == 0) atomic_max_u32(j1.stat, __builtin_bit_cast(uint32_t, gmax));
         }
     }
 }
@@ -953,6 +973,35 @@ __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float *__rest
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = tile[(c8 + e) * 65 + px];
         planes_store8(Db, ((p0 + px) * dps + c0 + c8) * 2, pl, x, p0 + px < HW && c0 + c8 < C);
+    }
+}
+
+// The module's three 1x1 projections (functions.py:29,32,35) as the operands of ONE stacked GEMM, packed by ONE launch:
+//   w   (N, C) fp32, N = 2 Cq + C rows: query | key | value weights;   b (N) fp32: their biases
+//   w3  (N, 3 C) bf16: row n = [wh | wl | wh]   (the K-concatenated operand of the split-bf16 x3 projection x^T W^T; may be null)
+//   w3t (C, 3 N) bf16: row c = [wh^T | wh^T | wl^T]   (of its adjoint dx = W^T dqkv^T; null with w3)
+// with wh = bf16_rne(w), wl = bf16_rne(w - wh) -- the split of bf16_split8 / torch's .to(bfloat16).  One thread per element; the
+// host side calls it on EVERY forward (3 us for 1.3 MB) instead of caching torch.cat / split results across calls: a cache
+// keyed on tensor versions goes stale under ``p.data`` updates, a launch per call cannot.
+__global__ __launch_bounds__(256) void pack_projection_kernel(const float *__restrict__ wq, const float *__restrict__ wk,
+                                                              const float *__restrict__ wv, const float *__restrict__ bq,
+                                                              const float *__restrict__ bk, const float *__restrict__ bv,
+                                                              float *__restrict__ w, float *__restrict__ b, uint16_t *__restrict__ w3,
+                                                              uint16_t *__restrict__ w3t, int C, int Cq) {
+    const int N = 2 * Cq + C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)N * C; e += (long)gridDim.x * 256) {
+        const int n = (int)(e / C), c = (int)(e - (long)n * C);
+        const float x = n < Cq ? wq[(long)n * C + c] : n < 2 * Cq ? wk[(long)(n - Cq) * C + c] : wv[(long)(n - 2 * Cq) * C + c];
+        w[e] = x;
+        if (c == 0) b[n] = n < Cq ? bq[n] : n < 2 * Cq ? bk[n - Cq] : bv[n - 2 * Cq];
+        if (w3) {
+            const uint32_t h = cvt_pk_bf16(x, 0.f) & 0xffffu;
+            const uint32_t l = cvt_pk_bf16(x - __builtin_bit_cast(float, h << 16), 0.f) & 0xffffu;
+            uint16_t *r = w3 + (long)n * 3 * C + c;
+            r[0] = (uint16_t)h; r[C] = (uint16_t)l; r[2 * C] = (uint16_t)h;
+            uint16_t *t = w3t + (long)c * 3 * N + n;
+            t[0] = (uint16_t)h; t[N] = (uint16_t)h; t[2 * N] = (uint16_t)l;
+        }
     }
 }
 

@@ -142,6 +142,20 @@ __device__ __forceinline__ void barrier_dma_keep() {
 // this wave's outstanding vector-memory operations (LDS-DMA pieces, loads, stores) have all completed
 __device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Cycle counters (tools: ccnet_cca_probe_*).  s_memtime ticks at the SHADER clock (MI355X_MICROARCH.md: "tick = shader cycle"),
+// s_memrealtime at the constant 100 MHz reference clock: the ratio of two deltas is the clock the wave really ran at --
+// what rocm-smi's "sclk" (the requested level) does not show when a power / thermal limit stretches the clock.
+__device__ __forceinline__ uint64_t shader_clock() { return __builtin_readcyclecounter(); }
+__device__ __forceinline__ uint64_t ref_clock() { return __builtin_amdgcn_s_memrealtime(); }
+__device__ __forceinline__ void short_sleep() { __builtin_amdgcn_s_sleep(8); }
+// XCC (= XCD) the wave runs on: HW_REG_XCC_ID (id 20), bits [3:0]
+__device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u); }
+
+// device-scope atomic max on a 32-bit word (order-independent: the result does not depend on which wave gets there first)
+__device__ __forceinline__ void atomic_max_u32(unsigned *p, uint32_t v) {
+    (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #define CCA_LDS_REGISTER(arr) do { } while (0)
 #define CCA_LDS_LD(p) (*(p))
 #define CCA_LDS_ST(p, v) do { *(p) = (v); } while (0)

@@ -566,29 +566,35 @@ def planes_cover(B, C, Cq, H, W):
     return max(H, W) <= 4 * 132 and Cq <= 64
 
 
-class _ProjectionCache:
-    """Stacked projection operands of one module, rebuilt only when a parameter changed (``torch.cat`` of the
-    three weights and the bf16 hi | lo splits ran on every forward AND every backward).  Keyed on the parameters' storage and
-    autograd version counters (in-place optimizer steps bump ``_version``; ``.data =`` swaps change ``data_ptr``)."""
+def _pack_projection(wq, bq, wk, bk, wv, bv, split):
+    """Stacked projection operands of one module application, packed by ONE launch (``ccnet_cca_pack_projection_f32``): the
+    stacked fp32 weight / bias and, with ``split``, the K-concatenated bf16 hi | lo operands of the split-bf16 x3 GEMMs.
 
-    def __init__(self):
-        self.key, self.val = None, None
-
-    def get(self, wq, bq, wk, bk, wv, bv, split):
-        ps = (wq, bq, wk, bk, wv, bv)
-        key = tuple((p.data_ptr(), p._version, p.device, p.dtype) for p in ps) + (bool(split),)
-        if key != self.key:
-            with torch.no_grad():
-                cq, C = wq.shape[0], wq.shape[1]
-                w = torch.cat([wq.reshape(cq, C), wk.reshape(cq, C), wv.reshape(C, C)], 0)          # (2Cq + C, C)
-                b = torch.cat([bq, bk, bv], 0)
-                val = {"w": w, "b": b, "bqk": b[:2 * cq].contiguous(), "bv": b[2 * cq:].contiguous()}
-                if split:
-                    wh, wl = _split_weight(w)
-                    val["w3"] = torch.cat([wh, wl, wh], 1).t()                                         # (3C, 2Cq + C) view
-                    val["w3t"] = torch.cat([wh.t(), wh.t(), wl.t()], 1)                                # (C, 3 (2Cq + C))
-            self.key, self.val = key, val
-        return self.val
+    Rounds 3-4 cached these per module, keyed on the parameters' ``data_ptr`` and ``_version``: ``p.data.add_()`` /
+    ``p.data.copy_()`` (EMA swaps, weight clipping, fused multi-tensor optimizers) change the values without bumping
+    ``_version``, and the node then ran forward AND backward on stale weights.  There is no cache any more: every
+    forward packs the CURRENT parameter values (one 3 us launch over 1.3 MB -- less than the key comparison's six ``data_ptr``
+    / ``_version`` reads cost in Python) and hands the result to its own backward through ``ctx``."""
+    cq, C = wq.shape[0], wq.shape[1]
+    n = 2 * cq + C
+    dev = wq.device
+    ps = [t.detach() if t.is_contiguous() else t.detach().contiguous() for t in (wq, bq, wk, bk, wv, bv)]
+    if any(t.dtype != torch.float32 or t.device != dev for t in ps):
+        raise RuntimeError("the fused projection needs fp32 parameters on one device")
+    w = torch.empty((n, C), device=dev, dtype=torch.float32)
+    b = torch.empty((n,), device=dev, dtype=torch.float32)
+    w3 = torch.empty((n, 3 * C), device=dev, dtype=torch.bfloat16) if split else None
+    w3t = torch.empty((C, 3 * n), device=dev, dtype=torch.bfloat16) if split else None
+    lib = _lib.get_lib()
+    with torch.cuda.device(dev):
+        lib.check(lib.ccnet_cca_pack_projection_f32(*(t.data_ptr() for t in ps), w.data_ptr(), b.data_ptr(),
+                                                    None if w3 is None else w3.data_ptr(), None if w3t is None else w3t.data_ptr(),
+                                                    C, cq, _stream()), "pack_projection")
+    val = {"w": w, "b": b, "bqk": b[:2 * cq], "bv": b[2 * cq:]}
+    if split:
+        val["w3"] = w3.t()                                                                      # (3C, 2Cq + C) view
+        val["w3t"] = w3t                                                                        # (C, 3 (2Cq + C))
+    return val
 
 
 class CrissCrossPlanesModuleFunction(torch.autograd.Function):
@@ -613,12 +619,12 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
     (bit-identical, one affinity + softmax launch pair)."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma, split_gemm=False, recompute=False, cache=None):
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma, split_gemm=False, recompute=False):
         x, gamma = _dev_f32("x", x), _dev_f32("gamma", gamma)
         B, C, H, W = x.shape
         cq, hw = wq.shape[0], H * W
         ct = 2 * cq + C
-        pc = (cache if cache is not None else _ProjectionCache()).get(wq, bq, wk, bk, wv, bv, split_gemm)
+        pc = _pack_projection(wq, bq, wk, bk, wv, bv, split_gemm)     # (the current parameter values, every call: no cache)
         x3 = None
         direct = max(H, W) <= 100           # strips <= 100: the plane-free form of the core (v stays fp32, no split pass)
         if split_gemm:
@@ -652,7 +658,7 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
         qk = qkv if direct else qkv[..., :2 * cq].contiguous()
         ctx.recompute = bool(recompute)
         ctx.split_gemm = bool(split_gemm)
-        ctx.cache = cache
+        ctx.pc = pc                      # the backward multiplies with the weights this forward saw
         ctx.direct = direct
         keep = [x3 if split_gemm else x, qk, qk if direct else vpl, gamma, wq, bq, wk, bk, wv, bv]
         if not ctx.recompute:
@@ -670,7 +676,7 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
         dy = _dev_f32("grad_output", dy)
         hw, ct = H * W, 2 * cq + C
         lib = _lib.get_lib()
-        pc = (ctx.cache if ctx.cache is not None else _ProjectionCache()).get(wq, bq, wk, bk, wv, bv, ctx.split_gemm)
+        pc = ctx.pc
         direct = ctx.direct
         p, bs, ps = (qk.data_ptr(), hw * ct, ct) if direct else (qk.data_ptr(), hw * 2 * cq, 2 * cq)
         if ctx.recompute:
@@ -703,7 +709,7 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
             dw = torch.bmm(dqt, xm.transpose(1, 2)).sum(0)                                    # (2Cq + C, C)
         dwq, dwk, dwv = dw[:cq], dw[cq:2 * cq], dw[2 * cq:]
         return (dx.view(B, C, H, W), dwq.reshape(cq, C, 1, 1), db[:cq], dwk.reshape(cq, C, 1, 1), db[cq:2 * cq],
-                dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma), None, None, None)
+                dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma), None, None)
 
 
 def criss_cross_attention(q, k, v, x, gamma, recompute_attention=False):
@@ -836,13 +842,14 @@ class CrissCrossAttention(nn.Module):
             return CrissCrossPMFunction.apply(qkv, xp, self.gamma, cq, self.recompute_attention).permute(0, 3, 1, 2)
         if r == "f32-planes":
             split_gemm = self.split_bf16_projections and x.shape[0] * x.shape[2] * x.shape[3] >= self.split_bf16_min_pixels
-            return CrissCrossPlanesModuleFunction.apply(x, *params, self.gamma, split_gemm, self.recompute_attention,
-                                                        self._projection_cache())
+            return CrissCrossPlanesModuleFunction.apply(x, *params, self.gamma, split_gemm, self.recompute_attention)
         if r == "f32-planes-cast":
             with torch.autocast(device_type="cuda", enabled=False):          # (the node's GEMMs are its own: fp32 / split-bf16 x3)
                 split_gemm = self.split_bf16_projections and x.shape[0] * x.shape[2] * x.shape[3] >= self.split_bf16_min_pixels
+                # (the node's projections are its own fp32 / split-bf16 x3 GEMMs on fp32 copies of the parameters -- a no-op for an
+                #  fp32 module under autocast: autocast does NOT govern them, unlike the reference's autocast convolutions)
                 y = CrissCrossPlanesModuleFunction.apply(x.float().contiguous(), *(p.float() for p in params), self.gamma.float(),
-                                                         split_gemm, self.recompute_attention, None)
+                                                         split_gemm, self.recompute_attention)
             return y.to(x.dtype)
         if r == "f32-strips-node":
             return CrissCrossModuleFunction.apply(x, *params, self.gamma, self.recompute_attention)
@@ -856,17 +863,6 @@ class CrissCrossAttention(nn.Module):
         out = CrissCrossFunction.apply(proj_query.float(), proj_key.float(), proj_value.float(),
                                        x.float(), self.gamma.float(), self.recompute_attention)
         return out.to(x.dtype)
-
-    def _projection_cache(self):
-        """per-module cache of the stacked / split projection operands (rebuilt when a parameter's version changes).  None while
-        a stream capture is running: a captured graph must CONTAIN the stacking / splitting of the weights (it is replayed after
-        optimizer steps), not bake in tensors a cache computed before the capture."""
-        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-            return None
-        c = self.__dict__.get("_proj_cache")
-        if c is None:
-            c = self.__dict__["_proj_cache"] = _ProjectionCache()
-        return c
 
     def _stacked_weight(self):
         return torch.cat([self.query_conv.weight, self.key_conv.weight, self.value_conv.weight], 0)
@@ -909,8 +905,8 @@ def graph_module(module: "CrissCrossAttention", sample_input: torch.Tensor, warm
     is ~25 torch ops + 12 kernel launches for ~0.3 ms of GPU work -- eager, the host cannot issue them that fast (VERDICT r3
     item 7); replayed as two graphs the step is bound by its kernels.  Everything the node does is capturable: the C ABI launches
     on the capturing stream, its side stream forks and joins inside the capture, workspaces come from torch's allocator (the
-    graph's private pool), and the stacked / split weights are rebuilt INSIDE the graph (``_projection_cache`` steps aside while
-    capturing), so replays see in-place optimizer updates.  Returns a callable ``f(x) -> y`` bound to ``sample_input``'s shape,
+    graph's private pool), and the stacked / split weights are packed INSIDE the graph (one launch per forward, no cache), so
+    replays see in-place optimizer updates.  Returns a callable ``f(x) -> y`` bound to ``sample_input``'s shape,
     dtype and memory format; gradients flow to ``x`` and to the module's parameters as usual."""
     if not sample_input.is_cuda:
         raise RuntimeError("graph_module: the module runs on an AMD GPU only")

@@ -51,8 +51,10 @@ def run(args, model_factory=None, quiet=False):
         torch.cuda.set_device(device)
         # train.py:152 sets cudnn.benchmark unconditionally.  On ROCm that makes MIOpen search its solvers per convolution
         # configuration at first use: for ResNet-101 at 769 x 769 the search alone ran past a 10-minute limit on an MI355X box with
-        # an empty MIOpen cache (measured, round 4) -- opt-in only
-        torch.backends.cudnn.benchmark = bool(getattr(args, "cudnn_benchmark", False))
+        # an empty MIOpen cache (measured, round 4) -- opt-in only.  Tri-state: without the option the process-wide flag is left as
+        # the embedding process set it; --cudnn-benchmark / --no-cudnn-benchmark set it.
+        if getattr(args, "cudnn_benchmark", None) is not None:
+            torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
     ddp = world > 1 or getattr(args, "force_ddp", False)      # (--force-ddp: the RCCL / DDP path on a single GPU)
     if ddp and not dist.is_initialized():
         dist.init_process_group("nccl" if use_cuda else "gloo")
@@ -135,9 +137,10 @@ def build_parser():
     ap.add_argument("--weight-decay", type=float, default=1e-4)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--bf16", action="store_true", help="autocast to bf16: convolutions in bf16, the attention core on the pixel-major bf16 kernels (fp32 attention / softmax / accumulate)")
-    ap.add_argument("--cudnn-benchmark", dest="cudnn_benchmark", action="store_true",
+    ap.add_argument("--cudnn-benchmark", dest="cudnn_benchmark", action="store_true", default=None,
                     help="set torch.backends.cudnn.benchmark as train.py:152 does (MIOpen then searches its solvers per convolution "
-                         "configuration at first use: minutes with an empty cache)")
+                         "configuration at first use: minutes with an empty cache); default: leave the process-wide flag untouched")
+    ap.add_argument("--no-cudnn-benchmark", dest="cudnn_benchmark", action="store_false")
     ap.add_argument("--cpu", action="store_true", help="tests only: gloo on CPU with an injected model")
     ap.add_argument("--no-destroy-group", dest="destroy_group", action="store_false")
     ap.add_argument("--force-ddp", action="store_true", help="wrap the model in DistributedDataParallel (RCCL process group) even at "

@@ -39,8 +39,14 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the functions declared in this header -- and nothing else -- are its dynamic
+ * symbols (tests/test_host.py compares ``nm -D`` with this header, both ways). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
-#define CCNET_CCA_VERSION 200          /* 0.2.0: fp32 v into the split-plane forward, ccnet_cca_attention_pm, option ABI with out-parameters */
+#define CCNET_CCA_VERSION 210          /* 0.2.1 (additive over 0.2.0): ccnet_cca_pack_projection_f32, ccnet_cca_probe_*, option "dqdk_exact" 2 (default),
+                                          backward workspaces 256 B larger (query the size, as always); only ccnet_* symbols are exported */
 
 #define CCNET_E_BADSHAPE   (-1)        /* non-positive dimension, or a size the kernels cannot index */
 #define CCNET_E_NULLPTR    (-2)        /* a required pointer is NULL */
@@ -263,6 +269,14 @@ int ccnet_cca_split_planes_f32(const float *src, uint16_t *dst, int B, int C, in
                                long dst_bs, int dst_ps, int layout, const float *bias, ccnet_stream_t stream);
 int ccnet_cca_nchw_to_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, long dst_bs,
                                  int dst_ps, int layout, ccnet_stream_t stream);
+/* The module's three 1x1 projections (functions.py:29,32,35: query_conv, key_conv, value_conv; weights (Cq|Cq|C, C) fp32, biases)
+ * packed for ONE stacked GEMM by ONE launch: ``w`` (2 Cq + C, C) fp32 = query | key | value rows, ``b`` (2 Cq + C) fp32, and --
+ * unless both are NULL -- the bf16 operands of the split-bf16 x3 GEMMs: ``w3`` (2 Cq + C, 3 C), row n = [wh | wl | wh], and
+ * ``w3t`` (C, 3 (2 Cq + C)), row c = [wh^T | wh^T | wl^T], wh = bf16_rne(w), wl = bf16_rne(w - wh).  The Python host calls it on
+ * every forward instead of caching stacked weights across calls (a cache keyed on tensor versions is stale after ``p.data``
+ * updates; a 3 us launch cannot be). */
+int ccnet_cca_pack_projection_f32(const float *wq, const float *bq, const float *wk, const float *bk, const float *wv, const float *bv,
+                                  float *w, float *b, uint16_t *w3, uint16_t *w3t, int C, int Cq, ccnet_stream_t stream);
 int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v, const float *v_bias, uint16_t *v_planes,
                                  const float *x, const float *gamma, float *y, float *A,
                                  int B, int C, int Cq, int H, int W,
@@ -308,11 +322,13 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
  *                    instead of two (these launches are latency chains); 0: the two-slot form.  Same arithmetic, same bits.
  *   "energy_tail"  1 (default): the fp32 energies launch of the pixel-major / split-plane entries (strips <= 100, C/8 <= 64) cuts the
  *                    strips beyond its whole rounds of workgroups into tile-row parts (a short last round); 0: one workgroup per strip.
- *   "dqdk_exact"   1: ca_backward of the fp32 pixel-major / split-plane entry points (strips <= 100) multiplies in exact fp32
- *                    (v_mfma_f32_16x16x4_f32) instead of split-bf16 x3 -- for callers whose logits are hotter than the default
- *                    initialisation's: with q, k ~ N(0, s^2) at C/8 = 64 the default arithmetic keeps max |d dq| <= 1e-3 up to
- *                    s ~ 1.5 (5.5e-4 at s = 1; everywhere ~1e-5 of max |dq|: it is a relative error), the exact form up to
- *                    s ~ 3; +25 us per launch at (8,512,97,97).  0 (default). */
+ *   "dqdk_exact"   ca_backward of the fp32 pixel-major / split-plane entry points (strips <= 100): 0 split-bf16 x3 (error ~1.2e-5 of
+ *                    max |dq|, |dk|: 4e-4 at the reference's initialisation scale, 1.5e-3 with q, k three times hotter);
+ *                    1 exact fp32 (v_mfma_f32_16x16x4_f32; +25 us per launch at (8,512,97,97); leaves the 5e-6 of the upstream dA);
+ *                    2 (default) AUTOMATIC: the x3 launches publish max |dq|, |dk| in the workspace, an exact pair follows on the
+ *                    stream and exits at once unless that maximum exceeds 64 -- hot logits are redone in exact fp32 by the device
+ *                    itself (no host synchronisation, capturable), cool ones pay two empty launches.  The absolute 1e-3 bar then
+ *                    holds up to q, k ~ N(0, 3^2) at C/8 = 64 (tests/test_gpu_parity.py, logit-scale sweep). */
 int ccnet_cca_set_option(const char *name, int value, int *previous);
 int ccnet_cca_get_option(const char *name, int *value);
 
@@ -323,11 +339,30 @@ int ccnet_cca_get_option(const char *name, int *value);
 int ccnet_cca_profile_begin(int max_launches);
 int ccnet_cca_profile_end(float *ms, char *names, int name_stride, int cap);
 
+/* Device-state probes (measurement aids; bench.py prints what they read on the metric's line, see csrc/cca_probe.hpp).
+ * A wave reads two counters: shader cycles and the constant 100 MHz reference clock -- the ratio of two deltas is the clock
+ * it really ran at, which rocm-smi's requested level does not show under a power / thermal limit.
+ * ccnet_cca_probe_clock: ``nwg`` single-wave workgroups sample (shader, reference) every ``interval_ticks`` reference ticks,
+ *   ``nsamples`` times: samples[(wg * nsamples + s) * 2 + {0, 1}], then samples[2 * nwg * nsamples + wg] = the XCC of workgroup
+ *   wg (buffer: (2 * nwg * nsamples + nwg) uint64).  Launch it on a stream of its own NEXT TO what is to be observed.
+ * ccnet_cca_probe_mfma: ``nwg`` workgroups of 4 waves, each wave ``iters`` x 8 v_mfma_f32_16x16x32_bf16 (131072 * iters flops);
+ *   clk[wg * 4 + {0..3}] = shader start, reference start, shader end, reference end of wave 0; ``sink``: 256 * nwg floats.
+ * ccnet_cca_probe_dma: ``nwg`` workgroups fill a 25 KiB LDS tile by LDS-DMA (25 pieces of 4 rows x 256 B, rows
+ *   ``row_stride_bytes`` apart: a column strip of a pixel-major tensor) ``reps`` times from random places of ``src``;
+ *   clk[wg * 4 + {0..3}] = sum of the issue -> landed latencies (shader cycles), their maximum, reference start / end. */
+int ccnet_cca_probe_clock(unsigned long long *samples, int nwg, int nsamples, int interval_ticks, ccnet_stream_t stream);
+int ccnet_cca_probe_mfma(unsigned long long *clk, float *sink, int nwg, int iters, ccnet_stream_t stream);
+int ccnet_cca_probe_dma(const float *src, size_t src_bytes, unsigned long long *clk, int nwg, int reps, int row_stride_bytes,
+                        ccnet_stream_t stream);
+
 /* Device self-test of the MFMA fragment layout the kernels assume (asymmetric operands).
  * ``scratch`` >= 64 bytes of device memory.  The one entry point that synchronises ``stream`` (it copies
  * the verdict back).  Returns 0 when the layout matches, 1000 + #mismatches otherwise. */
 int ccnet_cca_mfma_selftest(float *scratch, ccnet_stream_t stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,12 @@ __device__ inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     return d;
 }
 
+// cycle counters of the probe kernels: the emulator has no clocks; a process-wide tick keeps the probe loops finite
+__device__ inline uint64_t shader_clock() { static uint64_t t = 0; return t += 24; }
+__device__ inline uint64_t ref_clock() { static uint64_t t = 0; return ++t; }
+__device__ inline void short_sleep() {}
+__device__ inline int xcc_id() { return 0; }
+__device__ inline void atomic_max_u32(unsigned *p, uint32_t v) { if (v > *p) *p = v; }
 __device__ inline void mfma_f32_result_fence() {}
 __device__ inline void wait_vmem_all() {}
 __device__ inline int uniform(int v) { return v; }

@@ -263,6 +263,17 @@ class EmuOps:
                                                               dbs, dct, dbs, dct, dbs, dct, _p(ws), nbytes, None))
         return dqkv, dgamma
 
+    def pack_projection(self, wq, bq, wk, bk, wv, bv, split=True):
+        """ccnet_cca_pack_projection_f32: (w (N, C) fp32, b (N), w3 (N, 3C) bf16 bits, w3t (C, 3N) bf16 bits)"""
+        cq, C = wq.shape[0], wq.shape[1]
+        n = 2 * cq + C
+        w, b = np.full((n, C), np.nan, np.float32), np.full(n, np.nan, np.float32)
+        w3 = np.full((n, 3 * C), 0xFFFF, np.uint16) if split else None
+        w3t = np.full((C, 3 * n), 0xFFFF, np.uint16) if split else None
+        self.lib.check(self.lib.ccnet_cca_pack_projection_f32(_p(wq), _p(bq), _p(wk), _p(bk), _p(wv), _p(bv), _p(w), _p(b),
+                                                              _p(w3), _p(w3t), C, cq, None))
+        return w, b, w3, w3t
+
     def mfma_selftest(self):
         scratch = np.zeros(16, np.float32)
         return self.lib.ccnet_cca_mfma_selftest(_p(scratch), None)

@@ -762,6 +762,29 @@ def test_plane_free_form_is_bit_identical_to_the_plane_form(ops, shape):
         ops.cca_forward_planes(big, None, np.zeros((1, C, 101, 2), np.float32), c["gamma"], cq)
 
 
+@pytest.mark.parametrize("C", [16, 64, 200])
+def test_projection_packer_matches_the_torch_formulation_bit_for_bit(ops, C):
+    """ccnet_cca_pack_projection_f32 (one launch per module forward, replaces the per-module cache ADVICE r4 found stale under
+    ``p.data`` updates): stacked weight / bias and the K-concatenated bf16 hi | lo operands of the split-bf16 x3 projection GEMMs,
+    against torch.cat + .to(bfloat16) -- what rounds 3-4 computed with six torch ops."""
+    cq = C // 8
+    rng = np.random.default_rng(C)
+    wq, wk, wv = (rng.standard_normal((n, C), dtype=np.float32) * 0.05 for n in (cq, cq, C))
+    bq, bk, bv = (rng.standard_normal(n, dtype=np.float32) for n in (cq, cq, C))
+    w, b, w3, w3t = ops.pack_projection(wq, bq, wk, bk, wv, bv)
+    wt = torch.cat([T(wq), T(wk), T(wv)], 0)
+    assert np.array_equal(w, wt.numpy()) and np.array_equal(b, np.concatenate([bq, bk, bv]))
+    wh = wt.to(torch.bfloat16)
+    wl = (wt - wh.float()).to(torch.bfloat16)
+    bits = lambda t: t.contiguous().view(torch.int16).numpy().view(np.uint16)          # noqa: E731
+    assert np.array_equal(w3, bits(torch.cat([wh, wl, wh], 1)))
+    assert np.array_equal(w3t, bits(torch.cat([wh.t(), wh.t(), wl.t()], 1)))
+    w2, b2, none3, none3t = ops.pack_projection(wq, bq, wk, bk, wv, bv, split=False)
+    assert np.array_equal(w2, w) and np.array_equal(b2, b) and none3 is None and none3t is None
+    assert ops.lib.ccnet_cca_pack_projection_f32(wq.ctypes.data, bq.ctypes.data, wk.ctypes.data, bk.ctypes.data, wv.ctypes.data,
+                                                 bv.ctypes.data, w.ctypes.data, b.ctypes.data, w3.ctypes.data, None, C, cq, None) == -2
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 96, 17, 20), (1, 64, 3, 97), (1, 64, 100, 3)])
 def test_exact_f32_ca_backward_option(ops, shape):
     """Option "dqdk_exact": ca_backward of the fp32 pixel-major / split-plane routes in exact fp32 (v_mfma_f32_16x16x4_f32, the
@@ -772,14 +795,37 @@ def test_exact_f32_ca_backward_option(ops, shape):
     c = rand_case(*shape, seed=77)
     qkv = np.ascontiguousarray(np.concatenate([_pm(c["q"]), _pm(c["k"]), _pm(c["v"])], axis=3))
     y, A = ops.cca_forward_planes(qkv, None, c["x"], c["gamma"], cq)
-    ref = ops.cca_backward_planes(c["dy"], qkv, None, A, c["gamma"], cq)
-    prev = ops.lib.set_option("dqdk_exact", 1)
+    assert ops.lib.get_option("dqdk_exact") == 2                                   # the default: automatic (below)
+    prev = ops.lib.set_option("dqdk_exact", 0)
     try:
+        ref = ops.cca_backward_planes(c["dy"], qkv, None, A, c["gamma"], cq)      # split-bf16 x3
+        ops.lib.set_option("dqdk_exact", 1)
         got = ops.cca_backward_planes(c["dy"], qkv, None, A, c["gamma"], cq)
         got_pm = ops.cca_backward_pm_bf16(_pm(c["dy"]), qkv, A, c["gamma"], cq)          # (fp32 qkv: the pixel-major fp32 entry points)
     finally:
         ops.lib.set_option("dqdk_exact", prev)
-    assert prev == 0 and ops.lib.get_option("dqdk_exact") == 0
+    assert prev == 2 and ops.lib.get_option("dqdk_exact") == 2
+    # AUTOMATIC (the default): the x3 launches publish max |dq|, |dk|; the exact pair that follows exits at once below the limit
+    # (64) and overwrites dq | dk beyond it -- decided on the device, per call.  Cool gradients: bit-identical to x3; the same
+    # problem with dy scaled until |dq| passes the limit: bit-identical to the exact form, on both fp32 entry-point families
+    auto_cool = ops.cca_backward_planes(c["dy"], qkv, None, A, c["gamma"], cq)
+    assert max(float(np.abs(ref[0][..., :2 * cq]).max()), 1e-30) < 64.0
+    assert np.array_equal(auto_cool[0], ref[0]) and np.array_equal(auto_cool[1], ref[1])
+    hot = (c["dy"] * np.float32(2.0 * 64.0 / max(float(np.abs(ref[0][..., :2 * cq]).max()), 1e-30))).astype(np.float32)
+    auto_hot = ops.cca_backward_planes(hot, qkv, None, A, c["gamma"], cq)
+    auto_hot_pm = ops.cca_backward_pm_bf16(_pm(hot), qkv, A, c["gamma"], cq)
+    ops.lib.set_option("dqdk_exact", 1)
+    try:
+        exact_hot = ops.cca_backward_planes(hot, qkv, None, A, c["gamma"], cq)
+        exact_hot_pm = ops.cca_backward_pm_bf16(_pm(hot), qkv, A, c["gamma"], cq)
+        ops.lib.set_option("dqdk_exact", 0)
+        x3_hot = ops.cca_backward_planes(hot, qkv, None, A, c["gamma"], cq)
+    finally:
+        ops.lib.set_option("dqdk_exact", 2)
+    assert float(np.abs(exact_hot[0][..., :2 * cq]).max()) > 64.0
+    assert np.array_equal(auto_hot[0], exact_hot[0]) and np.array_equal(auto_hot[1], exact_hot[1])
+    assert np.array_equal(auto_hot_pm[0], exact_hot_pm[0]) and np.array_equal(auto_hot_pm[1], exact_hot_pm[1])
+    assert not np.array_equal(auto_hot[0][..., :2 * cq], x3_hot[0][..., :2 * cq])               # (the redo really ran)
     yo, Ao = O.cca_core_forward(T(c["q"]), T(c["k"]), T(c["v"]), T(c["x"]), T(c["gamma"]))
     go = O.cca_core_backward(T(c["dy"]), T(c["q"]), T(c["k"]), T(c["v"]), Ao, T(c["gamma"]))
     nchw = lambda a: np.transpose(a, (0, 3, 1, 2))                                 # noqa: E731

@@ -24,10 +24,12 @@ DEFAULT_SETS = {
     "dA-3-stages-1s": {"da_stages": 3, "planes_overlap": 0},    # the energies launch as one workgroup per strip (2.02 rounds -> three)
     "one-stream": {"planes_overlap": 0},
     "overlap-1": {"planes_overlap": 1},
+    "dqdk-x3-only": {"dqdk_exact": 0},       # without the two gated exact launches of the automatic form (round 5): what they cost
+    "ring-2-per-cu": {"planes_ring": 1},     # the column ring passes with three slots and TWO workgroups per CU (slow-box A/B)
 }
 lib = _lib.get_lib()
 dev = torch.device("cuda:0")
-BASE = {"planes_ring": 2, "planes_stream": 1, "planes_overlap": -1, "planes_xcd": 1, "energy_tail": 1, "da_stages": 2, "dqdk_wpc3": 1}
+BASE = {"planes_ring": 2, "planes_stream": 1, "planes_overlap": -1, "planes_xcd": 1, "energy_tail": 1, "da_stages": 2, "dqdk_wpc3": 1, "dqdk_exact": 2}
 wl = bench.PlanesWorkload(lib, B, C, H, W, dev, 1234)
 ref = None
 for rnd in range(2):                       # two rounds: the order of the sets must not matter

@@ -1,0 +1,52 @@
+#!/bin/bash
+# Round-5 GPU call: smoke + GPU tests + bench (with the in-band device probe) + option A/B + rocprofv3 kernel stats (both stream
+# modes) + kernel-trace timeline.  On a SLOW box (strips_family >= 1.1 ms in the bench line) the closing set is the point of the
+# call: everything is taken there as well, tagged slow_box.  Everything lands in gpurun_out/<tag>.
+# usage (repo root on the GPU box): bash tools/gpu_round5.sh <tag> [quick|full|closing]
+set -u
+TAG=${1:-r5}; MODE=${2:-full}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd "$R"
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+echo "== host: $(nproc) cores; $(lscpu | grep 'Model name' | sed 's/.*: *//')" | tee "$OUT/host.txt"
+rocm-smi --showmaxpower --showpower --showclocks --showperflevel > "$OUT/rocm_smi_idle.txt" 2>&1
+echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; echo "smoke rc=$?" | tee -a "$OUT/smoke.log"; tail -4 "$OUT/smoke.log"
+echo "== bench"; timeout 900 python bench.py --gpus 1 --steps 50 --warmup 10 --no-train > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; tail -5 "$OUT/bench.err"
+python3 - "$OUT/bench.json" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    keep = {k: d.get(k) for k in ("ms_per_step", "value", "fwd_ms", "bwd_ms", "eager_ms_per_step", "graph_ms_per_step", "gpu_kernel_sum_ms",
+                                  "overlap_gain_ms", "module_ms_per_step", "gpu_state_under_load", "gpu_probe", "strips_family", "launch_ms")}
+    print(json.dumps(keep, indent=1)[:5000])
+    sf = d.get("strips_family") or {}
+    slow = isinstance(sf, dict) and float(sf.get("ms_per_step", 0)) >= 1.1
+    open(sys.argv[1].replace("bench.json", "box_class.txt"), "w").write("slow\n" if slow else "normal\n")
+except Exception as e:
+    print("bench line unreadable:", e)
+PY
+BOX=$(cat "$OUT/box_class.txt" 2>/dev/null || echo unknown); echo "== box class: $BOX"
+echo "== pytest -m gpu"; timeout 1800 python -m pytest tests -m gpu -q -rA --no-header -p no:cacheprovider -x > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest_gpu.log"
+grep -E "^(FAILED|ERROR)|passed|failed|headline max-abs|logit-scale|vs the ORACLE|Error|error" "$OUT/pytest_gpu.log" | tail -60
+[ "$MODE" = "quick" ] && exit 0
+echo "== ab_options"; timeout 900 python tools/ab_options.py > "$OUT/ab_options.txt" 2>&1; echo "ab rc=$?"; grep "==" "$OUT/ab_options.txt"; grep " us " "$OUT/ab_options.txt" | head -30
+echo "== rocprofv3 kernel stats"
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python "$R/bench.py" --steps 20 --warmup 5 --no-extras > "$OUT/prof_bench.json" 2> "$OUT/prof.err"; echo "rocprof rc=$?"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_single" -- python "$R/bench.py" --steps 20 --warmup 5 --no-extras --overlap 0 > "$OUT/prof_single_bench.json" 2> "$OUT/prof_single.err"; echo "rocprof (single stream) rc=$?"
+cd "$R"
+F=$(find "$OUT/prof_single" -name "*kernel_stats*.csv" | head -1)
+[ -n "$F" ] && head -20 "$F"
+find "$OUT/prof" "$OUT/prof_single" -name "*kernel_trace*.csv" -size +20M -delete
+echo "== kernel-trace timeline"; bash tools/timeline.sh "$TAG" > "$OUT/timeline.log" 2>&1; tail -3 "$OUT/timeline_graph.txt"
+if [ "$MODE" = "closing" ]; then
+  echo "== module, small batches"; timeout 600 python tools/module_small_batch.py > "$OUT/module_small_batches.txt" 2>&1; tail -4 "$OUT/module_small_batches.txt"
+  echo "== PMC passes (fp32 step)"; bash tools/pmc.sh "$TAG" --iters 3 > "$OUT/pmc.log" 2>&1; tail -3 "$OUT/pmc.log"
+  cp "$R/gpurun_out/pmc_$TAG/summary.json" "$OUT/pmc_step_summary.json" 2>/dev/null
+  echo "== bench, bf16 configs[4]"; timeout 600 python bench.py --dtype bf16 --steps 30 --warmup 5 --no-train --no-cpu-baseline > "$OUT/bench_bf16.json" 2> "$OUT/bench_bf16.err"; head -c 600 "$OUT/bench_bf16.json"; echo
+  echo "== stress"; timeout 600 python tools/stress_pm.py 100 > "$OUT/stress_pm.log" 2>&1; tail -3 "$OUT/stress_pm.log"
+  find "$R/gpurun_out/pmc_$TAG" -name "*.csv" -size +5M -delete 2>/dev/null
+fi
+echo "== done ($BOX box)"

@@ -29,7 +29,7 @@ for B in (1, 2, 8):
             with torch.autocast("cuda", enabled=False):
                 params = (m.query_conv.weight, m.query_conv.bias, m.key_conv.weight, m.key_conv.bias, m.value_conv.weight, m.value_conv.bias)
                 sg = m.split_bf16_projections and B * 97 * 97 >= m.split_bf16_min_pixels
-                y = CrissCrossPlanesModuleFunction.apply(x, *params, m.gamma, sg, False, m._projection_cache())
+                y = CrissCrossPlanesModuleFunction.apply(x, *params, m.gamma, sg, False)
         y.backward(dy)
         return y
 
