@@ -555,20 +555,23 @@ def gpu_probe(lib, step, device, step_ms):
         nrep = max(20, int(40.0 / max(step_ms, 0.05)))
         out["clock_mhz_during_step"] = sample_clock(2000, 10, lambda: [step() for _ in range(nrep)])
         out["clock_mhz_during_step"]["replays_enqueued"] = nrep
-        # tile fills (a column strip of the packed fp32 projection at W = 97: rows of 256 B, 97 * 640 * 4 B apart)
+        # tile fills out of a 512 MiB source (they miss the L2): "strided" = a COLUMN strip of the packed fp32 projection at W = 97
+        # (rows of 256 B, 97 * 640 * 4 B apart: every row in another page), "contiguous" = 25 KiB in one piece (a ROW strip's
+        # tile).  A box that is slow on the column passes only shows up in the strided numbers.
         src = torch.empty(128 * 1024 * 1024, device=device).normal_()
-        stride = 97 * 640 * 4
-        for label, n, reps in (("idle", 1, 300), ("loaded", 768, 200)):
-            ck = torch.zeros(n * 4, dtype=torch.int64, device=device)
-            for _ in range(2):
-                lib.check(lib.ccnet_cca_probe_dma(src.data_ptr(), src.numel() * 4, ck.data_ptr(), n, reps, stride, main.cuda_stream), "probe_dma")
-            torch.cuda.synchronize()
-            k = ck.cpu().numpy().reshape(n, 4).astype("float64")
-            span = (k[:, 3].max() - k[:, 2].min()) * 1e-8
-            out[f"tile_fill_{label}"] = {"us_per_fill": round(float(((k[:, 3] - k[:, 2]) / reps).mean()) * 1e-2, 2),
-                                         "shader_cycles_mean": round(float((k[:, 0] / reps).mean()), 0),
-                                         "shader_cycles_max": int(k[:, 1].max()),
-                                         "stream_tb_s": round(n * reps * 25600.0 / span / 1e12, 3), "workgroups": n}
+        out["tile_fill"] = {}
+        for layout, stride in (("strided", 97 * 640 * 4), ("contiguous", 256)):
+            for label, n, reps in (("idle", 1, 300), ("loaded", 768, 200)):
+                ck = torch.zeros(n * 4, dtype=torch.int64, device=device)
+                for _ in range(2):
+                    lib.check(lib.ccnet_cca_probe_dma(src.data_ptr(), src.numel() * 4, ck.data_ptr(), n, reps, stride, main.cuda_stream), "probe_dma")
+                torch.cuda.synchronize()
+                k = ck.cpu().numpy().reshape(n, 4).astype("float64")
+                span = (k[:, 3].max() - k[:, 2].min()) * 1e-8
+                out["tile_fill"][f"{layout}_{label}"] = {
+                    "us_per_fill": round(float(((k[:, 3] - k[:, 2]) / reps).mean()) * 1e-2, 2),
+                    "shader_cycles_mean": round(float((k[:, 0] / reps).mean()), 0), "shader_cycles_max": int(k[:, 1].max()),
+                    "stream_tb_s": round(n * reps * 25600.0 / span / 1e12, 3), "workgroups": n}
         dst = torch.empty_like(src)
         dst.copy_(src)
         out["copy_f32_gb_s"] = round(2 * src.numel() * 4 / (time_region(lambda: dst.copy_(src), 10) * 1e-3) / 1e9, 1)

@@ -58,6 +58,8 @@ std::atomic<int> g_planes_xcd{1};
 // launches really run together: backward 0.451 -> 0.404 ms, step 0.727-0.749 -> 0.683-0.692 ms in the same run
 // (profiles/r04lg_ab_dA_two_stages.txt); alone the two-stage kernel is no slower (151.6 vs 159.8 us).
 std::atomic<int> g_da_stages{2};
+// "bf16_partial" 1 (default): the column -> row partial of the bf16 pixel-major family (aggregation and dv) is bf16, not fp32
+std::atomic<int> g_bf16_partial{1};
 std::atomic<int> g_dqdk_wpc3{1};            // "dqdk_wpc3": ca_backward of the fp32 routes at C/8 <= 64 on the three-workgroups-per-CU form of gmap_kernel
 std::atomic<int> g_energy_tail{1};          // the fp32 energies launch cuts the strips beyond its whole rounds into tile-row parts
 // "dqdk_exact": ca_backward of the fp32 pixel-major / split-plane routes (strips <= 100).  1 = multiply in exact fp32 instead of
@@ -803,6 +805,19 @@ int launch_gmap_pm(const float *T, const FT *F, const FT *resid, const float *ga
     const GmapPlan gc = gmap_plan(B * W, C), gr = gmap_plan(B * H, C);
     if (std::is_same<FT, bf16_t>::value && g_planes_ring.load() != 0) {
         // bf16 features: the column pass on the ring kernel (three feature tiles, stores from the accumulators)
+        if constexpr (std::is_same<FT, bf16_t>::value && !NCHW) {
+            if (g_bf16_partial.load()) {
+                // ... and its partial as bf16 (what the reference's bf16 arithmetic rounds out_H / the column half of dv to anyway):
+                // half the bytes of the fp32 partial, written once and read once per pass
+                CCA_LAUNCH((cca::gmap3_kernel<P, false, TRANS, false, 3, 2, bf16_t, bf16_t>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS), stream,
+                           T, F, (const float *)nullptr, gamma, reinterpret_cast<bf16_t *>(partial), C, H, W, fbs, fps, 0L, 0, pbs, C, gc.n_whole, gc.split);
+                if (int e = launch_status("gmap_pm(column, bf16 partial)")) return e;
+                CCA_LAUNCH((cca::gmap_kernel<P, true, TRANS, true, FT, FT, false, false, 2, false, false, true>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS),
+                           stream, T, F, (const float *)partial, resid, gamma, out, C, H, W, fbs, fps, pbs, C, rbs, rps, obs, ops,
+                           gr.n_whole, gr.split, cca::GmapJob<FT, FT>{});
+                return launch_status("gmap_pm(row, bf16 partial)");
+            }
+        }
         if constexpr (std::is_same<FT, bf16_t>::value)
             CCA_LAUNCH((cca::gmap3_kernel<P, false, TRANS, false, 3, 2, bf16_t>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS), stream,
                        T, F, (const float *)nullptr, gamma, partial, C, H, W, fbs, fps, 0L, 0, pbs, C, gc.n_whole, gc.split);
@@ -855,7 +870,7 @@ int launch_gmap_dual_pm(const float *dE, const FT *k, const FT *q, FT *dq, FT *d
                        0L, 0, pbs, Cq, gc3.n_whole, gc3.split, jc3);
             if (int e = launch_status("gmap_dual_pm(column, 3 per CU)")) return e;
             cca::GmapJob<FT, FT> jr3{q, pk, dk, qbs, dkbs, qps, dkps, gr3.grid};
-            if (autox) jr3.stat = red.stat;
+            if (autox) { jr3.stat = red.stat; jr3.gate_min = __builtin_bit_cast(unsigned, kDqdkAutoLimit); }
             CCA_LAUNCH((cca::gmap_kernel<P, true, false, true, FT, FT, false, true, 3>), dim3(cca::gmap_dual_grid(gr3.grid)), dim3(cca::GS_THREADS),
                        stream, dE, k, (const float *)pq, (const FT *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
                        0L, 0, dqbs, dqps, gr3.n_whole, gr3.split, jr3);
@@ -873,6 +888,7 @@ int launch_gmap_dual_pm(const float *dE, const FT *k, const FT *q, FT *dq, FT *d
                 if (int e = launch_status("gmap_dual_pm(column)")) return e;
                 cca::GmapJob<FT, FT> jr{q, pk, dk, qbs, dkbs, qps, dkps, gr.grid};
                 jr.stat = red.stat;
+                jr.gate_min = __builtin_bit_cast(unsigned, kDqdkAutoLimit);
                 CCA_LAUNCH((cca::gmap_kernel<P, true, false, true, FT, FT, false, true>), dim3(cca::gmap_dual_grid(gr.grid)), dim3(cca::GS_THREADS),
                            stream, dE, k, (const float *)pq, (const FT *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
                            0L, 0, dqbs, dqps, gr.n_whole, gr.split, jr);
@@ -1594,6 +1610,7 @@ const OptionRange *find_word_option(const std::string &n) {
         {"dqdk_wpc3", &g_dqdk_wpc3, 0, 1},
         {"da_stages", &g_da_stages, 2, 3},
         {"dqdk_exact", &g_dqdk_exact, 0, 2},
+        {"bf16_partial", &g_bf16_partial, 0, 1},
     };
     for (const OptionRange &o : table)
         if (n == o.name) return &o;

@@ -209,7 +209,7 @@ struct GmapJob {
     // magnitude (tests: logit-scale sweep), so only gradients beyond ~64 are redone in exact fp32
     unsigned *stat;
     const unsigned *gate;
-    unsigned gate_min;
+    unsigned gate_min;          // the limit (bits of a positive float): published / acted on only beyond it
 };
 // LONG strips: a strip of L > P positions is cut into nb blocks of ``long_block(L, nb)`` positions (the last one shorter).  A
 // workgroup then owns the QUERY block I of a strip and contracts over the KEY block J: out_I (+)= F_J . A_{I,J}^T; the key blocks
@@ -219,8 +219,9 @@ inline unsigned gmap_dual_grid(int nwg) { return 16u * (unsigned)((nwg + 7) / 8)
 
 // WPC: workgroups per CU the LDS budget is checked for (2 everywhere except the 132-position kernels on fp32 / split-plane
 // features, whose two feature tiles + output image take 104 KB: one workgroup per CU)
+// ABF (bf16 features, round 5): the addend -- the column partial -- is bf16 (see gmap3_kernel, OT): one 16-byte load of 8 channels
 template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT, bool NCHW = false, bool DUAL = false, int WPC = 2, bool LONG = false,
-          bool EXACT_F32 = false>
+          bool EXACT_F32 = false, bool ABF = false>
 __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__restrict__ T, const FT *__restrict__ F,
                                                               const float *__restrict__ addend,
                                                               const OT *__restrict__ resid,
@@ -336,7 +337,10 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                               NCHW ? (size_t)C * HW * sizeof(OT) : ((size_t)(HW - 1) * ops + C) * sizeof(OT));
     const FBuf Rb = make_fbuf(reinterpret_cast<const float *>(resid ? resid + (size_t)b * rbs : out),
                               !resid ? 4 : NCHW ? (size_t)C * HW * sizeof(OT) : ((size_t)(HW - 1) * rps + C) * sizeof(OT));
-    const FBuf Db = make_fbuf(ADD ? addend + (size_t)b * abs_ : T, ADD ? ((size_t)(HW - 1) * aps + C) * sizeof(float) : 4);
+    static_assert(!ABF || (ADD && OBF && !NCHW && !DUAL), "gmap: a bf16 addend feeds the bf16 family's final row passes");
+    const FBuf Db = make_fbuf(ADD ? (ABF ? reinterpret_cast<const float *>(reinterpret_cast<const uint16_t *>(addend) + (size_t)b * abs_)
+                                         : addend + (size_t)b * abs_) : T,
+                              ADD ? ((size_t)(HW - 1) * aps + C) * (ABF ? 2 : sizeof(float)) : 4);
     const float alpha = gamma ? gamma[0] : 1.f;
     const BandK kp = band_ksteps(Lk);
 
@@ -456,8 +460,19 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
             const bool ok = i < Lm && c < C;
             const int pix = pixM + i * pstep;
             if (ADD) {
+                if constexpr (ABF) {                      // 8 bf16 channels of the partial -> two fp32 quads
+                    const u32x4 pk = __builtin_bit_cast(u32x4, fbuf_load_x4(Db, ok ? (pix * aps + c) * 2 : kOobOffset, 0));
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        add0[k][2 * e] = __builtin_bit_cast(float, pk[e] << 16);
+                        add0[k][2 * e + 1] = __builtin_bit_cast(float, pk[e] & 0xffff0000u);
+                        add1[k][2 * e] = __builtin_bit_cast(float, pk[2 + e] << 16);
+                        add1[k][2 * e + 1] = __builtin_bit_cast(float, pk[2 + e] & 0xffff0000u);
+                    }
+                } else {
                 add0[k] = fbuf_load_x4(Db, ok ? (pix * aps + c) * 4 : kOobOffset, 0);
                 if (OBF) add1[k] = fbuf_load_x4(Db, ok ? (pix * aps + c + 4) * 4 : kOobOffset, 0);
+                }
             }
             if constexpr (RES) res[k] = __builtin_bit_cast(u32x4, fbuf_load_x4(Rb, (ok && resid) ? (pix * rps + c) * (int)sizeof(OT) : kOobOffset, 0));
         }
@@ -639,8 +654,11 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     }
     if constexpr (DUAL && ROW && !EXACT_F32 && !OBF) {
         if (j1.stat) {                                                      // (wave-uniform)
+            // only values BEYOND the limit are published (the gate compares with the same limit): the common case issues no atomic
+            // at all -- 25 k same-address atomics per launch serialise in one L2 channel (+55 us measured, profiles/r05a_*)
             gmax = wave_max(gmax);
-            if (lane == 0) atomic_max_u32(j1.stat, __builtin_bit_cast(uint32_t, gmax));
+            const uint32_t bits = __builtin_bit_cast(uint32_t, gmax);
+            if (lane == 0 && bits > j1.gate_min) atomic_max_u32(j1.stat, bits);
         }
     }
 }
@@ -663,11 +681,17 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
 // of a branch at the headline shape, where 512 slots left the second round half empty (profiles/r03c_family_compare.txt).
 // FT = bf16p_t (split planes: hi | lo tiles, three products) or bf16_t (bf16 features, BASELINE configs[4]: one tile, the two
 // products with the attention's hi and lo halves); the output is fp32 pixel-major either way (the column partial).
-template <int P, bool ROW, bool TRANS, bool ADD, int NBUF = 3, int WPC = 2, typename FT = bf16p_t>
+// OT = bf16_t (bf16 features only, round 5): the column PARTIAL leaves as bf16 -- what the reference's own bf16 arithmetic does
+// (functions.py:46-47 under bf16: out_H and out_W are each a bf16 bmm result before they are added) -- half the bytes of the
+// fp32 partial, which at BASELINE configs[4] was 2.2 GB of the step's 8.85 GB.  Two N tiles of a position are paired through one
+// lane exchange (lane ^ 16) so that a lane still stores 16 bytes: 8 consecutive bf16 channels.
+template <int P, bool ROW, bool TRANS, bool ADD, int NBUF = 3, int WPC = 2, typename FT = bf16p_t, typename OT = float>
 __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__restrict__ T, const FT *__restrict__ F,
                                                                const float *__restrict__ addend, const float *__restrict__ gamma,
-                                                               float *__restrict__ out, int C, int H, int W, long fbs, int fps,
+                                                               OT *__restrict__ out, int C, int H, int W, long fbs, int fps,
                                                                long abs_, int aps, long obs, int ops, int n_whole, int split) {
+    constexpr bool OBF = std::is_same<OT, bf16_t>::value;
+    static_assert(!OBF || (std::is_same<FT, bf16_t>::value && !ADD), "gmap3: the bf16 partial belongs to the bf16 family's column passes");
     constexpr int NT = (P + 15) / 16, TPW = (NT + GS_WAVES - 1) / GS_WAVES, NKS = P / 32;
     constexpr bool F32 = std::is_same<FT, float>::value;                // fp32 pixel-major features (F32T tiles, split per fragment)
     constexpr int NPL = std::is_same<FT, bf16p_t>::value ? 2 : 1;       // planes per feature tile
@@ -700,7 +724,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
     const FBuf Tb = make_fbuf(T + (size_t)b * HW * S, (size_t)HW * S * sizeof(float));
     const FBuf Fb = make_fbuf(reinterpret_cast<const float *>(F + (size_t)b * fbs),
                               F32 ? ((size_t)(HW - 1) * fps + C) * 4 : ((size_t)(HW - 1) * fps + NPL * C) * 2);
-    const FBuf Ob = make_fbuf(out + (size_t)b * obs, ((size_t)(HW - 1) * ops + C) * sizeof(float));
+    const FBuf Ob = make_fbuf(reinterpret_cast<const float *>(out + (size_t)b * obs), ((size_t)(HW - 1) * ops + C) * sizeof(OT));
     const FBuf Db = make_fbuf(ADD ? addend + (size_t)b * abs_ : T, ADD ? ((size_t)(HW - 1) * aps + C) * sizeof(float) : 4);
     const float alpha = gamma ? gamma[0] : 1.f;
     const BandK kp = band_ksteps(L);
@@ -766,7 +790,8 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
 #pragma unroll
     for (int a = 0; a < TPW; ++a) ntile_w += (wv + GS_WAVES * a) * 16 < L ? 1 : 0;
     auto nnt = [&](int cg) { const int rem = C - cg * GM_CG; return rem >= GM_CG ? 4 : (rem + 15) / 16; };
-    auto nacc = [&](int cg) { return (cg >= cg0 && cg < cg1) ? ntile_w * nnt(cg) : 0; };   // per-wave accesses of a group
+    // per-wave accesses of a group (bf16 output: one 16-byte store per PAIR of N tiles)
+    auto nacc = [&](int cg) { return (cg >= cg0 && cg < cg1) ? ntile_w * (OBF ? (nnt(cg) + 1) / 2 : nnt(cg)) : 0; };
     f32x4 addp[ADD ? 2 : 1][ADD ? TPW : 1][4];
     auto load_addend = [&](int cg, auto slot_c) {
         constexpr int slot = decltype(slot_c)::value;
@@ -858,6 +883,28 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
         for (int a = 0; a < TPW; ++a) {
             const int i = 16 * (wv + GS_WAVES * a) + ln;
             if ((wv + GS_WAVES * a) * 16 < L) {
+                if constexpr (OBF) {
+                    // N tiles (2 p, 2 p + 1): lanes with an even lg end up with 8 consecutive channels of tile 2 p (their own 4 and
+                    // the 4 of lane ^ 16), lanes with an odd lg with 8 of tile 2 p + 1 -- one 16-byte store of 8 bf16 each
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        if (cg * GM_CG + 32 * pr < C) {                      // (wave-uniform: the pair's first tile has channels)
+                            const bool odd = (lg & 1) != 0;
+                            const f32x4 t0 = alpha * acc[a][2 * pr], t1 = alpha * acc[a][2 * pr + 1];
+                            f32x4 mine, got;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                mine[e] = odd ? t1[e] : t0[e];
+                                got[e] = shfl_xor(odd ? t0[e] : t1[e], 16);
+                            }
+                            const f32x4 lo4 = odd ? got : mine, hi4 = odd ? mine : got;
+                            const int c = cg * GM_CG + 16 * (2 * pr + (odd ? 1 : 0)) + 8 * (lg >> 1);
+                            const f32x4 packed = __builtin_bit_cast(f32x4, u32x4{cvt_pk_bf16(lo4[0], lo4[1]), cvt_pk_bf16(lo4[2], lo4[3]),
+                                                                                 cvt_pk_bf16(hi4[0], hi4[1]), cvt_pk_bf16(hi4[2], hi4[3])});
+                            fbuf_store_x4(Ob, packed, (i < L && c < C) ? ((pix0 + i * pstep) * ops + c) * 2 : kOobOffset, 0);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     const int c = cg * GM_CG + 16 * nt + 4 * lg;
@@ -866,6 +913,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap3_kernel(const float *__r
                         if constexpr (ADD) u += addp[SL][a][nt];
                         fbuf_store_x4(Ob, u, (i < L && c < C) ? ((pix0 + i * pstep) * ops + c) * 4 : kOobOffset, 0);
                     }
+                }
                 }
             }
         }

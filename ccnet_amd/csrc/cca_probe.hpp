@@ -74,14 +74,19 @@ __global__ __launch_bounds__(GS_THREADS, 3) void probe_dma_kernel(const float *_
     uint64_t sum = 0, mx = 0;
     const uint64_t r0 = ref_clock();
     unsigned seed = 2654435761u * (blockIdx.x + 1);
+    // (rows of 256 B out of a row_stride-byte pitch: the tile's column offset is random too, so that the fills of a large source
+    //  come from HBM and not from a 0.5 MB working set that lives in the L2)
+    const unsigned ncol = row_stride >= 512 ? (unsigned)(row_stride / 256) : 1u;
     for (int r = 0; r < reps; ++r) {
         seed = seed * 1664525u + 1013904223u;
-        const int row0 = (int)(seed % (unsigned)(span_rows > 100 ? span_rows - 100 : 1));
+        const int row0 = (int)((seed >> 8) % (unsigned)(span_rows > 100 ? span_rows - 100 : 1));
+        seed = seed * 1664525u + 1013904223u;
+        const int col = 256 * (int)((seed >> 8) % ncol);
         barrier_dma_keep<0>();
         const uint64_t s0 = shader_clock();
         for (int it = wv; it < PROBE_TILE_PIECES; it += GS_WAVES) {
             const int row = row0 + 4 * it + (lane >> 4);
-            fbuf_load_to_lds_x4_uncounted(Sb, tile + it * 256, row * row_stride + 16 * (lane & 15));
+            fbuf_load_to_lds_x4_uncounted(Sb, tile + it * 256, row * row_stride + col + 16 * (lane & 15));
         }
         barrier_dma_keep<0>();
         const uint64_t d = shader_clock() - s0;

@@ -322,6 +322,10 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
  *                    instead of two (these launches are latency chains); 0: the two-slot form.  Same arithmetic, same bits.
  *   "energy_tail"  1 (default): the fp32 energies launch of the pixel-major / split-plane entries (strips <= 100, C/8 <= 64) cuts the
  *                    strips beyond its whole rounds of workgroups into tile-row parts (a short last round); 0: one workgroup per strip.
+ *   "bf16_partial" 1 (default): in the bf16 pixel-major entry points the column -> row partial of the aggregation and of dv is a bf16
+ *                    tensor (the reference's own bf16 arithmetic rounds out_H and the column half of dv to bf16 before adding the row
+ *                    half, functions.py:46-47): half the bytes of the fp32 partial, which was a quarter of the traffic of BASELINE
+ *                    configs[4]; 0: fp32 partial (round 2-4 behaviour).  fp32 families are not affected.
  *   "dqdk_exact"   ca_backward of the fp32 pixel-major / split-plane entry points (strips <= 100): 0 split-bf16 x3 (error ~1.2e-5 of
  *                    max |dq|, |dk|: 4e-4 at the reference's initialisation scale, 1.5e-3 with q, k three times hotter);
  *                    1 exact fp32 (v_mfma_f32_16x16x4_f32; +25 us per launch at (8,512,97,97); leaves the 5e-6 of the upstream dA);

@@ -239,7 +239,7 @@ def test_options_and_workspace_sizes_are_host_logic_behind_two_entry_points(devi
     lib = _lib.get_lib()
     assert len(_lib.declared_symbols()) <= 34          # (30 + the weight packer + three device-state probes of round 5)
     for name, default in (("impl", _lib.CCNET_IMPL_AUTO), ("precision", _lib.CCNET_PRECISION_DEFAULT), ("branch_mask", 3),
-                          ("planes_ring", 2), ("planes_stream", 1), ("planes_overlap", -1), ("planes_xcd", 1), ("energy_tail", 1), ("da_stages", 2), ("dqdk_wpc3", 1), ("dqdk_exact", 2)):
+                          ("planes_ring", 2), ("planes_stream", 1), ("planes_overlap", -1), ("planes_xcd", 1), ("energy_tail", 1), ("da_stages", 2), ("dqdk_wpc3", 1), ("dqdk_exact", 2), ("bf16_partial", 1)):
         assert lib.get_option(name) == default, name
     assert lib.set_option("planes_overlap", 0) == -1 and lib.get_option("planes_overlap") == 0
     assert lib.set_option("planes_overlap", -1) == 0

@@ -30,6 +30,8 @@ PY
 BOX=$(cat "$OUT/box_class.txt" 2>/dev/null || echo unknown); echo "== box class: $BOX"
 echo "== pytest -m gpu"; timeout 1800 python -m pytest tests -m gpu -q -rA --no-header -p no:cacheprovider -x > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest_gpu.log"
 grep -E "^(FAILED|ERROR)|passed|failed|headline max-abs|logit-scale|vs the ORACLE|Error|error" "$OUT/pytest_gpu.log" | tail -60
+echo "== bench, bf16 configs[4]"; timeout 600 python bench.py --dtype bf16 --steps 30 --warmup 5 --no-train --no-cpu-baseline > "$OUT/bench_bf16.json" 2> "$OUT/bench_bf16.err"; head -c 700 "$OUT/bench_bf16.json"; echo
+echo "== bf16 partial A/B"; timeout 600 python tools/bf16_partial_ab.py > "$OUT/bf16_partial_ab.txt" 2>&1; grep "==\|partial vs" "$OUT/bf16_partial_ab.txt"
 [ "$MODE" = "quick" ] && exit 0
 echo "== ab_options"; timeout 900 python tools/ab_options.py > "$OUT/ab_options.txt" 2>&1; echo "ab rc=$?"; grep "==" "$OUT/ab_options.txt"; grep " us " "$OUT/ab_options.txt" | head -30
 echo "== rocprofv3 kernel stats"
@@ -45,7 +47,6 @@ if [ "$MODE" = "closing" ]; then
   echo "== module, small batches"; timeout 600 python tools/module_small_batch.py > "$OUT/module_small_batches.txt" 2>&1; tail -4 "$OUT/module_small_batches.txt"
   echo "== PMC passes (fp32 step)"; bash tools/pmc.sh "$TAG" --iters 3 > "$OUT/pmc.log" 2>&1; tail -3 "$OUT/pmc.log"
   cp "$R/gpurun_out/pmc_$TAG/summary.json" "$OUT/pmc_step_summary.json" 2>/dev/null
-  echo "== bench, bf16 configs[4]"; timeout 600 python bench.py --dtype bf16 --steps 30 --warmup 5 --no-train --no-cpu-baseline > "$OUT/bench_bf16.json" 2> "$OUT/bench_bf16.err"; head -c 600 "$OUT/bench_bf16.json"; echo
   echo "== stress"; timeout 600 python tools/stress_pm.py 100 > "$OUT/stress_pm.log" 2>&1; tail -3 "$OUT/stress_pm.log"
   find "$R/gpurun_out/pmc_$TAG" -name "*.csv" -size +5M -delete 2>/dev/null
 fi
