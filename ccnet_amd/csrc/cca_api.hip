@@ -1060,7 +1060,11 @@ int cca_backward_pm(const char *name, const FT *dy, const FT *q, const FT *k, co
     float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + sm);
     // t = un-scaled dA (the adjoint of the aggregation, functions.py:46-47), dv = gamma * A^T-weighted dy
     // dv (two C-sized, HBM-bound passes) is independent of the chain dA -> dE -> dq | dk: it runs on the side stream
-    const int overlap = g_planes_overlap.load() < 0 ? 1 : g_planes_overlap.load();
+    // (-1 = what measured best: 1 for fp32 features and for bf16 with the fp32 partial -- 1.917 -> 1.903 ms at configs[4], 1.959 with 2;
+    //  with the bf16 partial the column pass is light enough to share the CUs with dA: 1.64-1.70 -> 1.60-1.61 ms with 2,
+    //  profiles/r05b_bf16_partial_ab.txt)
+    const bool bf16_light = std::is_same<FT, bf16_t>::value && g_bf16_partial.load() != 0 && g_planes_ring.load() != 0;
+    const int overlap = g_planes_overlap.load() < 0 ? (bf16_light ? 2 : 1) : g_planes_overlap.load();
     SideFork sf(stream);
     if (overlap == 2) sf.fork();
     int e = gweight_pm<false, FT>(dy, v, scratch, B, C, H, W, dy_bs, dy_ps, v_bs, v_ps, stream);

@@ -452,13 +452,20 @@ def test_pixel_major_bf16_kernels_match_oracle(lib, dev, shape):
     go = O.cca_core_backward(f(dy), f(q), f(k), f(v), Ao, f(gamma))
     tol = lambda ref: 2.0 ** -8 * ref.abs() + TOL                           # noqa: E731
     g = qkv.grad
+    # the column -> row partial of the aggregation and of dv is a bf16 tensor since round 5 (option "bf16_partial": what the
+    # reference's own bf16 arithmetic does, out_H is a bf16 bmm result -- functions.py:46): one more rounding, of the COLUMN HALF
+    Hh = f(v).shape[2]
+    assert lib.get_option("bf16_partial") == 1
+    col = {"y": f(gamma) * torch.einsum("bhwj,bcjw->bchw", Ao[..., :Hh], f(v)),
+           "dv": f(gamma) * torch.einsum("bhwj,bchw->bcjw", Ao[..., :Hh], f(dy))}
     pairs = (("y", nchw(y), yo), ("dq", nchw(g[..., :cq]), go["dq"]), ("dk", nchw(g[..., cq:2 * cq]), go["dk"]),
              ("dv", nchw(g[..., 2 * cq:]), go["dv"]))
-    # reported: the worst excess over the pure output-rounding allowance 2^-8 |ref| (what the fp32 bar TOL has to cover)
-    print("pixel-major bf16 max excess over 2^-8|ref| vs oracle", shape,
-          {n: f"{float(((a - b).abs() - 2.0 ** -8 * b.abs()).max()):.1e}" for n, a, b in pairs})
+    allow = lambda n, b: 2.0 ** -8 * b.abs() + (2.0 ** -8 * col[n].abs() if n in col else 0.0)          # noqa: E731
+    # reported: the worst excess over the pure rounding allowance (what the fp32 bar TOL has to cover)
+    print("pixel-major bf16 max excess over the rounding allowance vs oracle", shape,
+          {n: f"{float(((a - b).abs() - allow(n, b)).max()):.1e}" for n, a, b in pairs})
     for n, a, b in pairs:
-        assert bool(((a - b).abs() <= tol(b)).all()), n
+        assert bool(((a - b).abs() <= allow(n, b) + TOL).all()), n
     assert torch.equal(xp.grad, dyp)
     assert abs(float(gamma.grad) - float(go["dgamma"])) < 1e-3 * max(1.0, abs(float(go["dgamma"])))
 
