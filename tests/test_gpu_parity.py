@@ -978,8 +978,15 @@ def test_pixel_major_bf16_module_route_and_full_size(lib, dev):
     gamma = torch.tensor([0.5], device=dev)
     ga = gamma.clone().requires_grad_(True)
     qkv.requires_grad_(True)
-    ya = CrissCrossPMBF16Function.apply(qkv, xp, ga, cq)
-    ya.backward(dyp)
+    # (i) with the fp32 column partial of rounds 2-4 ("bf16_partial" 0): one rounding of each output against the fp32 strip path
+    prev = lib.set_option("bf16_partial", 0)
+    try:
+        ya = CrissCrossPMBF16Function.apply(qkv, xp, ga, cq)
+        ya.backward(dyp)
+        torch.cuda.synchronize()
+    finally:
+        lib.set_option("bf16_partial", prev)
+    assert prev == 1
     b = [t.float().requires_grad_(True) for t in (q, k, v, x)] + [gamma.clone().requires_grad_(True)]
     del q, k, v, x
     yb = criss_cross_attention(*b)
@@ -991,22 +998,30 @@ def test_pixel_major_bf16_module_route_and_full_size(lib, dev):
     for got, ref, name in ((g[..., :cq], b[0].grad, "dq"), (g[..., cq:2 * cq], b[1].grad, "dk"), (g[..., 2 * cq:], b[2].grad, "dv")):
         assert bool(((nchw(got) - ref).abs() <= tol(ref)).all()), name
     assert abs(float(ga.grad) - float(b[4].grad)) < 2e-3 * max(1.0, abs(float(b[4].grad)))
-    # images 0 and B - 1 of the full batch against the CPU ORACLE (the op has no cross-image term, so one image of the
-    # batch is a (1,512,129,129) problem): the full-size run is pinned to the oracle, not only to the other HIP family
+    # (ii) the DEFAULT arithmetic (bf16 column partial, round 5): images 0 and B - 1 of the full batch against the CPU ORACLE (the op
+    # has no cross-image term, so one image of the batch is a (1,512,129,129) problem) -- the full-size run is pinned to the oracle,
+    # not only to the other HIP family.  Allowance: one rounding of each output + one of the column half of y / dv
+    qkv.grad = None
+    ga.grad = None
+    ya = CrissCrossPMBF16Function.apply(qkv, xp, ga, cq)
+    ya.backward(dyp)
+    g = qkv.grad
     f = lambda t: t.detach().float().cpu()                                  # noqa: E731
-    tolo = lambda ref: 2.0 ** -8 * ref.abs() + TOL                          # noqa: E731
     for i in (0, B - 1):
         sl = slice(i, i + 1)
         qi, ki, vi, xi = (f(t[sl]) for t in b[:4])
         yo, Ao = O.cca_core_forward(qi, ki, vi, xi, f(gamma))
         go = O.cca_core_backward(f(dy[sl]), qi, ki, vi, Ao, f(gamma))
+        col = {"y": 0.5 * torch.einsum("bhwj,bcjw->bchw", Ao[..., :H], vi),
+               "dv": 0.5 * torch.einsum("bhwj,bchw->bcjw", Ao[..., :H], f(dy[sl]))}
         cpu = lambda t: f(t[sl]).permute(0, 3, 1, 2)                        # noqa: E731
         pairs = (("y", cpu(ya), yo), ("dq", cpu(g[..., :cq]), go["dq"]), ("dk", cpu(g[..., cq:2 * cq]), go["dk"]),
                  ("dv", cpu(g[..., 2 * cq:]), go["dv"]))
-        print(f"configs[4] full batch, image {i} vs oracle: max excess over 2^-8|ref|",
-              {n: f"{float(((a_ - r_).abs() - 2.0 ** -8 * r_.abs()).max()):.1e}" for n, a_, r_ in pairs})
+        allow = lambda n, r_: 2.0 ** -8 * r_.abs() + (2.0 ** -8 * col[n].abs() if n in col else 0.0)     # noqa: E731
+        print(f"configs[4] full batch, image {i} vs oracle: max excess over the rounding allowance",
+              {n: f"{float(((a_ - r_).abs() - allow(n, r_)).max()):.1e}" for n, a_, r_ in pairs})
         for n, a_, r_ in pairs:
-            assert bool(((a_ - r_).abs() <= tolo(r_)).all()), (i, n)
+            assert bool(((a_ - r_).abs() <= allow(n, r_) + TOL).all()), (i, n)
     del b, ya, yb, g, qkv, xp, dyp, dy
     torch.cuda.empty_cache()
     # module route: bf16 channels_last activations

@@ -28,7 +28,7 @@ except Exception as e:
     print("bench line unreadable:", e)
 PY
 BOX=$(cat "$OUT/box_class.txt" 2>/dev/null || echo unknown); echo "== box class: $BOX"
-echo "== pytest -m gpu"; timeout 1800 python -m pytest tests -m gpu -q -rA --no-header -p no:cacheprovider -x > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest_gpu.log"
+echo "== pytest -m gpu"; timeout 1800 python -m pytest tests -m gpu -q -rA --no-header -p no:cacheprovider > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest_gpu.log"
 grep -E "^(FAILED|ERROR)|passed|failed|headline max-abs|logit-scale|vs the ORACLE|Error|error" "$OUT/pytest_gpu.log" | tail -60
 echo "== bench, bf16 configs[4]"; timeout 600 python bench.py --dtype bf16 --steps 30 --warmup 5 --no-train --no-cpu-baseline > "$OUT/bench_bf16.json" 2> "$OUT/bench_bf16.err"; head -c 700 "$OUT/bench_bf16.json"; echo
 echo "== bf16 partial A/B"; timeout 600 python tools/bf16_partial_ab.py > "$OUT/bf16_partial_ab.txt" 2>&1; grep "==\|partial vs" "$OUT/bf16_partial_ab.txt"
