@@ -1383,10 +1383,13 @@ def test_pixel_major_family_on_random_geometries(lib, dev, dtype):
         yo, Ao = O.cca_core_forward(f(q), f(k), f(v), f(x), torch.tensor([0.5]))
         go = O.cca_core_backward(f(dy), f(q), f(k), f(v), Ao, torch.tensor([0.5]))
         tol = (lambda ref: 2.0 ** -8 * ref.abs() + TOL) if bf else (lambda ref: torch.full_like(ref, TOL))
+        # bf16: + one rounding of the COLUMN HALF of y / dv (the bf16 column partial, option "bf16_partial", round 5)
+        col = {"y": 0.5 * torch.einsum("bhwj,bcjw->bchw", Ao[..., :H], f(v)).abs() * 2.0 ** -8,
+               "dv": 0.5 * torch.einsum("bhwj,bchw->bcjw", Ao[..., :H], f(dy)).abs() * 2.0 ** -8} if bf else {}
         g = qkv.grad
         for got, ref, name in ((y, yo, "y"), (g[..., :cq], go["dq"], "dq"), (g[..., cq:2 * cq], go["dk"], "dk"),
                                (g[..., 2 * cq:], go["dv"], "dv")):
-            assert bool(((nchw(got) - ref).abs() <= tol(ref)).all()), (shape, name, float((nchw(got) - ref).abs().max()))
+            assert bool(((nchw(got) - ref).abs() <= tol(ref) + col.get(name, 0.0)).all()), (shape, name, float((nchw(got) - ref).abs().max()))
         assert abs(float(gamma.grad) - float(go["dgamma"])) < 2e-3 * max(1.0, abs(float(go["dgamma"]))), shape
 
 
