@@ -566,6 +566,19 @@ def planes_cover(B, C, Cq, H, W):
     return max(H, W) <= 4 * 132 and Cq <= 64
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """one extra torch stream per device for launches the module forks off its own chain (the affinity + softmax launches next to the
+    v GEMM): plain wait_stream fork / join, capturable, invisible to the caller's stream order"""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+    return s
+
+
 def _pack_projection(wq, bq, wk, bk, wv, bv, split):
     """Stacked projection operands of one module application, packed by ONE launch (``ccnet_cca_pack_projection_f32``): the
     stacked fp32 weight / bias and, with ``split``, the K-concatenated bf16 hi | lo operands of the split-bf16 x3 GEMMs.
@@ -592,6 +605,7 @@ def _pack_projection(wq, bq, wk, bk, wv, bv, split):
                                                     C, cq, _stream()), "pack_projection")
     val = {"w": w, "b": b, "bqk": b[:2 * cq], "bv": b[2 * cq:]}
     if split:
+        val["w3b"] = w3                                                                         # (2Cq + C, 3C): rows [wh | wl | wh]
         val["w3"] = w3.t()                                                                      # (3C, 2Cq + C) view
         val["w3t"] = w3t                                                                        # (C, 3 (2Cq + C))
     return val
@@ -627,30 +641,50 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
         pc = _pack_projection(wq, bq, wk, bk, wv, bv, split_gemm)     # (the current parameter values, every call: no cache)
         x3 = None
         direct = max(H, W) <= 100           # strips <= 100: the plane-free form of the core (v stays fp32, no split pass)
-        if split_gemm:
-            x3 = nchw_to_planes(x, PLANES_HHL, torch.bfloat16)                              # (B, H, W, 3, C): xh | xh | xl
-            if direct:                      # the whole bias in the GEMM's epilogue
-                qkv = torch.addmm(pc["b"], x3.view(B * hw, 3 * C), pc["w3"], out_dtype=torch.float32).view(B, hw, ct)
-                v_bias = None
-            else:
-                qkv = torch.mm(x3.view(B * hw, 3 * C), pc["w3"], out_dtype=torch.float32).view(B, hw, ct)
-                # the bias without a pass over the whole output: q | k in place (a fifth of it), v where its slice is split
-                qkv[..., :2 * cq].add_(pc["bqk"])
-                v_bias = pc["bv"]
-        else:
-            qkv = torch.baddbmm(pc["b"].view(1, 1, -1), x.view(B, C, hw).transpose(1, 2), pc["w"].t().unsqueeze(0).expand(B, -1, -1))
-            v_bias = None
         lib = _lib.get_lib()
         y = torch.empty_like(x)
         A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
         vpl = None if direct else torch.empty((B, H, W, 2, C), device=x.device, dtype=torch.int16)
-        p, bs, ps = qkv.data_ptr(), hw * ct, ct
-        with torch.cuda.device(x.device):
-            _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0), x.device)
-            lib.check(lib.ccnet_cca_forward_planes_f32(p, p + 4 * cq, p + 8 * cq, None if v_bias is None else v_bias.data_ptr(),
-                                                       None if direct else vpl.data_ptr(), x.data_ptr(), gamma.data_ptr(), y.data_ptr(),
-                                                       A.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps, bs, ps,
-                                                       hw * 2 * C, 2 * C, wsp, wsn, _stream()), "cca_forward_planes")
+        bs, ps = hw * ct, ct
+        if split_gemm:
+            # q | k and v as TWO GEMMs into the channel slices of one packed tensor (the stock bf16 -> fp32 GEMM runs N = 128 + N = 512
+            # in 73 + 194 us where N = 640 takes 329, profiles/r05e_module_gemm_probe.txt; same bits), and the affinity + softmax
+            # launches -- 70 us of latency-bound work that needs only q | k and leaves the memory system idle -- on a second stream
+            # NEXT TO the matrix-bound v GEMM; the aggregation follows when both are through.
+            x3 = nchw_to_planes(x, PLANES_HHL, torch.bfloat16)                              # (B, H, W, 3, C): xh | xh | xl
+            x3v = x3.view(B * hw, 3 * C)
+            w3b = pc["w3b"]                                                                 # (2Cq + C, 3C) rows [wh | wl | wh]
+            qkv = torch.empty((B * hw, ct), device=x.device, dtype=torch.float32)
+            torch.addmm(pc["bqk"], x3v, w3b[:2 * cq].t(), out_dtype=torch.float32, out=qkv[:, :2 * cq])
+            p = qkv.data_ptr()
+            main, side = torch.cuda.current_stream(x.device), _side_stream(x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.cuda.device(x.device):
+                lib.check(lib.ccnet_cca_attention_pm(p, p + 4 * cq, A.data_ptr(), 0, B, cq, H, W, bs, ps, bs, ps, side.cuda_stream),
+                          "cca_attention_pm")
+            if direct:                      # the value bias in the GEMM's epilogue
+                torch.addmm(pc["bv"], x3v, w3b[2 * cq:].t(), out_dtype=torch.float32, out=qkv[:, 2 * cq:])
+                v_bias = None
+            else:                           # ... or added where the value slice is split into the core's planes
+                torch.mm(x3v, w3b[2 * cq:].t(), out_dtype=torch.float32, out=qkv[:, 2 * cq:])
+                v_bias = pc["bv"]
+            main.wait_stream(side)
+            qkv = qkv.view(B, hw, ct)
+            with torch.cuda.device(x.device):
+                _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0), x.device)
+                lib.check(lib.ccnet_cca_aggregate_planes_f32(A.data_ptr(), p + 8 * cq, None if v_bias is None else v_bias.data_ptr(),
+                                                             None if direct else vpl.data_ptr(), x.data_ptr(), gamma.data_ptr(),
+                                                             y.data_ptr(), B, C, H, W, bs, ps, hw * 2 * C, 2 * C, wsp, wsn, _stream()),
+                          "cca_aggregate_planes")
+        else:
+            qkv = torch.baddbmm(pc["b"].view(1, 1, -1), x.view(B, C, hw).transpose(1, 2), pc["w"].t().unsqueeze(0).expand(B, -1, -1))
+            p = qkv.data_ptr()
+            with torch.cuda.device(x.device):
+                _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0), x.device)
+                lib.check(lib.ccnet_cca_forward_planes_f32(p, p + 4 * cq, p + 8 * cq, None,
+                                                           None if direct else vpl.data_ptr(), x.data_ptr(), gamma.data_ptr(), y.data_ptr(),
+                                                           A.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps, bs, ps,
+                                                           hw * 2 * C, 2 * C, wsp, wsn, _stream()), "cca_forward_planes")
         if not any(ctx.needs_input_grad):
             return y
         # plane-free: the packed projection itself is kept (its value slice is read again by the dA contraction); otherwise a copy
