@@ -633,7 +633,7 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
     (bit-identical, one affinity + softmax launch pair)."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma, split_gemm=False, recompute=False):
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma, split_gemm=False, recompute=False, fwd_mode=2):
         x, gamma = _dev_f32("x", x), _dev_f32("gamma", gamma)
         B, C, H, W = x.shape
         cq, hw = wq.shape[0], H * W
@@ -647,35 +647,51 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
         vpl = None if direct else torch.empty((B, H, W, 2, C), device=x.device, dtype=torch.int16)
         bs, ps = hw * ct, ct
         if split_gemm:
-            # q | k and v as TWO GEMMs into the channel slices of one packed tensor (the stock bf16 -> fp32 GEMM runs N = 128 + N = 512
-            # in 73 + 194 us where N = 640 takes 329, profiles/r05e_module_gemm_probe.txt; same bits), and the affinity + softmax
-            # launches -- 70 us of latency-bound work that needs only q | k and leaves the memory system idle -- on a second stream
-            # NEXT TO the matrix-bound v GEMM; the aggregation follows when both are through.
+            # ``fwd_mode`` 2 (default): q | k and v as TWO GEMMs into the channel slices of one packed tensor (the stock bf16 -> fp32
+            # GEMM runs N = 128 + N = 512 in 73 + 194 us where N = 640 takes 329, profiles/r05e_module_gemm_probe.txt; same bits), and
+            # the affinity + softmax launches -- 70 us of latency-bound work that needs only q | k and leaves the memory system idle
+            # -- on a second stream NEXT TO the matrix-bound v GEMM; the aggregation follows when both are through.
+            # 1: two GEMMs, everything on one stream; 0: one GEMM + the fused forward entry point (rounds 3-4).  (A/B: tools/module_fwd_ab.py)
             x3 = nchw_to_planes(x, PLANES_HHL, torch.bfloat16)                              # (B, H, W, 3, C): xh | xh | xl
             x3v = x3.view(B * hw, 3 * C)
             w3b = pc["w3b"]                                                                 # (2Cq + C, 3C) rows [wh | wl | wh]
             qkv = torch.empty((B * hw, ct), device=x.device, dtype=torch.float32)
-            torch.addmm(pc["bqk"], x3v, w3b[:2 * cq].t(), out_dtype=torch.float32, out=qkv[:, :2 * cq])
             p = qkv.data_ptr()
-            main, side = torch.cuda.current_stream(x.device), _side_stream(x.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side), torch.cuda.device(x.device):
-                lib.check(lib.ccnet_cca_attention_pm(p, p + 4 * cq, A.data_ptr(), 0, B, cq, H, W, bs, ps, bs, ps, side.cuda_stream),
-                          "cca_attention_pm")
-            if direct:                      # the value bias in the GEMM's epilogue
-                torch.addmm(pc["bv"], x3v, w3b[2 * cq:].t(), out_dtype=torch.float32, out=qkv[:, 2 * cq:])
-                v_bias = None
-            else:                           # ... or added where the value slice is split into the core's planes
-                torch.mm(x3v, w3b[2 * cq:].t(), out_dtype=torch.float32, out=qkv[:, 2 * cq:])
-                v_bias = pc["bv"]
-            main.wait_stream(side)
+            v_bias = None if direct else pc["bv"]      # (maps beyond 100 positions: the value bias is added where v is split into planes)
+            if fwd_mode == 0:
+                if direct:
+                    torch.addmm(pc["b"], x3v, pc["w3"], out_dtype=torch.float32, out=qkv)
+                else:
+                    torch.mm(x3v, pc["w3"], out_dtype=torch.float32, out=qkv)
+                    qkv[:, :2 * cq].add_(pc["bqk"])
+                with torch.cuda.device(x.device):
+                    _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0), x.device)
+                    lib.check(lib.ccnet_cca_forward_planes_f32(p, p + 4 * cq, p + 8 * cq, None if v_bias is None else v_bias.data_ptr(),
+                                                               None if direct else vpl.data_ptr(), x.data_ptr(), gamma.data_ptr(),
+                                                               y.data_ptr(), A.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps, bs, ps,
+                                                               hw * 2 * C, 2 * C, wsp, wsn, _stream()), "cca_forward_planes")
+            else:
+                torch.addmm(pc["bqk"], x3v, w3b[:2 * cq].t(), out_dtype=torch.float32, out=qkv[:, :2 * cq])
+                main = torch.cuda.current_stream(x.device)
+                side = _side_stream(x.device) if fwd_mode == 2 else main
+                if side is not main:
+                    side.wait_stream(main)
+                with torch.cuda.stream(side), torch.cuda.device(x.device):
+                    lib.check(lib.ccnet_cca_attention_pm(p, p + 4 * cq, A.data_ptr(), 0, B, cq, H, W, bs, ps, bs, ps, side.cuda_stream),
+                              "cca_attention_pm")
+                if direct:                      # the value bias in the GEMM's epilogue
+                    torch.addmm(pc["bv"], x3v, w3b[2 * cq:].t(), out_dtype=torch.float32, out=qkv[:, 2 * cq:])
+                else:
+                    torch.mm(x3v, w3b[2 * cq:].t(), out_dtype=torch.float32, out=qkv[:, 2 * cq:])
+                if side is not main:
+                    main.wait_stream(side)
+                with torch.cuda.device(x.device):
+                    _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0), x.device)
+                    lib.check(lib.ccnet_cca_aggregate_planes_f32(A.data_ptr(), p + 8 * cq, None if v_bias is None else v_bias.data_ptr(),
+                                                                 None if direct else vpl.data_ptr(), x.data_ptr(), gamma.data_ptr(),
+                                                                 y.data_ptr(), B, C, H, W, bs, ps, hw * 2 * C, 2 * C, wsp, wsn, _stream()),
+                              "cca_aggregate_planes")
             qkv = qkv.view(B, hw, ct)
-            with torch.cuda.device(x.device):
-                _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0), x.device)
-                lib.check(lib.ccnet_cca_aggregate_planes_f32(A.data_ptr(), p + 8 * cq, None if v_bias is None else v_bias.data_ptr(),
-                                                             None if direct else vpl.data_ptr(), x.data_ptr(), gamma.data_ptr(),
-                                                             y.data_ptr(), B, C, H, W, bs, ps, hw * 2 * C, 2 * C, wsp, wsn, _stream()),
-                          "cca_aggregate_planes")
         else:
             qkv = torch.baddbmm(pc["b"].view(1, 1, -1), x.view(B, C, hw).transpose(1, 2), pc["w"].t().unsqueeze(0).expand(B, -1, -1))
             p = qkv.data_ptr()
@@ -743,7 +759,7 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
             dw = torch.bmm(dqt, xm.transpose(1, 2)).sum(0)                                    # (2Cq + C, C)
         dwq, dwk, dwv = dw[:cq], dw[cq:2 * cq], dw[2 * cq:]
         return (dx.view(B, C, H, W), dwq.reshape(cq, C, 1, 1), db[:cq], dwk.reshape(cq, C, 1, 1), db[cq:2 * cq],
-                dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma), None, None)
+                dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma), None, None, None)
 
 
 def criss_cross_attention(q, k, v, x, gamma, recompute_attention=False):
@@ -794,6 +810,9 @@ class CrissCrossAttention(nn.Module):
     #: ... from this many pixels per call on (module fwd+bwd at 512 channels, 97 x 97: B = 8 2.23 -> 1.92 ms, B = 4 1.21 -> 1.11,
     #: B = 2 0.70 -> 0.75, B = 1 0.59 -> 0.74: below ~30k pixels the step is bound by host launches and the extra ops cost more)
     split_bf16_min_pixels = 32768
+    #: how the split-bf16 forward issues the projection (round 5): 2 = q | k and v as two GEMMs, affinity + softmax on a second stream
+    #: next to the v GEMM; 1 = two GEMMs on one stream; 0 = one stacked GEMM + the fused forward entry point (rounds 3-4).  Same bits.
+    projection_forward_mode = 2
     #: fp32 channels_last inputs run on the pixel-major family (x as (B, H, W, C) is then a free view: nothing is copied).
     pixel_major_for_channels_last = True
     #: bf16 inputs: strips <= 132 (C, C/8 divisible by 8) run on the pixel-major bf16 MFMA kernels; strips of 133 .. 528 positions
@@ -876,14 +895,15 @@ class CrissCrossAttention(nn.Module):
             return CrissCrossPMFunction.apply(qkv, xp, self.gamma, cq, self.recompute_attention).permute(0, 3, 1, 2)
         if r == "f32-planes":
             split_gemm = self.split_bf16_projections and x.shape[0] * x.shape[2] * x.shape[3] >= self.split_bf16_min_pixels
-            return CrissCrossPlanesModuleFunction.apply(x, *params, self.gamma, split_gemm, self.recompute_attention)
+            return CrissCrossPlanesModuleFunction.apply(x, *params, self.gamma, split_gemm, self.recompute_attention,
+                                                        self.projection_forward_mode)
         if r == "f32-planes-cast":
             with torch.autocast(device_type="cuda", enabled=False):          # (the node's GEMMs are its own: fp32 / split-bf16 x3)
                 split_gemm = self.split_bf16_projections and x.shape[0] * x.shape[2] * x.shape[3] >= self.split_bf16_min_pixels
                 # (the node's projections are its own fp32 / split-bf16 x3 GEMMs on fp32 copies of the parameters -- a no-op for an
                 #  fp32 module under autocast: autocast does NOT govern them, unlike the reference's autocast convolutions)
                 y = CrissCrossPlanesModuleFunction.apply(x.float().contiguous(), *(p.float() for p in params), self.gamma.float(),
-                                                         split_gemm, self.recompute_attention)
+                                                         split_gemm, self.recompute_attention, self.projection_forward_mode)
             return y.to(x.dtype)
         if r == "f32-strips-node":
             return CrissCrossModuleFunction.apply(x, *params, self.gamma, self.recompute_attention)

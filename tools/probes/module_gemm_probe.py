@@ -59,3 +59,20 @@ x3b = x3.view(B, 3 * hw, C)
 print("bwd dW  bmm + sum         %.1f us" % t(lambda: torch.bmm(d3.view(B, 3 * hw, ct).transpose(1, 2), x3b, out_dtype=torch.float32).sum(0)))
 dq = torch.randn(B, hw, ct, device=dev)
 print("bwd db  sum over pixels   %.1f us" % t(lambda: dq.sum(dim=(0, 1))))
+# dW as ONE GEMM over all B * 3 HW rows (K = 226 k, a 640 x 512 output: needs split-K inside the library) instead of B batched ones + a sum
+d3f, x3f = d3.view(B * 3 * hw, ct), x3.view(B * 3 * hw, C)
+try:
+    one = lambda: torch.mm(d3f.t(), x3f, out_dtype=torch.float32)                                   # noqa: E731
+    print("bwd dW  one mm over B*3HW rows  %.1f us" % t(one))
+    ref = torch.bmm(d3.view(B, 3 * hw, ct).transpose(1, 2), x3b, out_dtype=torch.float32).sum(0)
+    print("   max |one - (bmm + sum)| / |ref|max = %.3e" % float((one() - ref).abs().max() / ref.abs().max()))
+except Exception as e:
+    print("bwd dW one mm: failed:", str(e)[:200])
+for nb in (2, 4, 16, 32):
+    try:
+        d3n, x3n = d3.view(nb, B * 3 * hw // nb, ct) if (B * 3 * hw) % nb == 0 else None, x3.view(nb, B * 3 * hw // nb, C) if (B * 3 * hw) % nb == 0 else None
+        if d3n is None:
+            continue
+        print("bwd dW  bmm over %2d row blocks + sum  %.1f us" % (nb, t(lambda: torch.bmm(d3n.transpose(1, 2), x3n, out_dtype=torch.float32).sum(0))))
+    except Exception as e:
+        print("bwd dW", nb, "blocks: failed:", str(e)[:120])
