@@ -633,7 +633,7 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
     (bit-identical, one affinity + softmax launch pair)."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma, split_gemm=False, recompute=False, fwd_mode=2):
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma, split_gemm=False, recompute=False, fwd_mode=0):
         x, gamma = _dev_f32("x", x), _dev_f32("gamma", gamma)
         B, C, H, W = x.shape
         cq, hw = wq.shape[0], H * W
@@ -647,11 +647,10 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
         vpl = None if direct else torch.empty((B, H, W, 2, C), device=x.device, dtype=torch.int16)
         bs, ps = hw * ct, ct
         if split_gemm:
-            # ``fwd_mode`` 2 (default): q | k and v as TWO GEMMs into the channel slices of one packed tensor (the stock bf16 -> fp32
-            # GEMM runs N = 128 + N = 512 in 73 + 194 us where N = 640 takes 329, profiles/r05e_module_gemm_probe.txt; same bits), and
-            # the affinity + softmax launches -- 70 us of latency-bound work that needs only q | k and leaves the memory system idle
-            # -- on a second stream NEXT TO the matrix-bound v GEMM; the aggregation follows when both are through.
-            # 1: two GEMMs, everything on one stream; 0: one GEMM + the fused forward entry point (rounds 3-4).  (A/B: tools/module_fwd_ab.py)
+            # ``fwd_mode`` 0 (default): one stacked GEMM + the fused forward entry point.  2: q | k and v as TWO GEMMs into the channel
+            # slices of one packed tensor and the affinity + softmax launches (70 us of latency-bound work that needs only q | k) on
+            # a second stream NEXT TO the v GEMM, the aggregation when both are through; 1: two GEMMs, one stream.
+            # Measured equal within the spread (CrissCrossAttention.projection_forward_mode, tools/module_fwd_ab.py): not the default.
             x3 = nchw_to_planes(x, PLANES_HHL, torch.bfloat16)                              # (B, H, W, 3, C): xh | xh | xl
             x3v = x3.view(B * hw, 3 * C)
             w3b = pc["w3b"]                                                                 # (2Cq + C, 3C) rows [wh | wl | wh]
@@ -810,9 +809,13 @@ class CrissCrossAttention(nn.Module):
     #: ... from this many pixels per call on (module fwd+bwd at 512 channels, 97 x 97: B = 8 2.23 -> 1.92 ms, B = 4 1.21 -> 1.11,
     #: B = 2 0.70 -> 0.75, B = 1 0.59 -> 0.74: below ~30k pixels the step is bound by host launches and the extra ops cost more)
     split_bf16_min_pixels = 32768
-    #: how the split-bf16 forward issues the projection (round 5): 2 = q | k and v as two GEMMs, affinity + softmax on a second stream
-    #: next to the v GEMM; 1 = two GEMMs on one stream; 0 = one stacked GEMM + the fused forward entry point (rounds 3-4).  Same bits.
-    projection_forward_mode = 2
+    #: how the split-bf16 forward issues the projection: 0 (default) = one stacked GEMM + the fused forward entry point; 1 = q | k and v
+    #: as two GEMMs on one stream; 2 = two GEMMs with the affinity + softmax launches on a second stream next to the v GEMM (VERDICT r4
+    #: item 8).  Same bits.  Measured in the module at (8,512,97,97), same run (profiles/r05g_module_fwd_ab.txt): forward 0.607-0.623 /
+    #: 0.614-0.618 / 0.618-0.621 ms for 2 / 1 / 0 -- inside the run-to-run spread, kill criterion (-40 us) missed: in isolation the stock
+    #: GEMM runs N = 128 + N = 512 faster than N = 640 (profiles/r05e_module_gemm_probe.txt), inside the module it does not, and the
+    #: latency-bound affinity launch next to a matrix-bound GEMM slows the GEMM by what it hides.  Kept as an option, not as the default.
+    projection_forward_mode = 0
     #: fp32 channels_last inputs run on the pixel-major family (x as (B, H, W, C) is then a free view: nothing is copied).
     pixel_major_for_channels_last = True
     #: bf16 inputs: strips <= 132 (C, C/8 divisible by 8) run on the pixel-major bf16 MFMA kernels; strips of 133 .. 528 positions
