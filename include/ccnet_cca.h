@@ -209,7 +209,7 @@ int ccnet_cca_backward_pm_bf16(const uint16_t *dy, const uint16_t *q, const uint
 
 /* The same core on fp32 pixel-major views (strips <= 100, C % 4 == 0, Cq % 4 == 0, every bs / ps a multiple of 4): one
  * strip per workgroup instead of 8 per workgroup -- 26x more workgroups per launch, which is what 1-2 images per GPU
- * need.  fp32 features are split into bf16 hi + lo on the fly (the three-product form of DESIGN.md 3.7);
+ * need (HISTORY.md 3.8).  fp32 features are split into bf16 hi + lo on the fly (the three-product form of HISTORY.md 3.7);
  * same arguments, semantics and workspace as the bf16 pair.  (What the module runs for channels_last fp32 inputs; NCHW fp32
  * inputs take the split-plane path below.) */
 int ccnet_cca_forward_pm_f32(const float *q, const float *k, const float *v, const float *x,

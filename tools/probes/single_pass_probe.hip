@@ -10,7 +10,7 @@
 //           three-slot LDS ring (1 KiB LDS-DMA pieces, counted vmcnt: the library's fill machinery)
 //   mode 1  the same, NOT XCD-pinned (tiles of an image spread over the 8 L2s)
 //   mode 2  reference, what the two strip passes read today: every column strip and every row strip once (2 x 154 MB from HBM)
-// Output: us per launch, bytes into LDS per second, and the time the two real passes take for comparison.
+// Output: us per launch, bytes into LDS per second, and the time the two real passes take for comparison (HISTORY.md 3.6).
 // Build: hipcc --offload-arch=gfx950 -O3 single_pass_probe.hip -o single_pass_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
