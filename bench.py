@@ -584,7 +584,7 @@ def gpu_probe(lib, step, device, step_ms):
     return out
 
 
-def planes_launch_bytes(B, C, H, W):
+def planes_launch_bytes(B, C, H, W, auto_exact=True):
     """Algorithmic (compulsory) bytes of every launch of one split-plane step, in issue order: what the launch must read and
     write once, from the tensor sizes of SURVEY 8(d) (feature C-sized 4*P*C, Cq-sized 4*P*Cq, attention-shaped 4*P*S)."""
     P, S, Cq = B * H * W, H + W, C // 8
@@ -603,9 +603,13 @@ def planes_launch_bytes(B, C, H, W):
         ("dv, column pass (dy, A/2 -> partial)", 2 * fc + att // 2, r"gmap3_kernel<\d+, false, true, false"),
         ("dv, row pass (dy, A/2, partial -> dv)", 3 * fc + att // 2, r"gmap_kernel<\d+, true, true, true, cca::bf16p_t"),
         ("softmax backward + dgamma partials", 3 * att, r"softmax_bwd_kernel"),
-        ("dq | dk, column pass (+ dgamma reduction)", att // 2 + 4 * fq, r"gmap_kernel<\d+, false, false, false, float, float, false, true"),
-        ("dq | dk, row pass", att // 2 + 6 * fq, r"gmap_kernel<\d+, true, false, true, float, float, false, true"),
-    ]
+        ("dq | dk, column pass (+ dgamma reduction)", att // 2 + 4 * fq, r"gmap_kernel<\d+, false, false, false, float, float, false, true, \d, false, false"),
+        ("dq | dk, row pass", att // 2 + 6 * fq, r"gmap_kernel<\d+, true, false, true, float, float, false, true, \d, false, false"),
+    ] + ([
+        # option "dqdk_exact" 2 (the default, strips <= 100): the exact-f32 pair that follows and exits at once unless max |dq|, |dk| > 64
+        ("dq | dk exact redo, column pass (gated: exits at once)", 0, r"gmap_kernel<\d+, false, false, false, float, float, false, true, \d, false, true"),
+        ("dq | dk exact redo, row pass (gated: exits at once)", 0, r"gmap_kernel<\d+, true, false, true, float, float, false, true, \d, false, true"),
+    ] if auto_exact and max(H, W) <= 100 else [])
 
 
 def planes_roofline(lib, wl, step_ms, launch_ms):
@@ -618,7 +622,7 @@ def planes_roofline(lib, wl, step_ms, launch_ms):
            "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(ach / HBM_COPY_GBS, 4),
            "level": "op (one core fwd+bwd)", "algorithmic_bytes": nbytes, "step_ms": round(step_ms, 4),
            "traffic": (traffic or {}).get("_step_total_bytes")}
-    table = planes_launch_bytes(B, C, H, W)
+    table = planes_launch_bytes(B, C, H, W, auto_exact=lib.get_option("dqdk_exact") == 2)
 
     def pmc_bytes(pattern):
         import re
@@ -629,7 +633,7 @@ def planes_roofline(lib, wl, step_ms, launch_ms):
         rows = [{"launch": what, "kernel": name, "ms": ms, "bytes": nb, "traffic": pmc_bytes(pat)}
                 for (what, nb, pat), (name, ms) in zip(table, launch_ms)]
         obj["launches"] = [{"launch": r["launch"], "ms": r["ms"], "algorithmic_bytes": r["bytes"], "traffic": r["traffic"],
-                            "achieved_gbs": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1) if r["ms"] > 0 else None} for r in rows]
+                            "achieved_gbs": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1) if r["ms"] > 0 and r["bytes"] else None} for r in rows]
         dom = max(rows, key=lambda r: r["ms"])
         obj["dominant_kernel"] = {"kernel": dom["kernel"], "launch": dom["launch"], "kernel_ms": round(dom["ms"], 4),
                                   "algorithmic_bytes": dom["bytes"],
@@ -1139,6 +1143,17 @@ def main(argv=None, workload_factory=None):
         bwd_ms = time_region(wl.backward, 10)
         out["fwd_ms"], out["bwd_ms"] = round(fwd_ms, 4), round(bwd_ms, 4)
         out.update(launch_accounting(lib, wl, graph))
+        if isinstance(wl, PlanesWorkload):
+            # what the automatic exact dq | dk (option "dqdk_exact" 2, the shipped default) costs in THIS step: the same step with the
+            # x3 launches only.  ~0.01 ms = two gated launches that exit at once; ~0.13 ms would mean the redo ran
+            prev = lib.set_option("dqdk_exact", 0)
+            try:
+                for _ in range(3):
+                    wl.step()
+                out["dqdk_auto"] = {"eager_ms_per_step_x3_only": round(time_region(wl.step, 20), 4)}
+            finally:
+                lib.set_option("dqdk_exact", prev)
+            out["dqdk_auto"]["cost_ms"] = round(out["eager_ms_per_step"] - out["dqdk_auto"]["eager_ms_per_step_x3_only"], 4)
         out["gpu_state_under_load"] = gpu_state_under_load(step, local)
         out["gpu_probe"] = gpu_probe(lib, step, device, ms)
         if isinstance(wl, PlanesWorkload):

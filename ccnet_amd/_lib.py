@@ -61,7 +61,6 @@ _PROTOTYPES = {
     "ccnet_cca_pack_projection_f32": (c_int, [_P] * 10 + [c_int, c_int, _P]),
     "ccnet_cca_forward_planes_f32": (c_int, [_P] * 9 + [c_int] * 5 + [c_long, c_int] * 4 + [_P, c_size_t, _P]),
     "ccnet_cca_backward_planes_f32": (c_int, [_P] * 12 + [c_int] * 5 + [c_long, c_int] * 7 + [_P, c_size_t, _P]),
-    "ccnet_cca_aggregate_planes_f32": (c_int, [_P] * 7 + [c_int] * 4 + [c_long, c_int] * 2 + [_P, c_size_t, _P]),
     "ccnet_cca_attention_pm": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, c_long, c_int, _P]),
     "ccnet_cca_shape_uses_mfma": (c_int, [c_int, c_int, c_int, c_int]),
     "ccnet_cca_mfma_selftest": (c_int, [_P, _P]),

@@ -1473,7 +1473,7 @@ int ccnet_cca_pack_projection_f32(const float *wq, const float *bq, const float 
     return launch_status("pack_projection");
 }
 
-// functions.py:42-49 given the attention tensor: aggregation + epilogue (shared by the fused forward and the stand-alone entry)
+// functions.py:42-49 given the attention tensor: aggregation + epilogue (the second half of the fused forward)
 static int aggregate_planes_impl(const char *name, const float *A, const float *v, const float *v_bias, uint16_t *v_planes,
                                  const float *x, const float *gamma, float *y, int B, int C, int H, int W,
                                  long v_bs, int v_ps, long vp_bs, int vp_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
@@ -1520,19 +1520,6 @@ int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v,
     if (int e = gweight_energies_f32(q, k, A, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
     if (int e = softmax_forward(A, A, B, H, W, stream)) return e;
     return aggregate_planes_impl("cca_forward_planes", A, v, v_bias, v_planes, x, gamma, y, B, C, H, W, v_bs, v_ps, vp_bs, vp_ps,
-                                 workspace, workspace_bytes, stream);
-}
-
-/* functions.py:42-49 alone -- aggregation + epilogue from a GIVEN attention tensor (what ccnet_cca_attention_pm leaves): the second
- * half of ccnet_cca_forward_planes_f32, same arguments, same kernels, same bits.  A caller that computes q | k and v by separate
- * GEMMs runs ccnet_cca_attention_pm next to the v GEMM on another stream and this entry point after both (the module does). */
-int ccnet_cca_aggregate_planes_f32(const float *A, const float *v, const float *v_bias, uint16_t *v_planes,
-                                   const float *x, const float *gamma, float *y, int B, int C, int H, int W,
-                                   long v_bs, int v_ps, long vp_bs, int vp_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
-    if (int e = require_both_branches("cca_aggregate_planes_f32")) return e;
-    if (!A || (!v_planes && !v) || !x || !gamma || !y) return fail(CCNET_E_NULLPTR, "cca_aggregate_planes: null tensor");
-    if (int e = check_planes_problem("cca_aggregate_planes: strips <= 528 positions, C % 8 == 0", B, C, 4, H, W, true)) return e;
-    return aggregate_planes_impl("cca_aggregate_planes", A, v, v_bias, v_planes, x, gamma, y, B, C, H, W, v_bs, v_ps, vp_bs, vp_ps,
                                  workspace, workspace_bytes, stream);
 }
 

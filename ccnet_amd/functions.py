@@ -566,19 +566,6 @@ def planes_cover(B, C, Cq, H, W):
     return max(H, W) <= 4 * 132 and Cq <= 64
 
 
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device):
-    """one extra torch stream per device for launches the module forks off its own chain (the affinity + softmax launches next to the
-    v GEMM): plain wait_stream fork / join, capturable, invisible to the caller's stream order"""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    s = _SIDE_STREAMS.get(key)
-    if s is None:
-        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device)
-    return s
-
-
 def _pack_projection(wq, bq, wk, bk, wv, bv, split):
     """Stacked projection operands of one module application, packed by ONE launch (``ccnet_cca_pack_projection_f32``): the
     stacked fp32 weight / bias and, with ``split``, the K-concatenated bf16 hi | lo operands of the split-bf16 x3 GEMMs.
@@ -605,7 +592,6 @@ def _pack_projection(wq, bq, wk, bk, wv, bv, split):
                                                     C, cq, _stream()), "pack_projection")
     val = {"w": w, "b": b, "bqk": b[:2 * cq], "bv": b[2 * cq:]}
     if split:
-        val["w3b"] = w3                                                                         # (2Cq + C, 3C): rows [wh | wl | wh]
         val["w3"] = w3.t()                                                                      # (3C, 2Cq + C) view
         val["w3t"] = w3t                                                                        # (C, 3 (2Cq + C))
     return val
@@ -633,7 +619,7 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
     (bit-identical, one affinity + softmax launch pair)."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma, split_gemm=False, recompute=False, fwd_mode=0):
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma, split_gemm=False, recompute=False):
         x, gamma = _dev_f32("x", x), _dev_f32("gamma", gamma)
         B, C, H, W = x.shape
         cq, hw = wq.shape[0], H * W
@@ -647,59 +633,29 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
         vpl = None if direct else torch.empty((B, H, W, 2, C), device=x.device, dtype=torch.int16)
         bs, ps = hw * ct, ct
         if split_gemm:
-            # ``fwd_mode`` 0 (default): one stacked GEMM + the fused forward entry point.  2: q | k and v as TWO GEMMs into the channel
-            # slices of one packed tensor and the affinity + softmax launches (70 us of latency-bound work that needs only q | k) on
-            # a second stream NEXT TO the v GEMM, the aggregation when both are through; 1: two GEMMs, one stream.
-            # Measured equal within the spread (CrissCrossAttention.projection_forward_mode, tools/module_fwd_ab.py): not the default.
+            # (round 5 also built this forward as TWO GEMMs -- q | k, then v -- with the affinity + softmax launches on a second stream
+            #  next to the v GEMM and the aggregation half of the entry point after both, VERDICT r4 item 8: module forward 0.607-0.623
+            #  against 0.618-0.621 ms in the same run, inside the spread; kill criterion (-40 us) missed, removed.
+            #  profiles/r05g_module_fwd_ab.txt, commits 743958e..ecb3563.)
             x3 = nchw_to_planes(x, PLANES_HHL, torch.bfloat16)                              # (B, H, W, 3, C): xh | xh | xl
-            x3v = x3.view(B * hw, 3 * C)
-            w3b = pc["w3b"]                                                                 # (2Cq + C, 3C) rows [wh | wl | wh]
-            qkv = torch.empty((B * hw, ct), device=x.device, dtype=torch.float32)
-            p = qkv.data_ptr()
-            v_bias = None if direct else pc["bv"]      # (maps beyond 100 positions: the value bias is added where v is split into planes)
-            if fwd_mode == 0:
-                if direct:
-                    torch.addmm(pc["b"], x3v, pc["w3"], out_dtype=torch.float32, out=qkv)
-                else:
-                    torch.mm(x3v, pc["w3"], out_dtype=torch.float32, out=qkv)
-                    qkv[:, :2 * cq].add_(pc["bqk"])
-                with torch.cuda.device(x.device):
-                    _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0), x.device)
-                    lib.check(lib.ccnet_cca_forward_planes_f32(p, p + 4 * cq, p + 8 * cq, None if v_bias is None else v_bias.data_ptr(),
-                                                               None if direct else vpl.data_ptr(), x.data_ptr(), gamma.data_ptr(),
-                                                               y.data_ptr(), A.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps, bs, ps,
-                                                               hw * 2 * C, 2 * C, wsp, wsn, _stream()), "cca_forward_planes")
+            if direct:                      # the whole bias in the GEMM's epilogue
+                qkv = torch.addmm(pc["b"], x3.view(B * hw, 3 * C), pc["w3"], out_dtype=torch.float32).view(B, hw, ct)
+                v_bias = None
             else:
-                torch.addmm(pc["bqk"], x3v, w3b[:2 * cq].t(), out_dtype=torch.float32, out=qkv[:, :2 * cq])
-                main = torch.cuda.current_stream(x.device)
-                side = _side_stream(x.device) if fwd_mode == 2 else main
-                if side is not main:
-                    side.wait_stream(main)
-                with torch.cuda.stream(side), torch.cuda.device(x.device):
-                    lib.check(lib.ccnet_cca_attention_pm(p, p + 4 * cq, A.data_ptr(), 0, B, cq, H, W, bs, ps, bs, ps, side.cuda_stream),
-                              "cca_attention_pm")
-                if direct:                      # the value bias in the GEMM's epilogue
-                    torch.addmm(pc["bv"], x3v, w3b[2 * cq:].t(), out_dtype=torch.float32, out=qkv[:, 2 * cq:])
-                else:
-                    torch.mm(x3v, w3b[2 * cq:].t(), out_dtype=torch.float32, out=qkv[:, 2 * cq:])
-                if side is not main:
-                    main.wait_stream(side)
-                with torch.cuda.device(x.device):
-                    _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0), x.device)
-                    lib.check(lib.ccnet_cca_aggregate_planes_f32(A.data_ptr(), p + 8 * cq, None if v_bias is None else v_bias.data_ptr(),
-                                                                 None if direct else vpl.data_ptr(), x.data_ptr(), gamma.data_ptr(),
-                                                                 y.data_ptr(), B, C, H, W, bs, ps, hw * 2 * C, 2 * C, wsp, wsn, _stream()),
-                              "cca_aggregate_planes")
-            qkv = qkv.view(B, hw, ct)
+                qkv = torch.mm(x3.view(B * hw, 3 * C), pc["w3"], out_dtype=torch.float32).view(B, hw, ct)
+                # the bias without a pass over the whole output: q | k in place (a fifth of it), v where its slice is split
+                qkv[..., :2 * cq].add_(pc["bqk"])
+                v_bias = pc["bv"]
         else:
             qkv = torch.baddbmm(pc["b"].view(1, 1, -1), x.view(B, C, hw).transpose(1, 2), pc["w"].t().unsqueeze(0).expand(B, -1, -1))
-            p = qkv.data_ptr()
-            with torch.cuda.device(x.device):
-                _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0), x.device)
-                lib.check(lib.ccnet_cca_forward_planes_f32(p, p + 4 * cq, p + 8 * cq, None,
-                                                           None if direct else vpl.data_ptr(), x.data_ptr(), gamma.data_ptr(), y.data_ptr(),
-                                                           A.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps, bs, ps,
-                                                           hw * 2 * C, 2 * C, wsp, wsn, _stream()), "cca_forward_planes")
+            v_bias = None
+        p = qkv.data_ptr()
+        with torch.cuda.device(x.device):
+            _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0), x.device)
+            lib.check(lib.ccnet_cca_forward_planes_f32(p, p + 4 * cq, p + 8 * cq, None if v_bias is None else v_bias.data_ptr(),
+                                                       None if direct else vpl.data_ptr(), x.data_ptr(), gamma.data_ptr(), y.data_ptr(),
+                                                       A.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps, bs, ps,
+                                                       hw * 2 * C, 2 * C, wsp, wsn, _stream()), "cca_forward_planes")
         if not any(ctx.needs_input_grad):
             return y
         # plane-free: the packed projection itself is kept (its value slice is read again by the dA contraction); otherwise a copy
@@ -758,7 +714,7 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
             dw = torch.bmm(dqt, xm.transpose(1, 2)).sum(0)                                    # (2Cq + C, C)
         dwq, dwk, dwv = dw[:cq], dw[cq:2 * cq], dw[2 * cq:]
         return (dx.view(B, C, H, W), dwq.reshape(cq, C, 1, 1), db[:cq], dwk.reshape(cq, C, 1, 1), db[cq:2 * cq],
-                dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma), None, None, None)
+                dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma), None, None)
 
 
 def criss_cross_attention(q, k, v, x, gamma, recompute_attention=False):
@@ -809,13 +765,6 @@ class CrissCrossAttention(nn.Module):
     #: ... from this many pixels per call on (module fwd+bwd at 512 channels, 97 x 97: B = 8 2.23 -> 1.92 ms, B = 4 1.21 -> 1.11,
     #: B = 2 0.70 -> 0.75, B = 1 0.59 -> 0.74: below ~30k pixels the step is bound by host launches and the extra ops cost more)
     split_bf16_min_pixels = 32768
-    #: how the split-bf16 forward issues the projection: 0 (default) = one stacked GEMM + the fused forward entry point; 1 = q | k and v
-    #: as two GEMMs on one stream; 2 = two GEMMs with the affinity + softmax launches on a second stream next to the v GEMM (VERDICT r4
-    #: item 8).  Same bits.  Measured in the module at (8,512,97,97), same run (profiles/r05g_module_fwd_ab.txt): forward 0.607-0.623 /
-    #: 0.614-0.618 / 0.618-0.621 ms for 2 / 1 / 0 -- inside the run-to-run spread, kill criterion (-40 us) missed: in isolation the stock
-    #: GEMM runs N = 128 + N = 512 faster than N = 640 (profiles/r05e_module_gemm_probe.txt), inside the module it does not, and the
-    #: latency-bound affinity launch next to a matrix-bound GEMM slows the GEMM by what it hides.  Kept as an option, not as the default.
-    projection_forward_mode = 0
     #: fp32 channels_last inputs run on the pixel-major family (x as (B, H, W, C) is then a free view: nothing is copied).
     pixel_major_for_channels_last = True
     #: bf16 inputs: strips <= 132 (C, C/8 divisible by 8) run on the pixel-major bf16 MFMA kernels; strips of 133 .. 528 positions
@@ -898,15 +847,14 @@ class CrissCrossAttention(nn.Module):
             return CrissCrossPMFunction.apply(qkv, xp, self.gamma, cq, self.recompute_attention).permute(0, 3, 1, 2)
         if r == "f32-planes":
             split_gemm = self.split_bf16_projections and x.shape[0] * x.shape[2] * x.shape[3] >= self.split_bf16_min_pixels
-            return CrissCrossPlanesModuleFunction.apply(x, *params, self.gamma, split_gemm, self.recompute_attention,
-                                                        self.projection_forward_mode)
+            return CrissCrossPlanesModuleFunction.apply(x, *params, self.gamma, split_gemm, self.recompute_attention)
         if r == "f32-planes-cast":
             with torch.autocast(device_type="cuda", enabled=False):          # (the node's GEMMs are its own: fp32 / split-bf16 x3)
                 split_gemm = self.split_bf16_projections and x.shape[0] * x.shape[2] * x.shape[3] >= self.split_bf16_min_pixels
                 # (the node's projections are its own fp32 / split-bf16 x3 GEMMs on fp32 copies of the parameters -- a no-op for an
                 #  fp32 module under autocast: autocast does NOT govern them, unlike the reference's autocast convolutions)
                 y = CrissCrossPlanesModuleFunction.apply(x.float().contiguous(), *(p.float() for p in params), self.gamma.float(),
-                                                         split_gemm, self.recompute_attention, self.projection_forward_mode)
+                                                         split_gemm, self.recompute_attention)
             return y.to(x.dtype)
         if r == "f32-strips-node":
             return CrissCrossModuleFunction.apply(x, *params, self.gamma, self.recompute_attention)

@@ -282,14 +282,6 @@ int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v,
                                  int B, int C, int Cq, int H, int W,
                                  long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long vp_bs, int vp_ps,
                                  void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
-/* functions.py:42-49 alone: aggregation + epilogue from a GIVEN attention tensor ``A`` (what ccnet_cca_attention_pm leaves) -- the
- * second half of ccnet_cca_forward_planes_f32: same v / v_bias / v_planes / x / gamma / y arguments, same kernels, same bits,
- * workspace CCNET_WS_PLANES_FORWARD.  For a caller whose q | k and v come out of separate GEMMs: ccnet_cca_attention_pm runs on
- * a second stream NEXT TO the v GEMM, this entry point after both (the Python module does exactly that; the energies + softmax
- * launches are latency-bound and leave the memory system idle, the GEMM is matrix-bound). */
-int ccnet_cca_aggregate_planes_f32(const float *A, const float *v, const float *v_bias, uint16_t *v_planes,
-                                   const float *x, const float *gamma, float *y, int B, int C, int H, int W,
-                                   long v_bs, int v_ps, long vp_bs, int vp_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
 /* The attention tensor alone from pixel-major q, k views (``bf16`` != 0: bf16 views as in the *_pm_bf16 entry points, else fp32
  * views as in the *_pm_f32 / *_planes_f32 ones): exactly what those forwards leave in ``A``.  The host calls it in the backward
  * pass when it did NOT keep A between forward and backward (recompute instead of save: SURVEY.md 8(f) rank 4,

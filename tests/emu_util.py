@@ -244,19 +244,6 @@ class EmuOps:
                                                              _p(ws), nbytes, None))
         return y, A
 
-    def cca_aggregate_planes(self, A, qkv, v_planes, x, gamma, cq, v_from_qkv=False, v_bias=None):
-        """ccnet_cca_aggregate_planes_f32: the second half of cca_forward_planes (functions.py:42-49) from a given attention tensor"""
-        B, H, W, ct = qkv.shape
-        C = ct - 2 * cq
-        y = np.full((B, C, H, W), np.nan, np.float32)
-        nbytes = self.lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 0)
-        ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
-        base, bs = qkv.ctypes.data, H * W * ct
-        self.lib.check(self.lib.ccnet_cca_aggregate_planes_f32(_p(A), base + 8 * cq if (v_from_qkv or v_planes is None) else None,
-                                                               _p(v_bias), _p(v_planes), _p(x), _p(gamma), _p(y), B, C, H, W,
-                                                               bs, ct, H * W * 2 * C, 2 * C, _p(ws), nbytes, None))
-        return y
-
     def cca_backward_planes(self, dy, qkv, v_planes, A, gamma, cq):
         """``v_planes`` None: the plane-free form (v read as fp32 out of qkv)"""
         B, H, W, ct = qkv.shape

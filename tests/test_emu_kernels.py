@@ -778,31 +778,6 @@ def test_plane_free_form_is_bit_identical_to_the_plane_form(ops, shape):
         ops.cca_forward_planes(big, None, np.zeros((1, C, 101, 2), np.float32), c["gamma"], cq)
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 96, 17, 20), (1, 64, 3, 97), (1, 64, 2, 140), (1, 32, 133, 5)])
-def test_attention_plus_aggregation_entry_points_equal_the_fused_forward(ops, shape):
-    """ccnet_cca_attention_pm followed by ccnet_cca_aggregate_planes_f32 (the module runs the first next to its v GEMM on a second
-    stream, round 5) is the fused ccnet_cca_forward_planes_f32 cut in two: y and A bit-identical, plane-free form and plane form
-    (incl. the value bias added while splitting), whole strips and blocked rows / columns."""
-    B, C, H, W = shape
-    cq = C // 8
-    c = rand_case(*shape, seed=515)
-    qkv = np.ascontiguousarray(np.concatenate([_pm(c["q"]), _pm(c["k"]), _pm(c["v"])], axis=3))
-    bias = np.random.default_rng(5).standard_normal(C).astype(np.float32)
-    forms = [(None, False, None)] if max(H, W) <= 100 else []
-    forms.append(("planes", True, bias))
-    for form, from_qkv, vb in forms:
-        vp = None if form is None else np.full((B, H, W, 2, C), 0xFFFF, np.uint16)
-        y, A = ops.cca_forward_planes(qkv, vp, c["x"], c["gamma"], cq, v_from_qkv=from_qkv, v_bias=vb)
-        A2 = np.full_like(A, np.nan)
-        base, bs, ct = qkv.ctypes.data, H * W * qkv.shape[3], qkv.shape[3]
-        ops.lib.check(ops.lib.ccnet_cca_attention_pm(base, base + 4 * cq, A2.ctypes.data, 0, B, cq, H, W, bs, ct, bs, ct, None))
-        vp2 = None if form is None else np.full((B, H, W, 2, C), 0xFFFF, np.uint16)
-        y2 = ops.cca_aggregate_planes(A2, qkv, vp2, c["x"], c["gamma"], cq, v_from_qkv=from_qkv, v_bias=vb)
-        assert np.array_equal(A2, A) and np.array_equal(y2, y), (form,)
-        if vp is not None:
-            assert np.array_equal(vp2, vp)
-
-
 @pytest.mark.parametrize("C", [16, 64, 200])
 def test_projection_packer_matches_the_torch_formulation_bit_for_bit(ops, C):
     """ccnet_cca_pack_projection_f32 (one launch per module forward, replaces the per-module cache ADVICE r4 found stale under

@@ -644,33 +644,6 @@ def test_parameter_updates_through_dot_data_are_seen_by_the_next_forward(lib, de
         assert torch.equal(m(x), y.detach()) and not torch.equal(m2(x), y.detach())
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 20, 24), (1, 64, 40, 140)])
-def test_projection_forward_modes_are_bit_identical(lib, dev, shape):
-    """CrissCrossAttention.projection_forward_mode (round 5): one stacked GEMM + the fused forward (0, default), q | k
-    and v as two GEMMs (1), the two GEMMs with ccnet_cca_attention_pm on a second stream next to the v GEMM and
-    ccnet_cca_aggregate_planes_f32 after both (2) -- y, dx and every parameter gradient bit for bit, plane-free form and plane form."""
-    from ccnet_amd import CrissCrossAttention
-    B, C, H, W = shape
-    torch.manual_seed(8)
-    m = CrissCrossAttention(C).to(dev)
-    m.split_bf16_min_pixels = 0                                              # (the split-bf16 x3 projection forms at any size)
-    with torch.no_grad():
-        m.gamma.fill_(0.5)
-    x = torch.randn(B, C, H, W, device=dev)
-    dy = torch.randn(B, C, H, W, device=dev)
-    outs = []
-    for mode in (0, 1, 2):
-        m.projection_forward_mode = mode
-        m.zero_grad(set_to_none=True)
-        xi = x.clone().requires_grad_(True)
-        y = m(xi)
-        y.backward(dy)
-        torch.cuda.synchronize()
-        outs.append([y.detach().clone(), xi.grad.clone()] + [p.grad.clone() for p in m.parameters()])
-    for o in outs[1:]:
-        assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
-
-
 def test_two_host_threads_drive_one_device_concurrently(lib, dev):
     """The reference's single-process multi-GPU path is ``nn.DataParallel`` (engine.py:76-77; what its README commands run):
     several HOST THREADS drive one library at the same time.  Here on the one GPU a test box has: two threads, two streams, two

@@ -52,7 +52,9 @@ if [ "$MODE" = "closing" ]; then
   echo "== module, small batches"; timeout 600 python tools/module_small_batch.py > "$OUT/module_small_batches.txt" 2>&1; tail -4 "$OUT/module_small_batches.txt"
   echo "== PMC passes (fp32 step)"; bash tools/pmc.sh "$TAG" --iters 3 > "$OUT/pmc.log" 2>&1; tail -3 "$OUT/pmc.log"
   cp "$R/gpurun_out/pmc_$TAG/summary.json" "$OUT/pmc_step_summary.json" 2>/dev/null
+  echo "== PMC passes (bf16 configs[4] step)"; bash tools/pmc.sh "${TAG}_bf16" --script tools/pm_bf16_time.py > "$OUT/pmc_bf16.log" 2>&1; tail -2 "$OUT/pmc_bf16.log"
+  cp "$R/gpurun_out/pmc_${TAG}_bf16/summary.json" "$OUT/bf16_config5_pmc_summary.json" 2>/dev/null
   echo "== stress"; timeout 600 python tools/stress_pm.py 100 > "$OUT/stress_pm.log" 2>&1; tail -3 "$OUT/stress_pm.log"
-  find "$R/gpurun_out/pmc_$TAG" -name "*.csv" -size +5M -delete 2>/dev/null
+  find "$R/gpurun_out/pmc_$TAG" "$R/gpurun_out/pmc_${TAG}_bf16" -name "*.csv" -size +5M -delete 2>/dev/null
 fi
 echo "== done ($BOX box)"
