@@ -1420,6 +1420,8 @@ static size_t ws_planes_bytes(int B, int C, int Cq, int H, int W, int backward) 
     return align256(base) + (backward ? planes_bytes(B, C, H, W) : 0);                       /* + dy as planes */
 }
 
+static size_t ws_split_colsum_bytes(int B, int C, int H, int W);
+
 size_t ccnet_cca_workspace_bytes(int entry, int B, int C, int Cq, int H, int W) {
     switch (entry) {
     case CCNET_WS_SOFTMAX_BACKWARD: return ws_softmax_backward_bytes(B, H, W);
@@ -1429,6 +1431,7 @@ size_t ccnet_cca_workspace_bytes(int entry, int B, int C, int Cq, int H, int W) 
     case CCNET_WS_PM_BACKWARD: return ws_pm_bytes(B, C, Cq, H, W, 1);
     case CCNET_WS_PLANES_FORWARD: return ws_planes_bytes(B, C, Cq, H, W, 0);
     case CCNET_WS_PLANES_BACKWARD: return ws_planes_bytes(B, C, Cq, H, W, 1);
+    case CCNET_WS_SPLIT_COLSUM: return ws_split_colsum_bytes(B, C, H, W);
     }
     return 0;
 }
@@ -1446,6 +1449,44 @@ int ccnet_cca_split_planes_f32(const float *src, uint16_t *dst, int B, int C, in
     const unsigned gx = (unsigned)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
     CCA_LAUNCH(cca::pm_split_kernel, dim3(gx, (unsigned)B), dim3(256), stream, src, (bf16p_t *)dst, C, hw, src_bs, src_ps, dst_bs, dst_ps, pl, bias);
     return launch_status("split_planes");
+}
+
+// grid of the split + column-sum launch: x extent a multiple of g = cpp / gcd(cpp, 256) (a thread then keeps its 8 channels), about
+// five workgroups per CU in all
+static unsigned split_colsum_gx(int B, int C, int H, int W) {
+    const int cpp = C / 8;
+    int a = cpp, b = 256;
+    while (b) { const int t = a % b; a = b; b = t; }
+    const int g = cpp / a;
+    const long items = (long)H * W * cpp;
+    long want = 1280 / (B > 0 ? B : 1);
+    if (want > (items + 255) / 256) want = (items + 255) / 256;
+    long gx = want / g * g;
+    if (gx < g) gx = g;
+    return (unsigned)gx;
+}
+static size_t ws_split_colsum_bytes(int B, int C, int H, int W) {
+    if (B <= 0 || C <= 0 || C % 8 || H <= 0 || W <= 0) return 0;
+    return (size_t)split_colsum_gx(B, C, H, W) * B * C * sizeof(float);
+}
+
+int ccnet_cca_split_planes_colsum_f32(const float *src, uint16_t *dst, float *colsum, void *workspace, size_t workspace_bytes,
+                                      int B, int C, int H, int W, long src_bs, int src_ps, long dst_bs, int dst_ps, int layout,
+                                      ccnet_stream_t stream) {
+    if (int e = check_shape(B, C, H, W)) return e;
+    if (!src || !dst || !colsum) return fail(CCNET_E_NULLPTR, "split_planes_colsum: null tensor");
+    cca::PlaneLayout pl;
+    if (!plane_layout(layout, C, &pl)) return fail(CCNET_E_BADFLAGS, "split_planes_colsum: layout is one of CCNET_PLANES_*");
+    if (int e = check_pm_view<float>("split_planes_colsum: source view (fp32 pixel-major)", src_bs, src_ps, C, H, W)) return e;
+    if (int e = check_planes_view("split_planes_colsum: destination view (C % 8, pixel stride >= planes * C)", dst_bs, dst_ps, C, H, W, pl.width / C)) return e;
+    if (!workspace || workspace_bytes < ws_split_colsum_bytes(B, C, H, W))
+        return fail(CCNET_E_WORKSPACE, "split_planes_colsum: workspace missing or too small (CCNET_WS_SPLIT_COLSUM)");
+    const unsigned gx = split_colsum_gx(B, C, H, W);
+    CCA_LAUNCH(cca::pm_split_colsum_kernel, dim3(gx, (unsigned)B), dim3(256), stream, src, (bf16p_t *)dst, C, H * W, src_bs, src_ps,
+               dst_bs, dst_ps, pl, (float *)workspace);
+    if (int e = launch_status("split_planes_colsum")) return e;
+    CCA_LAUNCH(cca::colsum_reduce_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), stream, (const float *)workspace, (int)(gx * B), C, colsum);
+    return launch_status("split_planes_colsum(reduce)");
 }
 
 int ccnet_cca_nchw_to_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, long dst_bs, int dst_ps,

@@ -989,6 +989,51 @@ __global__ __launch_bounds__(256) void pm_split_kernel(const float *__restrict__
     }
 }
 
+// pm_split_kernel + the COLUMN SUMS of the source (round 5): the module's backward needs dqkv as three-plane rows for its two GEMMs
+// AND the bias gradients db = sum over all pixels of dqkv -- two passes over the same 192 MB (72 + 47 us at (8,512,97,97)) become one.
+// The grid's x extent times 256 is a multiple of the chunks per pixel, so a thread meets the SAME 8 channels in every iteration and
+// keeps their sums in registers; a workgroup adds its threads' sums per chunk in thread order and writes one row of ``partials``
+// (gridDim.x * gridDim.y rows of C floats); colsum_reduce_kernel adds the rows in row order: fixed order throughout, deterministic.
+__global__ __launch_bounds__(256) void pm_split_colsum_kernel(const float *__restrict__ src, bf16p_t *__restrict__ dst, int C, int HW,
+                                                              long sbs, int sps, long dbs, int dps, PlaneLayout pl,
+                                                              float *__restrict__ partials) {
+    __shared__ float red[256 * 8];
+    CCA_LDS_REGISTER(red);
+    const int cpp = C >> 3;                                   // 8-channel chunks per pixel
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const FBuf Sb = make_fbuf(src + (size_t)b * sbs, ((size_t)(HW - 1) * sps + C) * sizeof(float));
+    const FBuf Db = make_fbuf(reinterpret_cast<const float *>(dst + (size_t)b * dbs), ((size_t)(HW - 1) * dps + pl.width) * 2);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int e = blockIdx.x * 256 + tid; e < HW * cpp; e += gridDim.x * 256) {
+        const int px = e / cpp, c = 8 * (e - px * cpp);
+        const f32x4 u = fbuf_load_x4(Sb, (px * sps + c) * 4, 0), v = fbuf_load_x4(Sb, (px * sps + c + 4) * 4, 0);
+        const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += x[k];
+        planes_store8(Db, (px * dps + c) * 2, pl, x, true);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) CCA_LDS_ST(red + tid * 8 + k, acc[k]);
+    __syncthreads();
+    // thread t of this workgroup worked on chunk (blockIdx.x * 256 + t) % cpp (constant over its iterations: gridDim.x * 256 % cpp == 0)
+    float *row = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * C;
+    const int first = (int)((blockIdx.x * 256u) % (unsigned)cpp);
+    for (int idx = tid; idx < C; idx += 256) {
+        const int c = idx >> 3, k = idx & 7;
+        float t = 0.f;
+        for (int t0 = (c - first + cpp) % cpp; t0 < 256; t0 += cpp) t += CCA_LDS_LD(red + t0 * 8 + k);
+        row[idx] = t;
+    }
+}
+// out[c] = sum over ``rows`` rows of partials[row][c], in row order (one thread per channel: coalesced across the row)
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restrict__ partials, int rows, int C, float *__restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float t = 0.f;
+    for (int r = 0; r < rows; ++r) t += partials[(size_t)r * C + c];
+    out[c] = t;
+}
+
 // NCHW fp32 -> planes (the gradient dy of an NCHW module output): 64 pixels x 64 channels per workgroup through a padded
 // LDS tile; reads runs of 64 pixels per channel, writes 128-byte plane rows.
 __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float *__restrict__ src, bf16p_t *__restrict__ dst, int C, int HW,

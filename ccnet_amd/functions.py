@@ -536,6 +536,23 @@ def split_planes(t: torch.Tensor, c0: int, C: int, layout: int = PLANES_HL, dtyp
     return out
 
 
+def split_planes_colsum(t: torch.Tensor, layout: int = PLANES_HLH, dtype=torch.bfloat16):
+    """``split_planes(t, 0, ps, layout)`` of the WHOLE fp32 pixel-major tensor ``t`` (B, H, W, ps) and, from the same pass, the sum of
+    ``t`` over all images and pixels (ps floats, fixed summation order): the module's backward needs dqkv both ways (three-plane
+    rows for its GEMMs, column sums as the bias gradients) -- ccnet_cca_split_planes_colsum_f32."""
+    B, H, W, ps = t.shape
+    n = 2 if layout == PLANES_HL else 3
+    out = torch.empty((B, H, W, n, ps), device=t.device, dtype=dtype)
+    colsum = torch.empty((ps,), device=t.device, dtype=torch.float32)
+    lib = _lib.get_lib()
+    with torch.cuda.device(t.device):
+        _ws, wsp, wsn = _workspace(lib.ccnet_cca_workspace_bytes(_lib.CCNET_WS_SPLIT_COLSUM, B, ps, 0, H, W), t.device)
+        lib.check(lib.ccnet_cca_split_planes_colsum_f32(t.data_ptr(), out.data_ptr(), colsum.data_ptr(), wsp, wsn, B, ps, H, W,
+                                                        t.stride(0), t.stride(2), H * W * n * ps, n * ps, layout, _stream()),
+                  "split_planes_colsum")
+    return out, colsum
+
+
 def nchw_to_planes(x: torch.Tensor, layout: int = PLANES_HL, dtype=torch.int16) -> torch.Tensor:
     """fp32 NCHW (B, C, H, W) -> planes (B, H, W, n, C) (transposed and split in one pass, csrc/cca_gmap.hpp)."""
     B, C, H, W = x.shape
@@ -699,15 +716,17 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
                                                         gamma.data_ptr(), g, g + 4 * cq, g + 8 * cq, dgamma.data_ptr(),
                                                         scratch.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps, bs, ps, hw * 2 * C, 2 * C,
                                                         gbs, ct, gbs, ct, gbs, ct, wsp, wsn, _stream()), "cca_backward_planes")
-        db = dqkv.sum(dim=(0, 1))
         if ctx.split_gemm:
             x3 = xs
-            d3 = split_planes(dqkv.view(B, H, W, ct), 0, ct, PLANES_HLH, torch.bfloat16)      # (B, H, W, 3, ct): dh | dl | dh
+            # (B, H, W, 3, ct): dh | dl | dh for the two GEMMs, and the bias gradients (the sum of dqkv over all pixels) out of the same
+            # pass over dqkv (round 5: split 72 us + torch sum 47 us -> one pass)
+            d3, db = split_planes_colsum(dqkv.view(B, H, W, ct), PLANES_HLH, torch.bfloat16)
             dx = torch.bmm(pc["w3t"].unsqueeze(0).expand(B, -1, -1), d3.view(B, hw, 3 * ct).transpose(1, 2),
                            out_dtype=torch.float32).add_(dy.view(B, C, hw))                   # dy + W^T dqkv^T  (NCHW)
             # rows (dh, xh), (dl, xh), (dh, xl) of every pixel: the three products, contracted over 3 HW rows per image
             dw = torch.bmm(d3.view(B, 3 * hw, ct).transpose(1, 2), x3.view(B, 3 * hw, C), out_dtype=torch.float32).sum(0)
         else:
+            db = dqkv.sum(dim=(0, 1))
             xm = xs.view(B, C, hw)
             dqt = dqkv.transpose(1, 2)                                                        # (B, 2Cq + C, HW) view
             dx = torch.baddbmm(dy.view(B, C, hw), pc["w"].t().unsqueeze(0).expand(B, -1, -1), dqt)  # dy + W^T dqkv^T  (NCHW)

@@ -102,6 +102,7 @@ const char *ccnet_cca_last_error_string(void);
 #define CCNET_WS_PM_BACKWARD      4    /* ccnet_cca_backward_pm_{bf16,f32} */
 #define CCNET_WS_PLANES_FORWARD   5    /* ccnet_cca_forward_planes_f32 */
 #define CCNET_WS_PLANES_BACKWARD  6    /* ccnet_cca_backward_planes_f32 */
+#define CCNET_WS_SPLIT_COLSUM     7    /* ccnet_cca_split_planes_colsum_f32 (Cq ignored) */
 size_t      ccnet_cca_workspace_bytes(int entry, int B, int C, int Cq, int H, int W);
 
 /* Affinity: replaces functions.py:30-34 (layout shuffles), :38 (bmm + INF), :39 (bmm), :40 (cat
@@ -267,6 +268,13 @@ int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W);
 #define CCNET_PLANES_HHL 4
 int ccnet_cca_split_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, int src_ps,
                                long dst_bs, int dst_ps, int layout, const float *bias, ccnet_stream_t stream);
+/* ccnet_cca_split_planes_f32 (no bias) that ALSO returns the column sums of its source in the same pass: ``colsum`` (C floats) =
+ * sum over all images and pixels of src[.., c], added in a fixed order (deterministic).  The module's backward needs dqkv as
+ * three-plane rows for its two GEMMs and its sum over pixels as the bias gradients (functions.py:29,32,35): one pass over dqkv
+ * instead of two.  ``workspace``: ccnet_cca_workspace_bytes(CCNET_WS_SPLIT_COLSUM, B, C, 0, H, W) bytes. */
+int ccnet_cca_split_planes_colsum_f32(const float *src, uint16_t *dst, float *colsum, void *workspace, size_t workspace_bytes,
+                                      int B, int C, int H, int W, long src_bs, int src_ps, long dst_bs, int dst_ps, int layout,
+                                      ccnet_stream_t stream);
 int ccnet_cca_nchw_to_planes_f32(const float *src, uint16_t *dst, int B, int C, int H, int W, long src_bs, long dst_bs,
                                  int dst_ps, int layout, ccnet_stream_t stream);
 /* The module's three 1x1 projections (functions.py:29,32,35: query_conv, key_conv, value_conv; weights (Cq|Cq|C, C) fp32, biases)

@@ -220,6 +220,18 @@ class EmuOps:
                                                            H * W * n * C, n * C, layout, None if bias is None else _p(bias), None))
         return dst
 
+    def split_planes_colsum(self, src_pm, layout=3):
+        """ccnet_cca_split_planes_colsum_f32: (planes uint16 (B, H, W, n, C), column sums (C,)) of the whole (B, H, W, C) tensor"""
+        B, H, W, C = src_pm.shape
+        n = 2 if layout == 2 else 3
+        dst = np.full((B, H, W, n, C), 0xFFFF, np.uint16)
+        colsum = np.full(C, np.nan, np.float32)
+        nbytes = self.lib.ccnet_cca_workspace_bytes(7, B, C, 0, H, W)
+        ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
+        self.lib.check(self.lib.ccnet_cca_split_planes_colsum_f32(_p(src_pm), _p(dst), _p(colsum), _p(ws), nbytes, B, C, H, W,
+                                                                  H * W * C, C, H * W * n * C, n * C, layout, None))
+        return dst, colsum
+
     def nchw_to_planes(self, src, layout=2):
         B, C, H, W = src.shape
         n = 2 if layout == 2 else 3

@@ -778,6 +778,24 @@ def test_plane_free_form_is_bit_identical_to_the_plane_form(ops, shape):
         ops.cca_forward_planes(big, None, np.zeros((1, C, 101, 2), np.float32), c["gamma"], cq)
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 6, 80), (1, 17, 20, 640), (3, 9, 1, 8), (1, 4, 7, 2112), (8, 13, 11, 72)])
+def test_split_planes_with_column_sums_in_one_pass(ops, shape):
+    """ccnet_cca_split_planes_colsum_f32 (round 5: the module's backward needs dqkv as three-plane rows AND its sum over all pixels):
+    the planes bit-identical to ccnet_cca_split_planes_f32, the column sums equal to a float64 sum within fp32 accumulation
+    error, and bit-identical run to run (fixed summation order; chunk counts below, at and above the 256 threads of a workgroup)."""
+    B, H, W, C = shape
+    rng = np.random.default_rng(C + B)
+    t = (rng.standard_normal((B, H, W, C)) * 3).astype(np.float32)
+    for layout in (3, 2):
+        ref = ops.split_planes(t, C, 0, layout)
+        planes, colsum = ops.split_planes_colsum(t, layout)
+        assert np.array_equal(planes, ref)
+        want = t.astype(np.float64).sum(axis=(0, 1, 2))
+        assert np.all(np.abs(colsum - want) <= 1e-5 * np.abs(t).astype(np.float64).sum(axis=(0, 1, 2)) + 1e-6)
+        again = ops.split_planes_colsum(t, layout)
+        assert np.array_equal(again[1], colsum) and np.array_equal(again[0], planes)
+
+
 @pytest.mark.parametrize("C", [16, 64, 200])
 def test_projection_packer_matches_the_torch_formulation_bit_for_bit(ops, C):
     """ccnet_cca_pack_projection_f32 (one launch per module forward, replaces the per-module cache ADVICE r4 found stale under
