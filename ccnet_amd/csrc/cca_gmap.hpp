@@ -1025,13 +1025,24 @@ __global__ __launch_bounds__(256) void pm_split_colsum_kernel(const float *__res
         row[idx] = t;
     }
 }
-// out[c] = sum over ``rows`` rows of partials[row][c], in row order (one thread per channel: coalesced across the row)
+// out[c] = sum over ``rows`` rows of partials[row][c] in a FIXED association: a workgroup owns 16 channels; thread (channel c, lane rl)
+// adds the rows rl, rl + 16, ... in order, then the 16 lanes of a channel are added in lane order.  (One thread per channel -- 1280
+// dependent loads on a dozen wavefronts -- took longer than the split pass itself: +190 us per module step, profiles/r05z_*.)
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restrict__ partials, int rows, int C, float *__restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[256];
+    CCA_LDS_REGISTER(red);
+    const int tid = threadIdx.x, c = blockIdx.x * 16 + (tid & 15), rl = tid >> 4;
     float t = 0.f;
-    for (int r = 0; r < rows; ++r) t += partials[(size_t)r * C + c];
-    out[c] = t;
+    if (c < C)
+        for (int r = rl; r < rows; r += 16) t += partials[(size_t)r * C + c];
+    CCA_LDS_ST(red + tid, t);
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float u = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) u += CCA_LDS_LD(red + 16 * k + (tid & 15));
+        out[c] = u;
+    }
 }
 
 // NCHW fp32 -> planes (the gradient dy of an NCHW module output): 64 pixels x 64 channels per workgroup through a padded
