@@ -1485,7 +1485,7 @@ int ccnet_cca_split_planes_colsum_f32(const float *src, uint16_t *dst, float *co
     CCA_LAUNCH(cca::pm_split_colsum_kernel, dim3(gx, (unsigned)B), dim3(256), stream, src, (bf16p_t *)dst, C, H * W, src_bs, src_ps,
                dst_bs, dst_ps, pl, (float *)workspace);
     if (int e = launch_status("split_planes_colsum")) return e;
-    CCA_LAUNCH(cca::colsum_reduce_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), stream, (const float *)workspace, (int)(gx * B), C, colsum);
+    CCA_LAUNCH(cca::colsum_reduce_kernel, dim3((unsigned)((C + 15) / 16)), dim3(16 * cca::CS_LANES), stream, (const float *)workspace, (int)(gx * B), C, colsum);
     return launch_status("split_planes_colsum(reduce)");
 }
 

@@ -1025,22 +1025,24 @@ __global__ __launch_bounds__(256) void pm_split_colsum_kernel(const float *__res
         row[idx] = t;
     }
 }
-// out[c] = sum over ``rows`` rows of partials[row][c] in a FIXED association: a workgroup owns 16 channels; thread (channel c, lane rl)
-// adds the rows rl, rl + 16, ... in order, then the 16 lanes of a channel are added in lane order.  (One thread per channel -- 1280
-// dependent loads on a dozen wavefronts -- took longer than the split pass itself: +190 us per module step, profiles/r05z_*.)
-__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restrict__ partials, int rows, int C, float *__restrict__ out) {
-    __shared__ float red[256];
+// out[c] = sum over ``rows`` rows of partials[row][c] in a FIXED association: a workgroup of 1024 threads owns 16 channels; thread
+// (channel c, lane rl < 64) adds the rows rl, rl + 64, ... in order, then the 64 lanes of a channel are added in lane order.  (One
+// thread per channel -- 1280 dependent loads on a dozen wavefronts -- took longer than the split pass itself: +190 us per module
+// step; 16 lanes per channel: 27 us; profiles/r05z_module_small_batches.txt, r05j_split_colsum_probe.txt.)
+constexpr int CS_LANES = 64;
+__global__ __launch_bounds__(16 * CS_LANES) void colsum_reduce_kernel(const float *__restrict__ partials, int rows, int C, float *__restrict__ out) {
+    __shared__ float red[16 * CS_LANES];
     CCA_LDS_REGISTER(red);
     const int tid = threadIdx.x, c = blockIdx.x * 16 + (tid & 15), rl = tid >> 4;
     float t = 0.f;
     if (c < C)
-        for (int r = rl; r < rows; r += 16) t += partials[(size_t)r * C + c];
+        for (int r = rl; r < rows; r += CS_LANES) t += partials[(size_t)r * C + c];
     CCA_LDS_ST(red + tid, t);
     __syncthreads();
     if (rl == 0 && c < C) {
         float u = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) u += CCA_LDS_LD(red + 16 * k + (tid & 15));
+#pragma unroll 8
+        for (int k = 0; k < CS_LANES; ++k) u += CCA_LDS_LD(red + 16 * k + (tid & 15));
         out[c] = u;
     }
 }
