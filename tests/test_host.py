@@ -95,6 +95,14 @@ def test_hot_path_kernels_have_no_scratch_and_no_spilled_vgprs(device_lib_path, 
     assert not bad, bad
 
 
+def test_integration_md_shows_the_tested_stub_verbatim():
+    """INTEGRATION.md section 2 claims to show tests/reference_side_stub.py -- the reference-side ctypes binding that
+    tests/test_gpu_parity.py::test_reference_side_stub_binds_the_fast_kernels runs on the GPU -- verbatim."""
+    stub = open(os.path.join(ROOT, "tests", "reference_side_stub.py")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "```python\n" + stub + "```" in doc
+
+
 def test_missing_library_fails_loudly(tmp_path):
     from ccnet_amd import _lib
     with pytest.raises(_lib.CcaError, match="no CPU or PyTorch fallback"):
