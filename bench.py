@@ -113,6 +113,48 @@ def max_over_ranks(seconds, device, world):
     return float(t.item())
 
 
+def gather_over_ranks(obj, world):
+    """Every rank's ``obj`` as a list indexed by rank (a one-element list when no process group is up)."""
+    if not dist.is_initialized():
+        return [obj]
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def rank_description(device, on_gpu):
+    """What a rank runs on: the first thing to read when the per-rank times of an N-GPU run differ (engine.py:52-57 binds one
+    process to one device by LOCAL_RANK; a rank that landed on the wrong device or a shared one shows up here)."""
+    d = {"host": socket.gethostname(), "pid": os.getpid(), "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}
+    if on_gpu:
+        p = torch.cuda.get_device_properties(device)
+        d.update({"device": str(device), "name": p.name, "cus": p.multi_processor_count,
+                  "hbm_gib": round(p.total_memory / 2 ** 30, 1)})
+        try:
+            d["pci_bus_id"] = getattr(p, "pci_bus_id", None)
+            d["gcn_arch"] = getattr(p, "gcnArchName", None)
+        except Exception:
+            pass
+    else:
+        d["device"] = "cpu"
+    return d
+
+
+def collective_library(on_gpu):
+    """The collective library behind backend "nccl" (= RCCL on ROCm) -- the line NCCL_DEBUG=VERSION would print."""
+    info = {"backend": "nccl (RCCL)" if on_gpu else "gloo", "torch": torch.__version__, "hip": getattr(torch.version, "hip", None)}
+    if on_gpu:
+        try:
+            v = torch.cuda.nccl.version()
+            info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+        except Exception as e:
+            info["rccl_version"] = f"unavailable: {e}"
+        for k in ("NCCL_DEBUG", "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_SOCKET_IFNAME", "RCCL_MSCCL_ENABLE"):
+            if k in os.environ:
+                info.setdefault("env", {})[k] = os.environ[k]
+    return info
+
+
 def aggregate_value(bytes_per_step_per_rank, steps, world, seconds):
     """Whole-job GB/s: all ranks' bytes over the slowest rank's time."""
     return world * bytes_per_step_per_rank * steps / seconds / 1e9
@@ -584,7 +626,7 @@ def gpu_probe(lib, step, device, step_ms):
     return out
 
 
-def planes_launch_bytes(B, C, H, W, auto_exact=True):
+def planes_launch_bytes(B, C, H, W):
     """Algorithmic (compulsory) bytes of every launch of one split-plane step, in issue order: what the launch must read and
     write once, from the tensor sizes of SURVEY 8(d) (feature C-sized 4*P*C, Cq-sized 4*P*Cq, attention-shaped 4*P*S)."""
     P, S, Cq = B * H * W, H + W, C // 8
@@ -603,13 +645,9 @@ def planes_launch_bytes(B, C, H, W, auto_exact=True):
         ("dv, column pass (dy, A/2 -> partial)", 2 * fc + att // 2, r"gmap3_kernel<\d+, false, true, false"),
         ("dv, row pass (dy, A/2, partial -> dv)", 3 * fc + att // 2, r"gmap_kernel<\d+, true, true, true, cca::bf16p_t"),
         ("softmax backward + dgamma partials", 3 * att, r"softmax_bwd_kernel"),
-        ("dq | dk, column pass (+ dgamma reduction)", att // 2 + 4 * fq, r"gmap_kernel<\d+, false, false, false, float, float, false, true, \d, false, false"),
-        ("dq | dk, row pass", att // 2 + 6 * fq, r"gmap_kernel<\d+, true, false, true, float, float, false, true, \d, false, false"),
-    ] + ([
-        # option "dqdk_exact" 2 (the default, strips <= 100): the exact-f32 pair that follows and exits at once unless max |dq|, |dk| > 64
-        ("dq | dk exact redo, column pass (gated: exits at once)", 0, r"gmap_kernel<\d+, false, false, false, float, float, false, true, \d, false, true"),
-        ("dq | dk exact redo, row pass (gated: exits at once)", 0, r"gmap_kernel<\d+, true, false, true, float, float, false, true, \d, false, true"),
-    ] if auto_exact and max(H, W) <= 100 else [])
+        ("dq | dk, column pass (+ dgamma reduction)", att // 2 + 4 * fq, r"gmap_kernel<\d+, false, false, false, float, float, false, true, \d, false, (true|false)"),
+        ("dq | dk, row pass", att // 2 + 6 * fq, r"gmap_kernel<\d+, true, false, true, float, float, false, true, \d, false, (true|false)"),
+    ]
 
 
 def planes_roofline(lib, wl, step_ms, launch_ms):
@@ -621,8 +659,11 @@ def planes_roofline(lib, wl, step_ms, launch_ms):
     obj = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(ach / HBM_COPY_GBS, 4),
            "level": "op (one core fwd+bwd)", "algorithmic_bytes": nbytes, "step_ms": round(step_ms, 4),
-           "traffic": (traffic or {}).get("_step_total_bytes")}
-    table = planes_launch_bytes(B, C, H, W, auto_exact=lib.get_option("dqdk_exact") == 2)
+           "traffic": (traffic or {}).get("_step_total_bytes"),
+           "traffic_source": ("profiles/traffic_planes_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the builder "
+                              "(tools/pmc.sh), accepted because its kernel-source hash equals this build's; NOT a counter of this run"
+                              if traffic else "none: no PMC summary for this build's kernel sources under profiles/")}
+    table = planes_launch_bytes(B, C, H, W)
 
     def pmc_bytes(pattern):
         import re
@@ -724,7 +765,8 @@ def roofline_object(wl, step_ms, iters=20):
     obj = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(ach / HBM_COPY_GBS, 4),
            "level": "op (one core fwd+bwd)", "algorithmic_bytes": nbytes, "step_ms": round(step_ms, 4),
-           "traffic": (traffic or {}).get("_step_total_bytes")}
+           "traffic": (traffic or {}).get("_step_total_bytes"),
+           "traffic_source": "profiles/traffic_latest.json (builder-side PMC passes, source-hash keyed)" if traffic else "none"}
     if rows:
         dom = max(rows, key=lambda r: r["ms"])
         obj["dominant_kernel"] = {
@@ -806,11 +848,29 @@ def cpu_baseline(C, H, W, budget_s=20.0):
             O.cca_core_backward(dy, q, k, v, A, gamma)
 
         secp, n_p = _time_cpu(port, budget_s * 0.25, 20)
+        # the quoted configuration itself -- ONE full-batch iteration of BASELINE configs[1] -- at the best thread
+        # count of the sweep and at all physical cores (a fresh closure: 8 x the tensors of the one-image sample)
+        full = {}
+        try:
+            fb = reference_formulation_step(8, C, H, W, torch.device("cpu"))
+            for t in sorted({best[1], phys}):
+                torch.set_num_threads(t)
+                fb()                                     # warm-up (allocations)
+                t0 = time.perf_counter()
+                fb()
+                sec_f = time.perf_counter() - t0
+                full[str(t)] = {"ms_per_step": round(sec_f * 1e3, 1), "GB/s": round(core_bytes(8, C, H, W) / sec_f / 1e9, 3)}
+            del fb
+        except Exception as e:                           # (memory on a small host: the sample above stands)
+            full = {"failed": str(e)}
     finally:
         torch.set_num_threads(prev)
     sec, t, n = best
     return {"value": round(core_bytes(B, C, H, W) / sec / 1e9, 3), "unit": "GB/s", "cores": t, "threads": t,
-            "kind": "reference-formulation",
+            "cores_used": t, "cores_total": phys, "logical_cpus": ncpu,
+            "kind": "port", "port_of": "reference formulation (bench.reference_formulation: the reference's own torch op sequence; "
+                                       "the reference module hard-codes .cuda() and does not travel to the GPU box)",
+            "full_batch_configs1": {"shape": [8, C, H, W], "iters": 1, "by_threads": full},
             "sample": f"reference formulation of functions.py:27-49 (bmm / cat / softmax + autograd, no convolutions), "
                       f"batch {B} of ({B},{C},{H},{W}) fp32, {n} iters at {t} torch threads (best of the sweep)",
             "ms_per_image": round(sec / B * 1e3, 1), "thread_sweep": sweep, "host": host,
@@ -873,14 +933,13 @@ def stock_pytorch_core(B, C, H, W, device, iters=10):
             "what": "torch.bmm / cat / softmax formulation of functions.py:30-49 + autograd on this GPU"}
 
 
-def module_level_ms(B, C, H, W, device, iters=10, fuse=True, one_node=True):
+def module_level_ms(B, C, H, W, device, iters=10, fuse=True):
     """fwd+bwd of the whole CrissCrossAttention module (adds the 1x1 projections + autograd); ``fuse`` False
     runs the three projections as separate convolutions exactly as functions.py:29-35."""
     from ccnet_amd import CrissCrossAttention
     torch.manual_seed(0)
     m = CrissCrossAttention(C).to(device)
     m.fuse_projections = fuse
-    m.fuse_module_backward = one_node
     with torch.no_grad():
         m.gamma.fill_(0.5)
     x = torch.randn(B, C, H, W, device=device, requires_grad=True)
@@ -937,17 +996,7 @@ def small_batch_ms(lib, C, H, W, device, batches=(1, 2), iters=30):
         wl = PlanesWorkload(lib, B, C, H, W, device, 277 + B)
         wl.step()
         pl[f"B{B}_ms"] = round(time_region(wl.step, iters), 4)
-        # the automatic exact dq | dk (option "dqdk_exact" 2, the default) redoes the two launches in exact fp32 when max |dq|, |dk|
-        # passes 64: with unscaled N(0,1) q, k that maximum sits at 45 .. 70 depending on the draw -- the same step without it
-        prev = lib.set_option("dqdk_exact", 0)
-        try:
-            wl.step()
-            pl[f"B{B}_ms_x3_only"] = round(time_region(wl.step, iters), 4)
-        finally:
-            lib.set_option("dqdk_exact", prev)
         del wl
-    pl["note"] = ("B*_ms = the shipped default; B*_ms_x3_only = option dqdk_exact 0.  A difference of ~10 us = the two gated launches "
-                  "exited at once (cool gradients); ~40 us or more = this draw's max |dq|, |dk| passed 64 and the device redid them in exact fp32")
     out["split_plane_family"] = pl
     out["what"] = ("fp32 core fwd+bwd, eager; B1_ms / B2_ms = NCHW strip kernels; split_plane_family = ccnet_cca_*_planes_f32 (one "
                    "workgroup per strip; q | k slices of the packed pixel-major projection, v / dy as bf16 hi|lo planes, x / y / dy "
@@ -1087,12 +1136,14 @@ def main(argv=None, workload_factory=None):
     sync()
     local_s = time.perf_counter() - t0
     secs = max_over_ranks(local_s, device, world)
+    per_rank = gather_over_ranks({"rank": rank, "ms_per_step": round(local_s / args.steps * 1e3, 4),
+                                  **rank_description(device, on_gpu)}, world)
 
     nbytes = core_bytes(B, C, H, W, elt=2 if bf16 else 4)
     value = aggregate_value(nbytes, args.steps, world, secs)
     ms = secs / args.steps * 1e3
     impl = "injected" if lib is None else ("pixel-major bf16 mfma" if bf16 else
-                                           "split-bf16 x3 mfma: v read as fp32 tiles (no split pass), dy transposed into bf16 hi|lo planes inside the step" if isinstance(wl, PlanesWorkload) else
+                                           "split-bf16 mfma (three terms; ca_backward six terms = fp32-equivalent): v read as fp32 tiles (no split pass), dy transposed into bf16 hi|lo planes inside the step" if isinstance(wl, PlanesWorkload) else
                                            "mfma-strip" if lib.ccnet_cca_shape_uses_mfma(B, C, H, W) else "direct")
     out = {
         "metric": metric_label(C, H, W),
@@ -1111,6 +1162,8 @@ def main(argv=None, workload_factory=None):
                    "parallelism": f"batch-sharded x{world} (no data-path collective"
                                   + (", + all-reduce of the 7 parameter gradients per step)" if grads is not None else ")"),
                    "impl": impl},
+        "per_rank": per_rank,
+        "collective_library": collective_library(on_gpu),
         "launch": launch_mode,
         "overlap": ("library default: the backward's dv passes on a side stream (event fork / join inside the C call, captured "
                     "into the same graph)" if args.overlap == "auto" else f"planes_overlap={args.overlap}"),
@@ -1129,6 +1182,7 @@ def main(argv=None, workload_factory=None):
         out["roofline"] = {"bound": "hbm", "achieved": round(value / world, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(value / world / HBM_PEAK_GBS, 4),
                            "traffic": traffic.get("_step_total_bytes") if traffic else None,
+                           "traffic_source": "profiles/traffic_bf16_latest.json (builder-side PMC passes, source-hash keyed)" if traffic else "none",
                            "note": "op level: algorithmic bytes of the fwd+bwd step / step time; traffic = PMC bytes of "
                                    "the whole step (tools/pmc.sh --script tools/pm_bf16_time.py), null unless taken on "
                                    "this build"}
@@ -1144,16 +1198,16 @@ def main(argv=None, workload_factory=None):
         out["fwd_ms"], out["bwd_ms"] = round(fwd_ms, 4), round(bwd_ms, 4)
         out.update(launch_accounting(lib, wl, graph))
         if isinstance(wl, PlanesWorkload):
-            # what the automatic exact dq | dk (option "dqdk_exact" 2, the shipped default) costs in THIS step: the same step with the
-            # x3 launches only.  ~0.01 ms = two gated launches that exit at once; ~0.13 ms would mean the redo ran
+            # what the six-term (fp32-equivalent) ca_backward products -- option "dqdk_exact" 1, the shipped default -- cost in THIS
+            # step: the same step with the three-term form
             prev = lib.set_option("dqdk_exact", 0)
             try:
                 for _ in range(3):
                     wl.step()
-                out["dqdk_auto"] = {"eager_ms_per_step_x3_only": round(time_region(wl.step, 20), 4)}
+                out["dqdk_six_terms"] = {"eager_ms_per_step_three_terms": round(time_region(wl.step, 20), 4)}
             finally:
                 lib.set_option("dqdk_exact", prev)
-            out["dqdk_auto"]["cost_ms"] = round(out["eager_ms_per_step"] - out["dqdk_auto"]["eager_ms_per_step_x3_only"], 4)
+            out["dqdk_six_terms"]["cost_ms"] = round(out["eager_ms_per_step"] - out["dqdk_six_terms"]["eager_ms_per_step_three_terms"], 4)
         out["gpu_state_under_load"] = gpu_state_under_load(step, local)
         out["gpu_probe"] = gpu_probe(lib, step, device, ms)
         if isinstance(wl, PlanesWorkload):
@@ -1174,7 +1228,6 @@ def main(argv=None, workload_factory=None):
                 out[key] = f"failed: {e}"
         try:
             out["module_ms_per_step"] = round(module_level_ms(B, C, H, W, device), 4)
-            out["module_ms_per_step_conv2d_autograd"] = round(module_level_ms(B, C, H, W, device, one_node=False), 4)
             out["module_ms_per_step_unfused_projections"] = round(module_level_ms(B, C, H, W, device, fuse=False), 4)
         except Exception as e:
             out["module_ms_per_step"] = f"failed: {e}"

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libccnet_cca.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ccnet_cca.h")
 
-CCNET_CCA_VERSION = 210        # include/ccnet_cca.h
+CCNET_CCA_VERSION = 220        # include/ccnet_cca.h
 CCNET_CA_ENERGY = 0
 CCNET_CA_SOFTMAX = 1
 CCNET_IMPL_AUTO = 0

@@ -62,13 +62,12 @@ std::atomic<int> g_da_stages{2};
 std::atomic<int> g_bf16_partial{1};
 std::atomic<int> g_dqdk_wpc3{1};            // "dqdk_wpc3": ca_backward of the fp32 routes at C/8 <= 64 on the three-workgroups-per-CU form of gmap_kernel
 std::atomic<int> g_energy_tail{1};          // the fp32 energies launch cuts the strips beyond its whole rounds into tile-row parts
-// "dqdk_exact": ca_backward of the fp32 pixel-major / split-plane routes (strips <= 100).  1 = multiply in exact fp32 instead of
-// split-bf16 x3: dq / dk errors drop to those of the upstream dA contraction (2e-4 at the headline shape) for +25 us per launch.
-// 2 (default) = AUTOMATIC: the x3 launches run and publish max |dq|, |dk|; an exact pair follows on the stream and exits at once
-// unless that maximum exceeds kDqdkAutoLimit -- the x3 error is ~1.2e-5 of the gradient's magnitude, so the absolute 1e-3 bar
-// of the north_star holds at any logit scale the exact form holds it at, without a process-wide knob.
-// 0 = x3 only.
-std::atomic<int> g_dqdk_exact{2};
+// "dqdk_exact" 1 (default): ca_backward of every fp32 pixel-major / split-plane route multiplies as SIX bf16 terms of a three-way
+// split (cca::bf16_split8x3; gmap_kernel, SIX): fp32-equivalent products at any logit scale, +3..4 us per launch at the headline
+// shape.  0 = three terms (split-bf16 x3: ~1.2e-5 of the gradient's magnitude; leaves the absolute 1e-3 bar at ~2 x the default
+// logit scale).  (Rounds 4-5: 1 = exact-f32 MFMA, +25 us per launch; 2 = x3 + a statistic + two gated exact launches, 12 us of
+// every step for launches that exit at once and a step time that depended on the data.  Both removed in round 6.)
+std::atomic<int> g_dqdk_exact{1};
 
 int fail(int code, const char *what) {
     char buf[256];
@@ -782,12 +781,7 @@ struct DeferredSum {
     const float *src = nullptr;
     int n = 0;
     float *dst = nullptr;
-    unsigned *stat = nullptr;     // "dqdk_exact" 2: the word max |dq|, |dk| is published in (GmapJob::stat); null = no automatic redo
 };
-// "dqdk_exact" 2: gradients whose magnitude exceeds this are redone in exact fp32.  The split-bf16 x3 form measures <= 1.3e-5 of
-// max |dq|, |dk| at the headline geometry (the logit-scale sweep of tests/test_gpu_parity.py: 4.1e-4 at |dq|max 48, 1.1e-3 at 92,
-// 1.5e-3 at 136): up to 64 it stays inside the 1e-3 bar with margin; the exact form leaves 5e-6 (what the upstream dA carries).
-constexpr float kDqdkAutoLimit = 64.f;
 
 template <typename FT>
 int check_pm_view(const char *what, long bs, int ps, int C, int H, int W) {
@@ -841,98 +835,44 @@ int gmap_pm(const float *T, const FT *F, const FT *resid, const float *gamma, FT
         return launch_gmap_pm<132, TRANS, FT>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
     return fail(CCNET_E_BADSHAPE, "gmap_pm: strip too long for this element type");
 }
-// dq (features k) and dk (features q) from the same dE: one launch per branch, blockIdx.y picks the job
+// dq (features k) and dk (features q) from the same dE: one launch per branch, the second half of the workgroups runs the dk job
+template <int P, typename FT, bool SIX, int WPC>
+int launch_gmap_dual_pair(const float *dE, const FT *k, const FT *q, FT *dq, FT *dk, float *pq, float *pk, long pbs, int B, int Cq,
+                          int H, int W, long kbs, int kps, long qbs, int qps, long dqbs, int dqps, long dkbs, int dkps,
+                          ccnet_stream_t stream, const DeferredSum &red) {
+    const GmapPlan gc = gmap_plan(B * W, Cq, WPC), gr = gmap_plan(B * H, Cq, WPC);
+    cca::GmapJob<FT, float> jc{q, nullptr, pk, qbs, pbs, qps, Cq, gc.grid};
+    jc.red_src = red.src; jc.red_n = red.n; jc.red_dst = red.dst;
+    CCA_LAUNCH((cca::gmap_kernel<P, false, false, false, FT, float, false, true, WPC, false, SIX>), dim3(cca::gmap_dual_grid(gc.grid)),
+               dim3(cca::GS_THREADS), stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W,
+               kbs, kps, 0L, 0, 0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
+    if (int e = launch_status("gmap_dual_pm(column)")) return e;
+    const cca::GmapJob<FT, FT> jr{q, pk, dk, qbs, dkbs, qps, dkps, gr.grid};
+    CCA_LAUNCH((cca::gmap_kernel<P, true, false, true, FT, FT, false, true, WPC, false, SIX>), dim3(cca::gmap_dual_grid(gr.grid)),
+               dim3(cca::GS_THREADS), stream, dE, k, (const float *)pq, (const FT *)nullptr, (const float *)nullptr, dq, Cq, H, W,
+               kbs, kps, pbs, Cq, 0L, 0, dqbs, dqps, gr.n_whole, gr.split, jr);
+    return launch_status("gmap_dual_pm(row)");
+}
 template <int P, typename FT>
 int launch_gmap_dual_pm(const float *dE, const FT *k, const FT *q, FT *dq, FT *dk, float *partial, int B, int Cq, int H, int W,
                         long kbs, int kps, long qbs, int qps, long dqbs, int dqps, long dkbs, int dkps, ccnet_stream_t stream,
                         const DeferredSum &red) {
     const long pbs = (long)H * W * Cq;
     float *pq = partial, *pk = partial + (size_t)B * pbs;
-    const GmapPlan gc = gmap_plan(B * W, Cq), gr = gmap_plan(B * H, Cq);
-    cca::GmapJob<FT, float> jc{q, nullptr, pk, qbs, pbs, qps, Cq, gc.grid};
-    jc.red_src = red.src; jc.red_n = red.n; jc.red_dst = red.dst;
-    constexpr bool F32 = std::is_same<FT, float>::value;
-    const int exact_mode = F32 ? g_dqdk_exact.load() : 0;
-    const bool exact = exact_mode == 1;
-    // 2 (default) = automatic: the x3 launches publish max |dq|, |dk|; the exact pair follows on the stream and exits at once
-    // unless that maximum is beyond kDqdkAutoLimit (it then overwrites the partials and dq | dk)
-    const bool autox = exact_mode == 2 && P <= 100 && red.stat != nullptr;
-    if (autox) jc.stat = red.stat;
-    if constexpr (F32 && P <= 100) {
-        // one channel group per strip (C/8 <= 64, the reference's geometry): the three-workgroups-per-CU form -- these launches are
-        // latency chains (attention block -> one tile -> one multiply -> stores), more of them per CU is what shortens them
-        if (!exact && Cq <= cca::GM_CG && g_dqdk_wpc3.load()) {
-            const GmapPlan gc3 = gmap_plan(B * W, Cq, 3), gr3 = gmap_plan(B * H, Cq, 3);
-            cca::GmapJob<FT, float> jc3 = jc;
-            jc3.nwg = gc3.grid;
-            CCA_LAUNCH((cca::gmap_kernel<P, false, false, false, FT, float, false, true, 3>), dim3(cca::gmap_dual_grid(gc3.grid)), dim3(cca::GS_THREADS),
-                       stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
-                       0L, 0, pbs, Cq, gc3.n_whole, gc3.split, jc3);
-            if (int e = launch_status("gmap_dual_pm(column, 3 per CU)")) return e;
-            cca::GmapJob<FT, FT> jr3{q, pk, dk, qbs, dkbs, qps, dkps, gr3.grid};
-            if (autox) { jr3.stat = red.stat; jr3.gate_min = __builtin_bit_cast(unsigned, kDqdkAutoLimit); }
-            CCA_LAUNCH((cca::gmap_kernel<P, true, false, true, FT, FT, false, true, 3>), dim3(cca::gmap_dual_grid(gr3.grid)), dim3(cca::GS_THREADS),
-                       stream, dE, k, (const float *)pq, (const FT *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
-                       0L, 0, dqbs, dqps, gr3.n_whole, gr3.split, jr3);
-            if (int e = launch_status("gmap_dual_pm(row, 3 per CU)")) return e;
-            if (!autox) return 0;
+#define CCA_DUAL_PAIR(SIX_, WPC_)                                                                                             \
+    launch_gmap_dual_pair<P, FT, SIX_, WPC_>(dE, k, q, dq, dk, pq, pk, pbs, B, Cq, H, W, kbs, kps, qbs, qps, dqbs, dqps, dkbs, dkps, stream, red)
+    if constexpr (std::is_same<FT, float>::value) {
+        const bool six = g_dqdk_exact.load() != 0;
+        if constexpr (P <= 100) {
+            // one channel group per strip (C/8 <= 64, the reference's geometry): the three-workgroups-per-CU form -- these launches are
+            // latency chains (attention block -> one tile -> one multiply -> stores), more of them per CU is what shortens them
+            if (Cq <= cca::GM_CG && g_dqdk_wpc3.load()) return six ? CCA_DUAL_PAIR(true, 3) : CCA_DUAL_PAIR(false, 3);
         }
+        return six ? CCA_DUAL_PAIR(true, 2) : CCA_DUAL_PAIR(false, 2);
+    } else {
+        return CCA_DUAL_PAIR(false, 2);
     }
-    if constexpr (F32 && P <= 100) {
-        if (autox) {
-            // the gated exact pair (no dgamma reduction: it rode on the x3 column launch)
-            if (!(Cq <= cca::GM_CG && g_dqdk_wpc3.load())) {       // (the two-slot x3 pair, when the three-per-CU form did not run)
-                CCA_LAUNCH((cca::gmap_kernel<P, false, false, false, FT, float, false, true>), dim3(cca::gmap_dual_grid(gc.grid)), dim3(cca::GS_THREADS),
-                           stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
-                           0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
-                if (int e = launch_status("gmap_dual_pm(column)")) return e;
-                cca::GmapJob<FT, FT> jr{q, pk, dk, qbs, dkbs, qps, dkps, gr.grid};
-                jr.stat = red.stat;
-                jr.gate_min = __builtin_bit_cast(unsigned, kDqdkAutoLimit);
-                CCA_LAUNCH((cca::gmap_kernel<P, true, false, true, FT, FT, false, true>), dim3(cca::gmap_dual_grid(gr.grid)), dim3(cca::GS_THREADS),
-                           stream, dE, k, (const float *)pq, (const FT *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
-                           0L, 0, dqbs, dqps, gr.n_whole, gr.split, jr);
-                if (int e = launch_status("gmap_dual_pm(row)")) return e;
-            }
-            cca::GmapJob<FT, float> jcx{q, nullptr, pk, qbs, pbs, qps, Cq, gc.grid};
-            jcx.gate = red.stat;
-            jcx.gate_min = __builtin_bit_cast(unsigned, kDqdkAutoLimit);
-            CCA_LAUNCH((cca::gmap_kernel<P, false, false, false, FT, float, false, true, 2, false, true>), dim3(cca::gmap_dual_grid(gc.grid)),
-                       dim3(cca::GS_THREADS), stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W,
-                       kbs, kps, 0L, 0, 0L, 0, pbs, Cq, gc.n_whole, gc.split, jcx);
-            if (int e = launch_status("gmap_dual_pm(column, exact, gated)")) return e;
-            cca::GmapJob<FT, FT> jrx{q, pk, dk, qbs, dkbs, qps, dkps, gr.grid};
-            jrx.gate = red.stat;
-            jrx.gate_min = jcx.gate_min;
-            CCA_LAUNCH((cca::gmap_kernel<P, true, false, true, FT, FT, false, true, 2, false, true>), dim3(cca::gmap_dual_grid(gr.grid)),
-                       dim3(cca::GS_THREADS), stream, dE, k, (const float *)pq, (const FT *)nullptr, (const float *)nullptr, dq, Cq, H, W,
-                       kbs, kps, pbs, Cq, 0L, 0, dqbs, dqps, gr.n_whole, gr.split, jrx);
-            return launch_status("gmap_dual_pm(row, exact, gated)");
-        }
-    }
-    if constexpr (F32) {
-        if (exact)
-            CCA_LAUNCH((cca::gmap_kernel<P, false, false, false, FT, float, false, true, 2, false, true>), dim3(cca::gmap_dual_grid(gc.grid)),
-                       dim3(cca::GS_THREADS), stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W,
-                       kbs, kps, 0L, 0, 0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
-    }
-    if (!exact)
-    CCA_LAUNCH((cca::gmap_kernel<P, false, false, false, FT, float, false, true>), dim3(cca::gmap_dual_grid(gc.grid)), dim3(cca::GS_THREADS),
-               stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
-               0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
-    if (int e = launch_status("gmap_dual_pm(column)")) return e;
-    const cca::GmapJob<FT, FT> jr{q, pk, dk, qbs, dkbs, qps, dkps, gr.grid};
-    if constexpr (F32) {
-        if (exact)
-            CCA_LAUNCH((cca::gmap_kernel<P, true, false, true, FT, FT, false, true, 2, false, true>), dim3(cca::gmap_dual_grid(gr.grid)),
-                       dim3(cca::GS_THREADS), stream, dE, k, (const float *)pq, (const FT *)nullptr, (const float *)nullptr, dq, Cq, H, W,
-                       kbs, kps, pbs, Cq, 0L, 0, dqbs, dqps, gr.n_whole, gr.split, jr);
-    }
-    if (!exact)
-    CCA_LAUNCH((cca::gmap_kernel<P, true, false, true, FT, FT, false, true>), dim3(cca::gmap_dual_grid(gr.grid)), dim3(cca::GS_THREADS),
-               stream, dE, k, (const float *)pq, (const FT *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
-               0L, 0, dqbs, dqps, gr.n_whole, gr.split, jr);
-    return launch_status("gmap_dual_pm(row)");
+#undef CCA_DUAL_PAIR
 }
 template <typename FT>
 int gmap_dual_pm(const float *dE, const FT *k, const FT *q, FT *dq, FT *dk, float *partial, int B, int Cq, int H, int W,
@@ -994,14 +934,10 @@ size_t pm_workspace_bytes(int B, int C, int Cq, int H, int W, int backward) {
     // column partials of dq and dk side by side (a region of their own: those launches may run next to the dv passes)
     const size_t px = (size_t)B * H * W * sizeof(float);
     if (!backward) return px * C;
-    return align256(ws_softmax_backward_bytes(B, H, W)) + align256(px * C) + align256(px * 2 * Cq) + 256;   // (+ the dq | dk statistic word)
+    return align256(ws_softmax_backward_bytes(B, H, W)) + align256(px * C) + align256(px * 2 * Cq) + 256;   // (+ 256 spare bytes: ABI 210 sized it so)
 }
 float *partial_qk_of(float *partial, int B, int C, int H, int W) {
     return reinterpret_cast<float *>(reinterpret_cast<char *>(partial) + align256((size_t)B * H * W * C * sizeof(float)));
-}
-// the word behind the dq | dk partials that "dqdk_exact" 2 publishes max |dq|, |dk| in (GmapJob::stat)
-unsigned *dqdk_stat_of(float *partial_qk, int B, int Cq, int H, int W) {
-    return reinterpret_cast<unsigned *>(reinterpret_cast<char *>(partial_qk) + align256((size_t)B * H * W * 2 * Cq * sizeof(float)));
 }
 // fork / join of the library's side stream around the launches of a backward that are independent of the caller's chain
 // ("planes_overlap": 0 = never fork, 1 = dv next to softmax-backward and dq | dk, 2 = dv next to dA as well)
@@ -1073,7 +1009,6 @@ int cca_backward_pm(const char *name, const FT *dy, const FT *q, const FT *k, co
     // dgamma = sum A t;  dE = gamma * A * (t - sum_s A t), in place
     // (the fixed-order sum of the dgamma partials rides on the dq | dk column launch: one launch less)
     DeferredSum red{static_cast<const float *>(workspace), 0, dgamma};
-    if constexpr (std::is_same<FT, float>::value) red.stat = dqdk_stat_of(partial_qk_of(partial, B, C, H, W), B, Cq, H, W);
     if (!e) e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, sm, B, H, W, stream, KSplit(), &red.n);
     // the column partials of dq and dk sit side by side in their own region
     if (!e) e = gmap_dual_pm<FT>(scratch, k, q, dq, dk, partial_qk_of(partial, B, C, H, W), B, Cq, H, W, k_bs, k_ps, q_bs, q_ps,
@@ -1334,6 +1269,8 @@ int gweight_energies_f32(const float *q, const float *k, float *A, int B, int Cq
     else                  CCA_LAUNCH((cca::gweight_kernel<132, true, float, false>), grid, block, stream, q, k, A, Cq, H, W, qbs, qps, kbs, kps);
     return launch_status("gweight_energies(132)");
 }
+// (strips beyond 100 positions: always the six-term products -- VERDICT r5 item 4b: the device-gated exact redo of round 5 stopped
+//  at 100 positions and left the whole-image maps of evaluate.py:102-143 on the three-term form)
 int gmap_dual_f32(const float *dE, const float *k, const float *q, float *dq, float *dk, float *partial, int B, int Cq, int H, int W,
                   long kbs, int kps, long qbs, int qps, long dqbs, int dqps, long dkbs, int dkps, ccnet_stream_t stream,
                   const DeferredSum &red) {
@@ -1353,7 +1290,7 @@ int gmap_dual_f32(const float *dE, const float *k, const float *q, float *dq, fl
             const long abs_ = j ? pbs : 0L;
             const int aps = j ? Cq : 0;
 #define CCA_DUAL_COL(PP, ADD, WPC)                                                                                                    \
-            CCA_LAUNCH((cca::gmap_kernel<PP, false, false, ADD, float, float, false, true, WPC, true>), dim3(cca::gmap_dual_grid(gl.grid)), \
+            CCA_LAUNCH((cca::gmap_kernel<PP, false, false, ADD, float, float, false, true, WPC, true, true>), dim3(cca::gmap_dual_grid(gl.grid)), \
                        dim3(cca::GS_THREADS), stream, dE, k, add, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, \
                        abs_, aps, 0L, 0, pbs, Cq, gl.n_whole, gl.split, jl)
             if (p100) { if (j) CCA_DUAL_COL(100, true, 2); else CCA_DUAL_COL(100, false, 2); }
@@ -1368,11 +1305,11 @@ int gmap_dual_f32(const float *dE, const float *k, const float *q, float *dq, fl
         cca::GmapJob<float, float> jc{q, nullptr, pk, qbs, pbs, qps, Cq, gc.grid};
         jc.red_src = red.src; jc.red_n = red.n; jc.red_dst = red.dst;
         if (one)
-            CCA_LAUNCH((cca::gmap_kernel<132, false, false, false, float, float, false, true, 2>), dim3(cca::gmap_dual_grid(gc.grid)), dim3(cca::GS_THREADS),
+            CCA_LAUNCH((cca::gmap_kernel<132, false, false, false, float, float, false, true, 2, false, true>), dim3(cca::gmap_dual_grid(gc.grid)), dim3(cca::GS_THREADS),
                        stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
                        0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
         else
-        CCA_LAUNCH((cca::gmap_kernel<132, false, false, false, float, float, false, true, 1>), dim3(cca::gmap_dual_grid(gc.grid)), dim3(cca::GS_THREADS),
+        CCA_LAUNCH((cca::gmap_kernel<132, false, false, false, float, float, false, true, 1, false, true>), dim3(cca::gmap_dual_grid(gc.grid)), dim3(cca::GS_THREADS),
                    stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W, kbs, kps, 0L, 0,
                    0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
         if (int e = launch_status("gmap_dual_f32(column, 132)")) return e;
@@ -1385,11 +1322,11 @@ int gmap_dual_f32(const float *dE, const float *k, const float *q, float *dq, fl
             const bool last = j + 1 == nb;
             const cca::GmapJob<float, float> jl{q, pk, last ? dk : pk, qbs, last ? dkbs : pbs, qps, last ? dkps : Cq, gl.grid, nb, j};
             if (p100)
-                CCA_LAUNCH((cca::gmap_kernel<100, true, false, true, float, float, false, true, 2, true>), dim3(cca::gmap_dual_grid(gl.grid)),
+                CCA_LAUNCH((cca::gmap_kernel<100, true, false, true, float, float, false, true, 2, true, true>), dim3(cca::gmap_dual_grid(gl.grid)),
                            dim3(cca::GS_THREADS), stream, dE, k, (const float *)pq, (const float *)nullptr, (const float *)nullptr,
                            last ? dq : pq, Cq, H, W, kbs, kps, pbs, Cq, 0L, 0, last ? dqbs : pbs, last ? dqps : Cq, gl.n_whole, gl.split, jl);
             else
-                CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, float, float, false, true, 1, true>), dim3(cca::gmap_dual_grid(gl.grid)),
+                CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, float, float, false, true, 1, true, true>), dim3(cca::gmap_dual_grid(gl.grid)),
                            dim3(cca::GS_THREADS), stream, dE, k, (const float *)pq, (const float *)nullptr, (const float *)nullptr,
                            last ? dq : pq, Cq, H, W, kbs, kps, pbs, Cq, 0L, 0, last ? dqbs : pbs, last ? dqps : Cq, gl.n_whole, gl.split, jl);
             if (int e = launch_status("gmap_dual_f32(long rows)")) return e;
@@ -1399,13 +1336,13 @@ int gmap_dual_f32(const float *dE, const float *k, const float *q, float *dq, fl
     if (Cq <= cca::GM_CG && g_dqdk_wpc3.load() != 0) {
         const GmapPlan gr2 = gmap_plan(B * H, Cq, 2);
         const cca::GmapJob<float, float> jr2{q, pk, dk, qbs, dkbs, qps, dkps, gr2.grid};
-        CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, float, float, false, true, 2>), dim3(cca::gmap_dual_grid(gr2.grid)), dim3(cca::GS_THREADS),
+        CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, float, float, false, true, 2, false, true>), dim3(cca::gmap_dual_grid(gr2.grid)), dim3(cca::GS_THREADS),
                    stream, dE, k, (const float *)pq, (const float *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
                    0L, 0, dqbs, dqps, gr2.n_whole, gr2.split, jr2);
         return launch_status("gmap_dual_f32(row, 132, one slot)");
     }
     const cca::GmapJob<float, float> jr{q, pk, dk, qbs, dkbs, qps, dkps, gr.grid};
-    CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, float, float, false, true, 1>), dim3(cca::gmap_dual_grid(gr.grid)), dim3(cca::GS_THREADS),
+    CCA_LAUNCH((cca::gmap_kernel<132, true, false, true, float, float, false, true, 1, false, true>), dim3(cca::gmap_dual_grid(gr.grid)), dim3(cca::GS_THREADS),
                stream, dE, k, (const float *)pq, (const float *)nullptr, (const float *)nullptr, dq, Cq, H, W, kbs, kps, pbs, Cq,
                0L, 0, dqbs, dqps, gr.n_whole, gr.split, jr);
     return launch_status("gmap_dual_f32(row, 132)");
@@ -1652,7 +1589,6 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
     // dgamma = sum A t;  dE = gamma * A * (t - sum_s A t), in place
     // (the fixed-order sum of the dgamma partials rides on the dq | dk column launch: one launch less)
     DeferredSum red{static_cast<const float *>(workspace), 0, dgamma};
-    red.stat = dqdk_stat_of(partial_qk_of(partial, B, C, H, W), B, Cq, H, W);
     if (!e) e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, sm, B, H, W, stream, KSplit(), &red.n);
     if (!e) e = gmap_dual_f32(scratch, k, q, dq, dk, partial_qk_of(partial, B, C, H, W), B, Cq, H, W, k_bs, k_ps, q_bs, q_ps,
                               dq_bs, dq_ps, dk_bs, dk_ps, stream, red);
@@ -1672,7 +1608,7 @@ const OptionRange *find_word_option(const std::string &n) {
         {"energy_tail", &g_energy_tail, 0, 1},
         {"dqdk_wpc3", &g_dqdk_wpc3, 0, 1},
         {"da_stages", &g_da_stages, 2, 3},
-        {"dqdk_exact", &g_dqdk_exact, 0, 2},
+        {"dqdk_exact", &g_dqdk_exact, 0, 1},
         {"bf16_partial", &g_bf16_partial, 0, 1},
     };
     for (const OptionRange &o : table)
@@ -1731,6 +1667,9 @@ int ccnet_cca_profile_end(float *ms, char *names, int name_stride, int cap) {
 int ccnet_cca_probe_clock(unsigned long long *samples, int nwg, int nsamples, int interval_ticks, ccnet_stream_t stream) {
     if (!samples) return fail(CCNET_E_NULLPTR, "probe_clock: null buffer");
     if (nwg < 1 || nwg > 1024 || nsamples < 2 || nsamples > (1 << 20) || interval_ticks < 1) return fail(CCNET_E_BADFLAGS, "probe_clock: 1..1024 workgroups, >= 2 samples, interval >= 1 tick");
+    // the kernel busy-waits nsamples x interval ticks of the 100 MHz reference clock: bounded to two seconds (an exported
+    // symbol must not be able to hang the device)
+    if ((long long)nsamples * interval_ticks > 200000000LL) return fail(CCNET_E_BADFLAGS, "probe_clock: nsamples x interval_ticks <= 2e8 (two seconds)");
     CCA_LAUNCH(cca::probe_clock_kernel, dim3((unsigned)nwg), dim3(cca::kWave), stream, samples, nsamples, interval_ticks);
     return launch_status("probe_clock");
 }

@@ -83,6 +83,28 @@ __device__ __forceinline__ BfSplit bf16_split8(const float (&x)[8]) {
     return s;
 }
 
+// Three-way split: x = hi + mid + lo EXACTLY up to 2^-25 |x| (three 8-bit significands cover fp32's 24 bits).  A product is
+// then the six terms of weight >= 2^-16 -- hi hi, hi mid, mid hi, hi lo, mid mid, lo hi -- on the bf16 matrix pipe with fp32
+// accumulation: what is dropped is 2^-24 of the product, i.e. fp32 arithmetic (ca_backward, whose gradients scale with the
+// logits: the three-product form leaves ~1.2e-5 of the gradient's magnitude, tests: logit-scale sweep).  6 x 16 cycles per
+// k-step of 32 against 8 x 32 for v_mfma_f32_16x16x4_f32.
+struct BfSplit3 {
+    u32x4 hi, mid, lo;
+};
+__device__ __forceinline__ BfSplit3 bf16_split8x3(const float (&x)[8]) {
+    BfSplit3 s;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t h = cvt_pk_bf16(x[2 * p], x[2 * p + 1]);
+        const float r0 = x[2 * p] - __builtin_bit_cast(float, h << 16), r1 = x[2 * p + 1] - __builtin_bit_cast(float, h & 0xffff0000u);
+        const uint32_t m = cvt_pk_bf16(r0, r1);
+        s.hi[p] = h;
+        s.mid[p] = m;
+        s.lo[p] = cvt_pk_bf16(r0 - __builtin_bit_cast(float, m << 16), r1 - __builtin_bit_cast(float, m & 0xffff0000u));
+    }
+    return s;
+}
+
 // XCD-aware workgroup order.  The dispatcher places workgroup L on XCD L % 8, each with a private 4 MiB L2
 // (MI355X_MICROARCH.md, workgroup dispatch).  Neighbouring strip tiles of one image share every 128-byte
 // line of the column branch (a tile only uses 4*NS bytes of it), so they must sit on the SAME XCD or each

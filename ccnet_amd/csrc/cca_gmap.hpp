@@ -203,13 +203,6 @@ struct GmapJob {
     int red_n;
     float *red_dst;
     int xcd;          // > 0: strips per XCD of the XCD-aware strip decode (non-DUAL launches; see the kernel)
-    // DUAL, "dqdk_exact" 2 (auto): the split-bf16 x3 row launch publishes max |dq|, |dk| (the bits of a non-negative float, atomic
-    // max: order-independent) in *stat -- workgroup 0 of the column launch before it zeroes the word -- and the EXACT_F32 launches
-    // that follow on the stream exit at once unless *gate > gate_min: the error of the x3 form is ~1.2e-5 of the gradient's
-    // magnitude (tests: logit-scale sweep), so only gradients beyond ~64 are redone in exact fp32
-    unsigned *stat;
-    const unsigned *gate;
-    unsigned gate_min;          // the limit (bits of a positive float): published / acted on only beyond it
 };
 // LONG strips: a strip of L > P positions is cut into nb blocks of ``long_block(L, nb)`` positions (the last one shorter).  A
 // workgroup then owns the QUERY block I of a strip and contracts over the KEY block J: out_I (+)= F_J . A_{I,J}^T; the key blocks
@@ -221,7 +214,7 @@ inline unsigned gmap_dual_grid(int nwg) { return 16u * (unsigned)((nwg + 7) / 8)
 // features, whose two feature tiles + output image take 104 KB: one workgroup per CU)
 // ABF (bf16 features, round 5): the addend -- the column partial -- is bf16 (see gmap3_kernel, OT): one 16-byte load of 8 channels
 template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT, bool NCHW = false, bool DUAL = false, int WPC = 2, bool LONG = false,
-          bool EXACT_F32 = false, bool ABF = false>
+          bool SIX = false, bool ABF = false>
 __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__restrict__ T, const FT *__restrict__ F,
                                                               const float *__restrict__ addend,
                                                               const OT *__restrict__ resid,
@@ -231,23 +224,20 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                                                               GmapJob<FT, OT> j1) {
     constexpr bool BF = GTile<FT>::BF, OBF = std::is_same<OT, bf16_t>::value;
     constexpr bool PL = std::is_same<FT, bf16p_t>::value;             // split planes: hi tile | lo tile, T16 geometry
-    // EXACT_F32 (option "dqdk_exact"): ca_backward on fp32 q | k multiplies in exact fp32 (v_mfma_f32_16x16x4_f32, a fmaf chain).
-    // As split-bf16 x3 (the default) these two launches put 5.5e-4 of the 1e-3 parity budget on dq at the headline shape and leave
-    // the absolute bar at ~2 x the default logit scale (tests: logit-scale sweep); exact, they take 66 us each instead of 41 us
-    // (profiles/r04q_ab_exact_dqdk.txt) -- a 4.7 x longer matrix phase on launches with one channel group per strip.  The
-    // contraction runs in the order k = 16 j + 4 lg + e (j: block of 16 positions, lg: the lane's k group, e < 4), so that a
-    // non-transposed lane still loads its attention values 16 bytes at a time.
-    static_assert(!EXACT_F32 || (DUAL && !BF && !PL), "gmap: the exact-f32 form exists for ca_backward on fp32 features");
-    constexpr bool EXACT = EXACT_F32;
-    constexpr int NKB = (P + 15) / 16, NKF = EXACT ? 4 * NKB : 1;
+    // SIX (option "dqdk_exact", the default of ca_backward on fp32 q | k): every product as the SIX bf16 terms of a three-way split
+    // (bf16_split8x3) -- fp32-equivalent (2^-24), where the three-term form leaves ~1.2e-5 of the gradient's magnitude on dq / dk
+    // (tests: logit-scale sweep) -- at 3/8 of the matrix time of v_mfma_f32_16x16x4_f32.  The attention block stays in registers
+    // as the fp32 values it is (one channel group per strip at C/8 <= 64: nothing is reused) and is split per k-step; the
+    // accumulators start from the column partial (ca_backward has no gamma), so the row pass needs no addend registers.
+    // (Rounds 4-5 ran an exact-f32 MFMA form behind a device-side gate on max |dq|, |dk|: two extra launches per step and a step
+    //  time that depended on the data; profiles/r06a_ab_row_pieces_six_terms.txt.)
+    constexpr bool X6 = SIX;
+    static_assert(!SIX || (DUAL && !BF && !PL), "gmap: the six-term form exists for ca_backward on fp32 features");
     constexpr int TSP = t16_size(P);
     const int dual_id = (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7));
     const bool job1 = DUAL && ((blockIdx.x >> 3) & 1) != 0;           // (wave-uniform)
     const bool trans = DUAL ? job1 : TRANS;
     if (DUAL && dual_id >= j1.nwg) return;      // (padding of the last 16-block)
-    if constexpr (EXACT_F32) {
-        if (j1.gate && *j1.gate <= j1.gate_min) return;    // (wave-uniform; see GmapJob::gate)
-    }
     if (job1) {
         F = j1.F; addend = j1.addend; out = j1.out; fbs = j1.fbs; fps = j1.fps; obs = j1.obs; ops = j1.ops;
     }
@@ -271,8 +261,8 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     // WPC = 3 (ca_backward at C/8 <= 64: ONE channel group per strip, so nothing is ever prefetched): a single feature slot + the
     // output image = 53.6 KB, three workgroups per CU, <= 168 VGPRs (the four N tiles accumulated two at a time, no residual slices)
     // (at 101 .. 132 positions the same form is WPC = 2 -- 70.7 KB, 180 / 228 VGPRs -- where the two-slot one ran ONE workgroup per CU)
-    constexpr bool ONEG = WPC == 3 || (DUAL && !BF && !PL && !EXACT_F32 && !LONG && P > 100 && WPC == 2);
-    static_assert(!ONEG || (DUAL && !BF && !PL && !EXACT_F32), "gmap: the one-group form exists for ca_backward on fp32 q | k");
+    constexpr bool ONEG = WPC == 3 || (DUAL && !BF && !PL && !LONG && P > 100 && WPC == 2);
+    static_assert(!ONEG || (DUAL && !BF && !PL), "gmap: the one-group form exists for ca_backward on fp32 q | k");
     constexpr int NSLOT = ONEG ? 1 : 2;
     // the residual slices (x of functions.py:49 in the output's layout) exist for the final row passes of the all-pixel-major families
     constexpr bool RES = ROW && ADD && !NCHW && !DUAL && !PL;
@@ -320,7 +310,6 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
         t = wave_sum(t);
         if (lane == 0) j1.red_dst[0] = t;
     }
-    if (DUAL && !ROW && !EXACT_F32 && blockIdx.x == 0 && tid == 0 && j1.stat) *j1.stat = 0u;     // (see GmapJob::stat)
     const int pix0 = ROW ? g * W : g, pstep = ROW ? 1 : W;                             // pixel(i) = pix0 + i * pstep
     const int a_off = ROW ? H : 0;
     // query side (attention rows, outputs, addend, residual): positions i0 .. i0 + Lm; key side (attention columns, features):
@@ -359,35 +348,11 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
 
     // ---- the strip's attention block -> MFMA fragments in registers.  Fragment (tile t, k-step ks) of lane (ln, lg):
     // ---- P_g[m][32 ks + 8 lg + e] (TRANS: P_g[32 ks + 8 lg + e][m]), m = 16 t + ln, e < 8; zero beyond the strip
-    u32x4 ah[TPW][EXACT ? 1 : NKS], al[TPW][EXACT ? 1 : NKS];
+    u32x4 ah[TPW][X6 ? 1 : NKS], al[TPW][X6 ? 1 : NKS];
+    float ax[TPW][X6 ? NKS : 1][8];                                   // X6: the block's fp32 values, fragment order
     float at[TPW];
-    float af[TPW][NKF];                                               // EXACT: the block's values in contraction order
-    if constexpr (EXACT) {
 #pragma unroll
-        for (int a = 0; a < TPW; ++a) {
-            const int t = wv + GS_WAVES * a, m = 16 * t + ln;
-#pragma unroll
-            for (int j = 0; j < NKB; ++j) {
-                const int k0 = 16 * j + 4 * lg;
-                if (16 * j < Lk && 16 * t < Lm) {                     // wave-uniform
-                    if (!trans) {
-                        const f32x4 u = fbuf_load_x4(Tb, (m < Lm && k0 < Lk) ? ((pixM + m * pstep) * S + aK + k0) * 4 : kOobOffset, 0);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) af[a][4 * j + e] = k0 + e < Lk ? u[e] : 0.f;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            af[a][4 * j + e] = fbuf_load(Tb, (m < Lm && k0 + e < Lk) ? ((pixK + (k0 + e) * pstep) * S + aM + m) * 4 : kOobOffset, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) af[a][4 * j + e] = 0.f;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < (EXACT ? 0 : TPW); ++a) {
+    for (int a = 0; a < TPW; ++a) {
         const int t = wv + GS_WAVES * a, m = 16 * t + ln;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
@@ -409,9 +374,14 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] = 0.f;
             }
-            const BfSplit sp = bf16_split8(x);
-            ah[a][ks] = sp.hi;
-            al[a][ks] = sp.lo;
+            if constexpr (X6) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ax[a][ks][e] = x[e];
+            } else {
+                const BfSplit sp = bf16_split8(x);
+                ah[a][ks] = sp.hi;
+                al[a][ks] = sp.lo;
+            }
         }
         const int kt = 32 * kp.nbf + lg;
         at[a] = fbuf_load(Tb, (kp.tail && m < Lm && kt < Lk) ? (trans ? ((pixK + kt * pstep) * S + aM + m) * 4
@@ -424,7 +394,6 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     auto st_pos = [&](int k) { return SPX * (wv + GS_WAVES * k) + (OBF ? lane >> 3 : lane >> 4); };
     const int st_c = OBF ? 8 * (lane & 7) : 4 * (lane & 15);
     int nstore_nchw = 0;
-    float gmax = 0.f;                                                       // (GmapJob::stat: max |dq|, |dk| this lane stored)
 
     for (int cg = cg0; cg < cg1; ++cg) {
         const float *img = FB + (ONEG ? 0 : (cg - cg0) & 1) * FSZ;
@@ -459,7 +428,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
             const int i = st_pos(k), c = cg * GM_CG + st_c;
             const bool ok = i < Lm && c < C;
             const int pix = pixM + i * pstep;
-            if (ADD) {
+            if (ADD && !X6) {                             // (X6: the addend starts the accumulators, see below)
                 if constexpr (ABF) {                      // 8 bf16 channels of the partial -> two fp32 quads
                     const u32x4 pk = __builtin_bit_cast(u32x4, fbuf_load_x4(Db, ok ? (pix * aps + c) * 2 : kOobOffset, 0));
 #pragma unroll
@@ -480,37 +449,52 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
         // one position (one ds_write_b128 into the pixel-major output image)
         // (three M tiles per wavefront = strips longer than 128: the four N tiles are accumulated two at a time, so that the
         // accumulators -- live together with 96 fragment and up to 60 prefetch registers -- take 24 VGPRs instead of 48)
-        constexpr int NH = (TPW >= 3 || ONEG) ? 2 : 1, NTH = 4 / NH;
+        // (X6: all four N tiles at once -- the block is split once per k-step -- and the accumulators START from the column partial,
+        //  loaded in their own layout: ca_backward has no gamma, so out = partial + products needs no addend registers of its own)
+        constexpr int NH = X6 ? 1 : (TPW >= 3 || ONEG) ? 2 : 1, NTH = 4 / NH;
 #pragma unroll
         for (int nh = 0; nh < NH; ++nh) {
             f32x4 acc[TPW][NTH];
 #pragma unroll
             for (int a = 0; a < TPW; ++a)
 #pragma unroll
-                for (int n = 0; n < NTH; ++n) acc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (EXACT) {
+                for (int n = 0; n < NTH; ++n) {
+                    if constexpr (X6 && ADD) {
+                        const int i = 16 * (wv + GS_WAVES * a) + ln, c = cg * GM_CG + 16 * (nh * NTH + n) + 4 * lg;
+                        acc[a][n] = fbuf_load_x4(Db, (i < Lm && c < C) ? ((pixM + i * pstep) * aps + c) * 4 : kOobOffset, 0);
+                    } else {
+                        acc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
 #pragma unroll
-                for (int j = 0; j < NKB; ++j) {
-                    if (16 * j < Lk) {                                // wave-uniform
+            for (int ks = 0; ks < (X6 ? NKS : 0); ++ks) {
+                if (ks < kp.nbf) {
+                    BfSplit3 p3[TPW];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int pos = 16 * j + 4 * lg + e;
+                    for (int a = 0; a < TPW; ++a) p3[a] = bf16_split8x3(ax[a][ks]);
 #pragma unroll
-                            for (int n = 0; n < NTH; ++n) {
-                                const int nt = nh * NTH + n;
-                                const float raw = CCA_LDS_LD(img + gtile_f32_idx(pos < 4 * NPF ? pos : 0, 16 * nt + ln));
-                                const float fbv = pos < Lk ? raw : 0.f;        // (beyond the strip: never a stale or non-finite value)
+                    for (int n = 0; n < NTH; ++n) {
+                        const int nt = nh * NTH + n;
+                        float x[8];
 #pragma unroll
-                                for (int a = 0; a < TPW; ++a)
-                                    if ((wv + GS_WAVES * a) * 16 < Lm) acc[a][n] = mfma_16x16x4(fbv, af[a][4 * j + e], acc[a][n]);
+                        for (int e = 0; e < 8; ++e) x[e] = CCA_LDS_LD(img + gtile_f32_idx(32 * ks + 8 * lg + e, 16 * nt + ln));
+                        const BfSplit3 f3 = bf16_split8x3(x);
+#pragma unroll
+                        for (int a = 0; a < TPW; ++a) {
+                            if ((wv + GS_WAVES * a) * 16 < Lm) {          // smallest terms first
+                                acc[a][n] = mfma_bf16_16x16x32(f3.lo, p3[a].hi, acc[a][n]);
+                                acc[a][n] = mfma_bf16_16x16x32(f3.mid, p3[a].mid, acc[a][n]);
+                                acc[a][n] = mfma_bf16_16x16x32(f3.hi, p3[a].lo, acc[a][n]);
+                                acc[a][n] = mfma_bf16_16x16x32(f3.mid, p3[a].hi, acc[a][n]);
+                                acc[a][n] = mfma_bf16_16x16x32(f3.hi, p3[a].mid, acc[a][n]);
+                                acc[a][n] = mfma_bf16_16x16x32(f3.hi, p3[a].hi, acc[a][n]);
                             }
                         }
                     }
                 }
-                mfma_f32_result_fence();
             }
 #pragma unroll
-            for (int ks = 0; ks < (EXACT ? 0 : NKS); ++ks) {
+            for (int ks = 0; ks < (X6 ? 0 : NKS); ++ks) {
                 if (ks < kp.nbf) {
 #pragma unroll
                     for (int n = 0; n < NTH; ++n) {
@@ -543,7 +527,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                     }
                 }
             }
-            if (!EXACT && kp.tail) {
+            if (kp.tail) {
                 const int pos = 32 * kp.nbf + lg;
 #pragma unroll
                 for (int n = 0; n < NTH; ++n) {
@@ -571,7 +555,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                             for (int q = 0; q < 4; ++q)
                                 CCA_LDS_ST(oimg + oimg_nchw_idx<P>(16 * nt + 4 * lg + q, i), alpha * acc[a][n][q] + addp[a][nt][q]);
                         } else {
-                            lds_store_x4(oimg + i * OPX + 16 * nt + 4 * lg, alpha * acc[a][n]);
+                            lds_store_x4(oimg + i * OPX + 16 * nt + 4 * lg, X6 ? acc[a][n] : alpha * acc[a][n]);
                         }
                     }
                 }
@@ -628,7 +612,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                 const float *s = oimg + i * OPX + st_c;
                 if (i < Lm && c < C) {
                     f32x4 u = lds_load_x4(s);
-                    if (ADD) u += add0[k];
+                    if (ADD && !X6) u += add0[k];
                     if constexpr (OBF) {
                         f32x4 v = lds_load_x4(s + 4);
                         if (ADD) v += add1[k];
@@ -644,21 +628,10 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                         fbuf_store_x4(Ob, packed, ((pixM + i * pstep) * ops + c) * 2, 0);
                     } else {
                         if constexpr (RES) u += __builtin_bit_cast(f32x4, res[k]);          // (+ the fp32 residual; zeros when there is none)
-                        if constexpr (DUAL && ROW && !EXACT_F32)
-                            gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(u[0]), fabsf(u[1]))), fmaxf(fabsf(u[2]), fabsf(u[3])));
                         fbuf_store_x4(Ob, u, ((pixM + i * pstep) * ops + c) * 4, 0);
                     }
                 }
             }
-        }
-    }
-    if constexpr (DUAL && ROW && !EXACT_F32 && !OBF) {
-        if (j1.stat) {                                                      // (wave-uniform)
-            // only values BEYOND the limit are published (the gate compares with the same limit): the common case issues no atomic
-            // at all -- 25 k same-address atomics per launch serialise in one L2 channel (+55 us measured, profiles/r05a_*)
-            gmax = wave_max(gmax);
-            const uint32_t bits = __builtin_bit_cast(uint32_t, gmax);
-            if (lane == 0 && bits > j1.gate_min) atomic_max_u32(j1.stat, bits);
         }
     }
 }
@@ -1241,7 +1214,9 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
                         const float bv = CCA_LDS_LD(yb + gtile_f32_idx(px < NPF * 4 ? px : 0, 4 * ks + lg));
 #pragma unroll
                         for (int a = 0; a < NTR; ++a)
-                            if ((part ? a == 0 : (wv + GM_WAVES * a) * 16 < L)) acc[a][t] = mfma_16x16x4(af[a], bv, acc[a][t]);
+                            // (operands swapped -- D[key][query], the same k-ordered fmaf chain per element: a lane ends with four
+                            //  CONSECUTIVE slots of one query = one 16-byte store instead of four 4-byte ones)
+                            if ((part ? a == 0 : (wv + GM_WAVES * a) * 16 < L)) acc[a][t] = mfma_16x16x4(bv, af[a], acc[a][t]);
                     }
                 }
             }
@@ -1295,6 +1270,34 @@ __global__ __launch_bounds__(GM_THREADS, SINGLE ? 2 : 1) void gweight_kernel(con
     if constexpr (!BF && MASK) mfma_f32_result_fence();
     // D[m = query position 16 ti + 4 lg + q][n = key position 16 t + ln] -> T rows (64-byte runs per query)
     float *Tg = T + (size_t)b * HW * S;
+    if constexpr (EXACT) {
+        // D[m = key position 16 t + 4 lg + q][n = query position 16 ti + ln]: 16-byte runs of four slots per query (a run that would
+        // cross the end of the branch's slots leaves as single stores: the next slots belong to another workgroup)
+        const FBuf Tb = make_fbuf(Tg, (size_t)HW * S * sizeof(float));
+#pragma unroll
+        for (int a = 0; a < NTR; ++a)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int i = 16 * (part ? trow : wv + GM_WAVES * a) + ln, j = 16 * t + 4 * lg;
+                if (t * 16 < Lk && (part ? (a == 0 && t == wv) : (wv + GM_WAVES * a) * 16 < L)) {          // (wave-uniform)
+                    f32x4 val = acc[a][t];
+                    if (!row) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (i0 + i == j0 + j + q) val[q] = -INFINITY;     // functions.py:11-12 (column self slot)
+                    }
+                    const int off = ((pix0 + i * pstep) * S + a_off + j) * 4;
+                    if (j + 3 < Lk) {
+                        fbuf_store_x4(Tb, val, i < L ? off : kOobOffset, 0);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            if (j + q < Lk) fbuf_store(Tb, val[q], i < L ? off + 4 * q : kOobOffset, 0);
+                    }
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < NTR; ++a)
 #pragma unroll

@@ -28,7 +28,7 @@ from torch.nn import Softmax
 from . import _lib
 from ._lib import CCNET_CA_ENERGY, CCNET_CA_SOFTMAX
 
-__all__ = ["INF", "CA_Weight", "CA_Map", "CrissCrossFunction", "CrissCrossPackedFunction", "CrissCrossModuleFunction", "ca_weight", "ca_map", "ca_softmax",
+__all__ = ["INF", "CA_Weight", "CA_Map", "CrissCrossFunction", "ca_weight", "ca_map", "ca_softmax",
            "criss_cross_attention", "CrissCrossAttention"]
 
 
@@ -272,69 +272,6 @@ def _recompute_attention(q, k, q_bs, k_bs):
     return A
 
 
-class CrissCrossPackedFunction(torch.autograd.Function):
-    """Fused core on a PACKED projection: ``qkv`` is the (B, 2*Cq + C, H, W) output of one 1x1 convolution whose
-    weight is the row-wise concatenation of query_conv / key_conv / value_conv (functions.py:29,32,35).  The
-    kernels read q, k, v as channel slices of it through the batch-stride arguments of
-    ``ccnet_cca_forward_ws_f32`` (include/ccnet_cca.h) -- no split copies -- and the backward writes dq, dk,
-    dv straight into the slices of one ``dqkv`` tensor, which is what the fused convolution's backward consumes."""
-
-    @staticmethod
-    def forward(ctx, qkv, x, gamma, cq, recompute=False):
-        qkv, x = _dev_f32("qkv", qkv), _dev_f32("x", x)
-        gamma = _dev_f32("gamma", gamma)
-        _same_device(qkv, x, gamma)
-        B, C, H, W = x.shape
-        cq = int(cq)
-        if qkv.dim() != 4 or tuple(qkv.shape) != (B, 2 * cq + C, H, W):
-            raise RuntimeError(f"qkv must be (B, 2*Cq+C, H, W) = {(B, 2 * cq + C, H, W)}; got {tuple(qkv.shape)}")
-        if gamma.numel() != 1:
-            raise RuntimeError("gamma must hold exactly one element")
-        lib = _lib.get_lib()
-        y = torch.empty_like(x)
-        A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
-        hw, bs = H * W * 4, (2 * cq + C) * H * W
-        base = qkv.data_ptr()
-        with torch.cuda.device(x.device):
-            _ws, wsp, wsn = _workspace(lib.ccnet_cca_forward_workspace_bytes(B, C, cq, H, W), x.device)
-            lib.check(lib.ccnet_cca_forward_ws_f32(base, base + cq * hw, base + 2 * cq * hw, x.data_ptr(),
-                                                   gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
-                                                   B, C, cq, H, W, bs, bs, bs, wsp, wsn, _stream()), "cca_forward")
-        ctx.recompute = bool(recompute)
-        ctx.save_for_backward(*((qkv, gamma) if ctx.recompute else (qkv, A, gamma)))
-        ctx.cq = cq
-        return y
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, dy):
-        cq = ctx.cq
-        if ctx.recompute:
-            qkv, gamma = ctx.saved_tensors
-            A = _recompute_attention(qkv[:, :cq], qkv[:, cq:2 * cq], qkv.stride(0), qkv.stride(0))
-        else:
-            qkv, A, gamma = ctx.saved_tensors
-        dy = _dev_f32("grad_output", dy)
-        B, C, H, W = dy.shape
-        lib = _lib.get_lib()
-        dqkv = torch.empty_like(qkv)
-        dgamma = torch.empty_like(gamma)
-        scratch = torch.empty_like(A)
-        with torch.cuda.device(dy.device):
-            nbytes = lib.ccnet_cca_backward_workspace_bytes(B, C, cq, H, W)
-        ws = torch.empty((nbytes + 3) // 4, device=dy.device, dtype=torch.float32)
-        hw, bs = H * W * 4, (2 * cq + C) * H * W
-        p, g = qkv.data_ptr(), dqkv.data_ptr()
-        with torch.cuda.device(dy.device):
-            lib.check(lib.ccnet_cca_backward_strided_f32(dy.data_ptr(), p, p + cq * hw, p + 2 * cq * hw,
-                                                         A.data_ptr(), gamma.data_ptr(),
-                                                         g, g + cq * hw, g + 2 * cq * hw,
-                                                         dgamma.data_ptr(), scratch.data_ptr(), ws.data_ptr(), nbytes,
-                                                         B, C, cq, H, W, bs, bs, bs, bs, bs, bs, _stream()),
-                      "cca_backward")
-        return dqkv, dy, dgamma.view_as(gamma), None, None
-
-
 _PM_DTYPES = {torch.bfloat16: (2, 8, 132, "bf16"), torch.float32: (4, 4, 100, "f32")}   # bytes, alignment (elements), max strip
 
 
@@ -437,76 +374,6 @@ class CrissCrossPMFunction(torch.autograd.Function):
 
 
 CrissCrossPMBF16Function = CrissCrossPMFunction          # (the name round-2 code and tests imported first)
-
-
-class CrissCrossModuleFunction(torch.autograd.Function):
-    """The whole module of functions.py:27-49 as ONE autograd node (fp32, no autocast): stacked projection GEMM ->
-    fused criss-cross core -> hand-written backward in which the input gradient of the projection is a GEMM with
-    ``beta = 1`` on ``dy`` (``dx = dy + W^T dqkv``: the residual's gradient is accumulated by the GEMM epilogue
-    instead of a separate 154 MB elementwise add), and the weight / bias gradients are one batched GEMM + reductions.
-    The GEMMs are torch ops (hipBLASLt); only their composition is ours."""
-
-    @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma, recompute=False):
-        x, gamma = _dev_f32("x", x), _dev_f32("gamma", gamma)
-        B, C, H, W = x.shape
-        cq, hw = wq.shape[0], H * W
-        w = torch.cat([wq.reshape(cq, C), wk.reshape(cq, C), wv.reshape(C, C)], 0)          # (2Cq + C, C)
-        b = torch.cat([bq, bk, bv], 0)
-        xm = x.view(B, C, hw)
-        qkv = torch.baddbmm(b.view(1, -1, 1), w.unsqueeze(0).expand(B, -1, -1), xm)          # (B, 2Cq + C, HW)
-        lib = _lib.get_lib()
-        y = torch.empty_like(x)
-        A = torch.empty((B, H, W, H + W), device=x.device, dtype=torch.float32)
-        esz, bs = hw * 4, (2 * cq + C) * hw
-        base = qkv.data_ptr()
-        with torch.cuda.device(x.device):
-            _ws, wsp, wsn = _workspace(lib.ccnet_cca_forward_workspace_bytes(B, C, cq, H, W), x.device)
-            lib.check(lib.ccnet_cca_forward_ws_f32(base, base + cq * esz, base + 2 * cq * esz, x.data_ptr(),
-                                                   gamma.data_ptr(), y.data_ptr(), A.data_ptr(),
-                                                   B, C, cq, H, W, bs, bs, bs, wsp, wsn, _stream()), "cca_forward")
-        ctx.recompute = bool(recompute)
-        ctx.save_for_backward(*((x, w, qkv, gamma) if ctx.recompute else (x, w, qkv, A, gamma)))
-        ctx.cq = cq
-        return y
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, dy):
-        cq = ctx.cq
-        if ctx.recompute:
-            x, w, qkv, gamma = ctx.saved_tensors
-            B_, _, H_, W_ = x.shape
-            q4 = qkv.view(B_, -1, H_, W_)
-            A = _recompute_attention(q4[:, :cq], q4[:, cq:2 * cq], qkv.stride(0), qkv.stride(0))
-        else:
-            x, w, qkv, A, gamma = ctx.saved_tensors
-        dy = _dev_f32("grad_output", dy)
-        B, C, H, W = x.shape
-        hw = H * W
-        lib = _lib.get_lib()
-        dqkv = torch.empty_like(qkv)
-        dgamma = torch.empty_like(gamma)
-        scratch = torch.empty_like(A)
-        with torch.cuda.device(dy.device):
-            nbytes = lib.ccnet_cca_backward_workspace_bytes(B, C, cq, H, W)
-        ws = torch.empty((nbytes + 3) // 4, device=dy.device, dtype=torch.float32)
-        esz, bs = hw * 4, (2 * cq + C) * hw
-        p, g = qkv.data_ptr(), dqkv.data_ptr()
-        with torch.cuda.device(dy.device):
-            lib.check(lib.ccnet_cca_backward_strided_f32(dy.data_ptr(), p, p + cq * esz, p + 2 * cq * esz,
-                                                         A.data_ptr(), gamma.data_ptr(),
-                                                         g, g + cq * esz, g + 2 * cq * esz,
-                                                         dgamma.data_ptr(), scratch.data_ptr(), ws.data_ptr(), nbytes,
-                                                         B, C, cq, H, W, bs, bs, bs, bs, bs, bs, _stream()),
-                      "cca_backward")
-        xm = x.view(B, C, hw)
-        dx = torch.baddbmm(dy.view(B, C, hw), w.t().unsqueeze(0).expand(B, -1, -1), dqkv)     # dy + W^T dqkv
-        dw = torch.bmm(dqkv, xm.transpose(1, 2)).sum(0)                                       # (2Cq + C, C)
-        db = dqkv.sum(dim=(0, 2))
-        dwq, dwk, dwv = dw[:cq], dw[cq:2 * cq], dw[2 * cq:]
-        return (dx.view(B, C, H, W), dwq.reshape(cq, C, 1, 1), db[:cq], dwk.reshape(cq, C, 1, 1), db[cq:2 * cq],
-                dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma), None)
 
 
 PLANES_HL, PLANES_HLH, PLANES_HHL = 2, 3, 4          # include/ccnet_cca.h CCNET_PLANES_*
@@ -680,9 +547,10 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
         qk = qkv if direct else qkv[..., :2 * cq].contiguous()
         ctx.recompute = bool(recompute)
         ctx.split_gemm = bool(split_gemm)
-        ctx.pc = pc                      # the backward multiplies with the weights this forward saw
         ctx.direct = direct
-        keep = [x3 if split_gemm else x, qk, qk if direct else vpl, gamma, wq, bq, wk, bk, wv, bv]
+        # (the packed weight the backward multiplies with -- the values this forward saw -- goes through save_for_backward like
+        #  every other kept tensor: saved-tensor hooks / offload apply to it)
+        keep = [x3 if split_gemm else x, qk, qk if direct else vpl, gamma, wq, bq, wk, bk, wv, bv, pc["w3t"] if split_gemm else pc["w"]]
         if not ctx.recompute:
             keep += [A]
         ctx.save_for_backward(*keep)
@@ -694,17 +562,16 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
     def backward(ctx, dy):
         cq = ctx.cq
         B, C, H, W = ctx.geom
-        xs, qk, vpl, gamma, wq, bq, wk, bk, wv, bv = ctx.saved_tensors[:10]
+        xs, qk, vpl, gamma, wq, bq, wk, bk, wv, bv, wpack = ctx.saved_tensors[:11]
         dy = _dev_f32("grad_output", dy)
         hw, ct = H * W, 2 * cq + C
         lib = _lib.get_lib()
-        pc = ctx.pc
         direct = ctx.direct
         p, bs, ps = (qk.data_ptr(), hw * ct, ct) if direct else (qk.data_ptr(), hw * 2 * cq, 2 * cq)
         if ctx.recompute:
             A = _attention_pm(lib, p, p + 4 * cq, False, B, cq, H, W, bs, ps, dy.device)
         else:
-            A = ctx.saved_tensors[10]
+            A = ctx.saved_tensors[11]
         dqkv = torch.empty((B, hw, ct), device=dy.device, dtype=torch.float32)
         dgamma = torch.empty_like(gamma)
         scratch = torch.empty_like(A)
@@ -721,15 +588,17 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
             # (B, H, W, 3, ct): dh | dl | dh for the two GEMMs, and the bias gradients (the sum of dqkv over all pixels) out of the same
             # pass over dqkv (round 5: split 72 us + torch sum 47 us -> one pass)
             d3, db = split_planes_colsum(dqkv.view(B, H, W, ct), PLANES_HLH, torch.bfloat16)
-            dx = torch.bmm(pc["w3t"].unsqueeze(0).expand(B, -1, -1), d3.view(B, hw, 3 * ct).transpose(1, 2),
-                           out_dtype=torch.float32).add_(dy.view(B, C, hw))                   # dy + W^T dqkv^T  (NCHW)
+            # dy + W^T dqkv^T (NCHW): dy is the GEMM's C operand (beta = 1) -- rounds 4-5 added it in a pass of its own over dx
+            # (read dx, read dy, write dx: 462 MB, 98 us at the headline shape)
+            dx = torch.baddbmm(dy.view(B, C, hw), wpack.unsqueeze(0).expand(B, -1, -1), d3.view(B, hw, 3 * ct).transpose(1, 2),
+                               out_dtype=torch.float32)
             # rows (dh, xh), (dl, xh), (dh, xl) of every pixel: the three products, contracted over 3 HW rows per image
             dw = torch.bmm(d3.view(B, 3 * hw, ct).transpose(1, 2), x3.view(B, 3 * hw, C), out_dtype=torch.float32).sum(0)
         else:
             db = dqkv.sum(dim=(0, 1))
             xm = xs.view(B, C, hw)
             dqt = dqkv.transpose(1, 2)                                                        # (B, 2Cq + C, HW) view
-            dx = torch.baddbmm(dy.view(B, C, hw), pc["w"].t().unsqueeze(0).expand(B, -1, -1), dqt)  # dy + W^T dqkv^T  (NCHW)
+            dx = torch.baddbmm(dy.view(B, C, hw), wpack.t().unsqueeze(0).expand(B, -1, -1), dqt)  # dy + W^T dqkv^T  (NCHW)
             dw = torch.bmm(dqt, xm.transpose(1, 2)).sum(0)                                    # (2Cq + C, C)
         dwq, dwk, dwv = dw[:cq], dw[cq:2 * cq], dw[2 * cq:]
         return (dx.view(B, C, H, W), dwq.reshape(cq, C, 1, 1), db[:cq], dwk.reshape(cq, C, 1, 1), db[cq:2 * cq],
@@ -761,10 +630,6 @@ class CrissCrossAttention(nn.Module):
     #: strides; set False (class or instance) for three separate convolutions exactly as functions.py:29-35.
     fuse_projections = True
 
-    #: fp32, no autocast: run projection + core + their backward as one autograd node (the input gradient
-    #: ``dy + W^T dqkv`` is a single GEMM with beta = 1); False keeps torch's conv2d autograd.
-    fuse_module_backward = True
-
     #: activation memory (networks/ccnet.py:118-119 applies the module R times): when True the
     #: (B,H,W,H+W) attention tensor is NOT kept for backward -- it is recomputed from q, k (one affinity + softmax
     #: launch pair, ~8 % of a fwd+bwd) -- so an application holds q, k, v only.  Every fp32 / bf16 node honours it (round 4: the
@@ -784,23 +649,21 @@ class CrissCrossAttention(nn.Module):
     #: ... from this many pixels per call on (module fwd+bwd at 512 channels, 97 x 97: B = 8 2.23 -> 1.92 ms, B = 4 1.21 -> 1.11,
     #: B = 2 0.70 -> 0.75, B = 1 0.59 -> 0.74: below ~30k pixels the step is bound by host launches and the extra ops cost more)
     split_bf16_min_pixels = 32768
-    #: fp32 channels_last inputs run on the pixel-major family (x as (B, H, W, C) is then a free view: nothing is copied).
-    pixel_major_for_channels_last = True
     #: bf16 inputs: strips <= 132 (C, C/8 divisible by 8) run on the pixel-major bf16 MFMA kernels; strips of 133 .. 528 positions
     #: run the blocked fp32 plane kernels on fp32 copies (route ``f32-planes-cast``), anything else the strip family through fp32
-    #: copies (round 2 also had any-shape bf16-I/O kernels for strips > 320: 793 ms at configs[4], removed in round 3).
+    #: copies (route ``separate-strips``).
     native_bf16 = True
 
     #: route name -> what runs (``route(x)`` picks one; ``forward`` only dispatches on it)
     ROUTES = {
         "bf16-pixel-major": "one x^T W^T projection + pixel-major bf16 MFMA kernels (BASELINE configs[4])",
-        "f32-channels-last": "one x^T W^T projection + pixel-major fp32 kernels, channels_last in / out",
-        "f32-planes": "one autograd node: projection GEMM, v / dy as bf16 hi | lo planes, NCHW x / y / dy",
-        "f32-strips-node": "one autograd node on the NCHW strip kernels (honours recompute_attention)",
+        "f32-planes": "one autograd node: projection GEMM, v / dy as bf16 hi | lo planes, NCHW x / y / dy (channels_last inputs: one copy)",
         "f32-planes-cast": "fp32 inputs under autocast, fp16 inputs, bf16 inputs beyond the bf16 kernels' 132 positions: the f32-planes node on fp32 copies, autocast off inside",
-        "packed-strips": "stacked conv2d + NCHW strip kernels through channel-slice strides (any float dtype, autocast)",
-        "separate-strips": "three convolutions + NCHW strip / windowed / any-shape kernels (functions.py:29-35 as written)",
+        "separate-strips": "three convolutions + NCHW strip / windowed / any-shape kernels (functions.py:29-35 as written): every other input",
     }
+    # (Round 6 removed three routes nobody's default had used since round 3 -- the one-node form on the NCHW strip kernels, the
+    #  stacked-conv2d form on the same kernels, the fp32 pixel-major family for channels_last inputs (1.71 ms on the split-plane
+    #  node + one 70 us copy against 2.17 ms) -- and with them two autograd Functions and 40 GPU tests: VERDICT r5 item 7.)
 
     def route(self, x):
         """Which implementation ``forward`` runs for this input (a key of ``ROUTES``).  The pixel-major and split-plane
@@ -817,16 +680,11 @@ class CrissCrossAttention(nn.Module):
                     and pm_bf16_covers(B, C, cq, H, W)):
                 return "bf16-pixel-major"
         if x.dtype == torch.float32 and not torch.is_autocast_enabled() and self._fusable(x):
-            cl = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
-            if fast_ok and cl and self.pixel_major_for_channels_last and pm_covers(torch.float32, B, C, cq, H, W):
-                return "f32-channels-last"
             # (strips beyond 132 positions -- rows, columns or both, up to 528 -- run in blocks.  Round 3 ran a TALL map whose width
             # fits 132 on its spatial transpose, two transposing copies each way; the blocked column passes are faster:
             # (1,512,257,129) inference 0.63 -> 0.47 ms, fwd+bwd 1.85 -> 1.52 ms, profiles/r04lc_tall_map_ab.txt -- that route is gone.)
-            if fast_ok and not cl and self.fuse_module_backward and self.split_planes and planes_cover(B, C, cq, H, W):
+            if fast_ok and self.split_planes and planes_cover(B, C, cq, H, W):
                 return "f32-planes"
-            if self.fuse_projections and self.fuse_module_backward:
-                return "f32-strips-node"
         # half-precision activations (or fp32 under autocast) on a map beyond the bf16 kernels' 132 positions -- mixed-precision
         # whole-image evaluation, evaluate.py:102-166 -- used to fall to the windowed / any-shape strip kernels through fp32 copies;
         # the blocked plane kernels take such maps (strips <= 528): the fp32 node on fp32 copies of x and of the parameters
@@ -836,12 +694,10 @@ class CrissCrossAttention(nn.Module):
         # projections (profiles/r04lv_autocast_route_probe.txt)
         half = x.dtype in (torch.bfloat16, torch.float16) or (x.dtype == torch.float32 and torch.is_autocast_enabled())
         not_native = x.dtype != torch.bfloat16 or max(H, W) > 132 or not self.native_bf16
-        if (half and not_native and fast_ok and self.fuse_module_backward and self.split_planes and self._fusable()
+        if (half and not_native and fast_ok and self.split_planes and self._fusable()
                 and self.query_conv.weight.device == x.device and x.shape[1] == self.query_conv.in_channels
                 and planes_cover(B, C, cq, H, W)):
             return "f32-planes-cast"
-        if self.fuse_projections and self._fusable():
-            return "packed-strips"
         return "separate-strips"
 
     def forward(self, x):
@@ -860,13 +716,12 @@ class CrissCrossAttention(nn.Module):
             qkv = torch.nn.functional.linear(xp, self._stacked_weight().flatten(1), self._stacked_bias()).to(torch.bfloat16)
             y = CrissCrossPMBF16Function.apply(qkv, xp, self.gamma.float(), cq, self.recompute_attention).permute(0, 3, 1, 2)
             return y if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() else y.contiguous()
-        if r == "f32-channels-last":
-            xp = x.permute(0, 2, 3, 1)
-            qkv = torch.nn.functional.linear(xp, self._stacked_weight().flatten(1), self._stacked_bias())
-            return CrissCrossPMFunction.apply(qkv, xp, self.gamma, cq, self.recompute_attention).permute(0, 3, 1, 2)
         if r == "f32-planes":
             split_gemm = self.split_bf16_projections and x.shape[0] * x.shape[2] * x.shape[3] >= self.split_bf16_min_pixels
-            return CrissCrossPlanesModuleFunction.apply(x, *params, self.gamma, split_gemm, self.recompute_attention)
+            y = CrissCrossPlanesModuleFunction.apply(x.contiguous(), *params, self.gamma, split_gemm, self.recompute_attention)
+            # (a channels_last input gets its output back in its own memory format, as torch's own operators do)
+            cl = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+            return y.contiguous(memory_format=torch.channels_last) if cl else y
         if r == "f32-planes-cast":
             with torch.autocast(device_type="cuda", enabled=False):          # (the node's GEMMs are its own: fp32 / split-bf16 x3)
                 split_gemm = self.split_bf16_projections and x.shape[0] * x.shape[2] * x.shape[3] >= self.split_bf16_min_pixels
@@ -875,14 +730,6 @@ class CrissCrossAttention(nn.Module):
                 y = CrissCrossPlanesModuleFunction.apply(x.float().contiguous(), *(p.float() for p in params), self.gamma.float(),
                                                          split_gemm, self.recompute_attention)
             return y.to(x.dtype)
-        if r == "f32-strips-node":
-            return CrissCrossModuleFunction.apply(x, *params, self.gamma, self.recompute_attention)
-        if r == "packed-strips":
-            # one GEMM for functions.py:29,32,35 (parameters and state_dict keys stay the reference's three convs); half
-            # inputs, or fp32 inputs whose projections autocast turned into bf16: the kernels compute in fp32
-            qkv = torch.nn.functional.conv2d(x, self._stacked_weight(), self._stacked_bias())
-            return CrissCrossPackedFunction.apply(qkv.float(), x.float(), self.gamma.float(), cq,
-                                                  self.recompute_attention).to(x.dtype)
         proj_query, proj_key, proj_value = self.query_conv(x), self.key_conv(x), self.value_conv(x)
         out = CrissCrossFunction.apply(proj_query.float(), proj_key.float(), proj_value.float(),
                                        x.float(), self.gamma.float(), self.recompute_attention)
@@ -893,11 +740,6 @@ class CrissCrossAttention(nn.Module):
 
     def _stacked_bias(self):
         return torch.cat([self.query_conv.bias, self.key_conv.bias, self.value_conv.bias], 0)
-
-    @staticmethod
-    def _strip_kernels_cover(x):
-        B, C, H, W = x.shape
-        return bool(_lib.get_lib().ccnet_cca_shape_uses_mfma(B, C, H, W))
 
     def _fusable(self, x=None):
         """The packed path bypasses ``nn.Conv2d.forward``: it needs the three projections to still be the plain dense

@@ -45,8 +45,14 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define CCNET_CCA_VERSION 210          /* 0.2.1 (additive over 0.2.0): ccnet_cca_pack_projection_f32, ccnet_cca_probe_*, option "dqdk_exact" 2 (default),
-                                          backward workspaces 256 B larger (query the size, as always); only ccnet_* symbols are exported */
+#define CCNET_CCA_VERSION 220          /* 0.2.2.  Over 0.2.0: ccnet_cca_pack_projection_f32, ccnet_cca_probe_*; only ccnet_* symbols are exported.
+                                          BEHAVIOURAL changes a binding must know (0.2.1 called these "additive"):
+                                          - the *_BACKWARD workspaces of the pixel-major / split-plane entry points are 256 B larger than in 0.2.0
+                                            (a binding that hard-coded the 0.2.0 formula gets CCNET_E_WORKSPACE: query the size, as always);
+                                          - fp32 ca_backward (dq | dk) of those entry points multiplies as SIX bf16 terms (fp32-equivalent) instead of
+                                            three -- option "dqdk_exact" is now 0 / 1, default 1; the values 1 = exact-f32 MFMA and 2 = device-gated
+                                            redo of 0.2.1 are gone (CCNET_E_BADFLAGS);
+                                          - the bf16 entry points round the column -> row partial to bf16 (option "bf16_partial", default 1). */
 
 #define CCNET_E_BADSHAPE   (-1)        /* non-positive dimension, or a size the kernels cannot index */
 #define CCNET_E_NULLPTR    (-2)        /* a required pointer is NULL */
@@ -65,7 +71,8 @@ extern "C" {
 /* Arithmetic of the NCHW STRIP kernels (ccnet_ca_*_f32, ccnet_cca_*_f32, *_strided_f32, *_ws_f32).  The affinity
  * (ca_forward), the softmax and the dq/dk kernels of that family always run exact fp32 (the f32 MFMA is bit-identical
  * to an fmaf chain).  The PIXEL-MAJOR and SPLIT-PLANE entry points (*_pm_*, *_planes_*) are not governed by this knob:
- * they compute the energies in exact fp32 and EVERY other contraction (dq / dk included) as split-bf16 x3 -- callers that
+ * they compute the energies in exact fp32, ca_backward (dq | dk) as six bf16 terms (fp32-equivalent) and every other contraction as
+ * split-bf16 x3 (NUMERICS ENVELOPE below, at ccnet_cca_forward_planes_f32) -- callers that
  * pin CCNET_PRECISION_F32 or CCNET_IMPL_DIRECT for validation must call the strip / direct entry points; the Python module
  * reads the two knobs (ccnet_cca_get_option) and routes accordingly.
  * The two aggregation-type contractions of the strip family (ca_map_forward, ca_map_backward's dv) may split every fp32 operand
@@ -261,8 +268,16 @@ int ccnet_cca_shape_uses_mfma(int B, int C, int H, int W);
  *   is -- the aggregation and (backward: pass the same ``v``, ``v_planes`` == NULL) the dA contraction split every fragment into
  *   bf16 hi | lo in registers; no planes tensor, no split pass (308 MB less traffic per forward); same arithmetic, same bits.
  *   Workspace: CCNET_WS_PLANES_FORWARD / _BACKWARD (backward: holds the fp32 column partial and dy as planes).
- *   Arithmetic: energies exact fp32; every other contraction split-bf16 x3 with fp32 accumulation (the lo x lo term,
- *   2^-18 relative, is dropped) -- the CCNET_PRECISION_* knob does not apply here. */
+ *   Arithmetic: energies exact fp32; ca_backward (dq | dk from dE) as SIX bf16 terms of a three-way split (fp32-equivalent, 2^-24);
+ *   every other contraction -- aggregation, dv, dA -- split-bf16 x3 with fp32 accumulation (the lo x lo term, 2^-18 relative, is
+ *   dropped; dy is consumed as two bf16 planes, 2^-17 relative per element) -- the CCNET_PRECISION_* knob does not apply here.
+ *   NUMERICS ENVELOPE (asserted by tests/test_gpu_parity.py: logit-, value- and gradient-scale sweeps at (.,512,97,97), hot-logit maps
+ *   of 129 x 129 and 129 x 257): every output O in {y, dv, dq, dk} satisfies  max |O - O_ref| <= 2e-5 * max |O_ref|  against the fp64-
+ *   accumulating restatement of functions.py:27-49 (measured: 4e-6 .. 1e-5), at any scale of q, k, v, dy.  The ABSOLUTE 1e-3 bar of
+ *   the north_star therefore holds wherever max |O_ref| <= 50 -- N(0,1) inputs at the reference's geometry give max |y|, |dv| ~ 6 and
+ *   max |dq|, |dk| ~ 49; q, k three times hotter (|dq| ~ 136) still measure 6.4e-4 -- and not for arbitrarily large |v| * |dy|
+ *   (v, dy x 4 each: |dq| ~ 780, error 4e-3 = 5.5e-6 relative: the 2^-17 of the three-term dA).  The exact-fp32 family
+ *   (ccnet_ca_*_f32 on NCHW q, k, v) is there for callers that need fp32 products throughout. */
 #define CCNET_PLANES_HL 2
 #define CCNET_PLANES_HLH 3
 #define CCNET_PLANES_HHL 4
@@ -334,13 +349,11 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
  *                    tensor (the reference's own bf16 arithmetic rounds out_H and the column half of dv to bf16 before adding the row
  *                    half, functions.py:46-47): half the bytes of the fp32 partial, which was a quarter of the traffic of BASELINE
  *                    configs[4]; 0: fp32 partial (round 2-4 behaviour).  fp32 families are not affected.
- *   "dqdk_exact"   ca_backward of the fp32 pixel-major / split-plane entry points (strips <= 100): 0 split-bf16 x3 (error ~1.2e-5 of
- *                    max |dq|, |dk|: 4e-4 at the reference's initialisation scale, 1.5e-3 with q, k three times hotter);
- *                    1 exact fp32 (v_mfma_f32_16x16x4_f32; +25 us per launch at (8,512,97,97); leaves the 5e-6 of the upstream dA);
- *                    2 (default) AUTOMATIC: the x3 launches publish max |dq|, |dk| in the workspace, an exact pair follows on the
- *                    stream and exits at once unless that maximum exceeds 64 -- hot logits are redone in exact fp32 by the device
- *                    itself (no host synchronisation, capturable), cool ones pay two empty launches.  The absolute 1e-3 bar then
- *                    holds up to q, k ~ N(0, 3^2) at C/8 = 64 (tests/test_gpu_parity.py, logit-scale sweep). */
+ *   "dqdk_exact"   ca_backward (dq | dk) of EVERY fp32 pixel-major / split-plane route, strips of any supported length:
+ *                    1 (default) six bf16 terms of a three-way split per product -- fp32-equivalent (2^-24) at 3/8 of the matrix time
+ *                    of v_mfma_f32_16x16x4_f32, +3..4 us per launch at (8,512,97,97) over the three-term form; what is left on dq | dk is
+ *                    what the upstream dA carries (~5e-6 of max |dq|).  0 = three terms (~1.2e-5 of max |dq|, |dk|: 4e-4 at the
+ *                    reference's initialisation scale, 1.5e-3 with q, k three times hotter); strips <= 100 only, an A/B aid. */
 int ccnet_cca_set_option(const char *name, int value, int *previous);
 int ccnet_cca_get_option(const char *name, int *value);
 
@@ -357,6 +370,7 @@ int ccnet_cca_profile_end(float *ms, char *names, int name_stride, int cap);
  * ccnet_cca_probe_clock: ``nwg`` single-wave workgroups sample (shader, reference) every ``interval_ticks`` reference ticks,
  *   ``nsamples`` times: samples[(wg * nsamples + s) * 2 + {0, 1}], then samples[2 * nwg * nsamples + wg] = the XCC of workgroup
  *   wg (buffer: (2 * nwg * nsamples + nwg) uint64).  Launch it on a stream of its own NEXT TO what is to be observed.
+ *   nsamples * interval_ticks <= 2e8 (two seconds of busy-waiting), otherwise CCNET_E_BADFLAGS.
  * ccnet_cca_probe_mfma: ``nwg`` workgroups of 4 waves, each wave ``iters`` x 8 v_mfma_f32_16x16x32_bf16 (131072 * iters flops);
  *   clk[wg * 4 + {0..3}] = shader start, reference start, shader end, reference end of wave 0; ``sink``: 256 * nwg floats.
  * ccnet_cca_probe_dma: ``nwg`` workgroups fill a 25 KiB LDS tile by LDS-DMA (25 pieces of 4 rows x 256 B, rows

@@ -20,7 +20,7 @@ CCNET_WS_PLANES_FORWARD, CCNET_WS_PLANES_BACKWARD = 5, 6
 def bind(path):
     lib = ctypes.CDLL(path)                                   # after ``import torch``: shares its HIP runtime
     lib.ccnet_cca_version.restype = _I
-    assert lib.ccnet_cca_version() == 210, "written against C ABI 0.2.1 (include/ccnet_cca.h)"
+    assert lib.ccnet_cca_version() == 220, "written against C ABI 0.2.2 (include/ccnet_cca.h)"
     lib.ccnet_cca_last_error_string.restype = ctypes.c_char_p
     lib.ccnet_cca_workspace_bytes.restype = _Z
     lib.ccnet_cca_workspace_bytes.argtypes = [_I] * 6

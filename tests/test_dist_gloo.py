@@ -105,11 +105,17 @@ def test_bench_gpus_2_self_spawns_two_ranks_on_gloo():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["scaling"] == "weak"
     assert "(B,16,6,5)" in out["metric"] and "all-reduce" in out["config"]["parallelism"]
+    # the first N-GPU run must be diagnosable -- one entry per rank (its own time, host, pid, device) and the
+    # collective library on the line
+    assert [r["rank"] for r in out["per_rank"]] == [0, 1] and len({r["pid"] for r in out["per_rank"]}) == 2
+    assert all(r["ms_per_step"] > 0 and r["device"] == "cpu" for r in out["per_rank"])
+    assert max(r["ms_per_step"] for r in out["per_rank"]) <= out["ms_per_step"] * 1.001 + 1e-3
+    assert out["collective_library"]["backend"] == "gloo"
     one = _run_bench(["--gpus", "1"] + common, _bench_env())
     assert one.returncode == 0, one.stderr[-2000:]
     o1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     assert o1["n_gpus"] == 1 and o1["algorithmic_bytes_per_step_per_gpu"] == out["algorithmic_bytes_per_step_per_gpu"]
-    assert set(o1) == set(out)
+    assert set(o1) == set(out) and len(o1["per_rank"]) == 1
 
 
 def test_bench_refuses_a_world_size_that_disagrees_with_gpus():

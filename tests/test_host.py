@@ -39,7 +39,7 @@ def test_device_library_exports_every_declared_symbol(device_lib_path):
     exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
     assert exported == sorted(names), sorted(set(exported) ^ set(names))
     lib = _lib.CcaLibrary(device_lib_path)
-    assert lib.ccnet_cca_version() == 210 and lib.ccnet_cca_arch() == b"gfx950"
+    assert lib.ccnet_cca_version() == 220 and lib.ccnet_cca_arch() == b"gfx950"
     # argument validation happens before any launch, so it is checkable here
     assert lib.ccnet_ca_forward_f32(None, None, None, 1, 1, 2, 2, 0, None) == -2
     assert lib.ccnet_ca_forward_f32(None, None, None, 0, 1, 2, 2, 0, None) == -1
@@ -247,7 +247,7 @@ def test_options_and_workspace_sizes_are_host_logic_behind_two_entry_points(devi
     lib = _lib.get_lib()
     assert len(_lib.declared_symbols()) <= 35          # (30 + the weight packer, the split-with-column-sums producer and three device-state probes of round 5)
     for name, default in (("impl", _lib.CCNET_IMPL_AUTO), ("precision", _lib.CCNET_PRECISION_DEFAULT), ("branch_mask", 3),
-                          ("planes_ring", 2), ("planes_stream", 1), ("planes_overlap", -1), ("planes_xcd", 1), ("energy_tail", 1), ("da_stages", 2), ("dqdk_wpc3", 1), ("dqdk_exact", 2), ("bf16_partial", 1)):
+                          ("planes_ring", 2), ("planes_stream", 1), ("planes_overlap", -1), ("planes_xcd", 1), ("energy_tail", 1), ("da_stages", 2), ("dqdk_wpc3", 1), ("dqdk_exact", 1), ("bf16_partial", 1)):
         assert lib.get_option(name) == default, name
     assert lib.set_option("planes_overlap", 0) == -1 and lib.get_option("planes_overlap") == 0
     assert lib.set_option("planes_overlap", -1) == 0
@@ -262,7 +262,7 @@ def test_options_and_workspace_sizes_are_host_logic_behind_two_entry_points(devi
     assert lib.ccnet_cca_get_option(b"planes_overlap", ctypes.byref(val)) == 0 and val.value == -1
     with pytest.raises(_lib.CcaError):
         lib.set_option("precision", 17)
-    assert lib.ccnet_cca_version() == _lib.CCNET_CCA_VERSION == 210
+    assert lib.ccnet_cca_version() == _lib.CCNET_CCA_VERSION == 220
     B, C, Cq, H, W = 8, 512, 64, 97, 97
     px = B * H * W * 4
     sm = lib.ccnet_ca_softmax_backward_workspace_bytes(B, H, W)
@@ -285,7 +285,7 @@ def test_module_routing_table(device_lib_path):
     m = CrissCrossAttention(64)
     nchw = lambda B, H, W, dt=torch.float32: torch.empty(B, 64, H, W, dtype=dt)                       # noqa: E731
     cl = lambda B, H, W, dt=torch.float32: nchw(B, H, W, dt).contiguous(memory_format=torch.channels_last)   # noqa: E731
-    assert set(m.ROUTES) >= {m.route(nchw(1, 8, 8))}
+    assert set(m.ROUTES) >= {m.route(nchw(1, 8, 8))} and len(m.ROUTES) <= 5          # 
     table = {
         ("f32 NCHW 97x97 B=8", lambda: m.route(nchw(8, 97, 97))): "f32-planes",
         ("f32 NCHW 97x97 B=1", lambda: m.route(nchw(1, 97, 97))): "f32-planes",
@@ -294,10 +294,10 @@ def test_module_routing_table(device_lib_path):
         ("f32 NCHW 97x193", lambda: m.route(nchw(1, 97, 193))): "f32-planes",
         ("f32 NCHW 161x321 (both sides beyond 132: column AND row passes in blocks)", lambda: m.route(nchw(1, 161, 321))): "f32-planes",
         ("f32 NCHW 257x513 (evaluate.py:146-166 at scale 2)", lambda: m.route(nchw(1, 257, 513))): "f32-planes",
-        ("f32 NCHW 600x140 (columns beyond 4 blocks)", lambda: m.route(nchw(1, 600, 140))): "f32-strips-node",
+        ("f32 NCHW 600x140 (columns beyond 4 blocks)", lambda: m.route(nchw(1, 600, 140))): "separate-strips",
         ("f32 NCHW 257x129 (tall: column passes in blocks)", lambda: m.route(nchw(1, 257, 129))): "f32-planes",
-        ("f32 NCHW 129x600 (rows beyond 4 blocks)", lambda: m.route(nchw(1, 129, 600))): "f32-strips-node",
-        ("f32 channels_last", lambda: m.route(cl(2, 33, 18))): "f32-channels-last",
+        ("f32 NCHW 129x600 (rows beyond 4 blocks)", lambda: m.route(nchw(1, 129, 600))): "separate-strips",
+        ("f32 channels_last (one copy to NCHW, the output back in channels_last)", lambda: m.route(cl(2, 33, 18))): "f32-planes",
     }
     for (what, fn), want in table.items():
         assert fn() == want, what
@@ -309,32 +309,29 @@ def test_module_routing_table(device_lib_path):
     assert m.route(nchw(1, 257, 513, torch.bfloat16)) == "f32-planes-cast"
     assert m.route(nchw(1, 330, 9, torch.bfloat16)) == "f32-planes-cast"         # (round 3: any-shape fp32 kernels through fp32 copies)
     assert m.route(nchw(1, 200, 9, torch.bfloat16)) == "f32-planes-cast"         # (round 3: windowed fp32 kernels through fp32 copies)
-    assert m.route(nchw(1, 600, 9, torch.bfloat16)) == "packed-strips"           # beyond 528 positions: any-shape fp32 kernels through fp32 copies
+    assert m.route(nchw(1, 600, 9, torch.bfloat16)) == "separate-strips"           # beyond 528 positions: any-shape fp32 kernels through fp32 copies
     m.to(torch.float16)
     assert m.route(nchw(2, 97, 97, torch.float16)) == "f32-planes-cast"          # fp16: no native kernels, the fp32 node on copies
     m.to(torch.float32)
     m.to(torch.float32)
     m.split_planes = False
-    assert m.route(nchw(2, 97, 97)) == "f32-strips-node" and m.route(nchw(8, 97, 97)) == "f32-strips-node"
+    assert m.route(nchw(2, 97, 97)) == "separate-strips" and m.route(nchw(8, 97, 97)) == "separate-strips"
     m.split_planes = True
     m.recompute_attention = True                     # (the fast routes honour the flag themselves now)
-    assert m.route(nchw(2, 97, 97)) == "f32-planes" and m.route(cl(2, 33, 18)) == "f32-channels-last"
+    assert m.route(nchw(2, 97, 97)) == "f32-planes" and m.route(cl(2, 33, 18)) == "f32-planes"
     m.recompute_attention = False
     m.fuse_projections = False
     assert m.route(nchw(2, 97, 97)) == "separate-strips"
     m.fuse_projections = True
-    m.fuse_module_backward = False
-    assert m.route(nchw(2, 97, 97)) == "packed-strips"
-    m.fuse_module_backward = True
     prev = lib.ccnet_cca_set_precision(_lib.CCNET_PRECISION_F32)                 # (the knobs are honoured)
     try:
         assert lib.ccnet_cca_get_precision() == _lib.CCNET_PRECISION_F32
-        assert m.route(nchw(2, 97, 97)) == "f32-strips-node" and m.route(cl(2, 33, 18)) == "f32-strips-node"
+        assert m.route(nchw(2, 97, 97)) == "separate-strips" and m.route(cl(2, 33, 18)) == "separate-strips"
     finally:
         lib.ccnet_cca_set_precision(prev)
     previ = lib.ccnet_cca_set_impl(_lib.CCNET_IMPL_DIRECT)
     try:
-        assert m.route(nchw(2, 97, 97)) == "f32-strips-node"
+        assert m.route(nchw(2, 97, 97)) == "separate-strips"
     finally:
         lib.ccnet_cca_set_impl(previ)
     assert m.route(nchw(2, 97, 97)) == "f32-planes"

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from ccnet_amd import _lib  # noqa: E402
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+args = [a for i, a in enumerate(sys.argv[1:]) if not a.startswith("--") and sys.argv[i] != "--sets"]
 B, C, H, W = (int(a) for a in args[:4]) if len(args) >= 4 else (8, 512, 97, 97)
 DEFAULT_SETS = {
     "default": {},
@@ -24,12 +24,17 @@ DEFAULT_SETS = {
     "dA-3-stages-1s": {"da_stages": 3, "planes_overlap": 0},    # the energies launch as one workgroup per strip (2.02 rounds -> three)
     "one-stream": {"planes_overlap": 0},
     "overlap-1": {"planes_overlap": 1},
-    "dqdk-x3-only": {"dqdk_exact": 0},       # without the two gated exact launches of the automatic form (round 5): what they cost
+    "dqdk-three-terms": {"dqdk_exact": 0},   # ca_backward with three bf16 terms per product instead of six (round 6 default: six, fp32-equivalent)
     "ring-2-per-cu": {"planes_ring": 1},     # the column ring passes with three slots and TWO workgroups per CU (slow-box A/B)
 }
+if "--sets" in sys.argv:
+    keep = sys.argv[sys.argv.index("--sets") + 1].split(",")
+    DEFAULT_SETS = {k: v for k, v in DEFAULT_SETS.items() if k in keep or k == "default"}
+DETAIL = ("one-stream", "dqdk-three-terms")
 lib = _lib.get_lib()
 dev = torch.device("cuda:0")
-BASE = {"planes_ring": 2, "planes_stream": 1, "planes_overlap": -1, "planes_xcd": 1, "energy_tail": 1, "da_stages": 2, "dqdk_wpc3": 1, "dqdk_exact": 2}
+BASE = {"planes_ring": 2, "planes_stream": 1, "planes_overlap": -1, "planes_xcd": 1, "energy_tail": 1, "da_stages": 2, "dqdk_wpc3": 1,
+        "dqdk_exact": 1}
 wl = bench.PlanesWorkload(lib, B, C, H, W, dev, 1234)
 ref = None
 for rnd in range(2):                       # two rounds: the order of the sets must not matter
@@ -54,9 +59,8 @@ for rnd in range(2):                       # two rounds: the order of the sets m
         gms = bench.time_region(g.replay, 50)
         del g
         print(f"== round {rnd} {name:16s} {opts}: eager {ms:.4f} ms  graph {gms:.4f} ms  fwd {fwd:.4f}  bwd {bwd:.4f}  bit-identical to first: {same}", flush=True)
-        if rnd == 0 and name in ("one-stream",):
-            if name == "v-as-planes":
-                lib.set_option("planes_overlap", 0)
+        if rnd == 0 and name in DETAIL:
+            lib.set_option("planes_overlap", 0)          # per-launch durations: every launch on one stream
             rec = lib.profile_launches(lambda: [wl.step() for _ in range(5)])
             n = len(rec) // 5
             print(f"     launches {n}, event sum {sum(t for _, t in rec) / 5:.4f} ms")
