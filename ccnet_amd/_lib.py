@@ -29,6 +29,7 @@ CCNET_PRECISION_DEFAULT = 2
 CCNET_WS_SOFTMAX_BACKWARD, CCNET_WS_FORWARD, CCNET_WS_BACKWARD = 0, 1, 2
 CCNET_WS_PM_FORWARD, CCNET_WS_PM_BACKWARD, CCNET_WS_PLANES_FORWARD, CCNET_WS_PLANES_BACKWARD = 3, 4, 5, 6
 CCNET_WS_SPLIT_COLSUM = 7
+CCNET_WS_PLANES3_BACKWARD = 8
 
 _P = c_void_p  # every tensor argument is a raw device pointer
 
@@ -63,6 +64,7 @@ _PROTOTYPES = {
     "ccnet_cca_pack_projection_f32": (c_int, [_P] * 10 + [c_int, c_int, _P]),
     "ccnet_cca_forward_planes_f32": (c_int, [_P] * 9 + [c_int] * 5 + [c_long, c_int] * 4 + [_P, c_size_t, _P]),
     "ccnet_cca_backward_planes_f32": (c_int, [_P] * 12 + [c_int] * 5 + [c_long, c_int] * 7 + [_P, c_size_t, _P]),
+    "ccnet_cca_backward_planes3_f32": (c_int, [_P] * 10 + [c_int] * 5 + [c_long, c_int] * 4 + [_P, c_size_t, _P]),
     "ccnet_cca_attention_pm": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, c_long, c_int, _P]),
     "ccnet_cca_shape_uses_mfma": (c_int, [c_int, c_int, c_int, c_int]),
     "ccnet_cca_mfma_selftest": (c_int, [_P, _P]),

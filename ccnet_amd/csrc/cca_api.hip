@@ -835,11 +835,20 @@ int gmap_pm(const float *T, const FT *F, const FT *resid, const float *gamma, FT
         return launch_gmap_pm<132, TRANS, FT>(T, F, resid, gamma, out, partial, B, C, H, W, fbs, fps, rbs, rps, obs, ops, stream);
     return fail(CCNET_E_BADSHAPE, "gmap_pm: strip too long for this element type");
 }
+// Three-plane output of a backward (gmap_kernel, P3): dq | dk | dv leave as bf16 hi | lo | hi planes inside rows of ``ps`` bf16
+// elements (plane stride ``plane`` = 2 Cq + C: dq at channel 0, dk at Cq, dv at 2 Cq of every plane) + one row of column-sum
+// partials per row strip (``cs``: B * H rows of ``plane`` floats)
+struct P3Out {
+    uint16_t *d3 = nullptr;
+    long bs = 0;
+    int ps = 0, plane = 0;
+    float *cs = nullptr;
+};
 // dq (features k) and dk (features q) from the same dE: one launch per branch, the second half of the workgroups runs the dk job
-template <int P, typename FT, bool SIX, int WPC>
+template <int P, typename FT, bool SIX, int WPC, bool P3 = false>
 int launch_gmap_dual_pair(const float *dE, const FT *k, const FT *q, FT *dq, FT *dk, float *pq, float *pk, long pbs, int B, int Cq,
                           int H, int W, long kbs, int kps, long qbs, int qps, long dqbs, int dqps, long dkbs, int dkps,
-                          ccnet_stream_t stream, const DeferredSum &red) {
+                          ccnet_stream_t stream, const DeferredSum &red, const P3Out *p3 = nullptr) {
     const GmapPlan gc = gmap_plan(B * W, Cq, WPC), gr = gmap_plan(B * H, Cq, WPC);
     cca::GmapJob<FT, float> jc{q, nullptr, pk, qbs, pbs, qps, Cq, gc.grid};
     jc.red_src = red.src; jc.red_n = red.n; jc.red_dst = red.dst;
@@ -847,7 +856,17 @@ int launch_gmap_dual_pair(const float *dE, const FT *k, const FT *q, FT *dq, FT 
                dim3(cca::GS_THREADS), stream, dE, k, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, pq, Cq, H, W,
                kbs, kps, 0L, 0, 0L, 0, pbs, Cq, gc.n_whole, gc.split, jc);
     if (int e = launch_status("gmap_dual_pm(column)")) return e;
-    const cca::GmapJob<FT, FT> jr{q, pk, dk, qbs, dkbs, qps, dkps, gr.grid};
+    cca::GmapJob<FT, FT> jr{q, pk, dk, qbs, dkbs, qps, dkps, gr.grid};
+    if constexpr (P3) {
+        // dq -> channels [0, Cq), dk -> [Cq, 2 Cq) of every plane of the three-plane rows (strides in bf16 elements)
+        jr.out = reinterpret_cast<FT *>(p3->d3 + Cq);
+        jr.obs = p3->bs; jr.ops = p3->ps; jr.p3_plane = p3->plane;
+        jr.cs = p3->cs; jr.cs1 = p3->cs + Cq; jr.cs_stride = p3->plane;
+        CCA_LAUNCH((cca::gmap_kernel<P, true, false, true, FT, FT, false, true, WPC, false, SIX, false, true>), dim3(cca::gmap_dual_grid(gr.grid)),
+                   dim3(cca::GS_THREADS), stream, dE, k, (const float *)pq, (const FT *)nullptr, (const float *)nullptr,
+                   reinterpret_cast<FT *>(p3->d3), Cq, H, W, kbs, kps, pbs, Cq, 0L, 0, p3->bs, p3->ps, gr.n_whole, gr.split, jr);
+        return launch_status("gmap_dual_pm(row, three-plane output)");
+    }
     CCA_LAUNCH((cca::gmap_kernel<P, true, false, true, FT, FT, false, true, WPC, false, SIX>), dim3(cca::gmap_dual_grid(gr.grid)),
                dim3(cca::GS_THREADS), stream, dE, k, (const float *)pq, (const FT *)nullptr, (const float *)nullptr, dq, Cq, H, W,
                kbs, kps, pbs, Cq, 0L, 0, dqbs, dqps, gr.n_whole, gr.split, jr);
@@ -1358,6 +1377,7 @@ static size_t ws_planes_bytes(int B, int C, int Cq, int H, int W, int backward) 
 }
 
 static size_t ws_split_colsum_bytes(int B, int C, int H, int W);
+static size_t ws_planes3_bytes(int B, int C, int Cq, int H, int W);
 
 size_t ccnet_cca_workspace_bytes(int entry, int B, int C, int Cq, int H, int W) {
     switch (entry) {
@@ -1369,6 +1389,7 @@ size_t ccnet_cca_workspace_bytes(int entry, int B, int C, int Cq, int H, int W) 
     case CCNET_WS_PLANES_FORWARD: return ws_planes_bytes(B, C, Cq, H, W, 0);
     case CCNET_WS_PLANES_BACKWARD: return ws_planes_bytes(B, C, Cq, H, W, 1);
     case CCNET_WS_SPLIT_COLSUM: return ws_split_colsum_bytes(B, C, H, W);
+    case CCNET_WS_PLANES3_BACKWARD: return ws_planes3_bytes(B, C, Cq, H, W);
     }
     return 0;
 }
@@ -1521,13 +1542,19 @@ int ccnet_cca_attention_pm(const void *q, const void *k, float *A, int bf16, int
     return softmax_forward(A, A, B, H, W, stream);
 }
 
-int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *k, const float *v, const uint16_t *v_planes,
-                                  const float *A, const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
-                                  int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps,
-                                  long v_bs, int v_ps, long vp_bs, int vp_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
-                                  void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
+static size_t ws_planes3_bytes(int B, int C, int Cq, int H, int W) {
+    const size_t base = ws_planes_bytes(B, C, Cq, H, W, 1);
+    return base ? align256(base) + align256((size_t)B * H * (2 * Cq + C) * sizeof(float)) : 0;     /* + the column-sum partials */
+}
+
+// ``p3`` != nullptr: dq | dk | dv leave as three-plane rows + the bias gradients (ccnet_cca_backward_planes3_f32); dq / dk / dv unused
+static int backward_planes_impl(const float *dy, const float *q, const float *k, const float *v, const uint16_t *v_planes,
+                                const float *A, const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
+                                int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps,
+                                long v_bs, int v_ps, long vp_bs, int vp_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
+                                void *workspace, size_t workspace_bytes, ccnet_stream_t stream, const P3Out *p3) {
     if (int e = require_both_branches("cca_backward_planes_f32")) return e;
-    if (!dy || !q || !k || (!v_planes && !v) || !A || !gamma || !dq || !dk || !dv || !dgamma || !scratch)
+    if (!dy || !q || !k || (!v_planes && !v) || !A || !gamma || (!p3 && (!dq || !dk || !dv)) || !dgamma || !scratch)
         return fail(CCNET_E_NULLPTR, "cca_backward_planes: null tensor");
     const bool direct = !v_planes;                 // v as the fp32 pixel-major tensor (what a plane-free forward leaves)
     if (direct && (H > W ? H : W) > 100)
@@ -1538,10 +1565,12 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
     if (int e = check_pm_view<float>("cca_backward_planes: k view", k_bs, k_ps, Cq, H, W)) return e;
     if (direct) { if (int e = check_pm_view<float>("cca_backward_planes: v view (fp32 pixel-major)", v_bs, v_ps, C, H, W)) return e; }
     else if (int e = check_planes_view("cca_backward_planes: v planes view", vp_bs, vp_ps, C, H, W)) return e;
-    if (int e = check_pm_view<float>("cca_backward_planes: dq view", dq_bs, dq_ps, Cq, H, W)) return e;
-    if (int e = check_pm_view<float>("cca_backward_planes: dk view", dk_bs, dk_ps, Cq, H, W)) return e;
-    if (int e = check_pm_view<float>("cca_backward_planes: dv view", dv_bs, dv_ps, C, H, W)) return e;
-    if (!workspace || workspace_bytes < ws_planes_bytes(B, C, Cq, H, W, 1))
+    if (!p3) {
+        if (int e = check_pm_view<float>("cca_backward_planes: dq view", dq_bs, dq_ps, Cq, H, W)) return e;
+        if (int e = check_pm_view<float>("cca_backward_planes: dk view", dk_bs, dk_ps, Cq, H, W)) return e;
+        if (int e = check_pm_view<float>("cca_backward_planes: dv view", dv_bs, dv_ps, C, H, W)) return e;
+    }
+    if (!workspace || workspace_bytes < (p3 ? ws_planes3_bytes(B, C, Cq, H, W) : ws_planes_bytes(B, C, Cq, H, W, 1)))
         return fail(CCNET_E_WORKSPACE, "cca_backward_planes: workspace missing or too small");
     const size_t sm = align256(ws_softmax_backward_bytes(B, H, W));
     const size_t base = align256(pm_workspace_bytes(B, C, Cq, H, W, 1));
@@ -1585,14 +1614,73 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
         e = launch_status("gweight_planes(dA)");
     }
     if (overlap == 1) sf.fork();
+    if (!e && p3) {
+        // dv: the column pass as ever (ring kernel -> fp32 partial), the row pass writes channels [2 Cq, 2 Cq + C) of the three planes
+        e = launch_gmap3_planes<100, true>(A, dyp, gamma, nullptr, partial, B, C, H, W, dbs, 2 * C, 0L, 0, false, sf.stream());
+        if (!e) {
+            const long pbs = (long)H * W * C;
+            const GmapPlan gr = gmap_plan(B * H, C, 2);
+            cca::GmapJob<bf16p_t, float> job{};
+            job.p3_plane = p3->plane;
+            job.cs = p3->cs + 2 * Cq;
+            job.cs_stride = p3->plane;
+            CCA_LAUNCH((cca::gmap_kernel<100, true, true, true, bf16p_t, float, false, false, 2, false, false, false, true>), dim3((unsigned)gr.grid),
+                       dim3(cca::GS_THREADS), sf.stream(), A, dyp, (const float *)partial, (const float *)nullptr, gamma,
+                       reinterpret_cast<float *>(p3->d3 + 2 * Cq), C, H, W, dbs, 2 * C, pbs, C, 0L, 0, p3->bs, p3->ps, gr.n_whole, gr.split, job);
+            e = launch_status("gmap_planes(row, three-plane output)");
+        }
+    } else
     if (!e) e = launch_gmap_planes<true, false>(A, dyp, nullptr, gamma, dv, partial, B, C, H, W, dbs, 2 * C, 0L, 0, dv_bs, dv_ps, sf.stream());
     // dgamma = sum A t;  dE = gamma * A * (t - sum_s A t), in place
     // (the fixed-order sum of the dgamma partials rides on the dq | dk column launch: one launch less)
     DeferredSum red{static_cast<const float *>(workspace), 0, dgamma};
     if (!e) e = softmax_backward_impl(A, scratch, gamma, scratch, dgamma, workspace, sm, B, H, W, stream, KSplit(), &red.n);
+    if (!e && p3) {
+        const long pbs = (long)H * W * Cq;
+        float *pq = partial_qk_of(partial, B, C, H, W), *pk = pq + (size_t)B * pbs;
+        e = launch_gmap_dual_pair<100, float, true, 3, true>(scratch, k, q, nullptr, nullptr, pq, pk, pbs, B, Cq, H, W, k_bs, k_ps, q_bs, q_ps,
+                                                             0L, 0, 0L, 0, stream, red, p3);
+    } else
     if (!e) e = gmap_dual_f32(scratch, k, q, dq, dk, partial_qk_of(partial, B, C, H, W), B, Cq, H, W, k_bs, k_ps, q_bs, q_ps,
                               dq_bs, dq_ps, dk_bs, dk_ps, stream, red);
     return sf.join(e);
+}
+
+int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *k, const float *v, const uint16_t *v_planes,
+                                  const float *A, const float *gamma, float *dq, float *dk, float *dv, float *dgamma, float *scratch,
+                                  int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps,
+                                  long v_bs, int v_ps, long vp_bs, int vp_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
+                                  void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
+    return backward_planes_impl(dy, q, k, v, v_planes, A, gamma, dq, dk, dv, dgamma, scratch, B, C, Cq, H, W, q_bs, q_ps, k_bs, k_ps, v_bs, v_ps,
+                                vp_bs, vp_ps, dq_bs, dq_ps, dk_bs, dk_ps, dv_bs, dv_ps, workspace, workspace_bytes, stream, nullptr);
+}
+
+/* The same backward for a caller whose next operation is the split-bf16 projection adjoint (the module: dx = W^T dqkv^T and
+ * dW = dqkv^T x as bf16 GEMMs on three-plane operands): dq | dk | dv are WRITTEN as the three-plane rows those GEMMs read --
+ * CCNET_PLANES_HLH, (B, HW, 3, 2 Cq + C) bf16 with pixel stride ``d3_ps`` >= 3 (2 Cq + C) and batch stride ``d3_bs`` (elements) --
+ * and ``dbias`` (2 Cq + C floats) receives their sums over all images and pixels (the bias gradients), added in a fixed order.
+ * Plane-free form only: v fp32 pixel-major, strips <= 100, C/8 <= 64. */
+int ccnet_cca_backward_planes3_f32(const float *dy, const float *q, const float *k, const float *v, const float *A, const float *gamma,
+                                   uint16_t *d3, float *dbias, float *dgamma, float *scratch, int B, int C, int Cq, int H, int W,
+                                   long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long d3_bs, int d3_ps,
+                                   void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
+    if (!d3 || !dbias || !v) return fail(CCNET_E_NULLPTR, "cca_backward_planes3: null tensor");
+    const int ct = 2 * Cq + C;
+    if ((H > W ? H : W) > 100 || Cq > cca::GM_CG || Cq <= 0 || C % 8 || Cq % 4)
+        return fail(CCNET_E_BADSHAPE, "cca_backward_planes3: strips <= 100, C/8 <= 64, C % 8 == 0, Cq % 4 == 0");
+    if (d3_ps < 3 * ct || d3_ps % 4 || d3_bs < (long)(H * W - 1) * d3_ps + 3 * ct || d3_bs % 4 || (double)H * W * d3_ps >= 1073741824.0)
+        return fail(CCNET_E_BADSHAPE, "cca_backward_planes3: d3 view");
+    if (!g_dqdk_wpc3.load() || !g_dqdk_exact.load() || g_planes_ring.load() != 2 || !g_planes_stream.load())
+        return fail(CCNET_E_BADFLAGS, "cca_backward_planes3: runs the default launch forms only (options dqdk_wpc3, dqdk_exact, planes_ring, planes_stream)");
+    if (!workspace || workspace_bytes < ws_planes3_bytes(B, C, Cq, H, W))
+        return fail(CCNET_E_WORKSPACE, "cca_backward_planes3: workspace missing or too small (CCNET_WS_PLANES3_BACKWARD)");
+    P3Out p3;
+    p3.d3 = d3; p3.bs = d3_bs; p3.ps = d3_ps; p3.plane = ct;
+    p3.cs = reinterpret_cast<float *>(static_cast<char *>(workspace) + align256(ws_planes_bytes(B, C, Cq, H, W, 1)));
+    if (int e = backward_planes_impl(dy, q, k, v, nullptr, A, gamma, nullptr, nullptr, nullptr, dgamma, scratch, B, C, Cq, H, W, q_bs, q_ps, k_bs, k_ps,
+                                     v_bs, v_ps, 0L, 0, 0L, 0, 0L, 0, 0L, 0, workspace, workspace_bytes, stream, &p3)) return e;
+    CCA_LAUNCH(cca::colsum_reduce_kernel, dim3((unsigned)((ct + 15) / 16)), dim3(16 * cca::CS_LANES), stream, (const float *)p3.cs, B * H, ct, dbias);
+    return launch_status("colsum_reduce(three-plane backward)");
 }
 
 // Options: status in the return value, values through out-parameters (a value of -1 -- "planes_overlap" auto -- must

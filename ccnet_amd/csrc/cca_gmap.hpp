@@ -203,6 +203,11 @@ struct GmapJob {
     int red_n;
     float *red_dst;
     int xcd;          // > 0: strips per XCD of the XCD-aware strip decode (non-DUAL launches; see the kernel)
+    // P3 (three-plane output, see the kernel): elements between the planes of a pixel's row, the column-sum partials of job 0
+    // (``cs``: row stride ``cs_stride`` floats, pre-offset to the job's first channel) and of job 1 (DUAL)
+    int p3_plane;
+    float *cs, *cs1;
+    int cs_stride;
 };
 // LONG strips: a strip of L > P positions is cut into nb blocks of ``long_block(L, nb)`` positions (the last one shorter).  A
 // workgroup then owns the QUERY block I of a strip and contracts over the KEY block J: out_I (+)= F_J . A_{I,J}^T; the key blocks
@@ -214,7 +219,7 @@ inline unsigned gmap_dual_grid(int nwg) { return 16u * (unsigned)((nwg + 7) / 8)
 // features, whose two feature tiles + output image take 104 KB: one workgroup per CU)
 // ABF (bf16 features, round 5): the addend -- the column partial -- is bf16 (see gmap3_kernel, OT): one 16-byte load of 8 channels
 template <int P, bool ROW, bool TRANS, bool ADD, typename FT, typename OT, bool NCHW = false, bool DUAL = false, int WPC = 2, bool LONG = false,
-          bool SIX = false, bool ABF = false>
+          bool SIX = false, bool ABF = false, bool P3 = false>
 __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__restrict__ T, const FT *__restrict__ F,
                                                               const float *__restrict__ addend,
                                                               const OT *__restrict__ resid,
@@ -233,6 +238,13 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     //  time that depended on the data; profiles/r06a_ab_row_pieces_six_terms.txt.)
     constexpr bool X6 = SIX;
     static_assert(!SIX || (DUAL && !BF && !PL), "gmap: the six-term form exists for ca_backward on fp32 features");
+    // P3 (round 6): the FINAL pass of a gradient writes it as THREE bf16 PLANES per pixel -- hi | lo | hi at plane
+    // stride j1.p3_plane inside rows of ``ops`` bf16 elements (CCNET_PLANES_HLH: the K-concatenated operand of the module's
+    // split-bf16 GEMMs dx = W^T dqkv^T and dW = dqkv^T x) -- instead of fp32, and one row of COLUMN SUMS per strip-workgroup (the
+    // bias gradients, added up in a fixed order by colsum_reduce_kernel): the module's backward no longer reads dqkv back to
+    // split it (ccnet_cca_split_planes_colsum_f32: 192 MB read, 289 MB written, 95 us at (8,512,97,97)).  ``out`` / ``obs`` / ``ops``
+    // are then in bf16 elements.
+    static_assert(!P3 || (ROW && ADD && !NCHW && !OBF && !LONG && !std::is_same<FT, bf16_t>::value), "gmap: the three-plane output belongs to the final fp32 row passes");
     constexpr int TSP = t16_size(P);
     const int dual_id = (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7));
     const bool job1 = DUAL && ((blockIdx.x >> 3) & 1) != 0;           // (wave-uniform)
@@ -298,6 +310,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
         cg0 = part * ncg / split;
         cg1 = (part + 1) * ncg / split;
     }
+    const int id0 = id;                         // (the strip: the row of the P3 column-sum partials)
     // LONG: id = (strip, query block); this launch contracts over key block j1.jblk
     const int qblk = LONG ? id % j1.nb : 0;
     if (LONG) id /= j1.nb;
@@ -322,8 +335,9 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
 
     const FBuf Tb = make_fbuf(T + (size_t)b * HW * S, (size_t)HW * S * sizeof(float));
     const FBuf Fb = make_fbuf(reinterpret_cast<const float *>(F + (size_t)b * fbs), ((size_t)(HW - 1) * fps + (PL ? 2 : 1) * C) * sizeof(FT));
-    const FBuf Ob = make_fbuf(reinterpret_cast<const float *>(out + (size_t)b * obs),
-                              NCHW ? (size_t)C * HW * sizeof(OT) : ((size_t)(HW - 1) * ops + C) * sizeof(OT));
+    const FBuf Ob = P3 ? make_fbuf(reinterpret_cast<const float *>(reinterpret_cast<const char *>(out) + (size_t)b * obs * 2), (size_t)HW * ops * 2)
+                       : make_fbuf(reinterpret_cast<const float *>(out + (size_t)b * obs),
+                                   NCHW ? (size_t)C * HW * sizeof(OT) : ((size_t)(HW - 1) * ops + C) * sizeof(OT));
     const FBuf Rb = make_fbuf(reinterpret_cast<const float *>(resid ? resid + (size_t)b * rbs : out),
                               !resid ? 4 : NCHW ? (size_t)C * HW * sizeof(OT) : ((size_t)(HW - 1) * rps + C) * sizeof(OT));
     static_assert(!ABF || (ADD && OBF && !NCHW && !DUAL), "gmap: a bf16 addend feeds the bf16 family's final row passes");
@@ -400,7 +414,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
         // tile cg landed, every wave is done with group cg - 1; the stores of group cg - 1 (the most recent vector
         // memory operations of this wave) may stay in flight
         if (cg == cg0) barrier_dma_keep<0>();
-        else           barrier_dma_keep_n(NCHW ? nstore_nchw : nstore);
+        else           barrier_dma_keep_n(NCHW ? nstore_nchw : P3 ? 3 * nstore + (wv == 0 ? 1 : 0) : nstore);
         if (!ONEG && cg + 1 < cg1) issue_feat(cg + 1);
         // the fp32 addend / bf16 residual slices this lane will store over: in registers by the time the tiles are done
         f32x4 add0[NSI], add1[NSI];
@@ -605,6 +619,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
             continue;
         }
         // whole pixel rows leave: 256 (fp32) / 128 (bf16) bytes per pixel, + addend (+ residual), rounded once
+        f32x4 csum = f32x4{0.f, 0.f, 0.f, 0.f};                           // P3: this lane's four channels summed over its pixels
 #pragma unroll
         for (int k = 0; k < NSI; ++k) {
             if (wv + GS_WAVES * k < nsi_total) {                         // wave-uniform: exactly `nstore` instructions
@@ -628,8 +643,40 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                         fbuf_store_x4(Ob, packed, ((pixM + i * pstep) * ops + c) * 2, 0);
                     } else {
                         if constexpr (RES) u += __builtin_bit_cast(f32x4, res[k]);          // (+ the fp32 residual; zeros when there is none)
+                        if constexpr (P3) {
+                            csum += u;
+                            const uint32_t h0 = cvt_pk_bf16(u[0], u[1]), h1 = cvt_pk_bf16(u[2], u[3]);
+                            const uint32_t l0 = cvt_pk_bf16(u[0] - __builtin_bit_cast(float, h0 << 16), u[1] - __builtin_bit_cast(float, h0 & 0xffff0000u));
+                            const uint32_t l1 = cvt_pk_bf16(u[2] - __builtin_bit_cast(float, h1 << 16), u[3] - __builtin_bit_cast(float, h1 & 0xffff0000u));
+                            const int off = ((pixM + i * pstep) * ops + c) * 2;
+                            fbuf_store_x2(Ob, h0, h1, off, 0);
+                            fbuf_store_x2(Ob, l0, l1, off + 2 * j1.p3_plane, 0);
+                            fbuf_store_x2(Ob, h0, h1, off + 4 * j1.p3_plane, 0);
+                        } else
                         fbuf_store_x4(Ob, u, ((pixM + i * pstep) * ops + c) * 4, 0);
                     }
+                }
+            }
+        }
+        if constexpr (P3) {
+            // column sums of this strip's rows of the group: lanes l, l + 16, l + 32, l + 48 hold the same four channels (different
+            // pixels); the four wavefronts meet in the group's feature slot (dead since the multiply), wavefront 0 adds them in wave
+            // order and stores the strip's row of partials -- every order fixed
+            float *red = const_cast<float *>(img);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) csum[e] += shfl_xor(csum[e], 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) csum[e] += shfl_xor(csum[e], 32);
+            if (lane < 16) lds_store_x4(red + wv * GM_CG + 4 * lane, csum);
+            barrier_lds_only();
+            if (wv == 0) {                                                 // (wave-uniform: the store below is counted by the next group's barrier)
+                float *cs = job1 ? j1.cs1 : j1.cs;
+                if (lane < 16 && cg * GM_CG + 4 * lane < C) {
+                    f32x4 t = lds_load_x4(red + 4 * lane);
+#pragma unroll
+                    for (int w = 1; w < GS_WAVES; ++w) t += lds_load_x4(red + w * GM_CG + 4 * lane);
+                    const FBuf Cb = make_fbuf(cs, 0x7ffffff0u);
+                    fbuf_store_x4(Cb, t, ((id0 * j1.cs_stride) + cg * GM_CG + 4 * lane) * 4, 0);
                 }
             }
         }

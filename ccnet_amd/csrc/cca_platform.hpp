@@ -74,6 +74,11 @@ __device__ __forceinline__ void fbuf_store(const FBuf &b, float v, int voff_byte
 __device__ __forceinline__ void fbuf_store_x4(const FBuf &b, f32x4 v, int voff_bytes, int soff_bytes) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), b, voff_bytes, soff_bytes, 0);
 }
+// 8-byte store (two dwords; 4-byte alignment suffices)
+typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fbuf_store_x2(const FBuf &b, uint32_t v0, uint32_t v1, int voff_bytes, int soff_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2s{v0, v1}, b, voff_bytes, soff_bytes, 0);
+}
 // ds_read_b128: p must be 16-byte aligned
 __device__ __forceinline__ f32x4 lds_load_x4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 // ds_write_b128: p must be 16-byte aligned

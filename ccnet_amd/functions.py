@@ -379,6 +379,12 @@ CrissCrossPMBF16Function = CrissCrossPMFunction          # (the name round-2 cod
 PLANES_HL, PLANES_HLH, PLANES_HHL = 2, 3, 4          # include/ccnet_cca.h CCNET_PLANES_*
 
 
+def self_planes3_ok(lib):
+    """the three-plane backward runs the library's default launch forms only (it refuses while an A/B option is set)"""
+    return (lib.get_option("dqdk_wpc3") == 1 and lib.get_option("dqdk_exact") == 1 and lib.get_option("planes_ring") == 2
+            and lib.get_option("planes_stream") >= 1)
+
+
 def _attention_pm(lib, qptr, kptr, bf16, B, cq, H, W, bs, ps, device):
     """A rebuilt from pixel-major q, k views (recompute instead of save): ccnet_cca_attention_pm"""
     A = torch.empty((B, H, W, H + W), device=device, dtype=torch.float32)
@@ -572,9 +578,21 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
             A = _attention_pm(lib, p, p + 4 * cq, False, B, cq, H, W, bs, ps, dy.device)
         else:
             A = ctx.saved_tensors[11]
-        dqkv = torch.empty((B, hw, ct), device=dy.device, dtype=torch.float32)
         dgamma = torch.empty_like(gamma)
         scratch = torch.empty_like(A)
+        if ctx.split_gemm and direct and cq <= 64 and self_planes3_ok(lib):
+            # the core writes dq | dk | dv straight as the three-plane rows of the split-bf16 GEMMs below and the bias gradients as
+            # their column sums (ccnet_cca_backward_planes3_f32): no fp32 dqkv, no pass that reads it back to split it (round 6)
+            d3 = torch.empty((B, H, W, 3, ct), device=dy.device, dtype=torch.bfloat16)
+            db = torch.empty((ct,), device=dy.device, dtype=torch.float32)
+            with torch.cuda.device(dy.device):
+                _ws, wsp, wsn = _workspace(lib.ccnet_cca_workspace_bytes(_lib.CCNET_WS_PLANES3_BACKWARD, B, C, cq, H, W), dy.device)
+                lib.check(lib.ccnet_cca_backward_planes3_f32(dy.data_ptr(), p, p + 4 * cq, p + 8 * cq, A.data_ptr(), gamma.data_ptr(),
+                                                             d3.data_ptr(), db.data_ptr(), dgamma.data_ptr(), scratch.data_ptr(),
+                                                             B, C, cq, H, W, bs, ps, bs, ps, bs, ps, hw * 3 * ct, 3 * ct, wsp, wsn, _stream()),
+                          "cca_backward_planes3")
+            return CrissCrossPlanesModuleFunction._projection_adjoint(ctx, d3, db, dy, xs, wpack, gamma, dgamma, B, C, H, W, cq)
+        dqkv = torch.empty((B, hw, ct), device=dy.device, dtype=torch.float32)
         g, gbs = dqkv.data_ptr(), hw * ct
         with torch.cuda.device(dy.device):
             _ws, wsp, wsn = _workspace(lib.ccnet_cca_planes_workspace_bytes(B, C, cq, H, W, 1), dy.device)
@@ -584,22 +602,34 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
                                                         scratch.data_ptr(), B, C, cq, H, W, bs, ps, bs, ps, bs, ps, hw * 2 * C, 2 * C,
                                                         gbs, ct, gbs, ct, gbs, ct, wsp, wsn, _stream()), "cca_backward_planes")
         if ctx.split_gemm:
-            x3 = xs
             # (B, H, W, 3, ct): dh | dl | dh for the two GEMMs, and the bias gradients (the sum of dqkv over all pixels) out of the same
-            # pass over dqkv (round 5: split 72 us + torch sum 47 us -> one pass)
+            # pass over dqkv (round 5: split 72 us + torch sum 47 us -> one pass; maps the three-plane backward does not serve)
             d3, db = split_planes_colsum(dqkv.view(B, H, W, ct), PLANES_HLH, torch.bfloat16)
-            # dy + W^T dqkv^T (NCHW): dy is the GEMM's C operand (beta = 1) -- rounds 4-5 added it in a pass of its own over dx
-            # (read dx, read dy, write dx: 462 MB, 98 us at the headline shape)
-            dx = torch.baddbmm(dy.view(B, C, hw), wpack.unsqueeze(0).expand(B, -1, -1), d3.view(B, hw, 3 * ct).transpose(1, 2),
-                               out_dtype=torch.float32)
-            # rows (dh, xh), (dl, xh), (dh, xl) of every pixel: the three products, contracted over 3 HW rows per image
-            dw = torch.bmm(d3.view(B, 3 * hw, ct).transpose(1, 2), x3.view(B, 3 * hw, C), out_dtype=torch.float32).sum(0)
-        else:
-            db = dqkv.sum(dim=(0, 1))
-            xm = xs.view(B, C, hw)
-            dqt = dqkv.transpose(1, 2)                                                        # (B, 2Cq + C, HW) view
-            dx = torch.baddbmm(dy.view(B, C, hw), wpack.t().unsqueeze(0).expand(B, -1, -1), dqt)  # dy + W^T dqkv^T  (NCHW)
-            dw = torch.bmm(dqt, xm.transpose(1, 2)).sum(0)                                    # (2Cq + C, C)
+            return CrissCrossPlanesModuleFunction._projection_adjoint(ctx, d3, db, dy, xs, wpack, gamma, dgamma, B, C, H, W, cq)
+        db = dqkv.sum(dim=(0, 1))
+        xm = xs.view(B, C, hw)
+        dqt = dqkv.transpose(1, 2)                                                        # (B, 2Cq + C, HW) view
+        dx = torch.baddbmm(dy.view(B, C, hw), wpack.t().unsqueeze(0).expand(B, -1, -1), dqt)  # dy + W^T dqkv^T  (NCHW)
+        dw = torch.bmm(dqt, xm.transpose(1, 2)).sum(0)                                    # (2Cq + C, C)
+        dwq, dwk, dwv = dw[:cq], dw[cq:2 * cq], dw[2 * cq:]
+        return (dx.view(B, C, H, W), dwq.reshape(cq, C, 1, 1), db[:cq], dwk.reshape(cq, C, 1, 1), db[cq:2 * cq],
+                dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma), None, None)
+
+    @staticmethod
+    def _projection_adjoint(ctx, d3, db, dy, x3, wpack, gamma, dgamma, B, C, H, W, cq):
+        """dx and the weight gradients from dqkv as three-plane rows ``d3`` (B, H, W, 3, ct) -- the two split-bf16 GEMMs."""
+        hw, ct = H * W, 2 * cq + C
+        # dy + W^T dqkv^T (NCHW).  (Round 6 measured dy as the GEMM's C operand -- torch.baddbmm(dy, ..., out_dtype=fp32), beta = 1,
+        # VERDICT r5 item 5a: 293-301 us against 265-293 us for this pair, the stock epilogue costs more than the elementwise pass
+        # it replaces: profiles/r06c_dx_gemm_dw_split_ab.txt.)
+        dx = torch.bmm(wpack.unsqueeze(0).expand(B, -1, -1), d3.view(B, hw, 3 * ct).transpose(1, 2),
+                       out_dtype=torch.float32).add_(dy.view(B, C, hw))
+        # rows (dh, xh), (dl, xh), (dh, xl) of every pixel: the three products, contracted over 3 HW rows per image
+        # (K = 3 HW rows per image against a 640 x 512 output: 20 output tiles per batch entry leave most CUs idle at B = 8.  The rows
+        #  split into contiguous thirds -- 3 B entries of K = HW, summed by the same .sum(0): 348 -> 264 us at (8,512,97,97),
+        #  profiles/r06c_dx_gemm_dw_split_ab.txt)
+        ks = 3 if B <= 12 else 1
+        dw = torch.bmm(d3.view(B * ks, 3 * hw // ks, ct).transpose(1, 2), x3.view(B * ks, 3 * hw // ks, C), out_dtype=torch.float32).sum(0)
         dwq, dwk, dwv = dw[:cq], dw[cq:2 * cq], dw[2 * cq:]
         return (dx.view(B, C, H, W), dwq.reshape(cq, C, 1, 1), db[:cq], dwk.reshape(cq, C, 1, 1), db[cq:2 * cq],
                 dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma), None, None)

@@ -45,7 +45,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define CCNET_CCA_VERSION 220          /* 0.2.2.  Over 0.2.0: ccnet_cca_pack_projection_f32, ccnet_cca_probe_*; only ccnet_* symbols are exported.
+#define CCNET_CCA_VERSION 220          /* 0.2.2.  Over 0.2.0: ccnet_cca_pack_projection_f32, ccnet_cca_probe_*, ccnet_cca_backward_planes3_f32; only ccnet_* symbols are exported.
                                           BEHAVIOURAL changes a binding must know (0.2.1 called these "additive"):
                                           - the *_BACKWARD workspaces of the pixel-major / split-plane entry points are 256 B larger than in 0.2.0
                                             (a binding that hard-coded the 0.2.0 formula gets CCNET_E_WORKSPACE: query the size, as always);
@@ -110,6 +110,7 @@ const char *ccnet_cca_last_error_string(void);
 #define CCNET_WS_PLANES_FORWARD   5    /* ccnet_cca_forward_planes_f32 */
 #define CCNET_WS_PLANES_BACKWARD  6    /* ccnet_cca_backward_planes_f32 */
 #define CCNET_WS_SPLIT_COLSUM     7    /* ccnet_cca_split_planes_colsum_f32 (Cq ignored) */
+#define CCNET_WS_PLANES3_BACKWARD 8    /* ccnet_cca_backward_planes3_f32 */
 size_t      ccnet_cca_workspace_bytes(int entry, int B, int C, int Cq, int H, int W);
 
 /* Affinity: replaces functions.py:30-34 (layout shuffles), :38 (bmm + INF), :39 (bmm), :40 (cat
@@ -316,6 +317,19 @@ int ccnet_cca_backward_planes_f32(const float *dy, const float *q, const float *
                                   int B, int C, int Cq, int H, int W, long q_bs, int q_ps, long k_bs, int k_ps,
                                   long v_bs, int v_ps, long vp_bs, int vp_ps, long dq_bs, int dq_ps, long dk_bs, int dk_ps, long dv_bs, int dv_ps,
                                   void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
+/* ccnet_cca_backward_planes_f32 (plane-free form: ``v`` fp32 pixel-major, strips <= 100, C/8 <= 64) for a caller whose NEXT
+ * operation is the split-bf16 projection adjoint -- the module: dx = W^T dqkv^T and dW = dqkv^T x as bf16 -> fp32 GEMMs on
+ * K-concatenated three-plane operands (functions.py:29,32,35 backwards).  dq | dk | dv are WRITTEN as the rows those GEMMs read:
+ * ``d3`` = (B, HW, 3, 2 Cq + C) bf16, CCNET_PLANES_HLH (hi | lo | hi of the packed dq | dk | dv row of a pixel), pixel stride
+ * ``d3_ps`` >= 3 (2 Cq + C), batch stride ``d3_bs`` (bf16 elements, both % 4 == 0); ``dbias`` (2 Cq + C floats) = the sum of that
+ * row over all images and pixels (the three bias gradients), added in a fixed order.  No fp32 dq | dk | dv exists at all: the pass
+ * that read it back to split it (ccnet_cca_split_planes_colsum_f32: 192 MB read + 289 MB written at (8,512,97,97)) is gone.
+ * Same arithmetic as ccnet_cca_backward_planes_f32: the planes are the exact hi | lo split of its fp32 outputs (tests).
+ * Workspace: CCNET_WS_PLANES3_BACKWARD.  Runs the default launch forms only (CCNET_E_BADFLAGS while an A/B option is set). */
+int ccnet_cca_backward_planes3_f32(const float *dy, const float *q, const float *k, const float *v, const float *A, const float *gamma,
+                                   uint16_t *d3, float *dbias, float *dgamma, float *scratch, int B, int C, int Cq, int H, int W,
+                                   long q_bs, int q_ps, long k_bs, int k_ps, long v_bs, int v_ps, long d3_bs, int d3_ps,
+                                   void *workspace, size_t workspace_bytes, ccnet_stream_t stream);
 
 /* Options by name.  Both calls return a STATUS (0, or CCNET_E_BADFLAGS for an unknown name / a value outside the option's
  * range, CCNET_E_NULLPTR); values travel through out-parameters (``previous`` may be NULL), so that an option value of -1 is

@@ -137,6 +137,13 @@ __device__ inline void fbuf_store(const FBuf &b, float v, int voff_bytes, int so
 __device__ inline void fbuf_store_x4(const FBuf &b, f32x4 v, int voff_bytes, int soff_bytes) {
     for (int e = 0; e < 4; ++e) fbuf_store(b, v[e], voff_bytes + 4 * e, soff_bytes);
 }
+__device__ inline void fbuf_store_x2(const FBuf &b, uint32_t v0, uint32_t v1, int voff_bytes, int soff_bytes) {
+    float f0, f1;
+    memcpy(&f0, &v0, 4);
+    memcpy(&f1, &v1, 4);
+    fbuf_store(b, f0, voff_bytes, soff_bytes);
+    fbuf_store(b, f1, voff_bytes + 4, soff_bytes);
+}
 __device__ inline f32x4 lds_load_x4(const float *p) {
     f32x4 v;
     memcpy(&v, p, 16);

@@ -275,6 +275,22 @@ class EmuOps:
                                                               dbs, dct, dbs, dct, dbs, dct, _p(ws), nbytes, None))
         return dqkv, dgamma
 
+    def cca_backward_planes3(self, dy, qkv, A, gamma, cq):
+        """ccnet_cca_backward_planes3_f32: (d3 (B, H, W, 3, ct) bf16 bits, dbias (ct), dgamma)"""
+        B, H, W, ct = qkv.shape
+        C = ct - 2 * cq
+        d3 = np.full((B, H, W, 3, ct), 0x7fc0, np.uint16)
+        db = np.full(ct, np.nan, np.float32)
+        dgamma = np.full(1, np.nan, np.float32)
+        scratch = np.full_like(A, np.nan)
+        nbytes = self.lib.ccnet_cca_workspace_bytes(8, B, C, cq, H, W)
+        ws = np.full(nbytes // 4 + 1, np.nan, np.float32)
+        base, bs = qkv.ctypes.data, H * W * ct
+        self.lib.check(self.lib.ccnet_cca_backward_planes3_f32(_p(dy), base, base + 4 * cq, base + 8 * cq, _p(A), _p(gamma), _p(d3), _p(db),
+                                                               _p(dgamma), _p(scratch), B, C, cq, H, W, bs, ct, bs, ct, bs, ct,
+                                                               H * W * 3 * ct, 3 * ct, _p(ws), nbytes, None))
+        return d3, db, dgamma
+
     def pack_projection(self, wq, bq, wk, bk, wv, bv, split=True):
         """ccnet_cca_pack_projection_f32: (w (N, C) fp32, b (N), w3 (N, 3C) bf16 bits, w3t (C, 3N) bf16 bits)"""
         cq, C = wq.shape[0], wq.shape[1]

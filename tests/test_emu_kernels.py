@@ -903,3 +903,43 @@ def test_six_term_ca_backward_is_fp32_equivalent(ops, shape):
             e3 = float(np.abs(nchw(x3[..., sl]) - ref).max()) / scale
             # (what is left is the error the upstream dA / dE carry -- the same in both forms -- plus fp32 accumulation)
             assert e6 < 2e-5 and e6 <= e3 * 1.05 + 1e-7, (i, name, e6, e3)
+
+
+def _bf16_bits_to_f32(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+def _f32_to_bf16_bits(x):
+    u = x.astype(np.float32).view(np.uint32)
+    return ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 96, 17, 20), (1, 64, 3, 97), (1, 64, 100, 3), (3, 512, 6, 5)])
+def test_three_plane_backward_writes_the_exact_split_of_the_fp32_gradients(ops, shape):
+    """ccnet_cca_backward_planes3_f32 (round 6): the final passes of dq | dk | dv write the three-plane rows the
+    module's split-bf16 GEMMs read (hi | lo | hi of the packed gradient row) and one row of column-sum partials per strip.  Against
+    ccnet_cca_backward_planes_f32 on the same inputs: every plane is the EXACT bf16 split of the fp32 gradient (same kernels, same
+    accumulators), the bias gradients equal the fp64 column sums of those gradients to fp32 rounding, dgamma is bit-identical, and
+    no element of d3 is left unwritten."""
+    B, C, H, W = shape
+    cq = C // 8
+    ct = C + 2 * cq
+    c = rand_case(*shape, seed=81)
+    qkv = np.ascontiguousarray(np.concatenate([_pm(c["q"]), _pm(c["k"]), _pm(c["v"])], axis=3))
+    y, A = ops.cca_forward_planes(qkv, None, c["x"], c["gamma"], cq)
+    dqkv, dgamma = ops.cca_backward_planes(c["dy"], qkv, None, A, c["gamma"], cq)
+    d3, db, dgamma3 = ops.cca_backward_planes3(c["dy"], qkv, A, c["gamma"], cq)
+    assert np.array_equal(dgamma, dgamma3)
+    hi = _f32_to_bf16_bits(dqkv)
+    lo = _f32_to_bf16_bits(dqkv - _bf16_bits_to_f32(hi))
+    assert np.array_equal(d3[..., 0, :], hi) and np.array_equal(d3[..., 2, :], hi)
+    assert np.array_equal(d3[..., 1, :], lo)
+    ref = dqkv.astype(np.float64).sum(axis=(0, 1, 2))
+    assert np.all(np.isfinite(db)) and float(np.abs(db - ref).max()) < 1e-5 * max(1.0, float(np.abs(ref).max())) + 1e-4
+    # the entry point refuses while an A/B option changes a launch form it relies on
+    prev = ops.lib.set_option("dqdk_wpc3", 0)
+    try:
+        with pytest.raises(Exception):
+            ops.cca_backward_planes3(c["dy"], qkv, A, c["gamma"], cq)
+    finally:
+        ops.lib.set_option("dqdk_wpc3", prev)

@@ -747,7 +747,7 @@ def test_split_plane_core_logit_scale_sweep_at_the_headline_geometry(lib, dev, e
     assert lib.get_option("dqdk_exact") == 1                                 # (the default is the six-term form)
 
 
-@pytest.mark.parametrize("vs,ds", [(4.0, 1.0), (16.0, 1.0), (1.0, 4.0), (1.0, 16.0), (4.0, 4.0)])
+@pytest.mark.parametrize("vs,ds", [(16.0, 1.0), (1.0, 16.0), (4.0, 4.0)])
 def test_split_plane_core_value_and_gradient_scale_sweep_at_the_headline_geometry(lib, dev, vs, ds):
     """the split-bf16 x3 error of y / dv / dA scales with |v| and |dy| exactly as that of dq / dk scales with the
     logits, and only the latter had a sweep.  v ~ N(0, vs^2), dy ~ N(0, ds^2) at the headline geometry, one image through the
@@ -808,9 +808,11 @@ def test_hot_logits_on_maps_beyond_100_positions_hold_the_absolute_bar(lib, dev,
     assert rows["dq"][1] > 64.0                                              # (hot: beyond what the three-term form held)
 
 
-@pytest.mark.parametrize("shape", [(1, 512, 129, 257), (2, 256, 97, 193), (1, 64, 132, 400),
+# (round 6 dropped (2,256,97,193), (1,512,161,321) and (1,64,257,513) from this list: 33 s of CPU oracle for geometry classes the
+#  remaining four -- and the emulator suite's blocked-row / blocked-column cases -- cover)
+@pytest.mark.parametrize("shape", [(1, 512, 129, 257), (1, 64, 132, 400),
                                    # both sides beyond 132 (multi-scale whole-image evaluation, evaluate.py:146-166): blocked column passes too
-                                   (1, 512, 161, 321), (1, 64, 257, 513), (1, 128, 402, 134), (2, 64, 133, 135)])
+                                   (1, 128, 402, 134), (2, 64, 133, 135)])
 def test_long_rows_run_the_plane_kernels_and_match_the_oracle(lib, dev, shape):
     """evaluate.py:102-143,246: whole-image inference puts a 129 x 257 map through the module.  The split-plane path takes such
     rows in blocks of <= 132 positions, forward and backward: y (no_grad and with autograd) against the oracle at the north_star
@@ -859,7 +861,7 @@ def test_long_rows_at_random_geometries_match_the_strip_kernels(lib, dev):
     from ccnet_amd import CrissCrossAttention
     rng = np.random.default_rng(77)
     shapes = [(1, 32, 1, 133), (2, 96, 7, 401), (1, 64, 132, 528), (3, 32, 2, 300), (1, 160, 33, 134)]
-    for _ in range(7):
+    for _ in range(3):
         shapes.append((int(rng.integers(1, 3)), 32 * int(rng.integers(1, 6)), int(rng.integers(1, 40)), int(rng.integers(133, 529))))
     for B, C, H, W in shapes:
         torch.manual_seed(B * 1000 + H * 7 + W)
@@ -1450,3 +1452,37 @@ def test_split_planes_with_column_sums_on_the_device(lib, dev, shape):
     assert float((db.double() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
     d3b, dbb = split_planes_colsum(t, PLANES_HLH, torch.bfloat16)
     assert torch.equal(db, dbb)                                              # fixed-order sums: run-to-run bit-identical
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 64, 20, 24), (8, 512, 97, 97)])
+def test_three_plane_backward_on_the_device(lib, dev, shape):
+    """ccnet_cca_backward_planes3_f32 against ccnet_cca_backward_planes_f32 on the same buffers: the planes are
+    the exact hi | lo | hi split of the fp32 dq | dk | dv, the bias gradients their column sums, dgamma identical -- at the headline
+    shape too, where the dv row pass counts three stores per pixel row (and wavefront 0 one more) under its counted barriers."""
+    import bench
+    from ccnet_amd import _lib as L
+    B, C, H, W = shape
+    cq, ct, hw = C // 8, C + 2 * (C // 8), H * W
+    wl = bench.PlanesWorkload(lib, B, C, H, W, dev, 5)
+    wl.step()
+    torch.cuda.synchronize()
+    dqkv, dgamma = wl.dqkv.clone(), wl.dgamma.clone()
+    d3 = torch.full((B, H, W, 3, ct), float("nan"), device=dev, dtype=torch.bfloat16)
+    db = torch.full((ct,), float("nan"), device=dev)
+    n = lib.ccnet_cca_workspace_bytes(L.CCNET_WS_PLANES3_BACKWARD, B, C, cq, H, W)
+    ws = torch.empty(n // 4 + 64, device=dev)
+    p, bs = wl.qkv.data_ptr(), hw * ct
+    for _ in range(3):                                                        # (repeated: the counted barriers must hold run after run)
+        lib.check(lib.ccnet_cca_backward_planes3_f32(wl.dy.data_ptr(), p, p + 4 * cq, p + 8 * cq, wl.A.data_ptr(), wl.gamma.data_ptr(),
+                                                     d3.data_ptr(), db.data_ptr(), wl.dgamma.data_ptr(), wl.scratch.data_ptr(),
+                                                     B, C, cq, H, W, bs, ct, bs, ct, bs, ct, hw * 3 * ct, 3 * ct, ws.data_ptr(), n,
+                                                     torch.cuda.current_stream().cuda_stream), "cca_backward_planes3")
+    torch.cuda.synchronize()
+    hi = dqkv.to(torch.bfloat16)
+    lo = (dqkv - hi.float()).to(torch.bfloat16)
+    assert torch.equal(d3[..., 0, :], hi.view(B, H, W, ct)) and torch.equal(d3[..., 2, :], hi.view(B, H, W, ct))
+    assert torch.equal(d3[..., 1, :], lo.view(B, H, W, ct))
+    assert torch.equal(wl.dgamma, dgamma)
+    ref = dqkv.double().sum(dim=tuple(range(dqkv.dim() - 1)))
+    assert float((db.double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max())) + 1e-3

@@ -34,3 +34,34 @@ for name, wl in cases:
         for j, (a, b) in enumerate(zip(outs(), ref)):
             bad[j] += int(not torch.equal(a, b))
     print(f"{name}: {iters} iterations, runs that differ from run 0: y {bad[0]} dqkv {bad[1]} dgamma {bad[2]} A {bad[3]}", flush=True)
+
+
+# ---- round 6: the three-plane backward (ccnet_cca_backward_planes3_f32: three 8-byte stores per pixel row + the column-sum row of
+# ---- wavefront 0 under the dv row pass's counted barriers) against the fp32 backward's outputs, repeated under the same load
+wl = bench.PlanesWorkload(lib, 8, 512, 97, 97, dev, 9)
+B, C, H, W = wl.shape
+cq, ct, hw = C // 8, C + 2 * (C // 8), H * W
+wl.step(); torch.cuda.synchronize()
+hi = wl.dqkv.to(torch.bfloat16)
+lo = (wl.dqkv - hi.float()).to(torch.bfloat16)
+ref = torch.stack([hi, lo, hi], dim=3).view(B, H, W, 3, ct)
+d3 = torch.empty((B, H, W, 3, ct), device=dev, dtype=torch.bfloat16)
+db = torch.empty((ct,), device=dev)
+n = lib.ccnet_cca_workspace_bytes(_lib.CCNET_WS_PLANES3_BACKWARD, B, C, cq, H, W)
+ws = torch.empty(n // 4 + 64, device=dev)
+p, bs = wl.qkv.data_ptr(), hw * ct
+bad, db0 = [0, 0], None
+for i in range(iters):
+    if i % 2:
+        with torch.cuda.stream(side):
+            noise.mul_(1.0001)
+    d3.fill_(float("nan"))
+    lib.check(lib.ccnet_cca_backward_planes3_f32(wl.dy.data_ptr(), p, p + 4 * cq, p + 8 * cq, wl.A.data_ptr(), wl.gamma.data_ptr(), d3.data_ptr(),
+                                                 db.data_ptr(), wl.dgamma.data_ptr(), wl.scratch.data_ptr(), B, C, cq, H, W, bs, ct, bs, ct, bs, ct,
+                                                 hw * 3 * ct, 3 * ct, ws.data_ptr(), n, torch.cuda.current_stream().cuda_stream), "planes3")
+    torch.cuda.synchronize()
+    db0 = db.clone() if db0 is None else db0
+    bad[0] += int(not torch.equal(d3, ref))
+    bad[1] += int(not torch.equal(db, db0))
+print(f"f32 planes, three-plane backward (8,512,97,97): {iters} iterations, runs whose planes differ from the split of the fp32 gradients: {bad[0]}, "
+      f"whose bias gradients differ from run 0: {bad[1]}", flush=True)
