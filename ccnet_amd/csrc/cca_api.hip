@@ -68,15 +68,6 @@ std::atomic<int> g_energy_tail{1};          // the fp32 energies launch cuts the
 // logit scale).  (Rounds 4-5: 1 = exact-f32 MFMA, +25 us per launch; 2 = x3 + a statistic + two gated exact launches, 12 us of
 // every step for launches that exit at once and a step time that depended on the data.  Both removed in round 6.)
 std::atomic<int> g_dqdk_exact{1};
-// "dv_row_first" 1: the split-plane backward (plane-free form, strips <= 100) starts with the dv ROW pass reading dy straight from
-// NCHW (a row's positions are contiguous per channel there) -- it leaves the fp32 partial AND dy as bf16 planes, the by-product the
-// column-strip launches need -- and finishes dv with the COLUMN pass; 0 = dy -> planes as a pass of its own, column pass first
-// (rounds 3-5).  -154 MB of traffic per backward.
-std::atomic<int> g_dv_row_first{0};
-// "side_priority" 1: the library's side stream (the dv passes of a backward) is the device's LOWEST-priority stream, so that the
-// chain the step's length depends on -- dy -> planes, dA, softmax backward, dq | dk -- is dispatched first and the dv workgroups
-// fill what it leaves; 0 = a default-priority stream (rounds 3-5)
-std::atomic<int> g_side_priority{0};
 
 int fail(int code, const char *what) {
     char buf[256];
@@ -972,11 +963,11 @@ float *partial_qk_of(float *partial, int B, int C, int H, int W) {
 struct SideFork {
     hipStream_t main, side = nullptr;
     explicit SideFork(ccnet_stream_t m) : main((hipStream_t)m) {}
-    void fork() { if (!side) side = cca_side::fork(main, g_side_priority.load() != 0); }
+    void fork() { if (!side) side = cca_side::fork(main); }
     ccnet_stream_t stream() const { return side ? (ccnet_stream_t)side : (ccnet_stream_t)main; }
     // every path out of the backward joins (a capture must not end forked)
     int join(int e) {
-        if (side && !cca_side::join(main, side) && !e) e = fail(1, "cca_backward: joining the side stream failed");
+        if (side && !cca_side::join(main) && !e) e = fail(1, "cca_backward: joining the side stream failed");
         side = nullptr;
         return e;
     }
@@ -1586,23 +1577,9 @@ static int backward_planes_impl(const float *dy, const float *q, const float *k,
     float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + sm);
     uint16_t *dy_pl = reinterpret_cast<uint16_t *>(static_cast<char *>(workspace) + base);
     const long dbs = (long)H * W * 2 * C;
-    const bf16p_t *dyp = (const bf16p_t *)dy_pl, *vp = (const bf16p_t *)v_planes;
-    const bool row_first = g_dv_row_first.load() != 0 && direct && !p3 && (H > W ? H : W) <= 100;
-    if (row_first) {
-        // the dv ROW pass first, on dy as it arrives (NCHW rows): partial = gamma * (row half), and every tile it reads leaves as
-        // bf16 hi | lo planes as well -- what the pass below used to produce on its own
-        const long pbs = (long)H * W * C;
-        const GmapPlan gr = gmap_plan(B * H, C, 2);
-        cca::GmapJob<cca::nchwf_t, float> job{};
-        job.pl_out = dy_pl; job.pl_bs = dbs; job.pl_ps = 2 * C;
-        if (g_planes_xcd.load() && (B * H) % 8 == 0 && gr.n_whole % 8 == 0) job.xcd = B * H / 8;
-        CCA_LAUNCH((cca::gmap_kernel<100, true, true, false, cca::nchwf_t, float, false, false, 2>), dim3((unsigned)gr.grid), dim3(cca::GS_THREADS),
-                   stream, A, reinterpret_cast<const cca::nchwf_t *>(dy), (const float *)nullptr, (const float *)nullptr, gamma, partial, C, H, W,
-                   (long)C * H * W, 0, 0L, 0, 0L, 0, pbs, C, gr.n_whole, gr.split, job);
-        if (int e = launch_status("gmap_planes(dv row pass on NCHW dy, + planes)")) return e;
-    } else
     // dy (NCHW, the module's gradient) -> planes, once: it is a contraction operand of four launches
     if (int e = ccnet_cca_nchw_to_planes_f32(dy, dy_pl, B, C, H, W, (long)C * H * W, dbs, 2 * C, CCNET_PLANES_HL, stream)) return e;
+    const bf16p_t *dyp = (const bf16p_t *)dy_pl, *vp = (const bf16p_t *)v_planes;
     // dv (two C-sized, HBM-bound passes) is independent of the chain dA -> dE -> dq | dk: it runs on the library's side stream
     // next to that chain and joins before this function returns
     const int overlap = g_planes_overlap.load() < 0 ? 2 : g_planes_overlap.load();
@@ -1652,14 +1629,6 @@ static int backward_planes_impl(const float *dy, const float *q, const float *k,
                        reinterpret_cast<float *>(p3->d3 + 2 * Cq), C, H, W, dbs, 2 * C, pbs, C, 0L, 0, p3->bs, p3->ps, gr.n_whole, gr.split, job);
             e = launch_status("gmap_planes(row, three-plane output)");
         }
-    } else if (!e && row_first) {
-        // ... and the COLUMN pass finishes dv: planes (the by-product above), + the row partial
-        const long pbs = (long)H * W * C;
-        const GmapPlan gc = gmap_plan(B * W, C, 2);
-        CCA_LAUNCH((cca::gmap_kernel<100, false, true, true, bf16p_t, float, false, false, 2>), dim3((unsigned)gc.grid), dim3(cca::GS_THREADS),
-                   sf.stream(), A, dyp, (const float *)partial, (const float *)nullptr, gamma, dv, C, H, W, dbs, 2 * C, pbs, C, 0L, 0,
-                   dv_bs, dv_ps, gc.n_whole, gc.split, cca::GmapJob<bf16p_t, float>{});
-        e = launch_status("gmap_planes(dv column pass, final)");
     } else
     if (!e) e = launch_gmap_planes<true, false>(A, dyp, nullptr, gamma, dv, partial, B, C, H, W, dbs, 2 * C, 0L, 0, dv_bs, dv_ps, sf.stream());
     // dgamma = sum A t;  dE = gamma * A * (t - sum_s A t), in place
@@ -1728,8 +1697,6 @@ const OptionRange *find_word_option(const std::string &n) {
         {"dqdk_wpc3", &g_dqdk_wpc3, 0, 1},
         {"da_stages", &g_da_stages, 2, 3},
         {"dqdk_exact", &g_dqdk_exact, 0, 1},
-        {"dv_row_first", &g_dv_row_first, 0, 1},
-        {"side_priority", &g_side_priority, 0, 1},
         {"bf16_partial", &g_bf16_partial, 0, 1},
     };
     for (const OptionRange &o : table)

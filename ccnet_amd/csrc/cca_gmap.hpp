@@ -106,11 +106,6 @@ __device__ __forceinline__ uint32_t lds_load_u16(const float *base, int byte_off
 // tensor starts C elements later; the pixel stride (elements) is >= 2 C.
 // ---------------------------------------------------------------------------------------------------------------
 struct bf16p_t { uint16_t bits; };
-// NCHW fp32 features of a ROW strip (round 6: the module's gradient dy as it arrives -- a row's positions are contiguous per channel
-// there): the tile is [64 channels][P positions] exactly as the rows lie in memory, 16-byte LDS-DMA lanes, quad Q = 64 piece + lane
-// -> channel Q / (P / 4), positions 4 (Q % (P / 4)) .. + 3.  A fragment (8 consecutive positions of one channel) is two ds_read_b128;
-// with P = 100 or 132 the sixteen channels of a lane group fall 36 resp. 4 banks apart: conflict-free.
-struct nchwf_t { float v; };
 
 // "T16" tile of ONE plane: P positions x 64 channels as 1 KiB pieces of 8 positions x 128 B, no padding.  The 16-byte
 // chunk q of position p sits at chunk slot q ^ (p & 7) ^ (4 * ((p >> 3) & 1)): built for ds_read_b64_tr_b16 fragment
@@ -213,11 +208,6 @@ struct GmapJob {
     int p3_plane;
     float *cs, *cs1;
     int cs_stride;
-    // NCHW features (nchwf_t): the tile of every group also leaves as bf16 hi | lo PLANES (B, HW, 2, C) -- pixel stride pl_ps, batch
-    // stride pl_bs, elements -- for the launches that need the same tensor by COLUMNS (the dy -> planes pass becomes a by-product)
-    uint16_t *pl_out;
-    long pl_bs;
-    int pl_ps;
 };
 // LONG strips: a strip of L > P positions is cut into nb blocks of ``long_block(L, nb)`` positions (the last one shorter).  A
 // workgroup then owns the QUERY block I of a strip and contracts over the KEY block J: out_I (+)= F_J . A_{I,J}^T; the key blocks
@@ -239,8 +229,6 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                                                               GmapJob<FT, OT> j1) {
     constexpr bool BF = GTile<FT>::BF, OBF = std::is_same<OT, bf16_t>::value;
     constexpr bool PL = std::is_same<FT, bf16p_t>::value;             // split planes: hi tile | lo tile, T16 geometry
-    constexpr bool NF = std::is_same<FT, nchwf_t>::value;             // NCHW fp32 rows (see nchwf_t)
-    static_assert(!NF || (ROW && TRANS && !ADD && !NCHW && !DUAL && !LONG && !OBF), "gmap: NCHW features feed the transposed row pass that starts a partial");
     // SIX (option "dqdk_exact", the default of ca_backward on fp32 q | k): every product as the SIX bf16 terms of a three-way split
     // (bf16_split8x3) -- fp32-equivalent (2^-24), where the three-term form leaves ~1.2e-5 of the gradient's magnitude on dq / dk
     // (tests: logit-scale sweep) -- at 3/8 of the matrix time of v_mfma_f32_16x16x4_f32.  The attention block stays in registers
@@ -270,8 +258,8 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     // (16 consecutive positions, the same 4 channels) fall into 16 different bank quads (PMC: 45 % conflict cycles in the dv
     // row pass with the 4-pixel pieces of the feature-tile geometry, whose pad moved the bank once per 4 pixels)
     constexpr int OPX = GM_CG + 4;
-    constexpr int FSZ = NF ? GM_CG * P : PL ? 2 * TSP : GTile<FT>::size(P), OSZ = P * OPX;
-    constexpr int NPF = NF ? (GM_CG * P / 4 + kWave - 1) / kWave : PL ? 2 * t16_pieces(P) : GTile<FT>::pieces(P);
+    constexpr int FSZ = PL ? 2 * TSP : GTile<FT>::size(P), OSZ = P * OPX;
+    constexpr int NPF = PL ? 2 * t16_pieces(P) : GTile<FT>::pieces(P);
     constexpr int SPX = OBF ? 8 : 4;                                  // pixels per store instruction
     constexpr int NSI = NCHW ? 1 : ((P + SPX - 1) / SPX + GS_WAVES - 1) / GS_WAVES;   // store instructions per wave and group (max)
     constexpr int PO = P + 4, OIMG = NCHW ? GM_CG * PO : OSZ;         // NCHW: [channel][position] image, pitch PO
@@ -346,8 +334,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
     const int pixM = pix0 + i0 * pstep, pixK = pix0 + j0 * pstep, aK = a_off + j0, aM = a_off + i0;
 
     const FBuf Tb = make_fbuf(T + (size_t)b * HW * S, (size_t)HW * S * sizeof(float));
-    const FBuf Fb = NF ? make_fbuf(reinterpret_cast<const float *>(F + (size_t)b * fbs), (size_t)C * HW * sizeof(float))
-                       : make_fbuf(reinterpret_cast<const float *>(F + (size_t)b * fbs), ((size_t)(HW - 1) * fps + (PL ? 2 : 1) * C) * sizeof(FT));
+    const FBuf Fb = make_fbuf(reinterpret_cast<const float *>(F + (size_t)b * fbs), ((size_t)(HW - 1) * fps + (PL ? 2 : 1) * C) * sizeof(FT));
     const FBuf Ob = P3 ? make_fbuf(reinterpret_cast<const float *>(reinterpret_cast<const char *>(out) + (size_t)b * obs * 2), (size_t)HW * ops * 2)
                        : make_fbuf(reinterpret_cast<const float *>(out + (size_t)b * obs),
                                    NCHW ? (size_t)C * HW * sizeof(OT) : ((size_t)(HW - 1) * ops + C) * sizeof(OT));
@@ -362,11 +349,7 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
 
     auto issue_feat = [&](int cg) {
         for (int it = wv; it < NPF; it += GS_WAVES) {
-            if constexpr (NF) {
-                const int Q = kWave * it + lane, ch = Q / (P / 4), quad = Q - ch * (P / 4), c = cg * GM_CG + ch;
-                fbuf_load_to_lds_x4_uncounted(Fb, FB + ((cg - cg0) & 1) * FSZ + it * 256,
-                                              (ch < GM_CG && c < C && 4 * quad < Lk) ? (c * HW + pixK + 4 * quad) * 4 : kOobOffset);
-            } else if constexpr (PL) {
+            if constexpr (PL) {
                 const int plane = it >= NPF / 2;
                 t16_dma_piece(Fb, FB + ((cg - cg0) & 1) * FSZ + plane * TSP, it - plane * (NPF / 2), lane, pixK, pstep, Lk, fps,
                               cg * GM_CG, C, plane ? C : 0);
@@ -433,25 +416,6 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
         if (cg == cg0) barrier_dma_keep<0>();
         else           barrier_dma_keep_n(NCHW ? nstore_nchw : P3 ? 3 * nstore + (wv == 0 ? 1 : 0) : nstore);
         if (!ONEG && cg + 1 < cg1) issue_feat(cg + 1);
-        if constexpr (NF) {
-            // the tile as bf16 hi | lo planes: task t = 8 pixel + chunk (8 channels), lanes of a pixel store 128 contiguous bytes per plane.
-            // Issued BEFORE the group's result stores: the next group's counted barrier (which keeps only those in flight) covers them.
-            if (j1.pl_out) {                                               // (wave-uniform)
-                const FBuf Pb = make_fbuf(reinterpret_cast<const float *>(j1.pl_out + (size_t)b * j1.pl_bs), (size_t)HW * j1.pl_ps * 2);
-                const int ntask = 8 * Lk;
-                for (int t0 = kWave * wv; t0 < ntask; t0 += GS_THREADS) {   // (wave-uniform bound: an issued store has its first lane in range)
-                    const int t = t0 + lane, px = t >> 3, c8 = 8 * (t & 7), c = cg * GM_CG + c8;
-                    const bool ok = t < ntask && c < C;
-                    float x[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] = CCA_LDS_LD(img + (c8 + e) * P + (ok ? px : 0));
-                    const BfSplit sp = bf16_split8(x);
-                    const int off = ((pixK + px) * j1.pl_ps + c) * 2;
-                    fbuf_store_x4(Pb, __builtin_bit_cast(f32x4, sp.hi), ok ? off : kOobOffset, 0);
-                    fbuf_store_x4(Pb, __builtin_bit_cast(f32x4, sp.lo), ok ? off + 2 * C : kOobOffset, 0);
-                }
-            }
-        }
         // the fp32 addend / bf16 residual slices this lane will store over: in registers by the time the tiles are done
         f32x4 add0[NSI], add1[NSI];
         u32x4 res[NSI];
@@ -560,13 +524,6 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                             for (int e = 0; e < 8; ++e) x[e] = lds_load_u16(img, gtile_bf_byte(32 * ks + 8 * lg + e, 16 * nt + ln));
                             fb.hi = u32x4{x[0] | (x[1] << 16), x[2] | (x[3] << 16), x[4] | (x[5] << 16), x[6] | (x[7] << 16)};
                             fb.lo = fb.hi;
-                        } else if constexpr (NF) {
-                            const int pos = 32 * ks + 8 * lg;
-                            const f32x4 u = lds_load_x4(img + (16 * nt + ln) * P + pos), v = lds_load_x4(img + (16 * nt + ln) * P + pos + 4);
-                            float x[8];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { x[e] = pos + e < Lk ? u[e] : 0.f; x[4 + e] = pos + 4 + e < Lk ? v[e] : 0.f; }   // (beyond the row: the next row's values)
-                            fb = bf16_split8(x);
                         } else {
                             float x[8];
 #pragma unroll
@@ -593,11 +550,6 @@ __global__ __launch_bounds__(GS_THREADS, WPC) void gmap_kernel(const float *__re
                     if constexpr (PL) fbv = __builtin_bit_cast(float, lds_load_u16(img, t16_byte(pos, 16 * nt + ln)) << 16)
                                           + __builtin_bit_cast(float, lds_load_u16(img + TSP, t16_byte(pos, 16 * nt + ln)) << 16);
                     else if constexpr (BF) fbv = __builtin_bit_cast(float, lds_load_u16(img, gtile_bf_byte(pos, 16 * nt + ln)) << 16);
-                    else if constexpr (NF) {              // (hi + lo of the value, what the plane tiles hold: the same bits as the pass on planes)
-                        const float raw = CCA_LDS_LD(img + (16 * nt + ln) * P + (pos < P ? pos : 0)), xv = pos < Lk ? raw : 0.f;
-                        const float h = __builtin_bit_cast(float, cvt_pk_bf16(xv, 0.f) << 16);
-                        fbv = h + __builtin_bit_cast(float, cvt_pk_bf16(xv - h, 0.f) << 16);
-                    }
                     else              fbv = CCA_LDS_LD(img + gtile_f32_idx(pos, 16 * nt + ln));
 #pragma unroll
                     for (int a = 0; a < TPW; ++a)

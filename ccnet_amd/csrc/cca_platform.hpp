@@ -232,7 +232,7 @@ inline int end(float *ms, char *names, int name_stride, int cap, const char **wh
 // only: under stream capture the side stream joins the capture and comes back before it ends, i.e. the step stays one graph.
 namespace cca_side {
 struct Dev {
-    hipStream_t s = nullptr, s_lo = nullptr;      // default priority | the device's LOWEST priority (option "side_priority")
+    hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
 // ``may_create`` false: hand out the device's side stream only if it exists already (a stream must not be created while the
@@ -246,18 +246,15 @@ inline Dev *dev_state(bool may_create = true) {
     Dev &v = devs[d];
     if (!v.s && !may_create) return nullptr;
     if (!v.s) {
-        hipStream_t s = nullptr, lo = nullptr;
+        hipStream_t s = nullptr;
         hipEvent_t f = nullptr, j = nullptr;
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
-        if (hipStreamCreateWithPriority(&lo, hipStreamNonBlocking, least) != hipSuccess) { (void)hipGetLastError(); lo = nullptr; }
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&f, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&j, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             return nullptr;
         }
-        v.fork = f; v.join = j; v.s = s; v.s_lo = lo ? lo : s;
+        v.fork = f; v.join = j; v.s = s;
     }
     return &v;
 }
@@ -267,24 +264,23 @@ inline Dev *dev_state(bool may_create = true) {
 // both callers, and a join waits for all side work enqueued so far.)
 inline std::mutex &pair_lock() { static std::mutex mu; return mu; }
 // nullptr when the side stream cannot be had (the caller then stays on its own stream)
-inline hipStream_t fork(hipStream_t main, bool low_priority = false) {
+inline hipStream_t fork(hipStream_t main) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(main, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
     Dev *v = dev_state(cap == hipStreamCaptureStatusNone);      // first use inside a capture: stay on the caller's stream
     if (!v) return nullptr;
     std::lock_guard<std::mutex> lock(pair_lock());
-    const hipStream_t side = low_priority ? v->s_lo : v->s;
-    if (hipEventRecord(v->fork, main) != hipSuccess || hipStreamWaitEvent(side, v->fork, 0) != hipSuccess) {
+    if (hipEventRecord(v->fork, main) != hipSuccess || hipStreamWaitEvent(v->s, v->fork, 0) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
-    return side;
+    return v->s;
 }
-inline bool join(hipStream_t main, hipStream_t side) {
+inline bool join(hipStream_t main) {
     Dev *v = dev_state();
     if (!v) return false;
     std::lock_guard<std::mutex> lock(pair_lock());
-    return hipEventRecord(v->join, side) == hipSuccess && hipStreamWaitEvent(main, v->join, 0) == hipSuccess;
+    return hipEventRecord(v->join, v->s) == hipSuccess && hipStreamWaitEvent(main, v->join, 0) == hipSuccess;
 }
 }  // namespace cca_side
 

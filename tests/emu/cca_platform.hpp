@@ -200,8 +200,8 @@ inline int end(float *, char *, int, int, const char **why) { *why = "profile_en
 
 // the emulator runs every launch to completion: there is nothing to overlap, the "side stream" is the caller's
 namespace cca_side {
-inline hipStream_t fork(hipStream_t, bool = false) { return nullptr; }
-inline bool join(hipStream_t, hipStream_t) { return true; }
+inline hipStream_t fork(hipStream_t) { return nullptr; }
+inline bool join(hipStream_t) { return true; }
 }  // namespace cca_side
 
 inline int cca_current_device_cus() { return 0; }      // the host default (256) applies

@@ -943,25 +943,3 @@ def test_three_plane_backward_writes_the_exact_split_of_the_fp32_gradients(ops, 
             ops.cca_backward_planes3(c["dy"], qkv, A, c["gamma"], cq)
     finally:
         ops.lib.set_option("dqdk_wpc3", prev)
-
-
-@pytest.mark.parametrize("shape", [(2, 64, 5, 6), (1, 96, 17, 20), (1, 64, 3, 97), (1, 64, 100, 3), (8, 64, 5, 7), (1, 512, 6, 5), (2, 160, 4, 9)])
-def test_dv_row_pass_on_nchw_dy_with_the_planes_as_a_by_product(ops, shape):
-    """Option "dv_row_first" (round 6): the backward starts with the dv ROW pass reading dy straight from NCHW
-    rows -- it leaves the partial and, as a by-product, dy as bf16 hi | lo planes for the column-strip launches (dA, the dv column
-    pass, which now finishes dv) -- instead of transposing dy into planes in a pass of its own.  Same products in the same order, and
-    a + b = b + a: dq | dk | dv and dgamma bit-identical to the column-first form.  ((8,64,5,7): the XCD-aware strip decode.)"""
-    B, C, H, W = shape
-    cq = C // 8
-    c = rand_case(*shape, seed=83)
-    qkv = np.ascontiguousarray(np.concatenate([_pm(c["q"]), _pm(c["k"]), _pm(c["v"])], axis=3))
-    y, A = ops.cca_forward_planes(qkv, None, c["x"], c["gamma"], cq)
-    outs = []
-    for opt in (0, 1):
-        prev = ops.lib.set_option("dv_row_first", opt)
-        try:
-            outs.append(ops.cca_backward_planes(c["dy"], qkv, None, A, c["gamma"], cq))
-        finally:
-            ops.lib.set_option("dv_row_first", prev)
-    assert np.all(np.isfinite(outs[1][0]))
-    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])

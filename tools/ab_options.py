@@ -24,21 +24,17 @@ DEFAULT_SETS = {
     "dA-3-stages-1s": {"da_stages": 3, "planes_overlap": 0},    # the energies launch as one workgroup per strip (2.02 rounds -> three)
     "one-stream": {"planes_overlap": 0},
     "overlap-1": {"planes_overlap": 1},
-    "side-low-priority": {"side_priority": 1},   # round 6: the dv passes on the device's lowest-priority stream
-    "side-low-priority+row-first": {"side_priority": 1, "dv_row_first": 1},
-    "dv-row-first": {"dv_row_first": 1},     # round 6: the dv ROW pass first, on NCHW dy, the planes as its by-product (no dy -> planes pass)
-    "dv-column-first": {"dv_row_first": 0},  # rounds 3-5: dy -> planes as a pass of its own, the dv column pass first
     "dqdk-three-terms": {"dqdk_exact": 0},   # ca_backward with three bf16 terms per product instead of six (round 6 default: six, fp32-equivalent)
     "ring-2-per-cu": {"planes_ring": 1},     # the column ring passes with three slots and TWO workgroups per CU (slow-box A/B)
 }
 if "--sets" in sys.argv:
     keep = sys.argv[sys.argv.index("--sets") + 1].split(",")
     DEFAULT_SETS = {k: v for k, v in DEFAULT_SETS.items() if k in keep or k == "default"}
-DETAIL = ("one-stream", "dqdk-three-terms", "dv-row-first", "dv-column-first")
+DETAIL = ("one-stream", "dqdk-three-terms")
 lib = _lib.get_lib()
 dev = torch.device("cuda:0")
 BASE = {"planes_ring": 2, "planes_stream": 1, "planes_overlap": -1, "planes_xcd": 1, "energy_tail": 1, "da_stages": 2, "dqdk_wpc3": 1,
-        "dqdk_exact": 1, "dv_row_first": lib.get_option("dv_row_first"), "side_priority": lib.get_option("side_priority")}
+        "dqdk_exact": 1}
 wl = bench.PlanesWorkload(lib, B, C, H, W, dev, 1234)
 ref = None
 for rnd in range(2):                       # two rounds: the order of the sets must not matter
