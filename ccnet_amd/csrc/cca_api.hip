@@ -889,6 +889,9 @@ int launch_gmap_dual_pm(const float *dE, const FT *k, const FT *q, FT *dq, FT *d
         }
         return six ? CCA_DUAL_PAIR(true, 2) : CCA_DUAL_PAIR(false, 2);
     } else {
+        // (bf16 q | k on the one-group / three-workgroups-per-CU form, its row pass's accumulators starting from the partial -- 162 / 165
+        //  VGPRs at 132 positions, no spills -- measured SLOWER at configs[4]: dq | dk 130 + 120 -> 140 + 143 us, step 1.732 -> 1.743-1.753 ms,
+        //  profiles/r06g_bf16_dqdk_three_per_cu_ab.txt; not kept)
         return CCA_DUAL_PAIR(false, 2);
     }
 #undef CCA_DUAL_PAIR
@@ -1472,30 +1475,6 @@ int ccnet_cca_pack_projection_f32(const float *wq, const float *bq, const float 
     return launch_status("pack_projection");
 }
 
-// functions.py:42-49 given the attention tensor: aggregation + epilogue (the second half of the fused forward)
-static int aggregate_planes_impl(const char *name, const float *A, const float *v, const float *v_bias, uint16_t *v_planes,
-                                 const float *x, const float *gamma, float *y, int B, int C, int H, int W,
-                                 long v_bs, int v_ps, long vp_bs, int vp_ps, void *workspace, size_t workspace_bytes, ccnet_stream_t stream) {
-    (void)name;
-    const bool direct = !v_planes;                 // v stays the fp32 tensor it is: no planes, no split pass
-    if (direct && ((H > W ? H : W) > 100 || v_bias))
-        return fail(CCNET_E_BADSHAPE, "cca_forward_planes: the plane-free form (v_planes == NULL) serves strips <= 100 without a bias");
-    if (v) if (int e = check_pm_view<float>("cca_forward_planes: v view (fp32 pixel-major)", v_bs, v_ps, C, H, W)) return e;
-    if (!direct) if (int e = check_planes_view("cca_forward_planes: v planes view", vp_bs, vp_ps, C, H, W)) return e;
-    if ((double)C * H * W >= 536870912.0) return fail(CCNET_E_BADSHAPE, "cca_forward_planes: image exceeds 2^29 elements");
-    if (!workspace || workspace_bytes < ws_planes_bytes(B, C, C / 8 > 0 ? C / 8 : 1, H, W, 0))
-        return fail(CCNET_E_WORKSPACE, "cca_forward_planes: workspace missing or too small");
-    // v (fp32, the value slice of the projection) -> planes, inside the entry point (every pass the op needs belongs to
-    // the op).  On the caller's stream: running it on the side stream NEXT TO the affinity launch was measured and lost
-    // (fwd 0.334 -> 0.346 ms, three launch orders / a capped grid: profiles/r04m_ab_two_stage_lds_staging.txt, "split-*" rows).
-    if (v && !direct)
-        if (int e = ccnet_cca_split_planes_f32(v, v_planes, B, C, H, W, v_bs, v_ps, vp_bs, vp_ps, CCNET_PLANES_HL, v_bias, stream)) return e;
-    const long img = (long)C * H * W;
-    if (direct) return launch_gmap_direct_f32(A, v, x, gamma, y, (float *)workspace, B, C, H, W, v_bs, v_ps, img, img, stream);
-    return launch_gmap_planes<false, true>(A, (const bf16p_t *)v_planes, x, gamma, y, (float *)workspace, B, C, H, W, vp_bs, vp_ps,
-                                           img, 0, img, 0, stream);
-}
-
 int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v, const float *v_bias, uint16_t *v_planes,
                                  const float *x, const float *gamma, float *y, float *A,
                                  int B, int C, int Cq, int H, int W,
@@ -1518,8 +1497,15 @@ int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v,
     if ((double)C * H * W >= 536870912.0) return fail(CCNET_E_BADSHAPE, "cca_forward_planes: image exceeds 2^29 elements");
     if (int e = gweight_energies_f32(q, k, A, B, Cq, H, W, q_bs, q_ps, k_bs, k_ps, stream)) return e;
     if (int e = softmax_forward(A, A, B, H, W, stream)) return e;
-    return aggregate_planes_impl("cca_forward_planes", A, v, v_bias, v_planes, x, gamma, y, B, C, H, W, v_bs, v_ps, vp_bs, vp_ps,
-                                 workspace, workspace_bytes, stream);
+    // functions.py:42-49: aggregation + epilogue.  Longer strips: v (fp32, the value slice of the projection) -> planes first, inside the
+    // entry point (every pass the op needs belongs to the op), on the caller's stream: running it on the side stream NEXT
+    // TO the affinity launch was measured and lost (fwd 0.334 -> 0.346 ms: profiles/r04m_ab_two_stage_lds_staging.txt, "split-*" rows).
+    if (v && !direct)
+        if (int e = ccnet_cca_split_planes_f32(v, v_planes, B, C, H, W, v_bs, v_ps, vp_bs, vp_ps, CCNET_PLANES_HL, v_bias, stream)) return e;
+    const long img = (long)C * H * W;
+    if (direct) return launch_gmap_direct_f32(A, v, x, gamma, y, (float *)workspace, B, C, H, W, v_bs, v_ps, img, img, stream);
+    return launch_gmap_planes<false, true>(A, (const bf16p_t *)v_planes, x, gamma, y, (float *)workspace, B, C, H, W, vp_bs, vp_ps,
+                                           img, 0, img, 0, stream);
 }
 
 /* The attention tensor alone from pixel-major q, k views (what the pixel-major / split-plane forwards leave in ``A``): the host
