@@ -528,8 +528,11 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
             #  against 0.618-0.621 ms in the same run, inside the spread; kill criterion (-40 us) missed, removed.
             #  profiles/r05g_module_fwd_ab.txt, commits 743958e..ecb3563.)
             x3 = nchw_to_planes(x, PLANES_HHL, torch.bfloat16)                              # (B, H, W, 3, C): xh | xh | xl
-            if direct:                      # the whole bias in the GEMM's epilogue
-                qkv = torch.addmm(pc["b"], x3.view(B * hw, 3 * C), pc["w3"], out_dtype=torch.float32).view(B, hw, ct)
+            if direct:
+                # the bias as an in-place pass of its own: the stock GEMM's bias epilogue (torch.addmm, rounds 3-5) costs MORE than the
+                # elementwise pass it saves -- 285-318 us against 199-209 us for the bare product + 60 us for the add at (8,512,97,97),
+                # profiles/r06h_fwd_gemm_bias_ab.txt (the same finding as beta = 1 on the dx GEMM, r06c)
+                qkv = torch.mm(x3.view(B * hw, 3 * C), pc["w3"], out_dtype=torch.float32).add_(pc["b"]).view(B, hw, ct)
                 v_bias = None
             else:
                 qkv = torch.mm(x3.view(B * hw, 3 * C), pc["w3"], out_dtype=torch.float32).view(B, hw, ct)
