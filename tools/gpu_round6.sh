@@ -54,6 +54,25 @@ pmcbf16)
   find "$R/gpurun_out/pmc_${TAG}_bf16" -name "*.csv" -size +5M -delete 2>/dev/null;;
 dxab)
   echo "== dx GEMM A/B"; timeout 300 python tools/probes/dx_gemm_ab.py > "$OUT/dx_gemm_ab.txt" 2>&1; cat "$OUT/dx_gemm_ab.txt";;
+xprobe)
+  echo "== XCD exchange probe"; timeout 300 tools/probes/xcd_exchange_probe 16 20 > "$OUT/xcd_exchange_probe.txt" 2>&1; cat "$OUT/xcd_exchange_probe.txt"
+  cd /tmp && export TMPDIR=/tmp
+  for grp in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/xprobe_$grp" -- "$R/tools/probes/xcd_exchange_probe" 16 3 > "$OUT/xprobe_$grp.log" 2>&1; echo "pmc $grp rc=$?"
+  done
+  cd "$R"
+  python3 - "$OUT" <<'PY' | tee -a "$OUT/xcd_exchange_probe.txt"
+import csv, glob, sys, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(sys.argv[1] + "/xprobe_*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        agg[row["Kernel_Name"].split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for k, d in sorted(agg.items()):
+    if "k<" not in k: continue
+    f, w = d.get("FETCH_SIZE", [0]), d.get("WRITE_SIZE", [0])
+    print(f"PMC per launch {k}: fetch 2 x {sum(f) / len(f) / 1024:.1f} MiB (doubled as in tools/traffic_from_pmc.py), write {sum(w) / len(w) / 1024:.1f} MiB")
+PY
+  ;;
 module)
   echo "== module, small batches"; timeout 600 python tools/module_small_batch.py > "$OUT/module_small_batches.txt" 2>&1; tail -6 "$OUT/module_small_batches.txt";;
 stress)
