@@ -8,6 +8,7 @@
 #include "cca_common.hpp"
 #include "cca_direct.hpp"
 #include "cca_gmap.hpp"
+#include "cca_gemm.hpp"
 #include "cca_map.hpp"
 #include "cca_long.hpp"
 #include "cca_softmax.hpp"
@@ -1473,6 +1474,26 @@ int ccnet_cca_pack_projection_f32(const float *wq, const float *bq, const float 
     const unsigned gx = (unsigned)((items + 255) / 256 < 2048 ? (items + 255) / 256 : 2048);
     CCA_LAUNCH(cca::pack_projection_kernel, dim3(gx), dim3(256), stream, wq, wk, wv, bq, bk, bv, w, b, w3, w3t, C, Cq);
     return launch_status("pack_projection");
+}
+
+/* functions.py:29,32,35 as one stacked GEMM on bf16 operands with fp32 accumulation and output (cca_gemm.hpp):
+ * out[m][n] = sum_k a[m][k] * wt[n][k] + bias[n].  ``a``: (M, K) bf16, row stride lda; ``wt``: (N, K) bf16, row stride ldw; ``out``:
+ * (M, N) fp32, row stride ldo (elements; K, lda, ldw % 8 == 0, ldo % 4 == 0); ``bias`` may be NULL. */
+int ccnet_cca_projection_bf16(const uint16_t *a, const uint16_t *wt, const float *bias, float *out, int M, int N, int K,
+                              long lda, long ldw, long ldo, ccnet_stream_t stream) {
+    if (!a || !wt || !out) return fail(CCNET_E_NULLPTR, "projection_bf16: null tensor");
+    if (M <= 0 || N <= 0 || K <= 0 || K % 8 || lda % 8 || ldw % 8 || ldo % 4 || lda < K || ldw < K || ldo < N)
+        return fail(CCNET_E_BADSHAPE, "projection_bf16: K, lda, ldw % 8 == 0, ldo % 4 == 0, strides >= extents");
+    if ((double)M * lda >= 1073741824.0 || (double)N * ldw >= 1073741824.0 || (double)M * ldo >= 536870912.0)
+        return fail(CCNET_E_BADSHAPE, "projection_bf16: 31-bit byte offsets");
+    const unsigned grid = (unsigned)(((M + cca::PG_BM - 1) / cca::PG_BM) * ((N + cca::PG_BN - 1) / cca::PG_BN));
+    if (K % cca::PG_BK)
+        CCA_LAUNCH(cca::proj_gemm_kernel<true>, dim3(grid), dim3(cca::PG_THREADS), stream, (const cca::bf16_t *)a, (const cca::bf16_t *)wt,
+                   bias, out, M, N, K, (int)lda, (int)ldw, (int)ldo);
+    else
+        CCA_LAUNCH(cca::proj_gemm_kernel<false>, dim3(grid), dim3(cca::PG_THREADS), stream, (const cca::bf16_t *)a, (const cca::bf16_t *)wt,
+                   bias, out, M, N, K, (int)lda, (int)ldw, (int)ldo);
+    return launch_status("projection_bf16");
 }
 
 int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v, const float *v_bias, uint16_t *v_planes,

@@ -1,0 +1,172 @@
+// cca_gemm.hpp -- the module's forward projection (functions.py:29,32,35 as ONE stacked GEMM) as a hand-written MFMA kernel:
+//
+//     out[m][n] = sum_k A[m][k] * Wt[n][k] + bias[n]        A  (M, K) bf16, row stride lda   (x as three planes per pixel: K = 3 C)
+//                                                           Wt (N, K) bf16, row stride ldw   (the packed weight rows [wh | wl | wh])
+//                                                           out (M, ldo) fp32                (the pixel-major q | k | v the core reads)
+//
+// VERDICT r5 item 5c.  The stock bf16 -> fp32 GEMM runs this tall-skinny product (M = 75 272, N = 640, K = 1536) at 199-213 us
+// and its bias epilogue costs more than a pass of its own (285-330 us with it, 260-269 us as product + in-place add,
+// profiles/r06h_fwd_gemm_bias_ab.txt, r06n_fwd_gemm_ab.txt).  Here: both operands are K-contiguous, i.e. exactly the plane tiles of
+// cca_gmap.hpp (T16 geometry: 1 KiB LDS-DMA pieces of 8 rows x 64 k, fragments = one ds_read_b128 per lane) and the contraction is
+// gweight_kernel's with a large tile: workgroup = 256 x 128 outputs, 8 wavefronts of 64 x 64 (4 x 4 MFMA tiles of 16 x 16,
+// v_mfma_f32_16x16x32_bf16: 32 MFMAs per wavefront and 64-wide k step against 16 fragment reads; two wavefronts per SIMD, so one's
+// address / fill / wait instructions issue under the other's MFMAs), three LDS stages of 48 KiB.  The MFMA operands are SWAPPED
+// (D^T = Wt . A^T) so that a lane ends with four consecutive n of one m: the bias starts the accumulators and the results leave as
+// 16-byte stores straight from them, 256 contiguous bytes per row and wavefront.  Workgroup ids are decoded XCD-contiguously with
+// the N tiles of an M tile adjacent: the second to fifth read of an A tile is an L2 hit.
+//
+// The loop is a register ping-pong: a k step is two half steps of 16 MFMAs; the 8 fragment reads of the NEXT half step are
+// requested before the MFMAs of the current one (reads and waits outside the compiler's bookkeeping, cca_platform.hpp: across
+// the back edge hipcc waits for ALL tracked reads), and the stage barrier sits between the two halves -- by then every wavefront
+// holds its whole stage in registers, so the stage's slot is refilled at once and two stages (96 KiB) are in flight while one is
+// multiplied.  The fill is six instructions per wavefront whose per-lane offsets are loop invariants (rows clamped to the matrix:
+// tail rows are computed on a valid row's data and never stored), issued in the shadow of the second half's first MFMAs.
+//
+// Measured (profiles/r06n_gemm_elimination.txt): 199-206 us with the bias, i.e. the stock product's time without it.  By
+// elimination at this shape the kernel is bound by its LDS fill -- fills + barriers alone take 183 us (1.7 GB into LDS: 48 KiB per
+// workgroup and k step with 96 KiB in flight per CU against the loaded fetch latency), the MFMAs alone 117 us -- which is
+// where the stock kernel sits too; an L2 prefetch by a ninth wavefront made it slower (273-283 us: twice the requests), four
+// wavefronts of 128 x 64 with the same pipeline 206-230 us.
+#pragma once
+#include "cca_gmap.hpp"
+
+namespace cca {
+
+constexpr int PG_BM = 256, PG_BN = 128, PG_BK = 64, PG_THREADS = 512, PG_WAVES = PG_THREADS / kWave;
+constexpr int PG_APIECES = PG_BM / 8, PG_BPIECES = PG_BN / 8;                  // 1 KiB pieces of 8 rows x 64 k (bf16)
+constexpr int PG_STAGE = (PG_APIECES + PG_BPIECES) * T16_PIECE;                // dwords per stage (A tile | B tile)
+constexpr int PG_NBUF = 3;                                                     // 144 KiB
+constexpr int PG_NPA = PG_APIECES / PG_WAVES, PG_NPB = PG_BPIECES / PG_WAVES, PG_NPW = PG_NPA + PG_NPB;   // fill instructions per wavefront and stage
+
+template <bool KTAIL>
+__global__ __launch_bounds__(PG_THREADS, 1) void proj_gemm_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ Wt,
+                                                                  const float *__restrict__ bias, float *__restrict__ out,
+                                                                  int M, int N, int K, int lda, int ldw, int ldo) {
+    __shared__ __attribute__((aligned(16))) float lds[PG_NBUF * PG_STAGE];
+    CCA_LDS_REGISTER(lds);
+    const int ntn = (N + PG_BN - 1) / PG_BN;
+    const int lid = xcd_logical_id((int)blockIdx.x, (int)gridDim.x);
+    const int m0 = (lid / ntn) * PG_BM, n0 = (lid % ntn) * PG_BN;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
+    const int ln = lane & 15, lg = lane >> 4;
+    const int wm = wv >> 1, wn = wv & 1;                                       // this wavefront: rows wm * 64 .., columns wn * 64 ..
+    const FBuf Ab = make_fbuf(reinterpret_cast<const float *>(A), ((size_t)(M - 1) * lda + K) * 2);
+    const FBuf Wb = make_fbuf(reinterpret_cast<const float *>(Wt), ((size_t)(N - 1) * ldw + K) * 2);
+    const FBuf Ob = make_fbuf(out, ((size_t)(M - 1) * ldo + N) * sizeof(float));
+    const int nk = (K + PG_BK - 1) / PG_BK;
+
+    // fill: wavefront wv moves A pieces wv, wv + 4, .. and Wt pieces wv, wv + 4, ..; lane = (row lane >> 3 of the piece, LDS chunk
+    // slot lane & 7), which holds the row's 16-byte k chunk slot ^ row (t16_byte<false>)
+    int offa[PG_NPA], offb[PG_NPB];
+    {
+        const int pr = lane >> 3, q = (lane & 7) ^ pr;
+#pragma unroll
+        for (int p = 0; p < PG_NPA; ++p) {
+            const int r = m0 + 8 * (wv + PG_WAVES * p) + pr;
+            offa[p] = ((r < M ? r : M - 1) * lda + 8 * q) * 2;
+        }
+#pragma unroll
+        for (int p = 0; p < PG_NPB; ++p) {
+            const int r = n0 + 8 * (wv + PG_WAVES * p) + pr;
+            offb[p] = ((r < N ? r : N - 1) * ldw + 8 * q) * 2;
+        }
+    }
+    const int kq = 8 * ((lane & 7) ^ (lane >> 3));                             // first k of this lane's chunk within a stage
+    auto piece = [&](int it, int slot, int i) {                                // fill instruction i of PG_NPW (A pieces first)
+        float *as = lds + slot * PG_STAGE + wv * T16_PIECE;
+        // (KTAIL, a K that is no multiple of 64: chunks past the end of a row are fetched out of range = zeros)
+        const bool dead = KTAIL && it * PG_BK + kq >= K;
+        const int koff = it * PG_BK * 2;
+        if (i < PG_NPA) fbuf_load_to_lds_x4_uncounted(Ab, as + PG_WAVES * i * T16_PIECE, dead ? kOobOffset : offa[i] + koff);
+        else            fbuf_load_to_lds_x4_uncounted(Wb, as + (PG_APIECES + PG_WAVES * (i - PG_NPA)) * T16_PIECE,
+                                                      dead ? kOobOffset : offb[i - PG_NPA] + koff);
+    };
+    auto issue = [&](int it, int slot) {
+#pragma unroll
+        for (int i = 0; i < PG_NPW; ++i) piece(it, slot, i);
+    };
+    // fragments of one half step kk (32 k): 8 consecutive k of one row = one 16-byte read; chunk 4 kk + lg of a row lies 64 kk bytes
+    // from chunk lg, XORed (t16_byte<false>), the next 16 rows 2 KiB further
+    const int fra = t16_byte<false>(wm * 64 + ln, 8 * lg), frb = t16_byte<false>(wn * 64 + ln, 8 * lg) + PG_APIECES * T16_PIECE * 4;
+    auto read = [&](u32x4 (&bf)[4], u32x4 (&af)[4], int slot, int kk) {
+        const char *st = reinterpret_cast<const char *>(lds + slot * PG_STAGE);
+        const char *pb = st + (frb ^ (64 * kk)), *pa = st + (fra ^ (64 * kk));
+        bf[0] = lds_read_x4_uncounted<0>(pb);     bf[1] = lds_read_x4_uncounted<2048>(pb);
+        bf[2] = lds_read_x4_uncounted<4096>(pb);  bf[3] = lds_read_x4_uncounted<6144>(pb);
+        af[0] = lds_read_x4_uncounted<0>(pa);     af[1] = lds_read_x4_uncounted<2048>(pa);
+        af[2] = lds_read_x4_uncounted<4096>(pa);  af[3] = lds_read_x4_uncounted<6144>(pa);
+    };
+
+    // D^T[n][m]: lane (ln, lg) of tile (t, j) holds columns n0 + wn * 64 + 16 j + 4 lg .. + 3 of row m0 + wm * 64 + 16 t + ln
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + 16 * j + 4 * lg;
+        f32x4 b4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b4[q] = (bias && n + q < N) ? bias[n + q] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t][j] = b4;
+    }
+
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk > 2) issue(2, 2);
+    if (nk > 2)       barrier_dma_keep<2 * PG_NPW>();                         // stage 0 landed
+    else if (nk > 1)  barrier_dma_keep<PG_NPW>();
+    else              barrier_dma_keep<0>();
+    u32x4 b0[4], a0[4], b1[4], a1[4];
+    read(b0, a0, 0, 0);
+    int slot = 0;
+    for (int it = 0; it < nk; ++it) {
+        const int next = slot == PG_NBUF - 1 ? 0 : slot + 1;
+        read(b1, a1, slot, 1);
+        lds_wait_keep<8>(b0, a0);                  // the first half's fragments are here, the second half's on their way
+        sched_fence();                              // (the order is the pipeline: hipcc would otherwise regroup reads and MFMAs)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t][j] = mfma_bf16_16x16x32(b0[j], a0[t], acc[t][j]);
+        sched_fence();
+        const bool fill = it + 3 < nk;
+        if (it + 1 < nk) {
+            // stage it + 1 landed and every wavefront holds stage `it` in registers: its slot takes stage it + 3 at once; the
+            // fill of stage it + 2 (this wavefront's newest vector-memory operations) stays in flight
+            if (it + 2 < nk) barrier_dma_keep<PG_NPW>();
+            else             barrier_dma_keep<0>();
+        }
+        read(b0, a0, next, 0);                      // (after the last stage: eight reads of a dead slot that nobody uses)
+        lds_wait_keep<8>(b1, a1);
+        sched_fence();
+        // second half; the fill instructions of stage it + 3 ride in the shadow of its first MFMAs
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[t][j] = mfma_bf16_16x16x32(b1[j], a1[t], acc[t][j]);
+                if (4 * t + j < PG_NPW) {
+                    if (fill) piece(it + 3, slot, 4 * t + j);
+                    sched_fence();
+                }
+            }
+        sched_fence();
+        slot = next;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int m = m0 + wm * 64 + 16 * t + ln;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + 16 * j + 4 * lg;
+            if (n + 3 < N) {
+                fbuf_store_x4(Ob, acc[t][j], m < M ? (m * ldo + n) * 4 : kOobOffset, 0);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (n + q < N) fbuf_store(Ob, acc[t][j][q], m < M ? (m * ldo + n + q) * 4 : kOobOffset, 0);
+            }
+        }
+    }
+}
+
+}  // namespace cca

@@ -42,6 +42,9 @@ __device__ __forceinline__ void mfma_f32_result_fence() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// scheduling fence: the compiler may not move instructions across it (it still places the s_waitcnt each use needs)
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
 // tell the compiler a value is wave-uniform (it is: derived from the wave id) so it lives in SGPRs
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -122,6 +125,25 @@ __device__ __forceinline__ void fbuf_load_to_lds_x4_uncounted(const FBuf &b, flo
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff_bytes), "s"(lds_addr), "s"(b) : "memory");
+}
+
+// LDS reads outside the compiler's lgkmcnt bookkeeping, for a register ping-pong (cca_gemm.hpp): across a loop back edge hipcc
+// waits with lgkmcnt(0) before the first use of ANY tracked read -- also for the reads of the NEXT half step requested just
+// before, which are the ones the MFMAs are supposed to hide.  The kernel waits itself: lds_wait_keep<N>() returns once at
+// most N of this wave's LDS reads are outstanding (they return in order) and carries the fragment registers as operands,
+// so no use of them can be scheduled above it.
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read_x4_uncounted(const void *p) {
+    const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF) : "memory");
+    return r;
+}
+template <int KEEP>
+__device__ __forceinline__ void lds_wait_keep(u32x4 (&b)[4], u32x4 (&a)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])
+                 : "n"(KEEP) : "memory");
 }
 
 // Workgroup barrier that orders LDS traffic only: waits for this wave's LDS operations (lgkmcnt) but NOT for

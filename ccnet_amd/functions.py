@@ -487,6 +487,23 @@ def _pack_projection(wq, bq, wk, bk, wv, bv, split):
     return val
 
 
+def _projection_gemm(lib, a, wt, bias):
+    """``a @ wt.T + bias`` on bf16 operands, fp32 accumulation and output, by ``ccnet_cca_projection_bf16`` (functions.py:29,32,35 of
+    the reference as one stacked GEMM).  ``a``: (M, K) and ``wt``: (N, K), both K-contiguous.  None when the shape is outside the
+    entry point's contract (K % 8, N % 4, 31-bit byte offsets) -- the caller then uses the stock GEMM."""
+    M, K = a.shape
+    N = wt.shape[0]
+    if K % 8 or N % 4 or a.stride(1) != 1 or wt.stride(1) != 1 or a.stride(0) % 8 or wt.stride(0) % 8:
+        return None
+    if M * a.stride(0) >= 1 << 30 or N * wt.stride(0) >= 1 << 30 or M * N >= 1 << 29:
+        return None
+    out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    with torch.cuda.device(a.device):
+        lib.check(lib.ccnet_cca_projection_bf16(a.data_ptr(), wt.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K,
+                                                a.stride(0), wt.stride(0), N, _stream()), "projection_bf16")
+    return out
+
+
 class CrissCrossPlanesModuleFunction(torch.autograd.Function):
     """The whole module as ONE autograd node on the SPLIT-PLANE path (fp32, no autocast), the module's own tensors NCHW:
     the stacked projection is the GEMM ``x^T W^T`` whose (B, HW, 2Cq + C) output holds the pixel-major q | k | v; the core's
@@ -528,17 +545,14 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
             #  against 0.618-0.621 ms in the same run, inside the spread; kill criterion (-40 us) missed, removed.
             #  profiles/r05g_module_fwd_ab.txt, commits 743958e..ecb3563.)
             x3 = nchw_to_planes(x, PLANES_HHL, torch.bfloat16)                              # (B, H, W, 3, C): xh | xh | xl
-            if direct:
-                # the bias as an in-place pass of its own: the stock GEMM's bias epilogue (torch.addmm, rounds 3-5) costs MORE than the
-                # elementwise pass it saves -- 285-318 us against 199-209 us for the bare product + 60 us for the add at (8,512,97,97),
-                # profiles/r06h_fwd_gemm_bias_ab.txt (the same finding as beta = 1 on the dx GEMM, r06c)
-                qkv = torch.mm(x3.view(B * hw, 3 * C), pc["w3"], out_dtype=torch.float32).add_(pc["b"]).view(B, hw, ct)
-                v_bias = None
-            else:
-                qkv = torch.mm(x3.view(B * hw, 3 * C), pc["w3"], out_dtype=torch.float32).view(B, hw, ct)
-                # the bias without a pass over the whole output: q | k in place (a fifth of it), v where its slice is split
-                qkv[..., :2 * cq].add_(pc["bqk"])
-                v_bias = pc["bv"]
+            # the library's own GEMM (csrc/cca_gemm.hpp, round 6): bias in the accumulators, 199-206 us at (8,512,97,97) against
+            # 260-264 us for the stock product + an in-place bias pass and 285-318 us for the stock bias epilogue (torch.addmm, rounds
+            # 3-5) -- profiles/r06n_fwd_gemm_ab.txt, r06h_fwd_gemm_bias_ab.txt.  Shapes it does not take fall back to the stock pair.
+            qkv = _projection_gemm(lib, x3.view(B * hw, 3 * C), pc["w3"].t(), pc["b"])
+            if qkv is None:
+                qkv = torch.mm(x3.view(B * hw, 3 * C), pc["w3"], out_dtype=torch.float32).add_(pc["b"])
+            qkv = qkv.view(B, hw, ct)
+            v_bias = None
         else:
             qkv = torch.baddbmm(pc["b"].view(1, 1, -1), x.view(B, C, hw).transpose(1, 2), pc["w"].t().unsqueeze(0).expand(B, -1, -1))
             v_bias = None

@@ -301,6 +301,13 @@ int ccnet_cca_nchw_to_planes_f32(const float *src, uint16_t *dst, int B, int C, 
  * updates; a 3 us launch cannot be). */
 int ccnet_cca_pack_projection_f32(const float *wq, const float *bq, const float *wk, const float *bk, const float *wv, const float *bv,
                                   float *w, float *b, uint16_t *w3, uint16_t *w3t, int C, int Cq, ccnet_stream_t stream);
+/* The module's forward projection (functions.py:29,32,35 as ONE stacked GEMM) as a hand-written MFMA kernel (csrc/cca_gemm.hpp):
+ * out[m][n] = sum_k a[m][k] * wt[n][k] + bias[n], bf16 operands, fp32 accumulation and output.  ``a`` (M, K) row stride lda -- x as
+ * three bf16 planes per pixel (ccnet_cca_nchw_to_planes_f32, CCNET_PLANES_HHL: K = 3 C) --, ``wt`` (N, K) row stride ldw -- ``w3`` of
+ * ccnet_cca_pack_projection_f32 --, ``out`` (M, N) row stride ldo: the pixel-major q | k | v the core reads; ``bias`` (N) or NULL
+ * starts the accumulators (no epilogue pass).  K, lda, ldw % 8 == 0, ldo % 4 == 0 (elements). */
+int ccnet_cca_projection_bf16(const uint16_t *a, const uint16_t *wt, const float *bias, float *out, int M, int N, int K,
+                              long lda, long ldw, long ldo, ccnet_stream_t stream);
 int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v, const float *v_bias, uint16_t *v_planes,
                                  const float *x, const float *gamma, float *y, float *A,
                                  int B, int C, int Cq, int H, int W,

@@ -63,6 +63,8 @@ __device__ inline void short_sleep() {}
 __device__ inline int xcc_id() { return 0; }
 __device__ inline void atomic_max_u32(unsigned *p, uint32_t v) { if (v > *p) *p = v; }
 __device__ inline void mfma_f32_result_fence() {}
+__device__ inline void sched_fence() {}
+
 __device__ inline void wait_vmem_all() {}
 __device__ inline int uniform(int v) { return v; }
 __device__ inline int recompute_here(int v) { return v; }
@@ -178,6 +180,15 @@ __device__ inline u32x2 lds_read_tr16_b64(const void *p) {
     }
     return u32x2{(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16)};
 }
+
+template <int OFF>
+__device__ inline u32x4 lds_read_x4_uncounted(const void *p) {
+    u32x4 r;
+    memcpy(&r, (const char *)p + OFF, 16);
+    return r;
+}
+template <int KEEP>
+__device__ inline void lds_wait_keep(u32x4 (&)[4], u32x4 (&)[4]) {}
 
 __device__ inline void barrier_lds_only() { __syncthreads(); }
 template <int KEEP>

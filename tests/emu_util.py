@@ -291,6 +291,14 @@ class EmuOps:
                                                                H * W * 3 * ct, 3 * ct, _p(ws), nbytes, None))
         return d3, db, dgamma
 
+    def projection_bf16(self, a_bits, wt_bits, bias):
+        """ccnet_cca_projection_bf16: a (M, K) / wt (N, K) uint16 bf16 bits, bias (N) fp32 or None -> out (M, N) fp32"""
+        M, K = a_bits.shape
+        N = wt_bits.shape[0]
+        out = np.full((M, N), np.nan, np.float32)
+        self.lib.check(self.lib.ccnet_cca_projection_bf16(_p(a_bits), _p(wt_bits), _p(bias), _p(out), M, N, K, K, K, N, None))
+        return out
+
     def pack_projection(self, wq, bq, wk, bk, wv, bv, split=True):
         """ccnet_cca_pack_projection_f32: (w (N, C) fp32, b (N), w3 (N, 3C) bf16 bits, w3t (C, 3N) bf16 bits)"""
         cq, C = wq.shape[0], wq.shape[1]

@@ -1486,3 +1486,71 @@ def test_three_plane_backward_on_the_device(lib, dev, shape):
     assert torch.equal(wl.dgamma, dgamma)
     ref = dqkv.double().sum(dim=tuple(range(dqkv.dim() - 1)))
     assert float((db.double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max())) + 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mnk", [(37, 24, 72), (300, 136, 192), (1000, 640, 1536), (8 * 97 * 97, 640, 1536), (4 * 33 * 65, 80, 192)])
+def test_projection_gemm_on_the_device(lib, dev, mnk):
+    """ccnet_cca_projection_bf16 (csrc/cca_gemm.hpp; functions.py:29,32,35 of the reference as one stacked GEMM): bf16 operands are
+    exact in fp64, so the reference is the fp64 product -- the kernel's only error is its fp32 accumulation (tolerance 2e-6 of
+    sum_k |a||w| per output, the bound for K <= 1536 terms added in MFMA order).  Shapes: a K tail (72 = 64 + 8), M and N tails,
+    the module's shape at (8,512,97,97) and at a small map; strided operands; repeated launches (counted barriers); no bias."""
+    M, N, K = mnk
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    lda, ldw, ldo = K + 8, K + 16, N + 4
+    a = torch.zeros((M, lda), dtype=torch.bfloat16)
+    a[:, :K] = torch.randn((M, K), generator=g).to(torch.bfloat16)
+    a[:, K:] = float("nan")                                                   # (padding columns must never be read into a product)
+    w = torch.zeros((N, ldw), dtype=torch.bfloat16)
+    w[:, :K] = torch.randn((N, K), generator=g).to(torch.bfloat16)
+    w[:, K:] = float("nan")
+    bias = torch.randn((N,), generator=g)
+    a, w, bias = a.to(dev), w.to(dev), bias.to(dev)
+    out = torch.full((M, ldo), float("nan"), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        lib.check(lib.ccnet_cca_projection_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, lda, ldw, ldo, st),
+                  "projection_bf16")
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out[:, N:]).all())                                # nothing written past N
+    rows = slice(0, M) if M <= 4096 else torch.cat([torch.arange(0, 2048), torch.arange(M - 2048, M)]).to(dev)
+    ad, wd = a[rows, :K].double(), w[:, :K].double()
+    ref = ad @ wd.T + bias.double()
+    bound = 2e-6 * (ad.abs() @ wd.abs().T + bias.double().abs()) + 1e-30
+    assert bool(((out[rows, :N].double() - ref).abs() <= bound).all())
+    out2 = torch.empty((M, N), device=dev)
+    lib.check(lib.ccnet_cca_projection_bf16(a.data_ptr(), w.data_ptr(), None, out2.data_ptr(), M, N, K, lda, ldw, N, st), "projection_bf16")
+    torch.cuda.synchronize()
+    assert bool(((out2[rows].double() - (ref - bias.double())).abs() <= bound).all())
+    # contract: K, lda, ldw % 8, ldo % 4
+    assert lib.ccnet_cca_projection_bf16(a.data_ptr(), w.data_ptr(), None, out2.data_ptr(), M, N, K, lda + 1, ldw, N, st) != 0
+    assert lib.ccnet_cca_projection_bf16(a.data_ptr(), w.data_ptr(), None, out2.data_ptr(), M, N, K, lda, ldw, N + 2, st) != 0
+
+
+@pytest.mark.gpu
+def test_module_forward_runs_the_library_gemm(lib, dev):
+    """The split-plane module forward projects with ccnet_cca_projection_bf16: its output equals the stock product of the same
+    three-plane operands + bias to fp32 accumulation order (2e-6 relative to sum |x||w|), and the module's output with it matches
+    the module's output with the stock pair inside the route's own tolerance."""
+    from ccnet_amd import functions as F
+    B, C, H, W = 2, 64, 20, 24
+    cq, hw = C // 8, H * W
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn((B, C, H, W), generator=g).to(dev)
+    ps = [torch.randn(s, generator=g).to(dev) * 0.2 for s in ((cq, C), (cq,), (cq, C), (cq,), (C, C), (C,))]
+    gamma = torch.tensor([0.7], device=dev)
+    pc = F._pack_projection(*ps, True)
+    x3 = F.nchw_to_planes(x, F.PLANES_HHL, torch.bfloat16).view(B * hw, 3 * C)
+    got = F._projection_gemm(lib, x3, pc["w3"].t(), pc["b"])
+    assert got is not None
+    ref = x3.double() @ pc["w3"].double() + pc["b"].double()
+    bound = 2e-6 * (x3.double().abs() @ pc["w3"].double().abs() + pc["b"].double().abs()) + 1e-30
+    assert bool(((got.double() - ref).abs() <= bound).all())
+    y = F.CrissCrossPlanesModuleFunction.apply(x, *ps, gamma, True, False)
+    keep = F._projection_gemm
+    try:
+        F._projection_gemm = lambda *a: None                                  # the stock pair
+        y0 = F.CrissCrossPlanesModuleFunction.apply(x, *ps, gamma, True, False)
+    finally:
+        F._projection_gemm = keep
+    assert float((y - y0).abs().max()) <= 2e-5 * float(y0.abs().max())

@@ -52,6 +52,8 @@ pmcbf16)
   echo "== PMC passes (bf16 configs[4] step)"; bash tools/pmc.sh "${TAG}_bf16" --script tools/pm_bf16_time.py > "$OUT/pmc_bf16.log" 2>&1; tail -2 "$OUT/pmc_bf16.log"
   cp "$R/gpurun_out/pmc_${TAG}_bf16/summary.json" "$OUT/bf16_config5_pmc_summary.json" 2>/dev/null
   find "$R/gpurun_out/pmc_${TAG}_bf16" -name "*.csv" -size +5M -delete 2>/dev/null;;
+fwdab)
+  echo "== forward projection GEMM A/B"; timeout 300 python tools/probes/fwd_gemm_ab.py > "$OUT/fwd_gemm_ab.txt" 2>&1; cat "$OUT/fwd_gemm_ab.txt";;
 dxab)
   echo "== dx GEMM A/B"; timeout 300 python tools/probes/dx_gemm_ab.py > "$OUT/dx_gemm_ab.txt" 2>&1; cat "$OUT/dx_gemm_ab.txt";;
 xprobe)

@@ -24,6 +24,20 @@ variants = {
     "bmm over B entries, no bias": lambda: torch.bmm(x3.view(B, hw, 3 * C), w3.unsqueeze(0).expand(B, -1, -1), out_dtype=torch.float32),
     "addmm on a contiguous weight": None,
 }
+from ccnet_amd import _lib  # noqa: E402
+lib = _lib.get_lib()
+wt = w3.t()                                                               # (ct, 3C) contiguous: the packed buffer itself
+assert wt.is_contiguous()
+out_hw = torch.empty(B * hw, ct, device=dev)
+
+
+def handwritten():
+    lib.check(lib.ccnet_cca_projection_bf16(x3.data_ptr(), wt.data_ptr(), bias.data_ptr(), out_hw.data_ptr(), B * hw, ct, 3 * C,
+                                            3 * C, 3 * C, ct, torch.cuda.current_stream().cuda_stream), "projection_bf16")
+    return out_hw
+
+
+variants["hand-written MFMA GEMM, bias in the accumulators (csrc/cca_gemm.hpp)"] = handwritten
 w3c = w3.contiguous()
 variants["addmm on a contiguous weight"] = lambda: torch.addmm(bias, x3, w3c, out_dtype=torch.float32)
 ref = None
@@ -36,6 +50,6 @@ for rnd in range(2):
             if ref is None:
                 ref = r.view(B * hw, ct).clone()
             err = float((r.view(B * hw, ct) - ref).abs().max())
-            print(f"round {rnd}: {name:48s} {bench.time_region(f, 30) * 1e3:8.1f} us   max |diff| vs first {err:.2e}", flush=True)
+            print(f"round {rnd}: {name:72s} {bench.time_region(f, 30) * 1e3:8.1f} us   max |diff| vs first {err:.2e}", flush=True)
         except Exception as e:
-            print(f"round {rnd}: {name:48s} failed: {e}", flush=True)
+            print(f"round {rnd}: {name:72s} failed: {e}", flush=True)
