@@ -1476,6 +1476,14 @@ int ccnet_cca_pack_projection_f32(const float *wq, const float *bq, const float 
     return launch_status("pack_projection");
 }
 
+static int launch_proj_gemm(const cca::ProjGemmJob &job, const char *what, ccnet_stream_t stream) {
+    const long tiles = (long)((job.M + cca::PG_BM - 1) / cca::PG_BM) * ((job.N + cca::PG_BN - 1) / cca::PG_BN) * job.batches;
+    if (tiles >= 2147483647L) return fail(CCNET_E_BADSHAPE, "projection GEMM: too many tiles");
+    if (job.K % cca::PG_BK) CCA_LAUNCH(cca::proj_gemm_kernel<true>, dim3((unsigned)tiles), dim3(cca::PG_THREADS), stream, job);
+    else                    CCA_LAUNCH(cca::proj_gemm_kernel<false>, dim3((unsigned)tiles), dim3(cca::PG_THREADS), stream, job);
+    return launch_status(what);
+}
+
 /* functions.py:29,32,35 as one stacked GEMM on bf16 operands with fp32 accumulation and output (cca_gemm.hpp):
  * out[m][n] = sum_k a[m][k] * wt[n][k] + bias[n].  ``a``: (M, K) bf16, row stride lda; ``wt``: (N, K) bf16, row stride ldw; ``out``:
  * (M, N) fp32, row stride ldo (elements; K, lda, ldw % 8 == 0, ldo % 4 == 0); ``bias`` may be NULL. */
@@ -1486,14 +1494,24 @@ int ccnet_cca_projection_bf16(const uint16_t *a, const uint16_t *wt, const float
         return fail(CCNET_E_BADSHAPE, "projection_bf16: K, lda, ldw % 8 == 0, ldo % 4 == 0, strides >= extents");
     if ((double)M * lda >= 1073741824.0 || (double)N * ldw >= 1073741824.0 || (double)M * ldo >= 536870912.0)
         return fail(CCNET_E_BADSHAPE, "projection_bf16: 31-bit byte offsets");
-    const unsigned grid = (unsigned)(((M + cca::PG_BM - 1) / cca::PG_BM) * ((N + cca::PG_BN - 1) / cca::PG_BN));
-    if (K % cca::PG_BK)
-        CCA_LAUNCH(cca::proj_gemm_kernel<true>, dim3(grid), dim3(cca::PG_THREADS), stream, (const cca::bf16_t *)a, (const cca::bf16_t *)wt,
-                   bias, out, M, N, K, (int)lda, (int)ldw, (int)ldo);
-    else
-        CCA_LAUNCH(cca::proj_gemm_kernel<false>, dim3(grid), dim3(cca::PG_THREADS), stream, (const cca::bf16_t *)a, (const cca::bf16_t *)wt,
-                   bias, out, M, N, K, (int)lda, (int)ldw, (int)ldo);
-    return launch_status("projection_bf16");
+    cca::ProjGemmJob job{(const cca::bf16_t *)a, (const cca::bf16_t *)wt, bias, nullptr, out, M, N, K, (int)lda, (int)ldw, (int)ldo, 1, 0, 0, 0};
+    return launch_proj_gemm(job, "projection_bf16", stream);
+}
+
+/* The adjoint of the stacked projection with respect to its input (the backward-data of functions.py:29,32,35), NCHW:
+ * dx[b][c][p] = sum_k w[c][k] * d[b][p][k] + add[b][c][p] -- ``w`` (C, K) bf16 row stride ldw_ (``w3t`` of ccnet_cca_pack_projection_f32,
+ * K = 3 (2 Cq + C)), ``d`` (B, P, K) bf16, pixel stride ldd, batch stride d_bs (dq | dk | dv as three planes per pixel,
+ * ccnet_cca_backward_planes3_f32), ``add`` (B, C, P) fp32 or NULL (dy: the residual branch), ``dx`` (B, C, P) fp32, both contiguous.
+ * The same kernel as ccnet_cca_projection_bf16, one launch over B products; the addend starts the accumulators. */
+int ccnet_cca_projection_adjoint_bf16(const uint16_t *w, const uint16_t *d, const float *add, float *dx, int B, int C, int P, int K,
+                                      long ldw_, long ldd, long d_bs, ccnet_stream_t stream) {
+    if (!w || !d || !dx) return fail(CCNET_E_NULLPTR, "projection_adjoint_bf16: null tensor");
+    if (B <= 0 || C <= 0 || P <= 0 || K <= 0 || K % 8 || ldw_ % 8 || ldd % 8 || d_bs % 8 || ldw_ < K || ldd < K || d_bs < (long)(P - 1) * ldd + K)
+        return fail(CCNET_E_BADSHAPE, "projection_adjoint_bf16: K, ldw, ldd, d_bs % 8 == 0, strides >= extents");
+    if ((double)C * ldw_ >= 1073741824.0 || (double)P * ldd >= 1073741824.0 || (double)C * P >= 536870912.0)
+        return fail(CCNET_E_BADSHAPE, "projection_adjoint_bf16: 31-bit byte offsets per image");
+    cca::ProjGemmJob job{(const cca::bf16_t *)w, (const cca::bf16_t *)d, nullptr, add, dx, C, P, K, (int)ldw_, (int)ldd, P, B, 0, d_bs, (long)C * P};
+    return launch_proj_gemm(job, "projection_adjoint_bf16", stream);
 }
 
 int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v, const float *v_bias, uint16_t *v_planes,

@@ -38,21 +38,33 @@ constexpr int PG_STAGE = (PG_APIECES + PG_BPIECES) * T16_PIECE;                /
 constexpr int PG_NBUF = 3;                                                     // 144 KiB
 constexpr int PG_NPA = PG_APIECES / PG_WAVES, PG_NPB = PG_BPIECES / PG_WAVES, PG_NPW = PG_NPA + PG_NPB;   // fill instructions per wavefront and stage
 
+// one launch: ``batches`` products out_b = A_b . Wt_b^T (+ bias) (+ add_b); a batch stride of 0 shares the operand
+struct ProjGemmJob {
+    const bf16_t *A, *Wt;
+    const float *bias, *add;      // (N) or null; (batches, M, ldo) in the layout of ``out`` or null
+    float *out;
+    int M, N, K, lda, ldw, ldo, batches;
+    long sa, sw, so;              // batch strides in elements (A, Wt, out / add)
+};
+
 template <bool KTAIL>
-__global__ __launch_bounds__(PG_THREADS, 1) void proj_gemm_kernel(const bf16_t *__restrict__ A, const bf16_t *__restrict__ Wt,
-                                                                  const float *__restrict__ bias, float *__restrict__ out,
-                                                                  int M, int N, int K, int lda, int ldw, int ldo) {
+__global__ __launch_bounds__(PG_THREADS, 1) void proj_gemm_kernel(const ProjGemmJob job) {
     __shared__ __attribute__((aligned(16))) float lds[PG_NBUF * PG_STAGE];
     CCA_LDS_REGISTER(lds);
-    const int ntn = (N + PG_BN - 1) / PG_BN;
+    const int M = job.M, N = job.N, K = job.K, lda = job.lda, ldw = job.ldw, ldo = job.ldo;
+    const int ntm = (M + PG_BM - 1) / PG_BM, ntn = (N + PG_BN - 1) / PG_BN;
     const int lid = xcd_logical_id((int)blockIdx.x, (int)gridDim.x);
-    const int m0 = (lid / ntn) * PG_BM, n0 = (lid % ntn) * PG_BN;
+    const int bt = lid / (ntm * ntn), tl = lid - bt * (ntm * ntn);
+    // the axis with FEWER tiles runs fastest: the workgroups that share a tile of the other (streamed) operand are neighbours
+    const int m0 = (ntn <= ntm ? tl / ntn : tl % ntm) * PG_BM, n0 = (ntn <= ntm ? tl % ntn : tl / ntm) * PG_BN;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
     const int ln = lane & 15, lg = lane >> 4;
     const int wm = wv >> 1, wn = wv & 1;                                       // this wavefront: rows wm * 64 .., columns wn * 64 ..
-    const FBuf Ab = make_fbuf(reinterpret_cast<const float *>(A), ((size_t)(M - 1) * lda + K) * 2);
-    const FBuf Wb = make_fbuf(reinterpret_cast<const float *>(Wt), ((size_t)(N - 1) * ldw + K) * 2);
-    const FBuf Ob = make_fbuf(out, ((size_t)(M - 1) * ldo + N) * sizeof(float));
+    const float *bias = job.bias;
+    const FBuf Ab = make_fbuf(reinterpret_cast<const float *>(job.A + bt * job.sa), ((size_t)(M - 1) * lda + K) * 2);
+    const FBuf Wb = make_fbuf(reinterpret_cast<const float *>(job.Wt + bt * job.sw), ((size_t)(N - 1) * ldw + K) * 2);
+    const FBuf Ob = make_fbuf(job.out + bt * job.so, ((size_t)(M - 1) * ldo + N) * sizeof(float));
+    const FBuf Cb = make_fbuf(job.add ? job.add + bt * job.so : job.out, ((size_t)(M - 1) * ldo + N) * sizeof(float));
     const int nk = (K + PG_BK - 1) / PG_BK;
 
     // fill: wavefront wv moves A pieces wv, wv + 4, .. and Wt pieces wv, wv + 4, ..; lane = (row lane >> 3 of the piece, LDS chunk
@@ -97,7 +109,9 @@ __global__ __launch_bounds__(PG_THREADS, 1) void proj_gemm_kernel(const bf16_t *
         af[2] = lds_read_x4_uncounted<4096>(pa);  af[3] = lds_read_x4_uncounted<6144>(pa);
     };
 
-    // D^T[n][m]: lane (ln, lg) of tile (t, j) holds columns n0 + wn * 64 + 16 j + 4 lg .. + 3 of row m0 + wm * 64 + 16 t + ln
+    // D^T[n][m]: lane (ln, lg) of tile (t, j) holds columns n0 + wn * 64 + 16 j + 4 lg .. + 3 of row m0 + wm * 64 + 16 t + ln.
+    // The accumulators START from bias + addend (the stock GEMM's bias / beta = 1 epilogues cost more than a pass of their own):
+    // the addend's 16-byte loads are in flight next to the first three fills and are consumed (added to the bias) before the loop.
     f32x4 acc[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -108,6 +122,23 @@ __global__ __launch_bounds__(PG_THREADS, 1) void proj_gemm_kernel(const bf16_t *
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t][j] = b4;
     }
+    f32x4 addv[4][4];
+    if (job.add) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int m = m0 + wm * 64 + 16 * t + ln;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + 16 * j + 4 * lg;
+                if (n + 3 < N) {
+                    addv[t][j] = fbuf_load_x4(Cb, m < M ? (m * ldo + n) * 4 : kOobOffset, 0);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) addv[t][j][q] = fbuf_load(Cb, (m < M && n + q < N) ? (m * ldo + n + q) * 4 : kOobOffset, 0);
+                }
+            }
+        }
+    }
 
     issue(0, 0);
     if (nk > 1) issue(1, 1);
@@ -115,6 +146,12 @@ __global__ __launch_bounds__(PG_THREADS, 1) void proj_gemm_kernel(const bf16_t *
     if (nk > 2)       barrier_dma_keep<2 * PG_NPW>();                         // stage 0 landed
     else if (nk > 1)  barrier_dma_keep<PG_NPW>();
     else              barrier_dma_keep<0>();
+    if (job.add) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t][j] += addv[t][j];
+    }
     u32x4 b0[4], a0[4], b1[4], a1[4];
     read(b0, a0, 0, 0);
     int slot = 0;
@@ -162,7 +199,7 @@ __global__ __launch_bounds__(PG_THREADS, 1) void proj_gemm_kernel(const bf16_t *
                 fbuf_store_x4(Ob, acc[t][j], m < M ? (m * ldo + n) * 4 : kOobOffset, 0);
             } else {
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
+                for (int q = 0; q < 4; ++q)
                     if (n + q < N) fbuf_store(Ob, acc[t][j][q], m < M ? (m * ldo + n + q) * 4 : kOobOffset, 0);
             }
         }

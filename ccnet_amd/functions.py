@@ -504,6 +504,22 @@ def _projection_gemm(lib, a, wt, bias):
     return out
 
 
+def _projection_adjoint_gemm(lib, w, d, add):
+    """``add + w @ d[b].T`` per image by ``ccnet_cca_projection_adjoint_bf16``: ``w`` (C, K) and ``d`` (B, P, K) bf16, K-contiguous,
+    ``add`` (B, C, P) fp32 contiguous -> (B, C, P) fp32.  None when the shape is outside the entry point's contract."""
+    C, K = w.shape
+    B, P = d.shape[0], d.shape[1]
+    if K % 8 or w.stride(1) != 1 or d.stride(2) != 1 or w.stride(0) % 8 or d.stride(1) % 8 or d.stride(0) % 8 or not add.is_contiguous():
+        return None
+    if C * w.stride(0) >= 1 << 30 or P * d.stride(1) >= 1 << 30 or C * P >= 1 << 29:
+        return None
+    out = torch.empty((B, C, P), device=d.device, dtype=torch.float32)
+    with torch.cuda.device(d.device):
+        lib.check(lib.ccnet_cca_projection_adjoint_bf16(w.data_ptr(), d.data_ptr(), add.data_ptr(), out.data_ptr(), B, C, P, K,
+                                                        w.stride(0), d.stride(1), d.stride(0), _stream()), "projection_adjoint_bf16")
+    return out
+
+
 class CrissCrossPlanesModuleFunction(torch.autograd.Function):
     """The whole module as ONE autograd node on the SPLIT-PLANE path (fp32, no autocast), the module's own tensors NCHW:
     the stacked projection is the GEMM ``x^T W^T`` whose (B, HW, 2Cq + C) output holds the pixel-major q | k | v; the core's
@@ -636,11 +652,13 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
     def _projection_adjoint(ctx, d3, db, dy, x3, wpack, gamma, dgamma, B, C, H, W, cq):
         """dx and the weight gradients from dqkv as three-plane rows ``d3`` (B, H, W, 3, ct) -- the two split-bf16 GEMMs."""
         hw, ct = H * W, 2 * cq + C
-        # dy + W^T dqkv^T (NCHW).  (Round 6 measured dy as the GEMM's C operand -- torch.baddbmm(dy, ..., out_dtype=fp32), beta = 1,
-        # VERDICT r5 item 5a: 293-301 us against 265-293 us for this pair, the stock epilogue costs more than the elementwise pass
-        # it replaces: profiles/r06c_dx_gemm_dw_split_ab.txt.)
-        dx = torch.bmm(wpack.unsqueeze(0).expand(B, -1, -1), d3.view(B, hw, 3 * ct).transpose(1, 2),
-                       out_dtype=torch.float32).add_(dy.view(B, C, hw))
+        # dy + W^T dqkv^T (NCHW): the library's GEMM, one launch over the batch, dy starting the accumulators (csrc/cca_gemm.hpp).
+        # (The stock pair -- torch.bmm(..., out_dtype=fp32).add_(dy) -- ran at 265-293 us; with dy as the stock GEMM's C operand,
+        # torch.baddbmm, beta = 1, VERDICT r5 item 5a, at 293-301 us: profiles/r06c_dx_gemm_dw_split_ab.txt.)
+        dx = _projection_adjoint_gemm(_lib.get_lib(), wpack, d3.view(B, hw, 3 * ct), dy.view(B, C, hw))
+        if dx is None:
+            dx = torch.bmm(wpack.unsqueeze(0).expand(B, -1, -1), d3.view(B, hw, 3 * ct).transpose(1, 2),
+                           out_dtype=torch.float32).add_(dy.view(B, C, hw))
         # rows (dh, xh), (dl, xh), (dh, xl) of every pixel: the three products, contracted over 3 HW rows per image
         # (K = 3 HW rows per image against a 640 x 512 output: 20 output tiles per batch entry leave most CUs idle at B = 8.  The rows
         #  split into contiguous thirds -- 3 B entries of K = HW, summed by the same .sum(0): 348 -> 264 us at (8,512,97,97),

@@ -308,6 +308,13 @@ int ccnet_cca_pack_projection_f32(const float *wq, const float *bq, const float 
  * starts the accumulators (no epilogue pass).  K, lda, ldw % 8 == 0, ldo % 4 == 0 (elements). */
 int ccnet_cca_projection_bf16(const uint16_t *a, const uint16_t *wt, const float *bias, float *out, int M, int N, int K,
                               long lda, long ldw, long ldo, ccnet_stream_t stream);
+/* Its adjoint with respect to the input (the backward-data of functions.py:29,32,35), NCHW, by the same kernel in ONE launch over
+ * the batch: dx[b][c][p] = sum_k w[c][k] * d[b][p][k] + add[b][c][p].  ``w`` (C, K) bf16 row stride ldw -- ``w3t`` of
+ * ccnet_cca_pack_projection_f32, K = 3 (2 Cq + C) --, ``d`` (B, P, K) bf16 with pixel stride ldd and batch stride d_bs -- dq | dk | dv
+ * as three planes per pixel (ccnet_cca_backward_planes3_f32) --, ``add`` (B, C, P) fp32 or NULL -- dy, the residual branch: it starts
+ * the accumulators --, ``dx`` (B, C, P) fp32; add and dx contiguous, P = H W of any parity.  K, ldw, ldd, d_bs % 8 == 0. */
+int ccnet_cca_projection_adjoint_bf16(const uint16_t *w, const uint16_t *d, const float *add, float *dx, int B, int C, int P, int K,
+                                      long ldw, long ldd, long d_bs, ccnet_stream_t stream);
 int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v, const float *v_bias, uint16_t *v_planes,
                                  const float *x, const float *gamma, float *y, float *A,
                                  int B, int C, int Cq, int H, int W,

@@ -299,6 +299,14 @@ class EmuOps:
         self.lib.check(self.lib.ccnet_cca_projection_bf16(_p(a_bits), _p(wt_bits), _p(bias), _p(out), M, N, K, K, K, N, None))
         return out
 
+    def projection_adjoint_bf16(self, w_bits, d_bits, add):
+        """ccnet_cca_projection_adjoint_bf16: w (C, K) / d (B, P, K) uint16 bf16 bits, add (B, C, P) fp32 or None -> dx (B, C, P) fp32"""
+        C, K = w_bits.shape
+        B, P = d_bits.shape[0], d_bits.shape[1]
+        dx = np.full((B, C, P), np.nan, np.float32)
+        self.lib.check(self.lib.ccnet_cca_projection_adjoint_bf16(_p(w_bits), _p(d_bits), _p(add), _p(dx), B, C, P, K, K, K, P * K, None))
+        return dx
+
     def pack_projection(self, wq, bq, wk, bk, wv, bv, split=True):
         """ccnet_cca_pack_projection_f32: (w (N, C) fp32, b (N), w3 (N, 3C) bf16 bits, w3t (C, 3N) bf16 bits)"""
         cq, C = wq.shape[0], wq.shape[1]

@@ -961,3 +961,21 @@ def test_projection_gemm_matches_numpy(ops, mnk):
         want = ref + (0.0 if b is None else b.astype(np.float64))
         assert np.all(np.isfinite(got))
         assert float(np.abs(got - want).max()) < 2e-5 * max(1.0, float(np.abs(want).max())) * np.sqrt(K)
+
+
+@pytest.mark.parametrize("bcpk", [(2, 40, 35, 72), (1, 300, 133, 64), (3, 16, 260, 192)])
+def test_projection_adjoint_gemm_matches_numpy(ops, bcpk):
+    """ccnet_cca_projection_adjoint_bf16 (the backward-data of the stacked projection as the same kernel, batched, NCHW output with
+    the residual gradient starting the accumulators): dx[b][c][p] = sum_k w[c][k] d[b][p][k] + add[b][c][p] against numpy; odd
+    P (16-byte loads / stores at 4-byte alignment), partial tiles in C, P and K, with and without the addend."""
+    B, C, P, K = bcpk
+    rng = np.random.default_rng(5)
+    w = _f32_to_bf16_bits(rng.standard_normal((C, K)).astype(np.float32))
+    d = _f32_to_bf16_bits(rng.standard_normal((B, P, K)).astype(np.float32))
+    add = rng.standard_normal((B, C, P)).astype(np.float32)
+    ref = np.einsum("ck,bpk->bcp", _bf16_bits_to_f32(w).astype(np.float64), _bf16_bits_to_f32(d).astype(np.float64))
+    for a in (add, None):
+        got = ops.projection_adjoint_bf16(w, d, a)
+        want = ref + (0.0 if a is None else a.astype(np.float64))
+        assert np.all(np.isfinite(got))
+        assert float(np.abs(got - want).max()) < 2e-5 * max(1.0, float(np.abs(want).max())) * np.sqrt(K)

@@ -1554,3 +1554,39 @@ def test_module_forward_runs_the_library_gemm(lib, dev):
     finally:
         F._projection_gemm = keep
     assert float((y - y0).abs().max()) <= 2e-5 * float(y0.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bcpk", [(2, 40, 35, 72), (3, 64, 20 * 24, 3 * 80), (8, 512, 97 * 97, 3 * 640), (1, 300, 4099, 192)])
+def test_projection_adjoint_gemm_on_the_device(lib, dev, bcpk):
+    """ccnet_cca_projection_adjoint_bf16 (the backward-data of functions.py:29,32,35 by the kernel of the forward GEMM, one launch over
+    the batch, NCHW, dy starting the accumulators) against the fp64 product of the same bf16 values: tolerance 2e-6 of
+    sum_k |w||d| + |add| per output (fp32 accumulation order); odd P (16-byte accesses at 4-byte alignment), partial tiles in C, P, K,
+    padded operand strides, repeated launches, no addend; the module's shape (8,512,97,97) included."""
+    B, C, P, K = bcpk
+    g = torch.Generator(device="cpu").manual_seed(B + C + P + K)
+    ldw, ldd = K + 8, K + 24
+    w = torch.full((C, ldw), float("nan"), dtype=torch.bfloat16)
+    w[:, :K] = torch.randn((C, K), generator=g).to(torch.bfloat16)
+    w = w.to(dev)
+    d = torch.full((B, P + 1, ldd), float("nan"), dtype=torch.bfloat16, device=dev)
+    d[:, :P, :K] = torch.randn((B, P, K), generator=g).to(torch.bfloat16).to(dev)
+    add = torch.randn((B, C, P), generator=g).to(dev)
+    dx = torch.full((B, C, P), float("nan"), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        lib.check(lib.ccnet_cca_projection_adjoint_bf16(w.data_ptr(), d.data_ptr(), add.data_ptr(), dx.data_ptr(), B, C, P, K,
+                                                        ldw, ldd, (P + 1) * ldd, st), "projection_adjoint_bf16")
+    torch.cuda.synchronize()
+    cs = slice(0, C) if C * P <= 1 << 20 else slice(C - 40, C)
+    wd, dd = w[cs, :K].double(), d[:, :P, :K].double()
+    ref = torch.einsum("ck,bpk->bcp", wd, dd) + add[:, cs].double()
+    bound = 2e-6 * (torch.einsum("ck,bpk->bcp", wd.abs(), dd.abs()) + add[:, cs].double().abs()) + 1e-30
+    assert bool(((dx[:, cs].double() - ref).abs() <= bound).all())
+    assert bool(torch.isfinite(dx).all())
+    dx2 = torch.empty_like(dx)
+    lib.check(lib.ccnet_cca_projection_adjoint_bf16(w.data_ptr(), d.data_ptr(), None, dx2.data_ptr(), B, C, P, K, ldw, ldd, (P + 1) * ldd, st),
+              "projection_adjoint_bf16")
+    torch.cuda.synchronize()
+    assert bool(((dx2[:, cs].double() - (ref - add[:, cs].double())).abs() <= bound).all())
+    assert lib.ccnet_cca_projection_adjoint_bf16(w.data_ptr(), d.data_ptr(), None, dx2.data_ptr(), B, C, P, K, ldw + 4, ldd, (P + 1) * ldd, st) != 0

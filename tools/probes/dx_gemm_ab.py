@@ -33,14 +33,31 @@ def gemm_only():
     return torch.bmm(A, Bm, out_dtype=torch.float32)
 
 
-for f in (two_pass, folded, gemm_only):
+def library():
+    """ccnet_cca_projection_adjoint_bf16: the library's own GEMM, dy starting the accumulators (csrc/cca_gemm.hpp)"""
+    from ccnet_amd import functions as F, _lib
+    return F._projection_adjoint_gemm(_lib.get_lib(), w3t, d3, dy)
+
+
+def library_no_add():
+    from ccnet_amd import _lib
+    lib = _lib.get_lib()
+    out = torch.empty((B, C, hw), device=dev)
+    lib.check(lib.ccnet_cca_projection_adjoint_bf16(w3t.data_ptr(), d3.data_ptr(), None, out.data_ptr(), B, C, hw, 3 * ct, 3 * ct, 3 * ct,
+                                                    hw * 3 * ct, torch.cuda.current_stream().cuda_stream))
+    return out
+
+
+for f in (two_pass, folded, gemm_only, library, library_no_add):
     for _ in range(3):
         f()
 torch.cuda.synchronize()
 r0, r1 = two_pass(), folded()
 print("max |bmm + add - baddbmm| =", float((r0 - r1).abs().max()), " (|dx|max", float(r0.abs().max()), ")")
+print("max |bmm + add - library GEMM| =", float((r0 - library()).abs().max()))
 for rnd in range(2):
-    for name, f in (("bmm(out_dtype=fp32).add_(dy)", two_pass), ("baddbmm(dy, ..., out_dtype=fp32)", folded), ("bmm alone", gemm_only)):
+    for name, f in (("bmm(out_dtype=fp32).add_(dy)", two_pass), ("baddbmm(dy, ..., out_dtype=fp32)", folded), ("bmm alone", gemm_only),
+                    ("library GEMM, dy in the accumulators", library), ("library GEMM alone", library_no_add)):
         print(f"round {rnd}: {name:36s} {bench.time_region(f, 30) * 1e3:8.1f} us", flush=True)
 
 # ---- the weight gradient: dW = sum over images of dqkv_planes^T . x_planes (K = 3 HW rows per image, M = ct, N = C): 20 output tiles
