@@ -1514,6 +1514,26 @@ int ccnet_cca_projection_adjoint_bf16(const uint16_t *w, const uint16_t *d, cons
     return launch_proj_gemm(job, "projection_adjoint_bf16", stream);
 }
 
+/* The adjoint of the stacked projection with respect to its weight (the backward-weight of functions.py:29,32,35):
+ * sum_s part[s][n][c] = sum_r d[r][n] * x[r][c] over R rows -- ``d`` (R, N) bf16 row stride ldd: dq | dk | dv as three planes per pixel,
+ * ``x`` (R, C) bf16 row stride ldx: x as three planes per pixel (row r of one pairs with row r of the other: [dh | dl | dh] against
+ * [xh | xh | xl]) --, cut into S slabs of rows; ``part`` (S, N, C) fp32 receives one partial sum per slab (every element written:
+ * a slab without rows writes zeros) and the caller adds them in a fixed order.  N, C, ldd, ldx % 8 == 0. */
+int ccnet_cca_projection_wgrad_bf16(const uint16_t *d, const uint16_t *x, float *part, int R, int N, int C, long ldd, long ldx, int S,
+                                    ccnet_stream_t stream) {
+    if (!d || !x || !part) return fail(CCNET_E_NULLPTR, "projection_wgrad_bf16: null tensor");
+    if (R <= 0 || N <= 0 || C <= 0 || S <= 0 || N % 8 || C % 8 || ldd % 8 || ldx % 8 || ldd < N || ldx < C)
+        return fail(CCNET_E_BADSHAPE, "projection_wgrad_bf16: N, C, ldd, ldx % 8 == 0, strides >= extents, S >= 1");
+    if ((double)R * ldd >= 1073741824.0 || (double)R * ldx >= 1073741824.0 || (double)N * C >= 536870912.0)
+        return fail(CCNET_E_BADSHAPE, "projection_wgrad_bf16: 31-bit byte offsets");
+    const int slab = (int)(((long)R + (long)S * cca::PG_BK - 1) / ((long)S * cca::PG_BK)) * cca::PG_BK;
+    const long tiles = (long)((N + cca::PW_BN - 1) / cca::PW_BN) * ((C + cca::PW_BC - 1) / cca::PW_BC) * S;
+    if (tiles >= 2147483647L) return fail(CCNET_E_BADSHAPE, "projection_wgrad_bf16: too many tiles");
+    cca::ProjWgradJob job{(const cca::bf16_t *)d, (const cca::bf16_t *)x, part, R, N, C, (int)ldd, (int)ldx, S, slab};
+    CCA_LAUNCH(cca::proj_wgrad_kernel, dim3((unsigned)tiles), dim3(cca::PG_THREADS), stream, job);
+    return launch_status("projection_wgrad_bf16");
+}
+
 int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v, const float *v_bias, uint16_t *v_planes,
                                  const float *x, const float *gamma, float *y, float *A,
                                  int B, int C, int Cq, int H, int W,

@@ -206,4 +206,122 @@ __global__ __launch_bounds__(PG_THREADS, 1) void proj_gemm_kernel(const ProjGemm
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The weight gradient of the stacked projection (the backward-weight of functions.py:29,32,35):
+//
+//     dW[n][c] = sum_r D[r][n] * X[r][c]        D (R, N) bf16 rows: dq | dk | dv planes [dh | dl | dh] of every pixel (row stride ldd)
+//                                               X (R, C) bf16 rows: x planes [xh | xh | xl] of the same pixels     (row stride ldx)
+//
+// -- a contraction over ROWS (R = 3 B H W = 225 816 at (8,512,97,97)) into a 640 x 512 output: ten 128 x 256 output tiles, so the
+// rows are cut into S slabs (S x 10 ~ one workgroup per CU) and workgroup (slab, tile) writes its partial sum to ``part`` (S, N, C);
+// the host adds the S partials in a fixed order (deterministic, no atomics).  Both operands are contiguous ACROSS the contraction
+// axis, i.e. they are cca_gmap.hpp's plane tiles as they stand: a stage = 64 rows = two T16 tiles of D (64 n each) and four of X
+// (64 c each), 48 KiB moved by 6 LDS-DMA instructions per wavefront whose offsets advance by a constant; fragments = t16_frag
+// (two transposing reads, K down the tile's positions).  Geometry and pipeline as proj_gemm_kernel: 8 wavefronts of 64 n x 64 c,
+// three stages, the stage barrier between the two half steps.  (The stock route ran this as 24 batched GEMMs + a sum over the
+// batch: 264-268 us, profiles/r06o_dx_gemm_ab.txt.)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int PW_BN = 128, PW_BC = 256, PW_TILE = t16_size(PG_BK);                               // dwords per T16 tile of 64 rows
+constexpr int PW_NT = PW_BN / 64 + PW_BC / 64;                                                  // T16 tiles per stage (= fills per wavefront)
+static_assert(PW_NT * PW_TILE == PG_STAGE && PG_BK / 8 == PG_WAVES, "wgrad: one piece row of every tile per wavefront");
+
+struct ProjWgradJob {
+    const bf16_t *D, *X;
+    float *part;                  // (S, N, C)
+    int R, N, C, ldd, ldx, S, slab;   // slab = rows per slab, a multiple of 64
+};
+
+__global__ __launch_bounds__(PG_THREADS, 1) void proj_wgrad_kernel(const ProjWgradJob job) {
+    __shared__ __attribute__((aligned(16))) float lds[PG_NBUF * PG_STAGE];
+    CCA_LDS_REGISTER(lds);
+    const int N = job.N, C = job.C, ldd = job.ldd, ldx = job.ldx;
+    const int ntc = (C + PW_BC - 1) / PW_BC, ntn = (N + PW_BN - 1) / PW_BN;
+    const int lid = xcd_logical_id((int)blockIdx.x, (int)gridDim.x);                 // the tiles of one slab are neighbours (one XCD: shared rows)
+    const int sl = lid / (ntn * ntc), tl = lid - sl * (ntn * ntc);
+    const int n0 = (tl / ntc) * PW_BN, c0 = (tl % ntc) * PW_BC;
+    const int r0 = sl * job.slab, r1 = r0 + job.slab < job.R ? r0 + job.slab : job.R;
+    const int nk = r1 > r0 ? (r1 - r0 + PG_BK - 1) / PG_BK : 0;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = uniform(tid >> 6);
+    const int ln = lane & 15, lg = lane >> 4;
+    const int wn = wv >> 2, wc = wv & 3;                                             // this wavefront: n columns 64 wn .., c columns 64 wc ..
+    const FBuf Db = make_fbuf(reinterpret_cast<const float *>(job.D), ((size_t)(job.R - 1) * ldd + N) * 2);
+    const FBuf Xb = make_fbuf(reinterpret_cast<const float *>(job.X), ((size_t)(job.R - 1) * ldx + C) * 2);
+    const FBuf Ob = make_fbuf(job.part + (size_t)sl * N * C, (size_t)N * C * sizeof(float));
+
+    // fill: wavefront wv moves piece wv (rows 8 wv .. + 7 of the stage) of all six tiles; lane = (row lane >> 3, LDS chunk slot
+    // lane & 7), which holds the row's 16-byte channel chunk q (t16_dma_piece, FLIP layout)
+    const int pr = lane >> 3, q = (lane & 7) ^ pr ^ ((wv & 1) << 2), rs = 8 * wv + pr;       // row of this lane within a stage
+    int off[PW_NT];
+#pragma unroll
+    for (int t = 0; t < PW_NT; ++t) {
+        const bool isd = t < PW_BN / 64;
+        const int ch = (isd ? n0 + 64 * t : c0 + 64 * (t - PW_BN / 64)) + 8 * q;
+        off[t] = ch < (isd ? N : C) ? ((r0 + rs) * (isd ? ldd : ldx) + ch) * 2 : kOobOffset;      // (columns past the matrix: zeros)
+    }
+    auto issue = [&](int it, int slot) {
+        float *st = lds + slot * PG_STAGE + wv * T16_PIECE;
+        const bool dead = r0 + it * PG_BK + rs >= r1;                                            // rows past the slab: zeros
+#pragma unroll
+        for (int t = 0; t < PW_NT; ++t) {
+            const bool isd = t < PW_BN / 64;
+            const int o = (dead || off[t] == kOobOffset) ? kOobOffset : off[t] + it * PG_BK * (isd ? ldd : ldx) * 2;
+            fbuf_load_to_lds_x4_uncounted(isd ? Db : Xb, st + t * PW_TILE, o);
+        }
+    };
+
+    // lane (ln, lg) of tile (a, b) holds c = c0 + 64 wc + 16 b + 4 lg .. + 3 of n = n0 + 64 wn + 16 a + ln
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk > 2) issue(2, 2);
+    if (nk > 2)       barrier_dma_keep<2 * PW_NT>();                                 // stage 0 landed
+    else if (nk > 1)  barrier_dma_keep<PW_NT>();
+    else              barrier_dma_keep<0>();
+    int slot = 0;
+    for (int it = 0; it < nk; ++it) {
+        const float *dt = lds + slot * PG_STAGE + wn * PW_TILE, *xt = lds + slot * PG_STAGE + (PW_BN / 64 + wc) * PW_TILE;
+        u32x4 df[4], xf[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { df[a] = t16_frag(dt, 0, a, lane); xf[a] = t16_frag(xt, 0, a, lane); }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = mfma_bf16_16x16x32(xf[b], df[a], acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { df[a] = t16_frag(dt, 1, a, lane); xf[a] = t16_frag(xt, 1, a, lane); }
+        if (it + 1 < nk) {
+            // stage it + 1 landed and every wavefront holds the rest of stage `it` in registers (the barrier drains its LDS reads):
+            // the slot takes stage it + 3 at once, the fill of stage it + 2 stays in flight
+            if (it + 2 < nk) barrier_dma_keep<PW_NT>();
+            else             barrier_dma_keep<0>();
+            if (it + 3 < nk) issue(it + 3, slot);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = mfma_bf16_16x16x32(xf[b], df[a], acc[a][b]);
+        slot = slot == PG_NBUF - 1 ? 0 : slot + 1;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int n = n0 + 64 * wn + 16 * a + ln;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int c = c0 + 64 * wc + 16 * b + 4 * lg;
+            if (c + 3 < C) {
+                fbuf_store_x4(Ob, acc[a][b], n < N ? (n * C + c) * 4 : kOobOffset, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < C) fbuf_store(Ob, acc[a][b][e], n < N ? (n * C + c + e) * 4 : kOobOffset, 0);
+            }
+        }
+    }
+}
+
 }  // namespace cca

@@ -520,6 +520,26 @@ def _projection_adjoint_gemm(lib, w, d, add):
     return out
 
 
+def _projection_wgrad_gemm(lib, d, x):
+    """``d.T @ x`` over all rows by ``ccnet_cca_projection_wgrad_bf16``: ``d`` (R, N) and ``x`` (R, C) bf16 with contiguous rows ->
+    (N, C) fp32 (the S partial sums of the launch added in a fixed order).  None when the shape is outside the entry point's
+    contract."""
+    R, N = d.shape
+    C = x.shape[1]
+    if N % 8 or C % 8 or d.stride(1) != 1 or x.stride(1) != 1 or d.stride(0) % 8 or x.stride(0) % 8 or x.shape[0] != R:
+        return None
+    if R * d.stride(0) >= 1 << 30 or R * x.stride(0) >= 1 << 30:
+        return None
+    tiles = -(-N // 128) * -(-C // 256)
+    cus = torch.cuda.get_device_properties(d.device).multi_processor_count
+    S = max(1, min(cus // tiles if tiles <= cus else 1, -(-R // 64)))
+    part = torch.empty((S, N, C), device=d.device, dtype=torch.float32)
+    with torch.cuda.device(d.device):
+        lib.check(lib.ccnet_cca_projection_wgrad_bf16(d.data_ptr(), x.data_ptr(), part.data_ptr(), R, N, C, d.stride(0), x.stride(0), S,
+                                                      _stream()), "projection_wgrad_bf16")
+    return part.sum(0) if S > 1 else part[0]
+
+
 class CrissCrossPlanesModuleFunction(torch.autograd.Function):
     """The whole module as ONE autograd node on the SPLIT-PLANE path (fp32, no autocast), the module's own tensors NCHW:
     the stacked projection is the GEMM ``x^T W^T`` whose (B, HW, 2Cq + C) output holds the pixel-major q | k | v; the core's
@@ -659,12 +679,15 @@ class CrissCrossPlanesModuleFunction(torch.autograd.Function):
         if dx is None:
             dx = torch.bmm(wpack.unsqueeze(0).expand(B, -1, -1), d3.view(B, hw, 3 * ct).transpose(1, 2),
                            out_dtype=torch.float32).add_(dy.view(B, C, hw))
-        # rows (dh, xh), (dl, xh), (dh, xl) of every pixel: the three products, contracted over 3 HW rows per image
-        # (K = 3 HW rows per image against a 640 x 512 output: 20 output tiles per batch entry leave most CUs idle at B = 8.  The rows
-        #  split into contiguous thirds -- 3 B entries of K = HW, summed by the same .sum(0): 348 -> 264 us at (8,512,97,97),
-        #  profiles/r06c_dx_gemm_dw_split_ab.txt)
-        ks = 3 if B <= 12 else 1
-        dw = torch.bmm(d3.view(B * ks, 3 * hw // ks, ct).transpose(1, 2), x3.view(B * ks, 3 * hw // ks, C), out_dtype=torch.float32).sum(0)
+        # rows (dh, xh), (dl, xh), (dh, xl) of every pixel: the three products, contracted over all 3 B HW rows by the library's
+        # row-contraction GEMM (csrc/cca_gemm.hpp: S slabs of rows x ten output tiles ~ one workgroup per CU, S partials added here).
+        # (The stock route: 3 B batch entries of K = HW rows summed by .sum(0), 264-268 us at (8,512,97,97); B entries of K = 3 HW:
+        # 348-361 us -- profiles/r06c_dx_gemm_dw_split_ab.txt, r06o_dx_gemm_ab.txt.)
+        dw = _projection_wgrad_gemm(_lib.get_lib(), d3.view(B * hw * 3, ct), x3.view(B * hw * 3, C))
+        if dw is None:
+            ks = 3 if B <= 12 else 1
+            dw = torch.bmm(d3.view(B * ks, 3 * hw // ks, ct).transpose(1, 2), x3.view(B * ks, 3 * hw // ks, C),
+                           out_dtype=torch.float32).sum(0)
         dwq, dwk, dwv = dw[:cq], dw[cq:2 * cq], dw[2 * cq:]
         return (dx.view(B, C, H, W), dwq.reshape(cq, C, 1, 1), db[:cq], dwk.reshape(cq, C, 1, 1), db[cq:2 * cq],
                 dwv.reshape(C, C, 1, 1), db[2 * cq:], dgamma.view_as(gamma), None, None)

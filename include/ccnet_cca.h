@@ -315,6 +315,14 @@ int ccnet_cca_projection_bf16(const uint16_t *a, const uint16_t *wt, const float
  * the accumulators --, ``dx`` (B, C, P) fp32; add and dx contiguous, P = H W of any parity.  K, ldw, ldd, d_bs % 8 == 0. */
 int ccnet_cca_projection_adjoint_bf16(const uint16_t *w, const uint16_t *d, const float *add, float *dx, int B, int C, int P, int K,
                                       long ldw, long ldd, long d_bs, ccnet_stream_t stream);
+/* ... and with respect to the weight (the backward-weight of functions.py:29,32,35): sum_s part[s][n][c] = sum_r d[r][n] * x[r][c] over
+ * R = 3 B H W rows -- ``d`` (R, N) bf16 row stride ldd: dq | dk | dv as three planes per pixel [dh | dl | dh], ``x`` (R, C) bf16 row
+ * stride ldx: x as three planes per pixel [xh | xh | xl]; row r of one pairs with row r of the other.  The rows are cut into S slabs
+ * (S x ceil(N / 128) x ceil(C / 256) workgroups: choose S so that this is about the CU count); ``part`` (S, N, C) fp32 receives one
+ * partial sum per slab, every element written, and the caller adds the S partials in a fixed order (no atomics: run-to-run
+ * identical).  N, C, ldd, ldx % 8 == 0. */
+int ccnet_cca_projection_wgrad_bf16(const uint16_t *d, const uint16_t *x, float *part, int R, int N, int C, long ldd, long ldx, int S,
+                                    ccnet_stream_t stream);
 int ccnet_cca_forward_planes_f32(const float *q, const float *k, const float *v, const float *v_bias, uint16_t *v_planes,
                                  const float *x, const float *gamma, float *y, float *A,
                                  int B, int C, int Cq, int H, int W,

@@ -307,6 +307,14 @@ class EmuOps:
         self.lib.check(self.lib.ccnet_cca_projection_adjoint_bf16(_p(w_bits), _p(d_bits), _p(add), _p(dx), B, C, P, K, K, K, P * K, None))
         return dx
 
+    def projection_wgrad_bf16(self, d_bits, x_bits, S):
+        """ccnet_cca_projection_wgrad_bf16: d (R, N) / x (R, C) uint16 bf16 bits -> part (S, N, C) fp32"""
+        R, N = d_bits.shape
+        C = x_bits.shape[1]
+        part = np.full((S, N, C), np.nan, np.float32)
+        self.lib.check(self.lib.ccnet_cca_projection_wgrad_bf16(_p(d_bits), _p(x_bits), _p(part), R, N, C, N, C, S, None))
+        return part
+
     def pack_projection(self, wq, bq, wk, bk, wv, bv, split=True):
         """ccnet_cca_pack_projection_f32: (w (N, C) fp32, b (N), w3 (N, 3C) bf16 bits, w3t (C, 3N) bf16 bits)"""
         cq, C = wq.shape[0], wq.shape[1]

@@ -979,3 +979,19 @@ def test_projection_adjoint_gemm_matches_numpy(ops, bcpk):
         want = ref + (0.0 if a is None else a.astype(np.float64))
         assert np.all(np.isfinite(got))
         assert float(np.abs(got - want).max()) < 2e-5 * max(1.0, float(np.abs(want).max())) * np.sqrt(K)
+
+
+@pytest.mark.parametrize("rncs", [(200, 136, 264, 2), (64, 128, 256, 1), (700, 24, 40, 5), (130, 640, 512, 3)])
+def test_projection_wgrad_gemm_matches_numpy(ops, rncs):
+    """ccnet_cca_projection_wgrad_bf16 (the backward-weight of the stacked projection: a contraction over rows by transposing
+    fragment reads, cut into S slabs): the sum of the S partials against numpy on the same bf16 values; partial tiles in N and C,
+    row counts that leave a ragged last stage, a short last slab and (700 rows in 5 slabs of 192) a slab with no rows at all."""
+    R, N, C, S = rncs
+    rng = np.random.default_rng(3)
+    d = _f32_to_bf16_bits(rng.standard_normal((R, N)).astype(np.float32))
+    x = _f32_to_bf16_bits(rng.standard_normal((R, C)).astype(np.float32))
+    part = ops.projection_wgrad_bf16(d, x, S)
+    assert np.all(np.isfinite(part))
+    want = _bf16_bits_to_f32(d).astype(np.float64).T @ _bf16_bits_to_f32(x).astype(np.float64)
+    got = part.astype(np.float64).sum(0)
+    assert float(np.abs(got - want).max()) < 2e-5 * max(1.0, float(np.abs(want).max())) * np.sqrt(R)

@@ -1590,3 +1590,33 @@ def test_projection_adjoint_gemm_on_the_device(lib, dev, bcpk):
     torch.cuda.synchronize()
     assert bool(((dx2[:, cs].double() - (ref - add[:, cs].double())).abs() <= bound).all())
     assert lib.ccnet_cca_projection_adjoint_bf16(w.data_ptr(), d.data_ptr(), None, dx2.data_ptr(), B, C, P, K, ldw + 4, ldd, (P + 1) * ldd, st) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rncs", [(700, 24, 40, 5), (3 * 2 * 20 * 24, 80, 64, 7), (3 * 8 * 97 * 97, 640, 512, 25), (5000, 136, 264, 12)])
+def test_projection_wgrad_gemm_on_the_device(lib, dev, rncs):
+    """ccnet_cca_projection_wgrad_bf16 (the backward-weight of functions.py:29,32,35 as a contraction over rows in S slabs) against
+    the fp64 product of the same bf16 values: tolerance 2e-6 of sum_r |d||x| per output for the partial sums added in fp64 (each
+    partial is one fp32 accumulation chain), run-to-run identical partials, padded row strides, a slab without rows ((700, .., 5):
+    slabs of 192 rows), the module's shape (8,512,97,97) with S = 25."""
+    R, N, C, S = rncs
+    g = torch.Generator(device="cpu").manual_seed(R + N + C)
+    ldd, ldx = N + 8, C + 16
+    d = torch.full((R, ldd), float("nan"), dtype=torch.bfloat16, device=dev)
+    x = torch.full((R, ldx), float("nan"), dtype=torch.bfloat16, device=dev)
+    d[:, :N] = torch.randn((R, N), generator=g).to(torch.bfloat16).to(dev)
+    x[:, :C] = torch.randn((R, C), generator=g).to(torch.bfloat16).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    parts = []
+    for _ in range(3):
+        part = torch.full((S, N, C), float("nan"), device=dev)
+        lib.check(lib.ccnet_cca_projection_wgrad_bf16(d.data_ptr(), x.data_ptr(), part.data_ptr(), R, N, C, ldd, ldx, S, st), "projection_wgrad_bf16")
+        parts.append(part)
+    torch.cuda.synchronize()
+    assert torch.equal(parts[0], parts[1]) and torch.equal(parts[0], parts[2])
+    assert bool(torch.isfinite(parts[0]).all())
+    dd, xd = d[:, :N].double(), x[:, :C].double()
+    ref = dd.T @ xd
+    bound = 2e-6 * (dd.abs().T @ xd.abs()) + 1e-30
+    assert bool(((parts[0].double().sum(0) - ref).abs() <= bound).all())
+    assert lib.ccnet_cca_projection_wgrad_bf16(d.data_ptr(), x.data_ptr(), parts[0].data_ptr(), R, N + 4, C, ldd, ldx, S, st) != 0

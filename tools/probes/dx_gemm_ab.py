@@ -81,3 +81,23 @@ for s in (1, 3, 97):
         ref = r
     print(f"dW as {B * s:4d} batch entries of K = {3 * hw // s:6d}: {bench.time_region(dw, 20) * 1e3:8.1f} us   max |diff| vs s = 1: "
           f"{float((r - ref).abs().max()):.2e} (|dW|max {float(ref.abs().max()):.1f})", flush=True)
+
+# ---- the library's row-contraction GEMM (ccnet_cca_projection_wgrad_bf16, csrc/cca_gemm.hpp): S slabs x 10 output tiles
+from ccnet_amd import functions as F, _lib  # noqa: E402
+lib = _lib.get_lib()
+d2, x2 = d3.view(B * hw * 3, ct), x3.view(B * hw * 3, C)
+want = torch.bmm(d3.view(B, 3 * hw, ct).transpose(1, 2), x3.view(B, 3 * hw, C), out_dtype=torch.float32).sum(0)
+for _ in range(3):
+    got = F._projection_wgrad_gemm(lib, d2, x2)
+torch.cuda.synchronize()
+print(f"dW by the library's GEMM + sum of partials:  {bench.time_region(lambda: F._projection_wgrad_gemm(lib, d2, x2), 30) * 1e3:8.1f} us"
+      f"   max |diff| vs s = 1: {float((got - want).abs().max()):.2e}", flush=True)
+for S in (12, 25, 51):
+    part = torch.empty((S, ct, C), device=dev)
+    f = lambda: lib.check(lib.ccnet_cca_projection_wgrad_bf16(d2.data_ptr(), x2.data_ptr(), part.data_ptr(), B * hw * 3, ct, C, ct, C, S,
+                                                               torch.cuda.current_stream().cuda_stream))
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    print(f"   the launch alone, S = {S:3d} ({S * 10} workgroups): {bench.time_region(f, 30) * 1e3:8.1f} us", flush=True)
+
