@@ -45,7 +45,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define CCNET_CCA_VERSION 220          /* 0.2.2.  Over 0.2.0: ccnet_cca_pack_projection_f32, ccnet_cca_probe_*, ccnet_cca_backward_planes3_f32; only ccnet_* symbols are exported.
+#define CCNET_CCA_VERSION 220          /* 0.2.2.  Over 0.2.0: ccnet_cca_pack_projection_f32, ccnet_cca_probe_*, ccnet_cca_backward_planes3_f32, ccnet_cca_projection_bf16 / _adjoint_bf16 / _wgrad_bf16; only ccnet_* symbols are exported.
                                           BEHAVIOURAL changes a binding must know (0.2.1 called these "additive"):
                                           - the *_BACKWARD workspaces of the pixel-major / split-plane entry points are 256 B larger than in 0.2.0
                                             (a binding that hard-coded the 0.2.0 formula gets CCNET_E_WORKSPACE: query the size, as always);
