@@ -956,6 +956,33 @@ def module_level_ms(B, C, H, W, device, iters=10, fuse=True):
     return time_region(one, iters)
 
 
+def projection_gemms(lib, B, C, H, W, device, iters=20):
+    """The three GEMMs of the stacked 1x1 projections around the core (functions.py:29,32,35 and their adjoints) as the library's
+    own MFMA kernels (csrc/cca_gemm.hpp), timed launch by launch on synthetic three-plane bf16 operands of the module's shapes;
+    2 * M * N * K = the flops of ONE bf16 product (the split-bf16 x3 structure is inside K), priced against the dense bf16 MFMA peak."""
+    from ccnet_amd import functions as F
+    hw, ct = H * W, C + 2 * (C // 8)
+    g = torch.Generator(device=device).manual_seed(3)
+    r16 = lambda *shape: torch.randn(shape, device=device, generator=g).to(torch.bfloat16)
+    x3, w3, w3t, d3 = r16(B * hw, 3 * C), r16(ct, 3 * C), r16(C, 3 * ct), r16(B, hw, 3 * ct)
+    dy, bias = torch.randn((B, C, hw), device=device, generator=g), torch.randn((ct,), device=device, generator=g)
+    legs = {"forward (bias in the accumulators)": (lambda: F._projection_gemm(lib, x3, w3, bias), 2.0 * B * hw * ct * 3 * C),
+            "dx (NCHW, dy in the accumulators)": (lambda: F._projection_adjoint_gemm(lib, w3t, d3, dy), 2.0 * B * hw * C * 3 * ct),
+            "dW (row contraction in slabs + sum of partials)": (lambda: F._projection_wgrad_gemm(lib, d3.view(B * hw * 3, ct), x3.view(B * hw * 3, C)),
+                                                               2.0 * 3 * B * hw * ct * C)}
+    out = {"what": "ccnet_cca_projection_bf16 / _adjoint_bf16 / _wgrad_bf16 at the module's shapes, one launch each", "peak_tflops": 2500.0}
+    for name, (f, flops) in legs.items():
+        if f() is None:
+            out[name] = "outside the entry point's contract at this shape (the module uses the stock GEMM)"
+            continue
+        for _ in range(2):
+            f()
+        torch.cuda.synchronize()
+        ms = time_region(f, iters)
+        out[name] = {"us": round(ms * 1e3, 1), "TFLOP/s": round(flops / (ms * 1e-3) / 1e12, 1), "frac_of_mfma_peak": round(flops / (ms * 1e-3) / 2.5e15, 3)}
+    return out
+
+
 def rcca_head_ms(device, batches=(1, 2), iters=5):
     """BASELINE.json configs[2] (networks/ccnet.py:116-123): RCCAModule(2048, 512, 19), recurrence 2, fwd+bwd on a
     (B,2048,97,97) input -- the layer4 output of a 769x769 crop -- B in {1, 2}."""
@@ -1221,6 +1248,7 @@ def main(argv=None, workload_factory=None):
         for key, fn in (("bf16_config5", lambda: bf16_config5(lib, device)),
                         ("small_batch_core_ms", lambda: small_batch_ms(lib, C, H, W, device)),
                         ("rcca_head_R2_2048x97x97", lambda: rcca_head_ms(device)),
+                        ("projection_gemms", lambda: projection_gemms(lib, B, C, H, W, device)),
                         ("stock_pytorch_core", lambda: stock_pytorch_core(B, C, H, W, device))):
             try:
                 out[key] = fn()
