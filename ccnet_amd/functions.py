@@ -734,9 +734,12 @@ class CrissCrossAttention(nn.Module):
     #: operands, fp32 accumulate, ~1e-5 relative): fwd 496 -> 278, dx 488 -> 265, dW 508 -> 325 us at (8,512,97,97)
     #: (profiles/r03p_split_gemm_probe2.txt) for two extra producer passes.  False = fp32 GEMMs (torch's default fp32 path).
     split_bf16_projections = True
-    #: ... from this many pixels per call on (module fwd+bwd at 512 channels, 97 x 97: B = 8 2.23 -> 1.92 ms, B = 4 1.21 -> 1.11,
-    #: B = 2 0.70 -> 0.75, B = 1 0.59 -> 0.74: below ~30k pixels the step is bound by host launches and the extra ops cost more)
-    split_bf16_min_pixels = 32768
+    #: ... from this many pixels per call on.  0 since the GEMMs are the library's own kernels (round 6: every shape measured gains --
+    #: module fwd+bwd at (B,512,97,97), B = 1 / 2 / 3: 0.49-0.50 -> 0.44-0.45, 0.68 -> 0.47, 0.90 -> 0.62 ms; (1,512,129,129) 0.78 -> 0.56;
+    #: maps of 1-8 k pixels, bound by host launches, 0.48-0.50 -> 0.43-0.44: fewer torch ops on the path --
+    #: profiles/r06s_split_threshold_ab.txt).  Rounds 3-5, on stock GEMMs: 32768 (below ~30k pixels the extra producer passes cost
+    #: more than the GEMMs saved).
+    split_bf16_min_pixels = 0
     #: bf16 inputs: strips <= 132 (C, C/8 divisible by 8) run on the pixel-major bf16 MFMA kernels; strips of 133 .. 528 positions
     #: run the blocked fp32 plane kernels on fp32 copies (route ``f32-planes-cast``), anything else the strip family through fp32
     #: copies (route ``separate-strips``).
