@@ -1,4 +1,6 @@
-// cca_gemm.hpp -- the module's forward projection (functions.py:29,32,35 as ONE stacked GEMM) as a hand-written MFMA kernel:
+// cca_gemm.hpp -- the three GEMMs of the module's stacked 1x1 projections (functions.py:29,32,35 and their adjoints) as hand-written
+// MFMA kernels on the three-plane bf16 operands of the split-bf16 x3 scheme: proj_gemm_kernel (forward, and -- batched, NCHW, with an
+// addend -- the adjoint with respect to the input) and proj_wgrad_kernel (the adjoint with respect to the weight, below).
 //
 //     out[m][n] = sum_k A[m][k] * Wt[n][k] + bias[n]        A  (M, K) bf16, row stride lda   (x as three planes per pixel: K = 3 C)
 //                                                           Wt (N, K) bf16, row stride ldw   (the packed weight rows [wh | wl | wh])
@@ -11,9 +13,9 @@
 // gweight_kernel's with a large tile: workgroup = 256 x 128 outputs, 8 wavefronts of 64 x 64 (4 x 4 MFMA tiles of 16 x 16,
 // v_mfma_f32_16x16x32_bf16: 32 MFMAs per wavefront and 64-wide k step against 16 fragment reads; two wavefronts per SIMD, so one's
 // address / fill / wait instructions issue under the other's MFMAs), three LDS stages of 48 KiB.  The MFMA operands are SWAPPED
-// (D^T = Wt . A^T) so that a lane ends with four consecutive n of one m: the bias starts the accumulators and the results leave as
-// 16-byte stores straight from them, 256 contiguous bytes per row and wavefront.  Workgroup ids are decoded XCD-contiguously with
-// the N tiles of an M tile adjacent: the second to fifth read of an A tile is an L2 hit.
+// (D^T = Wt . A^T) so that a lane ends with four consecutive n of one m: bias and addend start the accumulators and the results
+// leave as 16-byte stores straight from them, 256 contiguous bytes per row and wavefront.  Workgroup ids are decoded XCD-contiguously
+// with the tiles that share a tile of the streamed operand adjacent: their second to fifth read of it is an L2 hit.
 //
 // The loop is a register ping-pong: a k step is two half steps of 16 MFMAs; the 8 fragment reads of the NEXT half step are
 // requested before the MFMAs of the current one (reads and waits outside the compiler's bookkeeping, cca_platform.hpp: across
@@ -22,11 +24,12 @@
 // multiplied.  The fill is six instructions per wavefront whose per-lane offsets are loop invariants (rows clamped to the matrix:
 // tail rows are computed on a valid row's data and never stored), issued in the shadow of the second half's first MFMAs.
 //
-// Measured (profiles/r06n_gemm_elimination.txt): 199-206 us with the bias, i.e. the stock product's time without it.  By
-// elimination at this shape the kernel is bound by its LDS fill -- fills + barriers alone take 183 us (1.7 GB into LDS: 48 KiB per
-// workgroup and k step with 96 KiB in flight per CU against the loaded fetch latency), the MFMAs alone 117 us -- which is
-// where the stock kernel sits too; an L2 prefetch by a ninth wavefront made it slower (273-283 us: twice the requests), four
-// wavefronts of 128 x 64 with the same pipeline 206-230 us.
+// Measured: 192-206 us with the bias (the stock product's time without it), dx 209-219 us with dy.  What bounds the k step
+// (~1 us against 0.44-0.48 us of MFMA; DESIGN.md 3.6, profiles/r06n_gemm_elimination.txt, r06r_gemm_residency_and_pmc.txt) is the
+// LDS array, not HBM: with both operands L2-resident the launch is only 10-15 % faster; per step and CU the array serves 128
+// ds_read_b128 wave-instructions (512 cycles) and takes 48 KiB of LDS-DMA writes (alone: 0.456 us, ~1000 cycles) against 1024 MFMA
+// cycles per SIMD.  Variants measured and dropped: declared plane structure with two tile rings (a third fewer bytes
+// into LDS), an L2 prefetch wavefront, a register-staged fill (ds_write_b128), padded row strides, four wavefronts of 128 x 64.
 #pragma once
 #include "cca_gmap.hpp"
 
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(PG_THREADS, 1) void proj_gemm_kernel(const ProjGemm
     const FBuf Cb = make_fbuf(job.add ? job.add + bt * job.so : job.out, ((size_t)(M - 1) * ldo + N) * sizeof(float));
     const int nk = (K + PG_BK - 1) / PG_BK;
 
-    // fill: wavefront wv moves A pieces wv, wv + 4, .. and Wt pieces wv, wv + 4, ..; lane = (row lane >> 3 of the piece, LDS chunk
+    // fill: wavefront wv moves A pieces wv, wv + 8, .. and Wt pieces wv, wv + 8; lane = (row lane >> 3 of the piece, LDS chunk
     // slot lane & 7), which holds the row's 16-byte k chunk slot ^ row (t16_byte<false>)
     int offa[PG_NPA], offb[PG_NPB];
     {
