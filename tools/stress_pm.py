@@ -65,3 +65,28 @@ for i in range(iters):
     bad[1] += int(not torch.equal(db, db0))
 print(f"f32 planes, three-plane backward (8,512,97,97): {iters} iterations, runs whose planes differ from the split of the fp32 gradients: {bad[0]}, "
       f"whose bias gradients differ from run 0: {bad[1]}", flush=True)
+
+
+# ---- round 6: the projection GEMMs (csrc/cca_gemm.hpp: counted LDS-DMA barriers, hand-counted LDS read waits, slab partials added
+# ---- in a fixed order) at the module's shapes and at ragged ones, repeated under the same load: outputs bit-identical to run 0
+from ccnet_amd import functions as F  # noqa: E402
+g = torch.Generator(device=dev).manual_seed(21)
+r16 = lambda *shape: torch.randn(shape, device=dev, generator=g).to(torch.bfloat16)  # noqa: E731
+for (B, C, H, W) in ((8, 512, 97, 97), (3, 288, 45, 67)):      # (the second: tails in M, N, K and in the slabs)
+    hw, ct = H * W, C + 2 * (C // 8)
+    x3, w3, w3t, d3 = r16(B * hw, 3 * C), r16(ct, 3 * C), r16(C, 3 * ct), r16(B, hw, 3 * ct)
+    dy, bias = torch.randn((B, C, hw), device=dev, generator=g), torch.randn((ct,), device=dev, generator=g)
+    run = lambda: (F._projection_gemm(lib, x3, w3, bias), F._projection_adjoint_gemm(lib, w3t, d3, dy),  # noqa: E731
+                   F._projection_wgrad_gemm(lib, d3.view(B * hw * 3, ct), x3.view(B * hw * 3, C)))
+    ref = run(); torch.cuda.synchronize()
+    assert all(t is not None and bool(torch.isfinite(t).all()) for t in ref)
+    bad = [0, 0, 0]
+    for i in range(iters):
+        if i % 2:
+            with torch.cuda.stream(side):
+                noise.mul_(1.0001)
+        out = run()
+        torch.cuda.synchronize()
+        for j, (a, b) in enumerate(zip(out, ref)):
+            bad[j] += int(not torch.equal(a, b))
+    print(f"projection GEMMs ({B},{C},{H},{W}): {iters} iterations, runs that differ from run 0: forward {bad[0]} dx {bad[1]} dW {bad[2]}", flush=True)
