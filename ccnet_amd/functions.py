@@ -489,18 +489,22 @@ def _pack_projection(wq, bq, wk, bk, wv, bv, split):
 
 def _projection_gemm(lib, a, wt, bias):
     """``a @ wt.T + bias`` on bf16 operands, fp32 accumulation and output, by ``ccnet_cca_projection_bf16`` (functions.py:29,32,35 of
-    the reference as one stacked GEMM).  ``a``: (M, K) and ``wt``: (N, K), both K-contiguous.  None when the shape is outside the
-    entry point's contract (K % 8, N % 4, 31-bit byte offsets) -- the caller then uses the stock GEMM."""
+    the reference as one stacked GEMM).  ``a``: (M, K) and ``wt``: (N, K), both K-contiguous.  Row counts beyond the entry point's
+    31-bit byte offsets run as several launches over row ranges.  None when the shape is outside the contract (K % 8, N % 4) --
+    the caller then uses the stock GEMM."""
     M, K = a.shape
     N = wt.shape[0]
-    if K % 8 or N % 4 or a.stride(1) != 1 or wt.stride(1) != 1 or a.stride(0) % 8 or wt.stride(0) % 8:
+    if K % 8 or N % 4 or a.stride(1) != 1 or wt.stride(1) != 1 or a.stride(0) % 8 or wt.stride(0) % 8 or N * wt.stride(0) >= 1 << 30:
         return None
-    if M * a.stride(0) >= 1 << 30 or N * wt.stride(0) >= 1 << 30 or M * N >= 1 << 29:
+    rows = min(((1 << 30) - 1) // a.stride(0), ((1 << 29) - 1) // N) // 256 * 256          # per launch: whole 256-row tiles
+    if rows <= 0:
         return None
     out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     with torch.cuda.device(a.device):
-        lib.check(lib.ccnet_cca_projection_bf16(a.data_ptr(), wt.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K,
-                                                a.stride(0), wt.stride(0), N, _stream()), "projection_bf16")
+        for m0 in range(0, M, rows):
+            m = min(rows, M - m0)
+            lib.check(lib.ccnet_cca_projection_bf16(a.data_ptr() + 2 * m0 * a.stride(0), wt.data_ptr(), bias.data_ptr(), out.data_ptr() + 4 * m0 * N,
+                                                    m, N, K, a.stride(0), wt.stride(0), N, _stream()), "projection_bf16")
     return out
 
 
@@ -522,22 +526,28 @@ def _projection_adjoint_gemm(lib, w, d, add):
 
 def _projection_wgrad_gemm(lib, d, x):
     """``d.T @ x`` over all rows by ``ccnet_cca_projection_wgrad_bf16``: ``d`` (R, N) and ``x`` (R, C) bf16 with contiguous rows ->
-    (N, C) fp32 (the S partial sums of the launch added in a fixed order).  None when the shape is outside the entry point's
-    contract."""
+    (N, C) fp32 (the partial sums of the launch -- of the launches, where the rows exceed the entry point's 31-bit byte offsets --
+    added in a fixed order).  None when the shape is outside the entry point's contract."""
     R, N = d.shape
     C = x.shape[1]
     if N % 8 or C % 8 or d.stride(1) != 1 or x.stride(1) != 1 or d.stride(0) % 8 or x.stride(0) % 8 or x.shape[0] != R:
         return None
-    if R * d.stride(0) >= 1 << 30 or R * x.stride(0) >= 1 << 30:
+    rows = ((1 << 30) - 1) // max(d.stride(0), x.stride(0)) // 64 * 64                     # per launch: whole 64-row stages
+    if rows <= 0:
         return None
     tiles = -(-N // 128) * -(-C // 256)
     cus = torch.cuda.get_device_properties(d.device).multi_processor_count
-    S = max(1, min(cus // tiles if tiles <= cus else 1, -(-R // 64)))
-    part = torch.empty((S, N, C), device=d.device, dtype=torch.float32)
+    chunks = [(r0, min(rows, R - r0)) for r0 in range(0, R, rows)]
+    slabs = [max(1, min(cus // tiles if tiles <= cus else 1, -(-r // 64))) for _, r in chunks]
+    part = torch.empty((sum(slabs), N, C), device=d.device, dtype=torch.float32)
     with torch.cuda.device(d.device):
-        lib.check(lib.ccnet_cca_projection_wgrad_bf16(d.data_ptr(), x.data_ptr(), part.data_ptr(), R, N, C, d.stride(0), x.stride(0), S,
-                                                      _stream()), "projection_wgrad_bf16")
-    return part.sum(0) if S > 1 else part[0]
+        s0 = 0
+        for (r0, r), S in zip(chunks, slabs):
+            lib.check(lib.ccnet_cca_projection_wgrad_bf16(d.data_ptr() + 2 * r0 * d.stride(0), x.data_ptr() + 2 * r0 * x.stride(0),
+                                                          part.data_ptr() + 4 * s0 * N * C, r, N, C, d.stride(0), x.stride(0), S, _stream()),
+                      "projection_wgrad_bf16")
+            s0 += S
+    return part.sum(0) if part.shape[0] > 1 else part[0]
 
 
 class CrissCrossPlanesModuleFunction(torch.autograd.Function):

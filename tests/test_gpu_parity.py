@@ -1620,3 +1620,28 @@ def test_projection_wgrad_gemm_on_the_device(lib, dev, rncs):
     bound = 2e-6 * (dd.abs().T @ xd.abs()) + 1e-30
     assert bool(((parts[0].double().sum(0) - ref).abs() <= bound).all())
     assert lib.ccnet_cca_projection_wgrad_bf16(d.data_ptr(), x.data_ptr(), parts[0].data_ptr(), R, N + 4, C, ldd, ldx, S, st) != 0
+
+
+@pytest.mark.gpu
+def test_projection_gemm_helpers_cut_rows_beyond_the_offset_limit_into_launches(lib, dev):
+    """``_projection_gemm`` / ``_projection_wgrad_gemm`` (ccnet_amd/functions.py): operands whose rows x row stride pass the entry points'
+    31-bit byte offsets run as several launches over row ranges (the module at B >= 64 of 97 x 97) -- here a row stride of 16 384
+    elements makes 70 000 rows cross the limit with little data; results against the fp64 product of the same bf16 values."""
+    from ccnet_amd import functions as F
+    M, K, N, C, ld = 70000, 64, 24, 40, 16384
+    g = torch.Generator(device="cpu").manual_seed(5)
+    a = torch.empty((M, ld), dtype=torch.bfloat16, device=dev)[:, :K]
+    a.copy_(torch.randn((M, K), generator=g).to(torch.bfloat16))
+    w = torch.randn((N, K), generator=g).to(torch.bfloat16).to(dev)
+    bias = torch.randn((N,), generator=g).to(dev)
+    assert M * a.stride(0) >= 1 << 30
+    out = F._projection_gemm(lib, a, w, bias)
+    ref = a.double() @ w.double().T + bias.double()
+    assert out is not None and float((out.double() - ref).abs().max()) < 1e-4
+    # the weight gradient: d (R, N) with the wide row stride, x (R, C) dense
+    d = torch.empty((M, ld), dtype=torch.bfloat16, device=dev)[:, :N]
+    d.copy_(torch.randn((M, N), generator=g).to(torch.bfloat16))
+    x = torch.randn((M, C), generator=g).to(torch.bfloat16).to(dev)
+    dw = F._projection_wgrad_gemm(lib, d, x)
+    refw = d.double().T @ x.double()
+    assert dw is not None and float((dw.double() - refw).abs().max()) < 2e-6 * float((d.double().abs().T @ x.double().abs()).max()) + 1e-6
