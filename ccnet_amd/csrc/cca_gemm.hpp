@@ -25,11 +25,12 @@
 // tail rows are computed on a valid row's data and never stored), issued in the shadow of the second half's first MFMAs.
 //
 // Measured: 192-206 us with the bias (the stock product's time without it), dx 209-219 us with dy.  What bounds the k step
-// (~1 us against 0.44-0.48 us of MFMA; DESIGN.md 3.6, profiles/r06n_gemm_elimination.txt, r06r_gemm_residency_and_pmc.txt) is the
-// LDS array, not HBM: with both operands L2-resident the launch is only 10-15 % faster; per step and CU the array serves 128
-// ds_read_b128 wave-instructions (512 cycles) and takes 48 KiB of LDS-DMA writes (alone: 0.456 us, ~1000 cycles) against 1024 MFMA
-// cycles per SIMD.  Variants measured and dropped: declared plane structure with two tile rings (a third fewer bytes
-// into LDS), an L2 prefetch wavefront, a register-staged fill (ds_write_b128), padded row strides, four wavefronts of 128 x 64.
+// (~1 us against 0.44-0.48 us of MFMA; DESIGN.md 3.6, profiles/r06n_gemm_elimination.txt, r06r_gemm_residency_and_pmc.txt) is
+// inside the CU, not HBM: with both operands L2-resident the launch is only 10-15 % faster.  The suspect is the LDS path -- per
+// step and CU 128 ds_read_b128 wave-instructions (512 LDS cycles) plus 48 KiB of LDS-DMA writes (alone: 0.456 us, ~1000 cycles)
+// against 1024 MFMA cycles per SIMD -- but the model is incomplete: the variant that cut the DMA bytes by a third (declared plane
+// structure, two tile rings) was no faster.  Also measured and dropped: an L2 prefetch wavefront, a register-staged
+// fill (ds_write_b128), padded row strides, four wavefronts of 128 x 64, the ping-pong in the dW kernel.
 #pragma once
 #include "cca_gmap.hpp"
 
